@@ -1,0 +1,166 @@
+/*
+ * seamlessclone_hip.h -- C ABI of libseamlessclone_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the seamless-clone (Poisson image editing, NORMAL_CLONE) hot path of
+ * wujinzhong/seamlessCloneOptimization.  The four my_seamlessclone_api_imp_* symbols keep the
+ * names the reference exports from seamlessClone-CUDA/seamlessclone_cuda.h:4-63 (thin
+ * wrappers over seamlessClone_imp.cu:239,265,354,365) and that its Python binding re-declares
+ * at seamlessClone-python-binding/SeamlessClone.cpp:37-44.  The reference passes cv::Mat* as
+ * void* and returns a cv::Mat by value; a C ABI cannot, so each cv::Mat becomes the
+ * {data, cols, rows, step} quadruple it wraps and the result is written in place into `body`
+ * (the reference's returned Mat aliases the caller's dest buffer, seamlessClone_imp.cpp:470).
+ *
+ * Images are 8-bit, BGR interleaved (CV_8UC3) for face/body and single channel (CV_8UC1)
+ * for mask, `step` = bytes per row.  All sc_hip_* entry points are additions: solver
+ * options, a device-resident run for callers whose images already live in HBM, run
+ * statistics, and stage-level hooks used by the parity tests.
+ *
+ * Threading: one instance <-> one HIP stream <-> one host thread at a time (reference:
+ * one instance per stream, not re-entrant).  No process-global state.
+ */
+#ifndef SEAMLESSCLONE_HIP_H
+#define SEAMLESSCLONE_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define SC_API __attribute__((visibility("default")))
+#else
+#define SC_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes (the reference aborts / asserts instead: seamlessClone_imp.cu:272-275,
+ *      seamlessClone_imp.cpp:432-436,1013) */
+#define SC_OK                 0
+#define SC_ERR_BAD_ARG       -1   /* null pointer, bad instance, bad option value          */
+#define SC_ERR_BAD_SIZE      -2   /* face/mask size mismatch, step too small, empty image  */
+#define SC_ERR_EMPTY_MASK    -3   /* bbox of mask!=0 degenerate (reference assert :1013)   */
+#define SC_ERR_ROI_OOB       -4   /* ROI leaves body (unchecked in the reference)          */
+#define SC_ERR_HIP           -5   /* HIP runtime error; see sc_hip_last_error()            */
+#define SC_ERR_NOT_CONVERGED -6   /* tol not reached within max_sweeps; result still written */
+
+/* OpenCV clone flags (only NORMAL_CLONE exists in the reference: seamlessClone_imp.cu:301) */
+#define SC_NORMAL_CLONE 1
+
+/* ---- solver selection */
+enum sc_method {
+    SC_METHOD_JACOBI = 0,    /* U' = 1/4 (l+r+u+d - lap), ping-pong                         */
+    SC_METHOD_RBGS   = 1,    /* red-black Gauss-Seidel (omega = 1)                          */
+    SC_METHOD_SOR    = 2,    /* red-black SOR, omega from opts (<=0: optimal for the ROI)   */
+    SC_METHOD_MULTIGRID = 3  /* V-cycles with red-black GS smoothing (converges at any ROI)  */
+};
+
+typedef struct sc_solver_opts {
+    int   method;            /* enum sc_method                                              */
+    int   max_sweeps;        /* sweeps (JACOBI/RBGS/SOR) or V-cycles (MULTIGRID) budget     */
+    float tol;               /* stop when ||lap - A u||_2 / ||lap||_2 <= tol; <=0: run
+                                exactly max_sweeps                                         */
+    int   check_every;       /* sweeps between residual checks (tol>0)                      */
+    float omega;             /* SOR relaxation; <=0 -> 2/(1+sin(pi/max(w,h)+1)) style optimum */
+    int   sweeps_per_launch; /* temporal blocking depth of the sweep kernel; 0 = library default */
+    int   reference_warmup;  /* 1: clone twice in place, as the reference's run() does
+                                (warm-up + 1, seamlessClone_imp.cu:303-318)                */
+    int   mg_pre, mg_post;   /* multigrid smoothing sweeps per level (0 = default 2/2)      */
+    int   reserved[6];
+} sc_solver_opts;
+
+/* ---- statistics of the last run */
+typedef struct sc_run_info {
+    int    x0, y0, W, H, ltx, lty;  /* patch offset, ROI size (ring included), ROI origin in body */
+    int    sweeps;                  /* sweeps (or V-cycles) executed                        */
+    int    converged;               /* 1 when tol reached (or tol<=0)                       */
+    double rel_residual;            /* last evaluated ||r||/||lap|| (NaN if never evaluated) */
+    float  ms_h2d, ms_mask, ms_pre, ms_solve, ms_post, ms_d2h; /* hipEvent times on the instance stream */
+    float  ms_device_total;         /* mask + pre + solve + post                            */
+    int    sweep_launches;          /* launches of the dominant sweep kernel in the last run */
+    float  ms_sweep_kernels;        /* hipEvent time spent in them (only when profiling enabled) */
+    size_t device_bytes;            /* arena bytes owned by the instance                    */
+} sc_run_info;
+
+/* ---- the reference's four entry points ------------------------------------------------- */
+
+/* seamlessclone_cuda.h:23-38 / seamlessClone_imp.cu:239-263.  Selects `gpu_id` (the
+ * reference only prints its properties), creates the stream and the grow-only arena.
+ * Returns NULL on failure. */
+SC_API void *my_seamlessclone_api_imp_create_instance(int gpu_id);
+
+/* seamlessclone_cuda.h:6-21 / seamlessClone_imp.cu:265-352.
+ * face = patch (CV_8UC3), body = destination (CV_8UC3, modified in place), mask (CV_8UC1,
+ * same size as face).  Host pointers.  bSync=true waits for completion before returning
+ * (and fills the timing fields); bSync=false returns after enqueueing when `body` is
+ * page-locked, otherwise it still completes before returning (the result must land in
+ * caller memory).  Returns SC_OK or a negative SC_ERR_*. */
+SC_API int my_seamlessclone_api_imp_run(void *instance,
+                                 const uint8_t *face, int face_cols, int face_rows, int face_step,
+                                 uint8_t *body, int body_cols, int body_rows, int body_step,
+                                 const uint8_t *mask, int mask_cols, int mask_rows, int mask_step,
+                                 int centerX, int centerY, int gpu_id, bool bSync);
+
+/* seamlessclone_cuda.h:40-55 / seamlessClone_imp.cu:354-363 */
+SC_API void my_seamlessclone_api_imp_destroy(void *instance);
+
+/* seamlessclone_cuda.h:57-61 / seamlessClone_imp.cu:365-370 */
+SC_API void my_seamlessclone_api_imp_sync(void *instance);
+
+/* ---- additions ------------------------------------------------------------------------- */
+
+SC_API void sc_hip_default_opts(sc_solver_opts *opts);
+SC_API int  sc_hip_set_solver(void *instance, const sc_solver_opts *opts);
+SC_API int  sc_hip_get_solver(void *instance, sc_solver_opts *opts);
+SC_API int  sc_hip_get_info(void *instance, sc_run_info *info);
+SC_API const char *sc_hip_last_error(void *instance);
+
+/* Same as run(), but face/body/mask are DEVICE pointers on the instance's GPU (inputs
+ * resident in HBM); body is updated in place on the device.  Asynchronous on the instance
+ * stream unless bSync. */
+SC_API int sc_hip_run_device(void *instance,
+                      const uint8_t *d_face, int face_cols, int face_rows, int face_step,
+                      uint8_t *d_body, int body_cols, int body_rows, int body_step,
+                      const uint8_t *d_mask, int mask_cols, int mask_rows, int mask_step,
+                      int centerX, int centerY, bool bSync);
+
+/* plain device-memory helpers so non-HIP hosts (ctypes, cgo, JNI) can stage images */
+SC_API void *sc_hip_malloc(void *instance, size_t bytes);
+SC_API void  sc_hip_free(void *instance, void *dptr);
+SC_API int   sc_hip_memcpy_h2d(void *instance, void *dptr, const void *hptr, size_t bytes);
+SC_API int   sc_hip_memcpy_d2h(void *instance, void *hptr, const void *dptr, size_t bytes);
+SC_API int   sc_hip_device_count(void);
+
+/* ---- stage-level hooks (parity tests drive each kernel through these) ------------------- */
+
+/* mask stage only (seamlessClone_imp.cpp:978-1071): geo = {x0,y0,W,H,ltx,lty}; M_out
+ * receives the 3x eroded ROI mask, dense W*H bytes (may be NULL). */
+SC_API int sc_hip_mask_stage(void *instance, const uint8_t *mask, int mask_cols, int mask_rows, int mask_step,
+                      int centerX, int centerY, int geo[6], uint8_t *M_out, size_t M_capacity);
+
+/* mask stage + fused pre-process (seamlessClone_imp.cpp:1920-2018): downloads the dst-ROI
+ * field B and the un-folded RHS lap, planar [3][H][W] float32, channel = BGR index. */
+SC_API int sc_hip_build_rhs(void *instance,
+                     const uint8_t *face, int face_cols, int face_rows, int face_step,
+                     const uint8_t *body, int body_cols, int body_rows, int body_step,
+                     const uint8_t *mask, int mask_cols, int mask_rows, int mask_step,
+                     int centerX, int centerY, int geo[6], float *B_out, float *lap_out, size_t plane_capacity);
+
+/* solver-only hooks on caller-supplied fields, planar [C][H][W] float32 (ring included). */
+SC_API int sc_hip_field_load(void *instance, int W, int H, int C, const float *U, const float *lap);
+SC_API int sc_hip_field_sweep(void *instance, int method, int sweeps, float omega, int sweeps_per_launch);
+SC_API int sc_hip_field_residual(void *instance, double out[2] /* sum r^2, sum lap^2 */);
+SC_API int sc_hip_field_solve(void *instance);                      /* run the configured solver on the loaded field */
+SC_API int sc_hip_field_store(void *instance, float *U_out);
+
+/* microbenchmark hook used by bench.py: runs `launches` launches of the sweep kernel
+ * (method, sweeps_per_launch) on the loaded field and returns the mean launch time measured
+ * with hipEvents on the instance stream. */
+SC_API int sc_hip_field_time_sweeps(void *instance, int method, int launches, int sweeps_per_launch, float omega,
+                             float *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEAMLESSCLONE_HIP_H */

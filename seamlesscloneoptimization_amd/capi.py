@@ -1,0 +1,301 @@
+"""ctypes binding of libseamlessclone_hip.so -- the C ABI declared in include/seamlessclone_hip.h.
+
+There is no CPU fallback: if the HIP library is missing or does not load this module raises,
+and every compute entry point needs a visible MI355X.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libseamlessclone_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "seamlessclone_hip.h")
+
+SC_OK = 0
+SC_ERR_BAD_ARG = -1
+SC_ERR_BAD_SIZE = -2
+SC_ERR_EMPTY_MASK = -3
+SC_ERR_ROI_OOB = -4
+SC_ERR_HIP = -5
+SC_ERR_NOT_CONVERGED = -6
+
+SC_METHOD_JACOBI = 0
+SC_METHOD_RBGS = 1
+SC_METHOD_SOR = 2
+SC_METHOD_MULTIGRID = 3
+
+ERR_NAMES = {
+    SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",
+    SC_ERR_ROI_OOB: "SC_ERR_ROI_OOB", SC_ERR_HIP: "SC_ERR_HIP", SC_ERR_NOT_CONVERGED: "SC_ERR_NOT_CONVERGED",
+}
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("method", C.c_int), ("max_sweeps", C.c_int), ("tol", C.c_float), ("check_every", C.c_int),
+                ("omega", C.c_float), ("sweeps_per_launch", C.c_int), ("reference_warmup", C.c_int),
+                ("mg_pre", C.c_int), ("mg_post", C.c_int), ("reserved", C.c_int * 6)]
+
+
+class RunInfo(C.Structure):
+    _fields_ = [("x0", C.c_int), ("y0", C.c_int), ("W", C.c_int), ("H", C.c_int), ("ltx", C.c_int), ("lty", C.c_int),
+                ("sweeps", C.c_int), ("converged", C.c_int), ("rel_residual", C.c_double),
+                ("ms_h2d", C.c_float), ("ms_mask", C.c_float), ("ms_pre", C.c_float), ("ms_solve", C.c_float),
+                ("ms_post", C.c_float), ("ms_d2h", C.c_float), ("ms_device_total", C.c_float),
+                ("sweep_launches", C.c_int), ("ms_sweep_kernels", C.c_float), ("device_bytes", C.c_size_t)]
+
+
+class SeamlessCloneError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+
+
+u8p = C.POINTER(C.c_uint8)
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int)
+f64p = C.POINTER(C.c_double)
+_IMG = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function name the public header declares (used by the CPU-side ABI test)."""
+    txt = open(HEADER_PATH).read()
+    return sorted(set(re.findall(r"SC_API[^;(]*?\b((?:my_seamlessclone_api_imp_|sc_hip_)\w+)\s*\(", txt)))
+
+
+def build(verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of the in-tree shared library (no GPU needed)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j4"]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc, gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.my_seamlessclone_api_imp_create_instance.argtypes = [C.c_int]
+    L.my_seamlessclone_api_imp_create_instance.restype = C.c_void_p
+    L.my_seamlessclone_api_imp_run.argtypes = [C.c_void_p] + _IMG * 3 + [C.c_int, C.c_int, C.c_int, C.c_bool]
+    L.my_seamlessclone_api_imp_run.restype = C.c_int
+    L.my_seamlessclone_api_imp_destroy.argtypes = [C.c_void_p]
+    L.my_seamlessclone_api_imp_destroy.restype = None
+    L.my_seamlessclone_api_imp_sync.argtypes = [C.c_void_p]
+    L.my_seamlessclone_api_imp_sync.restype = None
+    L.sc_hip_default_opts.argtypes = [C.POINTER(SolverOpts)]
+    L.sc_hip_default_opts.restype = None
+    L.sc_hip_set_solver.argtypes = [C.c_void_p, C.POINTER(SolverOpts)]
+    L.sc_hip_set_solver.restype = C.c_int
+    L.sc_hip_get_solver.argtypes = [C.c_void_p, C.POINTER(SolverOpts)]
+    L.sc_hip_get_solver.restype = C.c_int
+    L.sc_hip_get_info.argtypes = [C.c_void_p, C.POINTER(RunInfo)]
+    L.sc_hip_get_info.restype = C.c_int
+    L.sc_hip_last_error.argtypes = [C.c_void_p]
+    L.sc_hip_last_error.restype = C.c_char_p
+    L.sc_hip_run_device.argtypes = [C.c_void_p] + _IMG * 3 + [C.c_int, C.c_int, C.c_bool]
+    L.sc_hip_run_device.restype = C.c_int
+    L.sc_hip_malloc.argtypes = [C.c_void_p, C.c_size_t]
+    L.sc_hip_malloc.restype = C.c_void_p
+    L.sc_hip_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.sc_hip_free.restype = None
+    L.sc_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.sc_hip_memcpy_h2d.restype = C.c_int
+    L.sc_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.sc_hip_memcpy_d2h.restype = C.c_int
+    L.sc_hip_device_count.argtypes = []
+    L.sc_hip_device_count.restype = C.c_int
+    L.sc_hip_mask_stage.argtypes = [C.c_void_p] + _IMG + [C.c_int, C.c_int, i32p, u8p, C.c_size_t]
+    L.sc_hip_mask_stage.restype = C.c_int
+    L.sc_hip_build_rhs.argtypes = [C.c_void_p] + _IMG * 3 + [C.c_int, C.c_int, i32p, f32p, f32p, C.c_size_t]
+    L.sc_hip_build_rhs.restype = C.c_int
+    L.sc_hip_field_load.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p]
+    L.sc_hip_field_load.restype = C.c_int
+    L.sc_hip_field_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.sc_hip_field_sweep.restype = C.c_int
+    L.sc_hip_field_residual.argtypes = [C.c_void_p, f64p]
+    L.sc_hip_field_residual.restype = C.c_int
+    L.sc_hip_field_solve.argtypes = [C.c_void_p]
+    L.sc_hip_field_solve.restype = C.c_int
+    L.sc_hip_field_store.argtypes = [C.c_void_p, f32p]
+    L.sc_hip_field_store.restype = C.c_int
+    L.sc_hip_field_time_sweeps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)]
+    L.sc_hip_field_time_sweeps.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _img(a: np.ndarray):
+    """numpy HxW[x3] uint8 (row-contiguous, arbitrary row stride) -> (ptr, cols, rows, step)."""
+    if a.dtype != np.uint8:
+        raise TypeError("images must be uint8")
+    if a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    if a.strides[-1] != 1 or (a.ndim == 3 and a.strides[1] != ch):
+        raise ValueError("image rows must be contiguous (cv::Mat layout)")
+    return a.ctypes.data, a.shape[1], a.shape[0], a.strides[0]
+
+
+class Instance:
+    """Thin RAII wrapper over one library instance (one GPU, one stream)."""
+
+    def __init__(self, gpu_id: int = 0):
+        self.L = load()
+        self.h = self.L.my_seamlessclone_api_imp_create_instance(int(gpu_id))
+        if not self.h:
+            raise SeamlessCloneError(SC_ERR_HIP, f"cannot create an instance on GPU {gpu_id} "
+                                     "(no MI355X visible? there is no CPU fallback)")
+        self.gpu_id = gpu_id
+
+    # ---- lifetime
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.L.my_seamlessclone_api_imp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def sync(self):
+        self.L.my_seamlessclone_api_imp_sync(self.h)
+
+    def _check(self, rc, allow=()):
+        if rc != SC_OK and rc not in allow:
+            raise SeamlessCloneError(rc, (self.L.sc_hip_last_error(self.h) or b"").decode())
+        return rc
+
+    # ---- options / info
+    def default_opts(self) -> SolverOpts:
+        o = SolverOpts()
+        self.L.sc_hip_default_opts(C.byref(o))
+        return o
+
+    def set_solver(self, **kw) -> SolverOpts:
+        o = self.get_solver()
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        self._check(self.L.sc_hip_set_solver(self.h, C.byref(o)))
+        return o
+
+    def get_solver(self) -> SolverOpts:
+        o = SolverOpts()
+        self._check(self.L.sc_hip_get_solver(self.h, C.byref(o)))
+        return o
+
+    def info(self) -> RunInfo:
+        i = RunInfo()
+        self._check(self.L.sc_hip_get_info(self.h, C.byref(i)))
+        return i
+
+    # ---- the clone
+    def run(self, face, body, mask, cx, cy, sync=True, allow_not_converged=False):
+        """In place on `body` (reference semantics).  Returns the C return code."""
+        if not body.flags.writeable:
+            raise ValueError("body must be writeable: the clone is in place")
+        f, b, m = _img(face), _img(body), _img(mask)
+        rc = self.L.my_seamlessclone_api_imp_run(self.h, *f, *b, *m, int(cx), int(cy), self.gpu_id, bool(sync))
+        return self._check(rc, allow=(SC_ERR_NOT_CONVERGED,) if allow_not_converged else ())
+
+    # ---- device-resident images
+    def malloc(self, nbytes):
+        p = self.L.sc_hip_malloc(self.h, nbytes)
+        if not p:
+            raise SeamlessCloneError(SC_ERR_HIP, f"hipMalloc({nbytes}) failed")
+        return p
+
+    def free(self, p):
+        self.L.sc_hip_free(self.h, p)
+
+    def to_device(self, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        p = self.malloc(a.nbytes)
+        self._check(self.L.sc_hip_memcpy_h2d(self.h, p, a.ctypes.data, a.nbytes))
+        return p
+
+    def from_device(self, p, shape, dtype=np.uint8):
+        out = np.empty(shape, dtype)
+        self._check(self.L.sc_hip_memcpy_d2h(self.h, out.ctypes.data, p, out.nbytes))
+        return out
+
+    def run_device(self, d_face, fshape, d_body, bshape, d_mask, mshape, cx, cy, sync=True,
+                   allow_not_converged=False):
+        """shapes are (rows, cols); rows are dense (step = cols * channels)."""
+        rc = self.L.sc_hip_run_device(self.h, d_face, fshape[1], fshape[0], 3 * fshape[1],
+                                      d_body, bshape[1], bshape[0], 3 * bshape[1],
+                                      d_mask, mshape[1], mshape[0], mshape[1], int(cx), int(cy), bool(sync))
+        return self._check(rc, allow=(SC_ERR_NOT_CONVERGED,) if allow_not_converged else ())
+
+    # ---- stage hooks
+    def mask_stage(self, mask, cx, cy):
+        m = _img(mask)
+        geo = np.zeros(6, np.int32)
+        M = np.zeros(m[1] * m[2], np.uint8)
+        self._check(self.L.sc_hip_mask_stage(self.h, *m, int(cx), int(cy), geo.ctypes.data_as(i32p),
+                                             M.ctypes.data_as(u8p), M.size))
+        W, H = int(geo[2]), int(geo[3])
+        return geo, M[:W * H].reshape(H, W).copy()
+
+    def build_rhs(self, face, body, mask, cx, cy):
+        f, b, m = _img(face), _img(body), _img(mask)
+        geo = np.zeros(6, np.int32)
+        cap = m[1] * m[2]
+        B = np.zeros(3 * cap, np.float32)
+        lap = np.zeros(3 * cap, np.float32)
+        self._check(self.L.sc_hip_build_rhs(self.h, *f, *b, *m, int(cx), int(cy), geo.ctypes.data_as(i32p),
+                                            B.ctypes.data_as(f32p), lap.ctypes.data_as(f32p), cap))
+        W, H = int(geo[2]), int(geo[3])
+        return geo, B[:3 * W * H].reshape(3, H, W).copy(), lap[:3 * W * H].reshape(3, H, W).copy()
+
+    def field_load(self, U, lap):
+        U = np.ascontiguousarray(U, np.float32)
+        lap = np.ascontiguousarray(lap, np.float32)
+        assert U.shape == lap.shape and U.ndim == 3
+        Cc, H, W = U.shape
+        self._check(self.L.sc_hip_field_load(self.h, W, H, Cc, U.ctypes.data_as(f32p), lap.ctypes.data_as(f32p)))
+        self._fshape = (Cc, H, W)
+
+    def field_sweep(self, method, sweeps, omega=1.0, sweeps_per_launch=1):
+        self._check(self.L.sc_hip_field_sweep(self.h, int(method), int(sweeps), float(omega), int(sweeps_per_launch)))
+
+    def field_residual(self):
+        out = np.zeros(2, np.float64)
+        self._check(self.L.sc_hip_field_residual(self.h, out.ctypes.data_as(f64p)))
+        return float(out[0]), float(out[1])
+
+    def field_solve(self, allow_not_converged=False):
+        rc = self.L.sc_hip_field_solve(self.h)
+        return self._check(rc, allow=(SC_ERR_NOT_CONVERGED,) if allow_not_converged else ())
+
+    def field_store(self):
+        out = np.zeros(self._fshape, np.float32)
+        self._check(self.L.sc_hip_field_store(self.h, out.ctypes.data_as(f32p)))
+        return out
+
+    def field_time_sweeps(self, method, launches, sweeps_per_launch=1, omega=1.0) -> float:
+        ms = C.c_float(0)
+        self._check(self.L.sc_hip_field_time_sweeps(self.h, int(method), int(launches), int(sweeps_per_launch),
+                                                    float(omega), C.byref(ms)))
+        return float(ms.value)
+
+
+def device_count() -> int:
+    return int(load().sc_hip_device_count())

@@ -1,0 +1,564 @@
+// sc_api.cpp -- the extern "C" boundary of libseamlessclone_hip.so (include/seamlessclone_hip.h).
+//
+// Host orchestration of one clone (reference call stack: seamlessClone_imp.cu:265-352 ->
+// seamlessClone_imp.cpp:430-486 seamlessCloneGPU -> :2105-2135 run()):
+//   H2D mask -> bbox kernel -> 16-byte read-back (the one mid-pipeline sync the reference also
+//   has, :1012) -> H2D of the face/body ROI only -> fused erode -> fused pre-process ->
+//   iterative solve -> fused post-process into the body ROI -> D2H of the interior straight
+//   into the caller's image (replaces the reference's D2H + host splice loop, :470-483).
+#include "sc_instance.h"
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace sc;
+
+namespace sc {
+
+int hip_fail(Instance *I, hipError_t e, const char *what)
+{
+    if (I) {
+        I->err = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    return SC_ERR_HIP;
+}
+
+int ensure(Instance *I, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return SC_OK;
+    size_t ncap = bytes > 2 * b.cap ? bytes : 2 * b.cap; // grow-only, amortised (seamlessClone_imp.h:83,119-121)
+    ncap = (ncap + 4095) & ~(size_t)4095;
+    if (b.p) {
+        SC_HIP(I, hipStreamSynchronize(I->stream));
+        SC_HIP(I, hipFree(b.p));
+        I->arena_bytes -= b.cap;
+        b.p = nullptr; b.cap = 0;
+    }
+    SC_HIP(I, hipMalloc(&b.p, ncap));
+    SC_HIP(I, hipMemsetAsync(b.p, 0, ncap, I->stream));
+    b.cap = ncap;
+    I->arena_bytes += ncap;
+    return SC_OK;
+}
+
+static Field make_field(void *p, int W, int H, int C)
+{
+    Field f;
+    f.p = (float *)p; f.W = W; f.H = H; f.C = C;
+    f.pitch = round_up(W, 64);
+    f.plane = (size_t)f.pitch * H;
+    return f;
+}
+
+int setup_fields(Instance *I, int W, int H, int C)
+{
+    Field proto = make_field(nullptr, W, H, C);
+    const size_t bytes = proto.bytes() + 4096;
+    int rc;
+    if ((rc = ensure(I, I->d_U0, bytes))) return rc;
+    if ((rc = ensure(I, I->d_U1, bytes))) return rc;
+    if ((rc = ensure(I, I->d_F, bytes))) return rc;
+    I->U0 = make_field(I->d_U0.p, W, H, C);
+    I->U1 = make_field(I->d_U1.p, W, H, C);
+    I->F = make_field(I->d_F.p, W, H, C);
+    I->result_in_U1 = false;
+    I->mg.clear();
+    return SC_OK;
+}
+
+} // namespace sc
+
+static Instance *get(void *p)
+{
+    Instance *I = (Instance *)p;
+    if (!I || !I->ok()) return nullptr;
+    return I;
+}
+
+static int validate_images(Instance *I, const void *face, int fc, int fr, int fs, const void *body, int bc, int br,
+                           int bs, const void *mask, int mc, int mr, int ms)
+{
+    if (!face || !body || !mask) { I->err = "null image pointer"; return SC_ERR_BAD_ARG; }
+    if (fc <= 0 || fr <= 0 || bc <= 0 || br <= 0 || mc <= 0 || mr <= 0) { I->err = "empty image"; return SC_ERR_BAD_SIZE; }
+    if (fc != mc || fr != mr) { I->err = "face and mask sizes differ"; return SC_ERR_BAD_SIZE; }
+    if (fs < 3 * fc || bs < 3 * bc || ms < mc) { I->err = "row step smaller than the row"; return SC_ERR_BAD_SIZE; }
+    return SC_OK;
+}
+
+// bbox kernel + read-back; fills geo.  mask is a device pointer.
+static int device_bbox(Instance *I, const uint8_t *d_mask, int mc, int mr, int ms, int cx, int cy, Geo &g)
+{
+    I->h_rect[0] = mc - 1; I->h_rect[1] = 0; I->h_rect[2] = mr - 1; I->h_rect[3] = 0; // seamlessClone_imp.cpp:1006
+    SC_HIP(I, hipMemcpyAsync(I->d_rect, I->h_rect, 4 * sizeof(int), hipMemcpyHostToDevice, I->stream));
+    launch_mask_bbox(d_mask, mc, mr, ms, I->d_rect, I->stream);
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipMemcpyAsync(I->h_rect + 4, I->d_rect, 4 * sizeof(int), hipMemcpyDeviceToHost, I->stream));
+    SC_HIP(I, hipEventRecord(I->ev[2], I->stream));
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    const int x0 = I->h_rect[4], x1 = I->h_rect[5], y0 = I->h_rect[6], y1 = I->h_rect[7];
+    if (!((x1 - x0) > 0 && (y1 - y0) > 0)) { I->err = "mask has no usable non-zero region"; return SC_ERR_EMPTY_MASK; }
+    g.x0 = x0; g.y0 = y0; g.W = x1 - x0 + 1; g.H = y1 - y0 + 1;
+    g.ltx = cx - (g.W >> 1); // seamlessClone_imp.cpp:1066
+    g.lty = cy - (g.H >> 1);
+    return SC_OK;
+}
+
+static int check_roi(Instance *I, const Geo &g, int bc, int br)
+{
+    if (g.ltx < 0 || g.lty < 0 || g.ltx + g.W > bc || g.lty + g.H > br) {
+        I->err = "ROI leaves the destination image";
+        return SC_ERR_ROI_OOB;
+    }
+    return SC_OK;
+}
+
+// erode -> pre-process -> solve -> post-process on device-resident ROI origins
+static int device_clone(Instance *I, const uint8_t *d_mask, int ms, const uint8_t *face_org, int fstep,
+                        uint8_t *body_org, int bstep, const Geo &g, int passes)
+{
+    int rc;
+    I->mpitch = round_up(g.W, 64);
+    if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
+    if ((rc = setup_fields(I, g.W, g.H, 3))) return rc;
+    launch_mask_erode3(d_mask, ms, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    SC_HIP(I, hipEventRecord(I->ev[4], I->stream));
+    int solve_rc = SC_OK;
+    for (int pass = 0; pass < passes; ++pass) {
+        I->result_in_U1 = false;
+        launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
+                          I->stream);
+        if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[5], I->stream));
+        I->info.sweep_launches = 0;
+        solve_rc = solve(I);
+        if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
+        if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[6], I->stream));
+        launch_postprocess(result(I), body_org, bstep, I->stream);
+        SC_HIP(I, hipGetLastError());
+    }
+    SC_HIP(I, hipEventRecord(I->ev[7], I->stream));
+    return solve_rc;
+}
+
+static void fill_info_geo(Instance *I, const Geo &g)
+{
+    I->info.x0 = g.x0; I->info.y0 = g.y0; I->info.W = g.W; I->info.H = g.H; I->info.ltx = g.ltx; I->info.lty = g.lty;
+    I->info.device_bytes = I->arena_bytes;
+}
+
+static float ev_ms(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+    return ms;
+}
+
+extern "C" {
+
+void sc_hip_default_opts(sc_solver_opts *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->method = SC_METHOD_MULTIGRID;
+    o->max_sweeps = 30;      // V-cycles
+    o->tol = 1e-6f;
+    o->check_every = 1;
+    o->omega = 0.f;
+    o->sweeps_per_launch = 0;
+    o->reference_warmup = 0;
+    o->mg_pre = 2;
+    o->mg_post = 2;
+}
+
+int sc_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void *my_seamlessclone_api_imp_create_instance(int gpu_id)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || gpu_id < 0 || gpu_id >= n) {
+        fprintf(stderr, "seamlessclone_hip: cannot use GPU %d (%d visible)\n", gpu_id, n);
+        return nullptr;
+    }
+    if (hipSetDevice(gpu_id) != hipSuccess) return nullptr;
+    Instance *I = new (std::nothrow) Instance();
+    if (!I) return nullptr;
+    I->gpu = gpu_id;
+    sc_hip_default_opts(&I->opts);
+    bool ok = hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&I->h_rect, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&I->h_red, 2 * sizeof(double), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void **)&I->d_rect, 4 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&I->d_partials, 2 * sizeof(double) * residual_max_blocks()) == hipSuccess;
+    ok = ok && hipMalloc((void **)&I->d_red, 2 * sizeof(double)) == hipSuccess;
+    for (int i = 0; ok && i < 8; ++i) ok = hipEventCreate(&I->ev[i]) == hipSuccess;
+    ok = ok && hipEventCreate(&I->ev_k0) == hipSuccess && hipEventCreate(&I->ev_k1) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "seamlessclone_hip: instance creation failed on GPU %d: %s\n", gpu_id,
+                hipGetErrorString(hipGetLastError()));
+        my_seamlessclone_api_imp_destroy(I);
+        return nullptr;
+    }
+    return I;
+}
+
+void my_seamlessclone_api_imp_destroy(void *p)
+{
+    Instance *I = get(p);
+    if (!I) return;
+    (void)hipSetDevice(I->gpu);
+    if (I->stream) (void)hipStreamSynchronize(I->stream);
+    DevBuf *bufs[] = { &I->d_face, &I->d_body_roi, &I->d_mask, &I->d_M, &I->d_U0, &I->d_U1, &I->d_F };
+    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
+    if (I->d_rect) (void)hipFree(I->d_rect);
+    if (I->d_partials) (void)hipFree(I->d_partials);
+    if (I->d_red) (void)hipFree(I->d_red);
+    if (I->h_rect) (void)hipHostFree(I->h_rect);
+    if (I->h_red) (void)hipHostFree(I->h_red);
+    for (int i = 0; i < 8; ++i) if (I->ev[i]) (void)hipEventDestroy(I->ev[i]);
+    if (I->ev_k0) (void)hipEventDestroy(I->ev_k0);
+    if (I->ev_k1) (void)hipEventDestroy(I->ev_k1);
+    if (I->stream) (void)hipStreamDestroy(I->stream);
+    I->magic = 0;
+    delete I;
+}
+
+void my_seamlessclone_api_imp_sync(void *p)
+{
+    Instance *I = get(p);
+    if (!I) return;
+    (void)hipSetDevice(I->gpu);
+    (void)hipStreamSynchronize(I->stream);
+}
+
+int sc_hip_set_solver(void *p, const sc_solver_opts *o)
+{
+    Instance *I = get(p);
+    if (!I || !o) return SC_ERR_BAD_ARG;
+    if (o->method < SC_METHOD_JACOBI || o->method > SC_METHOD_MULTIGRID || o->max_sweeps < 0) {
+        I->err = "bad solver options";
+        return SC_ERR_BAD_ARG;
+    }
+    I->opts = *o;
+    return SC_OK;
+}
+
+int sc_hip_get_solver(void *p, sc_solver_opts *o)
+{
+    Instance *I = get(p);
+    if (!I || !o) return SC_ERR_BAD_ARG;
+    *o = I->opts;
+    return SC_OK;
+}
+
+int sc_hip_get_info(void *p, sc_run_info *info)
+{
+    Instance *I = get(p);
+    if (!I || !info) return SC_ERR_BAD_ARG;
+    I->info.device_bytes = I->arena_bytes;
+    *info = I->info;
+    return SC_OK;
+}
+
+const char *sc_hip_last_error(void *p)
+{
+    Instance *I = get(p);
+    if (!I) return "bad instance";
+    return I->err.c_str();
+}
+
+void *sc_hip_malloc(void *p, size_t bytes)
+{
+    Instance *I = get(p);
+    if (!I) return nullptr;
+    (void)hipSetDevice(I->gpu);
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    return d;
+}
+
+void sc_hip_free(void *p, void *d)
+{
+    Instance *I = get(p);
+    if (!I || !d) return;
+    (void)hipSetDevice(I->gpu);
+    (void)hipStreamSynchronize(I->stream);
+    (void)hipFree(d);
+}
+
+int sc_hip_memcpy_h2d(void *p, void *d, const void *h, size_t bytes)
+{
+    Instance *I = get(p);
+    if (!I || !d || !h) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    SC_HIP(I, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    return SC_OK;
+}
+
+int sc_hip_memcpy_d2h(void *p, void *h, const void *d, size_t bytes)
+{
+    Instance *I = get(p);
+    if (!I || !d || !h) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    SC_HIP(I, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, I->stream));
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    return SC_OK;
+}
+
+static void finish_timing(Instance *I, bool staged)
+{
+    // ev: 0 start | 1 mask on device | 2 bbox done | 3 ROI images on device | 4 erode done |
+    //     5 pre-process done | 6 solve done | 7 post-process done ; ev_k1 = D2H done
+    I->info.ms_h2d = staged ? ev_ms(I->ev[0], I->ev[1]) + ev_ms(I->ev[2], I->ev[3]) : 0.f;
+    I->info.ms_mask = ev_ms(I->ev[1], I->ev[2]) + ev_ms(I->ev[3], I->ev[4]);
+    I->info.ms_pre = ev_ms(I->ev[4], I->ev[5]);
+    I->info.ms_solve = ev_ms(I->ev[5], I->ev[6]);
+    I->info.ms_post = ev_ms(I->ev[6], I->ev[7]);
+    I->info.ms_d2h = staged ? ev_ms(I->ev[7], I->ev_k1) : 0.f;
+    I->info.ms_device_total = I->info.ms_mask + I->info.ms_pre + I->info.ms_solve + I->info.ms_post;
+}
+
+int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, int fs, uint8_t *body, int bc, int br,
+                                 int bs, const uint8_t *mask, int mc, int mr, int ms, int cx, int cy, int gpu_id,
+                                 bool bSync)
+{
+    (void)gpu_id; // the instance already owns its device (the reference ignores it as well, seamlessClone_imp.cu:265)
+    Instance *I = get(p);
+    if (!I) return SC_ERR_BAD_ARG;
+    I->err.clear();
+    SC_HIP(I, hipSetDevice(I->gpu));
+    int rc = validate_images(I, face, fc, fr, fs, body, bc, br, bs, mask, mc, mr, ms);
+    if (rc) return rc;
+    // --- mask to the device, bounding box
+    const int dms = round_up(mc, 256);
+    if ((rc = ensure(I, I->d_mask, (size_t)dms * mr))) return rc;
+    SC_HIP(I, hipEventRecord(I->ev[0], I->stream));
+    SC_HIP(I, hipMemcpy2DAsync(I->d_mask.p, dms, mask, ms, mc, mr, hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipEventRecord(I->ev[1], I->stream));
+    Geo g;
+    if ((rc = device_bbox(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, cx, cy, g))) return rc;
+    fill_info_geo(I, g);
+    if ((rc = check_roi(I, g, bc, br))) return rc;
+    // --- only the ROI of face and body travels (the reference uploads both images whole)
+    const int dfs = round_up(3 * g.W, 256);
+    if ((rc = ensure(I, I->d_face, (size_t)dfs * g.H))) return rc;
+    if ((rc = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return rc;
+    SC_HIP(I, hipMemcpy2DAsync(I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H,
+                               hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipMemcpy2DAsync(I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H,
+                               hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
+    const int passes = I->opts.reference_warmup ? 2 : 1;
+    rc = device_clone(I, (const uint8_t *)I->d_mask.p, dms, (const uint8_t *)I->d_face.p, dfs,
+                      (uint8_t *)I->d_body_roi.p, dfs, g, passes);
+    if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+    // --- interior straight into the caller's image
+    if (g.W > 2 && g.H > 2)
+        SC_HIP(I, hipMemcpy2DAsync(body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1), bs,
+                                   (const uint8_t *)I->d_body_roi.p + dfs + 3, dfs, 3 * (size_t)(g.W - 2), g.H - 2,
+                                   hipMemcpyDeviceToHost, I->stream));
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    bool must_sync = bSync;
+    if (!must_sync) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, body) != hipSuccess || attr.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            must_sync = true; // pageable destination: complete before returning
+        }
+    }
+    if (must_sync) {
+        SC_HIP(I, hipStreamSynchronize(I->stream));
+        finish_timing(I, true);
+    }
+    return rc;
+}
+
+int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, uint8_t *d_body, int bc, int br, int bs,
+                      const uint8_t *d_mask, int mc, int mr, int ms, int cx, int cy, bool bSync)
+{
+    Instance *I = get(p);
+    if (!I) return SC_ERR_BAD_ARG;
+    I->err.clear();
+    SC_HIP(I, hipSetDevice(I->gpu));
+    int rc = validate_images(I, d_face, fc, fr, fs, d_body, bc, br, bs, d_mask, mc, mr, ms);
+    if (rc) return rc;
+    SC_HIP(I, hipEventRecord(I->ev[0], I->stream));
+    SC_HIP(I, hipEventRecord(I->ev[1], I->stream));
+    Geo g;
+    if ((rc = device_bbox(I, d_mask, mc, mr, ms, cx, cy, g))) return rc;
+    fill_info_geo(I, g);
+    if ((rc = check_roi(I, g, bc, br))) return rc;
+    SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
+    const int passes = I->opts.reference_warmup ? 2 : 1;
+    rc = device_clone(I, d_mask, ms, d_face + (size_t)g.y0 * fs + 3 * g.x0, fs,
+                      d_body + (size_t)g.lty * bs + 3 * g.ltx, bs, g, passes);
+    if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    if (bSync) {
+        SC_HIP(I, hipStreamSynchronize(I->stream));
+        finish_timing(I, false);
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------- stage-level hooks
+
+int sc_hip_mask_stage(void *p, const uint8_t *mask, int mc, int mr, int ms, int cx, int cy, int geo[6], uint8_t *M_out,
+                      size_t M_capacity)
+{
+    Instance *I = get(p);
+    if (!I || !mask || !geo) return SC_ERR_BAD_ARG;
+    I->err.clear();
+    SC_HIP(I, hipSetDevice(I->gpu));
+    if (mc <= 0 || mr <= 0 || ms < mc) return SC_ERR_BAD_SIZE;
+    int rc;
+    const int dms = round_up(mc, 256);
+    if ((rc = ensure(I, I->d_mask, (size_t)dms * mr))) return rc;
+    SC_HIP(I, hipMemcpy2DAsync(I->d_mask.p, dms, mask, ms, mc, mr, hipMemcpyHostToDevice, I->stream));
+    Geo g;
+    if ((rc = device_bbox(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, cx, cy, g))) return rc;
+    fill_info_geo(I, g);
+    geo[0] = g.x0; geo[1] = g.y0; geo[2] = g.W; geo[3] = g.H; geo[4] = g.ltx; geo[5] = g.lty;
+    I->mpitch = round_up(g.W, 64);
+    if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
+    launch_mask_erode3((const uint8_t *)I->d_mask.p, dms, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    SC_HIP(I, hipGetLastError());
+    if (M_out) {
+        if (M_capacity < (size_t)g.W * g.H) return SC_ERR_BAD_SIZE;
+        SC_HIP(I, hipMemcpy2DAsync(M_out, g.W, I->d_M.p, I->mpitch, g.W, g.H, hipMemcpyDeviceToHost, I->stream));
+    }
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    return SC_OK;
+}
+
+static int download_field(Instance *I, const Field &f, float *out)
+{
+    for (int c = 0; c < f.C; ++c)
+        SC_HIP(I, hipMemcpy2DAsync(out + (size_t)c * f.W * f.H, (size_t)f.W * sizeof(float), f.at(c),
+                                   (size_t)f.pitch * sizeof(float), (size_t)f.W * sizeof(float), f.H,
+                                   hipMemcpyDeviceToHost, I->stream));
+    return SC_OK;
+}
+
+int sc_hip_build_rhs(void *p, const uint8_t *face, int fc, int fr, int fs, const uint8_t *body, int bc, int br, int bs,
+                     const uint8_t *mask, int mc, int mr, int ms, int cx, int cy, int geo[6], float *B_out,
+                     float *lap_out, size_t plane_capacity)
+{
+    Instance *I = get(p);
+    if (!I || !geo) return SC_ERR_BAD_ARG;
+    I->err.clear();
+    SC_HIP(I, hipSetDevice(I->gpu));
+    int rc = validate_images(I, face, fc, fr, fs, body, bc, br, bs, mask, mc, mr, ms);
+    if (rc) return rc;
+    if ((rc = sc_hip_mask_stage(p, mask, mc, mr, ms, cx, cy, geo, nullptr, 0))) return rc;
+    Geo g{ geo[0], geo[1], geo[2], geo[3], geo[4], geo[5] };
+    if ((rc = check_roi(I, g, bc, br))) return rc;
+    if (plane_capacity < (size_t)g.W * g.H) return SC_ERR_BAD_SIZE;
+    const int dfs = round_up(3 * g.W, 256);
+    if ((rc = ensure(I, I->d_face, (size_t)dfs * g.H))) return rc;
+    if ((rc = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return rc;
+    SC_HIP(I, hipMemcpy2DAsync(I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H,
+                               hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipMemcpy2DAsync(I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H,
+                               hipMemcpyHostToDevice, I->stream));
+    if ((rc = setup_fields(I, g.W, g.H, 3))) return rc;
+    launch_preprocess((const uint8_t *)I->d_body_roi.p, dfs, (const uint8_t *)I->d_face.p, dfs,
+                      (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F, I->stream);
+    SC_HIP(I, hipGetLastError());
+    if (B_out && (rc = download_field(I, I->U0, B_out))) return rc;
+    if (lap_out && (rc = download_field(I, I->F, lap_out))) return rc;
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    return SC_OK;
+}
+
+int sc_hip_field_load(void *p, int W, int H, int C, const float *U, const float *lap)
+{
+    Instance *I = get(p);
+    if (!I || !U || !lap) return SC_ERR_BAD_ARG;
+    I->err.clear();
+    SC_HIP(I, hipSetDevice(I->gpu));
+    if (W < 1 || H < 1 || C < 1 || C > 16) return SC_ERR_BAD_SIZE;
+    int rc;
+    if ((rc = setup_fields(I, W, H, C))) return rc;
+    // deterministic pads
+    SC_HIP(I, hipMemsetAsync(I->d_U0.p, 0, I->U0.bytes(), I->stream));
+    SC_HIP(I, hipMemsetAsync(I->d_U1.p, 0, I->U1.bytes(), I->stream));
+    SC_HIP(I, hipMemsetAsync(I->d_F.p, 0, I->F.bytes(), I->stream));
+    const size_t wb = (size_t)W * sizeof(float), pb = (size_t)I->U0.pitch * sizeof(float);
+    for (int c = 0; c < C; ++c) {
+        SC_HIP(I, hipMemcpy2DAsync(I->U0.at(c), pb, U + (size_t)c * W * H, wb, wb, H, hipMemcpyHostToDevice, I->stream));
+        SC_HIP(I, hipMemcpy2DAsync(I->U1.at(c), pb, U + (size_t)c * W * H, wb, wb, H, hipMemcpyHostToDevice, I->stream));
+        SC_HIP(I, hipMemcpy2DAsync(I->F.at(c), pb, lap + (size_t)c * W * H, wb, wb, H, hipMemcpyHostToDevice, I->stream));
+    }
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    return SC_OK;
+}
+
+int sc_hip_field_sweep(void *p, int method, int sweeps, float omega, int spl)
+{
+    Instance *I = get(p);
+    if (!I || !I->F.p) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    I->info.sweep_launches = 0;
+    int rc = run_sweeps(I, method, sweeps, omega, spl);
+    if (rc) return rc;
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    return SC_OK;
+}
+
+int sc_hip_field_residual(void *p, double out[2])
+{
+    Instance *I = get(p);
+    if (!I || !I->F.p || !out) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    return eval_residual(I, out);
+}
+
+int sc_hip_field_solve(void *p)
+{
+    Instance *I = get(p);
+    if (!I || !I->F.p) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    I->info.sweep_launches = 0;
+    int rc = solve(I);
+    hipError_t e = hipStreamSynchronize(I->stream);
+    if (e != hipSuccess) return hip_fail(I, e, "hipStreamSynchronize");
+    return rc;
+}
+
+int sc_hip_field_store(void *p, float *U_out)
+{
+    Instance *I = get(p);
+    if (!I || !I->F.p || !U_out) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    int rc = download_field(I, result(I), U_out);
+    if (rc) return rc;
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    return SC_OK;
+}
+
+int sc_hip_field_time_sweeps(void *p, int method, int launches, int spl, float omega, float *ms_per_launch)
+{
+    Instance *I = get(p);
+    if (!I || !I->F.p || !ms_per_launch || launches < 1) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    if (spl < 1) spl = 1;
+    int rc = run_sweeps(I, method, spl, omega, spl); // warm-up launch
+    if (rc) return rc;
+    I->info.sweep_launches = 0;
+    SC_HIP(I, hipEventRecord(I->ev_k0, I->stream));
+    rc = run_sweeps(I, method, launches * spl, omega, spl);
+    if (rc) return rc;
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    const int n = I->info.sweep_launches > 0 ? I->info.sweep_launches : 1;
+    *ms_per_launch = ev_ms(I->ev_k0, I->ev_k1) / (float)n;
+    return SC_OK;
+}
+
+} // extern "C"

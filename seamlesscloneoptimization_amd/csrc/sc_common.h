@@ -1,0 +1,57 @@
+// sc_common.h -- shared host-side declarations of libseamlessclone_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/seamlessclone_hip.h"
+
+namespace sc {
+
+// Planar float32 field: C planes of H rows, row pitch in floats (multiple of 64 = 256 B so
+// every row starts on a cache-line / float4 boundary; the ring column x=0 sits at the row
+// start, so float4 groups are aligned in ROI coordinates).
+struct Field {
+    float *p = nullptr;
+    int W = 0, H = 0, C = 0;
+    int pitch = 0;      // floats per row
+    size_t plane = 0;   // floats per plane (pitch * H rounded up to 64)
+    __host__ __device__ float *at(int c) const { return p + (size_t)c * plane; }
+    size_t bytes() const { return plane * (size_t)C * sizeof(float); }
+};
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ROI geometry (seamlessClone_imp.cpp:1014-1016,1066)
+struct Geo { int x0, y0, W, H, ltx, lty; };
+
+// 8-bit interleaved image view (cv::Mat {data, cols, rows, step})
+struct Img8 {
+    const uint8_t *p; int cols, rows, step;
+};
+
+// ---------------------------------------------------------------- kernel launchers (sc_kernels.hip)
+void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s);
+void launch_mask_erode3(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int mpitch, hipStream_t s);
+// body_org: pointer to the pixel that corresponds to ROI (0,0); face_org likewise (patch + offset)
+void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
+                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s);
+void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s);
+
+void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s);
+void launch_rb_half(Field U, Field F, int color, float omega, hipStream_t s);
+// fused temporally-blocked kernels (sc_sweep_tb.hip); return false when the shape is unsupported
+bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s);
+bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipStream_t s);
+
+// residual: d_out[0] = sum r^2, d_out[1] = sum lap^2 (double); d_partials holds >= 2*max_blocks doubles
+int  residual_max_blocks();
+void launch_residual(Field U, Field F, double *d_partials, double *d_out, hipStream_t s);
+
+// multigrid transfer operators
+void launch_restrict_residual(Field Uf, Field Ff, Field Fc, hipStream_t s);   // Fc = 4 * FW(Ff - A Uf)
+void launch_prolong_add(Field Uc, Field Uf, hipStream_t s);                    // Uf += P Uc (interior)
+void launch_fill_zero(Field U, hipStream_t s);
+
+} // namespace sc

@@ -1,0 +1,71 @@
+// sc_instance.h -- the per-GPU instance behind the C ABI: one HIP stream, a grow-only device
+// arena (the role SCImage plays in the reference, seamlessClone_imp.h:90-457: capacity only
+// ever grows, steady state does no hipMalloc), pinned mailboxes for the two small read-backs
+// (bounding box, residual norm) and hipEvents for per-stage timing.
+#pragma once
+#include "sc_common.h"
+#include <cmath>
+
+namespace sc {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct MGLevel {
+    Field U, F, T; // solution/correction, RHS, scratch (ping-pong partner)
+};
+
+struct Instance {
+    uint32_t magic = 0x5C10E001u;
+    int gpu = 0;
+    hipStream_t stream = nullptr;
+    sc_solver_opts opts{};
+    sc_run_info info{};
+    std::string err;
+
+    // staging copies for host-pointer runs
+    DevBuf d_face, d_body_roi, d_mask;
+    // ROI mask after 3x erode
+    DevBuf d_M;
+    int mpitch = 0;
+    // fields
+    DevBuf d_U0, d_U1, d_F;
+    Field U0, U1, F;      // current views into the buffers above
+    bool result_in_U1 = false;
+    // multigrid hierarchy (level 0 aliases U0/U1/F)
+    std::vector<DevBuf> mg_bufs;
+    std::vector<MGLevel> mg;
+    // reductions / mailboxes
+    int *d_rect = nullptr;
+    int *h_rect = nullptr;       // pinned
+    double *d_partials = nullptr;
+    double *d_red = nullptr;
+    double *h_red = nullptr;     // pinned
+    hipEvent_t ev[8]{};
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    size_t arena_bytes = 0;
+
+    bool ok() const { return magic == 0x5C10E001u; }
+};
+
+// error helper: records the message, returns SC_ERR_HIP
+int hip_fail(Instance *I, hipError_t e, const char *what);
+#define SC_HIP(I, call)                                                   \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return hip_fail((I), e_, #call);            \
+    } while (0)
+
+int ensure(Instance *I, DevBuf &b, size_t bytes);
+int setup_fields(Instance *I, int W, int H, int C);
+
+// solver drivers (sc_solver.cpp) -- operate on I->U0/U1/F, leave the answer in result(I)
+int solve(Instance *I);
+int run_sweeps(Instance *I, int method, int sweeps, float omega, int sweeps_per_launch);
+int eval_residual(Instance *I, double out[2]);
+Field &result(Instance *I);
+float optimal_omega(int W, int H);
+
+} // namespace sc

@@ -1,0 +1,426 @@
+// sc_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the seamless-clone hot path:
+// mask stage, fused pre-process, single-sweep Jacobi / red-black smoothers, residual norm,
+// multigrid transfer operators and the fused post-process.  wave = 64 lanes throughout.
+//
+// Reference behaviour (what, not how): seamlessClone-CUDA/seamlessClone_imp.cpp
+//   mask stage   :892-1071     pre-process :1920-2018     post-process :2078-2103
+// The iterative smoothers have no counterpart in the reference (it solves directly with a
+// DST); their specification is SURVEY.md Appendix A.5 and the CPU oracle (oracle/sc_oracle.c).
+//
+// Compiled with -ffp-contract=off: every float expression below is evaluated exactly as
+// written so the oracle can check the sweeps bit for bit.
+#include "sc_common.h"
+#include <limits.h>
+
+namespace sc {
+
+// ------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v; // valid in lane 0
+}
+
+// ------------------------------------------------------------------------------------------
+// mask stage
+// ------------------------------------------------------------------------------------------
+// Bounding box of mask != 0 with the 1-px border treated as zero (the reference first zeroes
+// the border of its device copy, seamlessClone_imp.cpp:967-976,989, then reduces with LDS +
+// global atomics, :927-963).  Here: per-lane scan of BB_ROWS rows, wave64 shuffle reduction,
+// LDS across the 4 waves, one set of 4 global atomics per block that saw a set pixel.
+// rect = {x_min, x_max, y_min, y_max}, host-seeded with {mw-1, 0, mh-1, 0} (:1006).
+constexpr int BB_ROWS = 16;
+
+__global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
+                                                   int *__restrict__ rect)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int yb = blockIdx.y * BB_ROWS;
+    int minx = INT_MAX, maxx = -1, miny = INT_MAX, maxy = -1;
+    if (x >= 1 && x < mw - 1) {
+#pragma unroll 4
+        for (int r = 0; r < BB_ROWS; ++r) {
+            const int y = yb + r;
+            if (y >= 1 && y < mh - 1 && mask[(size_t)y * mstep + x] != 0) {
+                minx = x; maxx = x;
+                miny = min(miny, y); maxy = max(maxy, y);
+            }
+        }
+    }
+    minx = wave_min_i(minx); maxx = wave_max_i(maxx);
+    miny = wave_min_i(miny); maxy = wave_max_i(maxy);
+    __shared__ int red[4][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[wave][0] = minx; red[wave][1] = maxx; red[wave][2] = miny; red[wave][3] = maxy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            minx = min(minx, red[w][0]); maxx = max(maxx, red[w][1]);
+            miny = min(miny, red[w][2]); maxy = max(maxy, red[w][3]);
+        }
+        if (maxx >= 0) {
+            atomicMin(&rect[0], minx); atomicMax(&rect[1], maxx);
+            atomicMin(&rect[2], miny); atomicMax(&rect[3], maxy);
+        }
+    }
+}
+
+void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s)
+{
+    dim3 grid((mw + 255) / 256, (mh + BB_ROWS - 1) / BB_ROWS);
+    hipLaunchKernelGGL(k_mask_bbox, grid, dim3(256), 0, s, mask, mw, mh, mstep, d_rect);
+}
+
+// Crop to the bounding box + three 3x3 erodes (seamlessClone_imp.cpp:1052-1062, kernel
+// :892-925) fused into one pass.  Each reference pass outputs 255 iff all nine inputs are 255
+// and forces the ROI frame to 0, so three passes equal: "ring(x,y) >= 3 and the 7x7 window is
+// all 255" -- evaluated separably (7-wide AND along x, then along y) on an LDS tile + 3 halo.
+constexpr int ER_TW = 64, ER_TH = 16;
+
+__global__ __launch_bounds__(256) void k_mask_erode3(const uint8_t *__restrict__ mask, int mstep, Geo g,
+                                                     uint8_t *__restrict__ M, int mpitch)
+{
+    __shared__ uint8_t a[ER_TH + 6][ER_TW + 8];
+    __shared__ uint8_t b[ER_TH + 6][ER_TW];
+    const int tx0 = blockIdx.x * ER_TW, ty0 = blockIdx.y * ER_TH;
+    for (int i = threadIdx.x; i < (ER_TH + 6) * (ER_TW + 6); i += 256) {
+        const int ry = i / (ER_TW + 6), rx = i - ry * (ER_TW + 6);
+        const int x = tx0 + rx - 3, y = ty0 + ry - 3;
+        uint8_t v = 0;
+        if (x >= 0 && x < g.W && y >= 0 && y < g.H) v = mask[(size_t)(y + g.y0) * mstep + (x + g.x0)] == 255;
+        a[ry][rx] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (ER_TH + 6) * ER_TW; i += 256) {
+        const int ry = i / ER_TW, rx = i - ry * ER_TW;
+        uint8_t v = a[ry][rx];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) v &= a[ry][rx + k];
+        b[ry][rx] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ER_TH * ER_TW; i += 256) {
+        const int ry = i / ER_TW, rx = i - ry * ER_TW;
+        const int x = tx0 + rx, y = ty0 + ry;
+        if (x < g.W && y < g.H) {
+            uint8_t v = b[ry][rx];
+#pragma unroll
+            for (int k = 1; k < 7; ++k) v &= b[ry + k][rx];
+            const int ring = min(min(x, g.W - 1 - x), min(y, g.H - 1 - y));
+            M[(size_t)y * mpitch + x] = (v && ring >= 3) ? 255 : 0;
+        }
+    }
+}
+
+void launch_mask_erode3(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int mpitch, hipStream_t s)
+{
+    dim3 grid((g.W + ER_TW - 1) / ER_TW, (g.H + ER_TH - 1) / ER_TH);
+    hipLaunchKernelGGL(k_mask_erode3, grid, dim3(256), 0, s, mask, mstep, g, M, mpitch);
+}
+
+// ------------------------------------------------------------------------------------------
+// fused pre-process: ROI crop + u8->f32 + forward-difference gradients of dst ROI and patch +
+// mask blend + backward-difference divergence  (seamlessClone_imp.cpp:1920-2018 in one pass,
+// no gdX/gdY round trip).  Writes the Dirichlet/initial field U0 = U1 = dst ROI and the
+// un-folded stencil RHS F = lap (0 on the ring).  The reflect-101 branches of the reference
+// (:1937,:1940,:1944,:1947) only feed gdX/gdY at the last column/row, which no interior
+// divergence reads, so they vanish here.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ body, int bstep,
+                                                    const uint8_t *__restrict__ face, int fstep,
+                                                    const uint8_t *__restrict__ M, int mpitch,
+                                                    Field U0, Field U1, Field F)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int W = U0.W, H = U0.H;
+    if (x >= W || y >= H) return;
+    const uint8_t *b = body + (size_t)y * bstep + 3 * x;
+    const uint8_t *p = face + (size_t)y * fstep + 3 * x;
+    const bool interior = (x >= 1) && (x <= W - 2) && (y >= 1) && (y <= H - 2);
+    float m = 0.f, ml = 0.f, mu = 0.f;
+    if (interior) {
+        const uint8_t *mp = M + (size_t)y * mpitch + x;
+        m = (float)mp[0] * (1.0f / 255.0f);
+        ml = (float)mp[-1] * (1.0f / 255.0f);
+        mu = (float)mp[-mpitch] * (1.0f / 255.0f);
+    }
+    const size_t o = (size_t)y * U0.pitch + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float b0 = (float)b[c];
+        float lap = 0.0f;
+        if (interior) {
+            const float bl = (float)b[c - 3], br = (float)b[c + 3];
+            const float bu = (float)b[c - bstep], bd = (float)b[c + bstep];
+            const float p0 = (float)p[c], pl = (float)p[c - 3], pr = (float)p[c + 3];
+            const float pu = (float)p[c - fstep], pd = (float)p[c + fstep];
+            const float gx = (1.0f - m) * (br - b0) + m * (pr - p0);
+            const float gxl = (1.0f - ml) * (b0 - bl) + ml * (p0 - pl);
+            const float gy = (1.0f - m) * (bd - b0) + m * (pd - p0);
+            const float gyu = (1.0f - mu) * (b0 - bu) + mu * (p0 - pu);
+            lap = (gx - gxl) + (gy - gyu);
+        }
+        U0.at(c)[o] = b0;
+        U1.at(c)[o] = b0;
+        F.at(c)[o] = lap;
+    }
+}
+
+void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
+                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s)
+{
+    dim3 grid((U0.W + 63) / 64, (U0.H + 3) / 4);
+    hipLaunchKernelGGL(k_preprocess, grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+}
+
+// fused post-process: clamp to [0,255], truncate toward zero, interleave, splice into the
+// destination at (lty+y, ltx+x) for the interior only (seamlessClone_imp.cpp:2091-2096 and
+// the host splice loop :470-483).
+__global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restrict__ body, int bstep)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < 1 || x > U.W - 2 || y < 1 || y > U.H - 2) return;
+    uint8_t *b = body + (size_t)y * bstep + 3 * x;
+    const size_t o = (size_t)y * U.pitch + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float d = U.at(c)[o];
+        d = d > 255.0f ? 255.0f : d;
+        d = d < 0.0f ? 0.0f : d;
+        b[c] = (uint8_t)d;
+    }
+}
+
+void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s)
+{
+    dim3 grid((U.W + 63) / 64, (U.H + 3) / 4);
+    hipLaunchKernelGGL(k_postprocess, grid, dim3(256), 0, s, U, body_org, bstep);
+}
+
+// ------------------------------------------------------------------------------------------
+// single-sweep smoothers (generic sizes; also the coarse-level smoothers of the multigrid)
+// ------------------------------------------------------------------------------------------
+// Jacobi, LDS-staged tile with 1-px halo.  Tile = 256 x JT_TH points (one wave spans a full
+// 256-float row as 64 float4), LDS row = [3 pad | left halo | 256 | right halo | 3 pad] so the
+// body stays 16-B aligned for ds_read_b128.  Left/right neighbours inside the row come from the
+// adjacent lanes (wave shuffles); only lane 0 / 63 read the halo columns from LDS.
+constexpr int JT_TW = 256, JT_TH = 16, JT_LDW = JT_TW + 8;
+
+__global__ __launch_bounds__(256) void k_jacobi(Field Uin, Field Uout, Field F)
+{
+    __shared__ __attribute__((aligned(16))) float t[JT_TH + 2][JT_LDW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.z;
+    const int tx0 = blockIdx.x * JT_TW, ty0 = blockIdx.y * JT_TH;
+    const int W = Uin.W, H = Uin.H, P = Uin.pitch;
+    const float *__restrict__ uin = Uin.at(c);
+    const int x = tx0 + 4 * lane;
+    for (int ry = wv; ry < JT_TH + 2; ry += 4) {
+        const int y = ty0 + ry - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool yok = (y >= 0) && (y < H);
+        if (yok && x < P) v = *reinterpret_cast<const float4 *>(uin + (size_t)y * P + x);
+        *reinterpret_cast<float4 *>(&t[ry][4 + 4 * lane]) = v;
+        if (lane == 0) t[ry][3] = (yok && tx0 > 0) ? uin[(size_t)y * P + tx0 - 1] : 0.f;
+        if (lane == 63) t[ry][4 + JT_TW] = (yok && tx0 + JT_TW < P) ? uin[(size_t)y * P + tx0 + JT_TW] : 0.f;
+    }
+    __syncthreads();
+    if (x >= P) return;
+    const float *__restrict__ f = F.at(c);
+    float *__restrict__ uout = Uout.at(c);
+#pragma unroll
+    for (int k = 0; k < JT_TH / 4; ++k) {
+        const int ry = wv + 4 * k, y = ty0 + ry;
+        if (y >= H) break;
+        const float4 c4 = *reinterpret_cast<const float4 *>(&t[ry + 1][4 + 4 * lane]);
+        const float4 u4 = *reinterpret_cast<const float4 *>(&t[ry][4 + 4 * lane]);
+        const float4 d4 = *reinterpret_cast<const float4 *>(&t[ry + 2][4 + 4 * lane]);
+        float l = __shfl_up(c4.w, 1, 64), r = __shfl_down(c4.x, 1, 64);
+        if (lane == 0) l = t[ry + 1][3];
+        if (lane == 63) r = t[ry + 1][4 + JT_TW];
+        const float4 f4 = *reinterpret_cast<const float4 *>(f + (size_t)y * P + x);
+        const bool yi = (y >= 1) && (y <= H - 2);
+        float4 o = c4;
+        if (yi) {
+            if (x + 0 >= 1 && x + 0 <= W - 2) o.x = 0.25f * (((l + c4.y) + (u4.x + d4.x)) - f4.x);
+            if (x + 1 <= W - 2) o.y = 0.25f * (((c4.x + c4.z) + (u4.y + d4.y)) - f4.y);
+            if (x + 2 <= W - 2) o.z = 0.25f * (((c4.y + c4.w) + (u4.z + d4.z)) - f4.z);
+            if (x + 3 <= W - 2) o.w = 0.25f * (((c4.z + r) + (u4.w + d4.w)) - f4.w);
+        }
+        *reinterpret_cast<float4 *>(uout + (size_t)y * P + x) = o;
+    }
+}
+
+void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s)
+{
+    dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + JT_TH - 1) / JT_TH, Uin.C);
+    hipLaunchKernelGGL(k_jacobi, grid, dim3(256), 0, s, Uin, Uout, F);
+}
+
+// One colour of a red-black Gauss-Seidel / SOR sweep, in place.  A colour-c point reads only
+// colour 1-c neighbours, none of which is written by this launch, so in-place float4
+// read-modify-write is race-free (unchanged components are stored back bit-identically).
+template <bool SOR>
+__global__ __launch_bounds__(256) void k_rb_half(Field U, Field F, int color, float omega)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.z;
+    const int W = U.W, H = U.H, P = U.pitch;
+    const int x = blockIdx.x * 256 + 4 * lane;
+    const int y = blockIdx.y * 4 + wv;
+    if (y < 1 || y > H - 2 || x >= P) return;
+    float *__restrict__ row = U.at(c) + (size_t)y * P;
+    const float4 c4 = *reinterpret_cast<const float4 *>(row + x);
+    const float4 u4 = *reinterpret_cast<const float4 *>(row - P + x);
+    const float4 d4 = *reinterpret_cast<const float4 *>(row + P + x);
+    const float4 f4 = *reinterpret_cast<const float4 *>(F.at(c) + (size_t)y * P + x);
+    float l = __shfl_up(c4.w, 1, 64), r = __shfl_down(c4.x, 1, 64);
+    if (lane == 0) l = (x > 0) ? row[x - 1] : 0.f;
+    if (lane == 63) r = (x + 4 < P) ? row[x + 4] : 0.f;
+    float4 o = c4;
+    const int par = (x + y + color) & 1; // 0: components 0,2 have colour `color`; 1: components 1,3
+#define SC_RB_UPD(dst, L, R, UU, DD, FF)                                   \
+    {                                                                      \
+        const float gs = 0.25f * ((((L) + (R)) + ((UU) + (DD))) - (FF));   \
+        dst = SOR ? (dst + omega * (gs - dst)) : gs;                       \
+    }
+    if (par == 0) {
+        if (x + 0 >= 1 && x + 0 <= W - 2) SC_RB_UPD(o.x, l, c4.y, u4.x, d4.x, f4.x)
+        if (x + 2 <= W - 2) SC_RB_UPD(o.z, c4.y, c4.w, u4.z, d4.z, f4.z)
+    } else {
+        if (x + 1 <= W - 2) SC_RB_UPD(o.y, c4.x, c4.z, u4.y, d4.y, f4.y)
+        if (x + 3 <= W - 2) SC_RB_UPD(o.w, c4.z, r, u4.w, d4.w, f4.w)
+    }
+#undef SC_RB_UPD
+    *reinterpret_cast<float4 *>(row + x) = o;
+}
+
+void launch_rb_half(Field U, Field F, int color, float omega, hipStream_t s)
+{
+    dim3 grid((U.W + 255) / 256, (U.H + 3) / 4, U.C);
+    if (omega == 1.0f)
+        hipLaunchKernelGGL(k_rb_half<false>, grid, dim3(256), 0, s, U, F, color, omega);
+    else
+        hipLaunchKernelGGL(k_rb_half<true>, grid, dim3(256), 0, s, U, F, color, omega);
+}
+
+// ------------------------------------------------------------------------------------------
+// residual norm: sum r^2 and sum lap^2, r = lap - ((l+r)+(u+d) - 4U), float32 per point,
+// double accumulation: per lane -> wave64 __shfl_down -> LDS across waves -> one partial pair
+// per block; a second single-block kernel folds the partials in a fixed order (deterministic,
+// no float atomics).
+// ------------------------------------------------------------------------------------------
+constexpr int RES_MAX_BLOCKS = 2048;
+int residual_max_blocks() { return RES_MAX_BLOCKS; }
+
+__global__ __launch_bounds__(256) void k_residual(Field U, Field F, double *__restrict__ partials, int row_groups)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int W = U.W, H = U.H, P = U.pitch;
+    const int xgroups = (W + 255) / 256;
+    const int total = xgroups * row_groups * U.C;
+    double r2 = 0.0, f2 = 0.0;
+    for (int job = blockIdx.x; job < total; job += gridDim.x) {
+        const int c = job / (xgroups * row_groups);
+        const int rem = job - c * (xgroups * row_groups);
+        const int rg = rem / xgroups, xg = rem - rg * xgroups;
+        const int x = xg * 256 + 4 * lane;
+        const int y = rg * 4 + wv;
+        if (y < 1 || y > H - 2 || x >= P) continue;
+        const float *__restrict__ row = U.at(c) + (size_t)y * P;
+        const float4 c4 = *reinterpret_cast<const float4 *>(row + x);
+        const float4 u4 = *reinterpret_cast<const float4 *>(row - P + x);
+        const float4 d4 = *reinterpret_cast<const float4 *>(row + P + x);
+        const float4 f4 = *reinterpret_cast<const float4 *>(F.at(c) + (size_t)y * P + x);
+        float l = __shfl_up(c4.w, 1, 64), r = __shfl_down(c4.x, 1, 64);
+        if (lane == 0) l = (x > 0) ? row[x - 1] : 0.f;
+        if (lane == 63) r = (x + 4 < P) ? row[x + 4] : 0.f;
+#define SC_RES(CC, L, R, UU, DD, FF, XI)                                          \
+    if ((XI) >= 1 && (XI) <= W - 2) {                                             \
+        const float s = (((L) + (R)) + ((UU) + (DD))) - 4.0f * (CC);              \
+        const float res = (FF) - s;                                               \
+        r2 += (double)res * (double)res;                                          \
+        f2 += (double)(FF) * (double)(FF);                                        \
+    }
+        SC_RES(c4.x, l, c4.y, u4.x, d4.x, f4.x, x + 0)
+        SC_RES(c4.y, c4.x, c4.z, u4.y, d4.y, f4.y, x + 1)
+        SC_RES(c4.z, c4.y, c4.w, u4.z, d4.z, f4.z, x + 2)
+        SC_RES(c4.w, c4.z, r, u4.w, d4.w, f4.w, x + 3)
+#undef SC_RES
+    }
+    r2 = wave_sum_d(r2);
+    f2 = wave_sum_d(f2);
+    __shared__ double red[4][2];
+    if (lane == 0) { red[wv][0] = r2; red[wv][1] = f2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        partials[2 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_residual_final(const double *__restrict__ partials, int n, double *__restrict__ out)
+{
+    double r2 = 0.0, f2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { r2 += partials[2 * i]; f2 += partials[2 * i + 1]; }
+    r2 = wave_sum_d(r2);
+    f2 = wave_sum_d(f2);
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[wv][0] = r2; red[wv][1] = f2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        out[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+void launch_residual(Field U, Field F, double *d_partials, double *d_out, hipStream_t s)
+{
+    const int row_groups = (U.H + 3) / 4;
+    const int xgroups = (U.W + 255) / 256;
+    long total = (long)row_groups * xgroups * U.C;
+    int blocks = (int)(total < RES_MAX_BLOCKS ? total : RES_MAX_BLOCKS);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_residual, dim3(blocks), dim3(256), 0, s, U, F, d_partials, row_groups);
+    hipLaunchKernelGGL(k_residual_final, dim3(1), dim3(256), 0, s, d_partials, blocks, d_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// misc
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill_zero(Field U)
+{
+    const size_t n4 = U.plane * (size_t)U.C / 4;
+    float4 *p = reinterpret_cast<float4 *>(U.p);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+void launch_fill_zero(Field U, hipStream_t s)
+{
+    size_t n4 = U.plane * (size_t)U.C / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_fill_zero, dim3(blocks), dim3(256), 0, s, U);
+}
+
+} // namespace sc

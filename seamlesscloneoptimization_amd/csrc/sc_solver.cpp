@@ -1,0 +1,115 @@
+// sc_solver.cpp -- host-side drivers of the iterative Poisson solve:
+// fixed-count or residual-terminated Jacobi / red-black GS / SOR sweeps, and the multigrid
+// V-cycle built from the same smoothers.  The reference has no iterative solver (it inverts
+// the same 5-point system with a DST, seamlessClone_imp.cpp:1814-1896); these drivers
+// converge to that system's solution.
+#include "sc_instance.h"
+#include <algorithm>
+
+namespace sc {
+
+Field &result(Instance *I) { return I->result_in_U1 ? I->U1 : I->U0; }
+static Field &other(Instance *I) { return I->result_in_U1 ? I->U0 : I->U1; }
+
+float optimal_omega(int W, int H)
+{
+    const double w = W - 2, h = H - 2;
+    if (w < 1 || h < 1) return 1.0f;
+    const double rho = 0.5 * (std::cos(M_PI / (w + 1.0)) + std::cos(M_PI / (h + 1.0)));
+    return (float)(2.0 / (1.0 + std::sqrt(std::max(0.0, 1.0 - rho * rho))));
+}
+
+int eval_residual(Instance *I, double out[2])
+{
+    launch_residual(result(I), I->F, I->d_partials, I->d_red, I->stream);
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipMemcpyAsync(I->h_red, I->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, I->stream));
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    out[0] = I->h_red[0];
+    out[1] = I->h_red[1];
+    return SC_OK;
+}
+
+// `sweeps` full sweeps of `method` on the current field.  sweeps_per_launch > 1 selects the
+// temporally blocked kernels (T sweeps fused in one launch); a remainder < T runs through a
+// shallower launch so the total is exact.
+int run_sweeps(Instance *I, int method, int sweeps, float omega, int spl)
+{
+    if (sweeps <= 0) return SC_OK;
+    if (spl <= 0) spl = I->opts.sweeps_per_launch;
+    if (spl <= 0) spl = 1;
+    if (method == SC_METHOD_JACOBI) {
+        int left = sweeps;
+        while (left > 0) {
+            int T = std::min(spl, left);
+            bool done = false;
+            if (T > 1) done = launch_jacobi_tb(result(I), other(I), I->F, T, I->stream);
+            if (!done) { T = 1; launch_jacobi(result(I), other(I), I->F, I->stream); }
+            I->result_in_U1 = !I->result_in_U1;
+            I->info.sweep_launches += 1;
+            left -= T;
+        }
+    } else if (method == SC_METHOD_RBGS || method == SC_METHOD_SOR) {
+        float om = 1.0f;
+        if (method == SC_METHOD_SOR) om = (omega > 0.f) ? omega : optimal_omega(I->F.W, I->F.H);
+        int left = sweeps;
+        while (left > 0) {
+            int T = std::min(spl, left);
+            bool done = false;
+            if (spl > 1) {
+                done = launch_rb_tb(result(I), other(I), I->F, T, om, I->stream);
+                if (done) I->result_in_U1 = !I->result_in_U1;
+            }
+            if (!done) {
+                T = 1;
+                launch_rb_half(result(I), I->F, 0, om, I->stream);
+                launch_rb_half(result(I), I->F, 1, om, I->stream);
+            }
+            I->info.sweep_launches += done ? 1 : 2;
+            left -= T;
+        }
+    } else {
+        I->err = "run_sweeps: unknown method";
+        return SC_ERR_BAD_ARG;
+    }
+    SC_HIP(I, hipGetLastError());
+    return SC_OK;
+}
+
+int mg_solve(Instance *I); // sc_multigrid.cpp
+
+int solve(Instance *I)
+{
+    const sc_solver_opts &o = I->opts;
+    I->info.sweeps = 0;
+    I->info.converged = 0;
+    I->info.rel_residual = NAN;
+    if (I->F.W < 3 || I->F.H < 3) { I->info.converged = 1; return SC_OK; } // no unknowns
+    if (o.method == SC_METHOD_MULTIGRID) return mg_solve(I);
+    if (o.tol <= 0.f) {
+        int rc = run_sweeps(I, o.method, o.max_sweeps, o.omega, o.sweeps_per_launch);
+        if (rc) return rc;
+        I->info.sweeps = o.max_sweeps;
+        I->info.converged = 1;
+        return SC_OK;
+    }
+    const int every = std::max(1, o.check_every);
+    int done = 0;
+    while (done < o.max_sweeps) {
+        const int n = std::min(every, o.max_sweeps - done);
+        int rc = run_sweeps(I, o.method, n, o.omega, o.sweeps_per_launch);
+        if (rc) return rc;
+        done += n;
+        double r[2];
+        rc = eval_residual(I, r);
+        if (rc) return rc;
+        const double rel = (r[1] > 0.0) ? std::sqrt(r[0] / r[1]) : std::sqrt(r[0]);
+        I->info.rel_residual = rel;
+        I->info.sweeps = done;
+        if (rel <= (double)o.tol) { I->info.converged = 1; return SC_OK; }
+    }
+    I->info.sweeps = done;
+    return SC_ERR_NOT_CONVERGED;
+}
+
+} // namespace sc
