@@ -67,7 +67,11 @@ typedef struct sc_solver_opts {
     int   reference_warmup;  /* 1: clone twice in place, as the reference's run() does
                                 (warm-up + 1, seamlessClone_imp.cu:303-318)                */
     int   mg_pre, mg_post;   /* multigrid smoothing sweeps per level (0 = default 2/2)      */
-    int   reserved[6];
+    float update_tol;        /* MULTIGRID stop rule: finish once the largest coarse-grid
+                                correction applied to the ROI in a V-cycle is <= update_tol grey
+                                levels (default 0.02; the remaining error is ~20x smaller).
+                                The float32 residual norm stalls earlier and is only reported. */
+    int   reserved[5];
 } sc_solver_opts;
 
 /* ---- statistics of the last run */
@@ -130,6 +134,7 @@ SC_API void *sc_hip_malloc(void *instance, size_t bytes);
 SC_API void  sc_hip_free(void *instance, void *dptr);
 SC_API int   sc_hip_memcpy_h2d(void *instance, void *dptr, const void *hptr, size_t bytes);
 SC_API int   sc_hip_memcpy_d2h(void *instance, void *hptr, const void *dptr, size_t bytes);
+SC_API int   sc_hip_memcpy_d2d_async(void *instance, void *dst, const void *src, size_t bytes); /* on the instance stream */
 SC_API int   sc_hip_device_count(void);
 
 /* ---- stage-level hooks (parity tests drive each kernel through these) ------------------- */
@@ -152,7 +157,8 @@ SC_API int sc_hip_field_load(void *instance, int W, int H, int C, const float *U
 SC_API int sc_hip_field_sweep(void *instance, int method, int sweeps, float omega, int sweeps_per_launch);
 SC_API int sc_hip_field_residual(void *instance, double out[2] /* sum r^2, sum lap^2 */);
 SC_API int sc_hip_field_solve(void *instance);                      /* run the configured solver on the loaded field */
-SC_API int sc_hip_field_store(void *instance, float *U_out);
+SC_API int sc_hip_field_shape(void *instance, int whc[3]);   /* W, H, C of the fields currently on the device */
+SC_API int sc_hip_field_store(void *instance, float *U_out, size_t capacity_floats);
 
 /* microbenchmark hook used by bench.py: runs `launches` launches of the sweep kernel
  * (method, sweeps_per_launch) on the loaded field and returns the mean launch time measured

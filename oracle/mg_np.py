@@ -1,0 +1,153 @@
+"""numpy restatement of the multigrid components the HIP library uses (TEST INFRASTRUCTURE ONLY).
+
+The reference has no multigrid (it solves directly, seamlessClone_imp.cpp:1814-1896); this file
+is the specification the GPU multigrid kernels are checked against: level geometry with one
+irregular last interval per direction, general red-black smoother, residual in float64,
+row-normalised transposed-interpolation restriction, bilinear prolongation.  The fixed point of
+the cycle is the solution of the same 5-point system oracle_np.solve_dst inverts, which is what
+the end-to-end parity tests compare against.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+def coarsen_1d(n: int, a: float):
+    if n % 2 == 1:
+        return (n - 1) // 2, (1.0 + a) / 2.0
+    if a >= 1.0:
+        return n // 2, a / 2.0
+    return n // 2 - 1, 1.0 + a / 2.0
+
+
+class Dim:
+    def __init__(self, n, a, nc):
+        self.n, self.alpha, self.nc = n, float(a), nc
+        self.cw_last = F32(2.0 / (1.0 + a))
+        self.d_last = F32(2.0 / a)
+        tail = n - 2 * nc
+        D = n + a - 2.0 * nc
+        self.tw1 = F32(1.0 - 1.0 / D) if tail >= 1 else F32(0)
+        self.tw2 = F32(1.0 - 2.0 / D) if tail >= 2 else F32(0)
+        self.inv_last = F32(1.0 / (1.5 + float(self.tw1) + float(self.tw2)))
+
+
+def build_levels(W: int, H: int):
+    """[(Dim x, Dim y)] from the ROI size, level 0 first (stop when min(n) <= 3)."""
+    ls = [(W - 2, 1.0, H - 2, 1.0)]
+    while min(ls[-1][0], ls[-1][2]) > 3:
+        nx, ax = coarsen_1d(ls[-1][0], ls[-1][1])
+        ny, ay = coarsen_1d(ls[-1][2], ls[-1][3])
+        if nx < 1 or ny < 1:
+            break
+        ls.append((nx, ax, ny, ay))
+    out = []
+    for i, (nx, ax, ny, ay) in enumerate(ls):
+        ncx = ls[i + 1][0] if i + 1 < len(ls) else 0
+        ncy = ls[i + 1][2] if i + 1 < len(ls) else 0
+        out.append((Dim(nx, ax, ncx), Dim(ny, ay, ncy)))
+    return out
+
+
+def _coefs(dx: Dim, dy: Dim):
+    W, H = dx.n + 2, dy.n + 2
+    cw = np.ones(W, F32); ddx = np.full(W, 2, F32)
+    cw[dx.n] = dx.cw_last; ddx[dx.n] = dx.d_last
+    cn = np.ones(H, F32); ddy = np.full(H, 2, F32)
+    cn[dy.n] = dy.cw_last; ddy[dy.n] = dy.d_last
+    return cw, ddx, cn, ddy
+
+
+def rb_gen(U, F, dx: Dim, dy: Dim, sweeps=1, omega=1.0):
+    """General red-black sweep on one plane (ring = 0), float32, kernel operation order:
+    gs = (((cw*l + r) + (cn*u + d)) - f) / (dx + dy)."""
+    U = U.astype(F32, copy=True)
+    H, W = U.shape
+    cw, ddx, cn, ddy = _coefs(dx, dy)
+    yy, xx = np.mgrid[0:H, 0:W]
+    inter = np.zeros((H, W), bool); inter[1:-1, 1:-1] = True
+    for _ in range(sweeps):
+        for color in (0, 1):
+            m = inter & (((xx + yy) & 1) == color)
+            s = np.zeros_like(U)
+            s[1:-1, 1:-1] = ((cw[None, 1:-1] * U[1:-1, :-2] + U[1:-1, 2:])
+                             + (cn[1:-1, None] * U[:-2, 1:-1] + U[2:, 1:-1]))
+            gs = np.zeros_like(U)
+            gs[1:-1, 1:-1] = (s[1:-1, 1:-1] - F[1:-1, 1:-1]) / (ddx[None, 1:-1] + ddy[1:-1, None])
+            new = gs if omega == 1.0 else U + F32(omega) * (gs - U)
+            U[m] = new[m]
+    return U
+
+
+def residual_field(U, F, dx: Dim, dy: Dim):
+    """R = F - A U on the interior, float64 arithmetic from float32 values, stored float32."""
+    cw, ddx, cn, ddy = (a.astype(np.float64) for a in _coefs(dx, dy))
+    U64 = U.astype(np.float64)
+    R = np.zeros_like(U64)
+    s = ((cw[None, 1:-1] * U64[1:-1, :-2] + U64[1:-1, 2:]) + (cn[1:-1, None] * U64[:-2, 1:-1] + U64[2:, 1:-1])
+         - (ddx[None, 1:-1] + ddy[1:-1, None]) * U64[1:-1, 1:-1])
+    R[1:-1, 1:-1] = F[1:-1, 1:-1].astype(np.float64) - s
+    return R.astype(F32)
+
+
+def interp_matrix(d: Dim):
+    """(n+2) x (nc+2) 1-D interpolation incl. ring rows/cols."""
+    P = np.zeros((d.n + 2, d.nc + 2), np.float64)
+    for i in range(1, d.n + 1):
+        if i <= 2 * d.nc:
+            if i % 2 == 0:
+                P[i, i // 2] = 1.0
+            else:
+                P[i, (i - 1) // 2] += 0.5
+                P[i, (i + 1) // 2] += 0.5
+        else:
+            P[i, d.nc] = float(d.tw1) if i - 2 * d.nc == 1 else float(d.tw2)
+    P[:, 0] = 0
+    P[:, d.nc + 1] = 0
+    return P
+
+
+def restrict(R, dx: Dim, dy: Dim):
+    """Fc = 4 * (row-normalised P^T) R, interior of the coarse plane."""
+    Px, Py = interp_matrix(dx), interp_matrix(dy)
+    Rx = Px.T.copy(); sx = Rx.sum(1); sx[sx == 0] = 1; Rx /= sx[:, None]
+    Ry = Py.T.copy(); sy = Ry.sum(1); sy[sy == 0] = 1; Ry /= sy[:, None]
+    Fc = 4.0 * (Ry @ R.astype(np.float64) @ Rx.T)
+    Fc[0, :] = Fc[-1, :] = 0
+    Fc[:, 0] = Fc[:, -1] = 0
+    return Fc.astype(F32)
+
+
+def prolong(E, dx: Dim, dy: Dim):
+    """P E on the fine plane (ring rows/cols = 0)."""
+    Px, Py = interp_matrix(dx), interp_matrix(dy)
+    out = Py @ E.astype(np.float64) @ Px.T
+    out[0, :] = out[-1, :] = 0
+    out[:, 0] = out[:, -1] = 0
+    return out.astype(F32)
+
+
+def vcycle(levels, l, U, F, pre=2, post=2):
+    dx, dy = levels[l]
+    if l == len(levels) - 1:
+        rho = 0.5 * (np.cos(np.pi / (dx.n + 1.0)) + np.cos(np.pi / (dy.n + 1.0)))
+        om = 2.0 / (1.0 + np.sqrt(max(0.0, 1.0 - rho * rho)))
+        return rb_gen(U, F, dx, dy, max(8, min(64, 2 * max(dx.n, dy.n))), float(F32(om)))
+    U = rb_gen(U, F, dx, dy, pre)
+    Fc = restrict(residual_field(U, F, dx, dy), dx, dy)
+    E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post)
+    U = U.copy()
+    U += prolong(E, dx, dy)
+    return rb_gen(U, F, dx, dy, post)
+
+
+def solve(U0, F, cycles=6):
+    """Multigrid solve of one plane: U0 carries the Dirichlet ring (level 0 is regular)."""
+    H, W = U0.shape
+    levels = build_levels(W, H)
+    U = U0.astype(F32, copy=True)
+    for _ in range(cycles):
+        U = vcycle(levels, 0, U, F)
+    return U

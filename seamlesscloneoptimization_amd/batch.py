@@ -1,0 +1,82 @@
+"""Batch / multi-GPU driver: independent images, one process per GPU, no data-path collective.
+
+The reference has no multi-GPU mode (its gpu_id argument only prints device properties,
+seamlessClone_imp.cu:243-250).  Each clone is independent, so a batch shards
+as image i -> rank i mod world; the only cross-rank traffic is the timing barrier and the
+max-over-ranks of the elapsed time, which run over torch.distributed (gloo: CPU scalars only,
+nothing on xGMI).  torch is imported lazily and only when world_size > 1.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> list[int]:
+    """Round-robin ownership: image i belongs to rank i % world (ragged tails allowed)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    return list(range(rank, n_items, world))
+
+
+class Comm:
+    """Barrier + max-reduction over ranks.  world == 1 needs no torch at all."""
+
+    def __init__(self, rank: int | None = None, world: int | None = None, backend: str = "gloo"):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+        self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        self._dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29531")
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            self._dist = dist
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def max(self, value: float) -> float:
+        if self._dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, value: float) -> float:
+        if self._dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self._dist is not None and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+            self._dist = None
+
+
+def timed_region(comm: Comm, sync, body):
+    """barrier + device sync | body() | device sync + barrier; returns max-over-ranks seconds."""
+    comm.barrier()
+    sync()
+    t0 = time.perf_counter()
+    body()
+    sync()
+    dt = time.perf_counter() - t0
+    comm.barrier()
+    return comm.max(dt)
+
+
+def run_batch(instance, items, clone_one):
+    """Run clone_one(instance, item) for every item this rank owns; returns units processed."""
+    n = 0
+    for it in items:
+        clone_one(instance, it)
+        n += 1
+    return n

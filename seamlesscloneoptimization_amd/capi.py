@@ -39,7 +39,7 @@ ERR_NAMES = {
 class SolverOpts(C.Structure):
     _fields_ = [("method", C.c_int), ("max_sweeps", C.c_int), ("tol", C.c_float), ("check_every", C.c_int),
                 ("omega", C.c_float), ("sweeps_per_launch", C.c_int), ("reference_warmup", C.c_int),
-                ("mg_pre", C.c_int), ("mg_post", C.c_int), ("reserved", C.c_int * 6)]
+                ("mg_pre", C.c_int), ("mg_post", C.c_int), ("update_tol", C.c_float), ("reserved", C.c_int * 5)]
 
 
 class RunInfo(C.Structure):
@@ -116,6 +116,8 @@ def load():
     L.sc_hip_memcpy_h2d.restype = C.c_int
     L.sc_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.sc_hip_memcpy_d2h.restype = C.c_int
+    L.sc_hip_memcpy_d2d_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.sc_hip_memcpy_d2d_async.restype = C.c_int
     L.sc_hip_device_count.argtypes = []
     L.sc_hip_device_count.restype = C.c_int
     L.sc_hip_mask_stage.argtypes = [C.c_void_p] + _IMG + [C.c_int, C.c_int, i32p, u8p, C.c_size_t]
@@ -130,7 +132,9 @@ def load():
     L.sc_hip_field_residual.restype = C.c_int
     L.sc_hip_field_solve.argtypes = [C.c_void_p]
     L.sc_hip_field_solve.restype = C.c_int
-    L.sc_hip_field_store.argtypes = [C.c_void_p, f32p]
+    L.sc_hip_field_shape.argtypes = [C.c_void_p, i32p]
+    L.sc_hip_field_shape.restype = C.c_int
+    L.sc_hip_field_store.argtypes = [C.c_void_p, f32p, C.c_size_t]
     L.sc_hip_field_store.restype = C.c_int
     L.sc_hip_field_time_sweeps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)]
     L.sc_hip_field_time_sweeps.restype = C.c_int
@@ -236,6 +240,9 @@ class Instance:
         self._check(self.L.sc_hip_memcpy_d2h(self.h, out.ctypes.data, p, out.nbytes))
         return out
 
+    def copy_d2d_async(self, dst, src, nbytes):
+        self._check(self.L.sc_hip_memcpy_d2d_async(self.h, dst, src, nbytes))
+
     def run_device(self, d_face, fshape, d_body, bshape, d_mask, mshape, cx, cy, sync=True,
                    allow_not_converged=False):
         """shapes are (rows, cols); rows are dense (step = cols * channels)."""
@@ -271,7 +278,11 @@ class Instance:
         assert U.shape == lap.shape and U.ndim == 3
         Cc, H, W = U.shape
         self._check(self.L.sc_hip_field_load(self.h, W, H, Cc, U.ctypes.data_as(f32p), lap.ctypes.data_as(f32p)))
-        self._fshape = (Cc, H, W)
+
+    def field_shape(self):
+        whc = np.zeros(3, np.int32)
+        self._check(self.L.sc_hip_field_shape(self.h, whc.ctypes.data_as(i32p)))
+        return int(whc[2]), int(whc[1]), int(whc[0])
 
     def field_sweep(self, method, sweeps, omega=1.0, sweeps_per_launch=1):
         self._check(self.L.sc_hip_field_sweep(self.h, int(method), int(sweeps), float(omega), int(sweeps_per_launch)))
@@ -286,8 +297,8 @@ class Instance:
         return self._check(rc, allow=(SC_ERR_NOT_CONVERGED,) if allow_not_converged else ())
 
     def field_store(self):
-        out = np.zeros(self._fshape, np.float32)
-        self._check(self.L.sc_hip_field_store(self.h, out.ctypes.data_as(f32p)))
+        out = np.zeros(self.field_shape(), np.float32)
+        self._check(self.L.sc_hip_field_store(self.h, out.ctypes.data_as(f32p), out.size))
         return out
 
     def field_time_sweeps(self, method, launches, sweeps_per_launch=1, omega=1.0) -> float:

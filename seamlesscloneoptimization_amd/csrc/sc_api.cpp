@@ -58,11 +58,13 @@ int setup_fields(Instance *I, int W, int H, int C)
     if ((rc = ensure(I, I->d_U0, bytes))) return rc;
     if ((rc = ensure(I, I->d_U1, bytes))) return rc;
     if ((rc = ensure(I, I->d_F, bytes))) return rc;
+    const bool same = I->F.p == I->d_F.p && I->U0.p == I->d_U0.p && I->U1.p == I->d_U1.p && I->F.W == W &&
+                      I->F.H == H && I->F.C == C;
     I->U0 = make_field(I->d_U0.p, W, H, C);
     I->U1 = make_field(I->d_U1.p, W, H, C);
     I->F = make_field(I->d_F.p, W, H, C);
     I->result_in_U1 = false;
-    I->mg.clear();
+    if (!same) I->mg.clear(); // the multigrid hierarchy is rebuilt only when the ROI shape changes
     return SC_OK;
 }
 
@@ -160,13 +162,14 @@ void sc_hip_default_opts(sc_solver_opts *o)
     memset(o, 0, sizeof(*o));
     o->method = SC_METHOD_MULTIGRID;
     o->max_sweeps = 30;      // V-cycles
-    o->tol = 1e-6f;
+    o->tol = 0.f;            // MULTIGRID stops on update_tol; the sweep methods on tol
     o->check_every = 1;
     o->omega = 0.f;
     o->sweeps_per_launch = 0;
     o->reference_warmup = 0;
     o->mg_pre = 2;
     o->mg_post = 2;
+    o->update_tol = 0.02f;
 }
 
 int sc_hip_device_count(void)
@@ -194,6 +197,8 @@ void *my_seamlessclone_api_imp_create_instance(int gpu_id)
     ok = ok && hipMalloc((void **)&I->d_rect, 4 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_partials, 2 * sizeof(double) * residual_max_blocks()) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_red, 2 * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&I->d_maxcorr, sizeof(unsigned)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&I->h_maxcorr, sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 8; ++i) ok = hipEventCreate(&I->ev[i]) == hipSuccess;
     ok = ok && hipEventCreate(&I->ev_k0) == hipSuccess && hipEventCreate(&I->ev_k1) == hipSuccess;
     if (!ok) {
@@ -217,6 +222,8 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->d_rect) (void)hipFree(I->d_rect);
     if (I->d_partials) (void)hipFree(I->d_partials);
     if (I->d_red) (void)hipFree(I->d_red);
+    if (I->d_maxcorr) (void)hipFree(I->d_maxcorr);
+    if (I->h_maxcorr) (void)hipHostFree(I->h_maxcorr);
     if (I->h_rect) (void)hipHostFree(I->h_rect);
     if (I->h_red) (void)hipHostFree(I->h_red);
     for (int i = 0; i < 8; ++i) if (I->ev[i]) (void)hipEventDestroy(I->ev[i]);
@@ -307,6 +314,15 @@ int sc_hip_memcpy_d2h(void *p, void *h, const void *d, size_t bytes)
     SC_HIP(I, hipSetDevice(I->gpu));
     SC_HIP(I, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, I->stream));
     SC_HIP(I, hipStreamSynchronize(I->stream));
+    return SC_OK;
+}
+
+int sc_hip_memcpy_d2d_async(void *p, void *dst, const void *src, size_t bytes)
+{
+    Instance *I = get(p);
+    if (!I || !dst || !src) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    SC_HIP(I, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, I->stream));
     return SC_OK;
 }
 
@@ -531,10 +547,19 @@ int sc_hip_field_solve(void *p)
     return rc;
 }
 
-int sc_hip_field_store(void *p, float *U_out)
+int sc_hip_field_shape(void *p, int whc[3])
+{
+    Instance *I = get(p);
+    if (!I || !I->F.p || !whc) return SC_ERR_BAD_ARG;
+    whc[0] = I->F.W; whc[1] = I->F.H; whc[2] = I->F.C;
+    return SC_OK;
+}
+
+int sc_hip_field_store(void *p, float *U_out, size_t capacity_floats)
 {
     Instance *I = get(p);
     if (!I || !I->F.p || !U_out) return SC_ERR_BAD_ARG;
+    if (capacity_floats < (size_t)I->F.W * I->F.H * I->F.C) { I->err = "field_store: buffer too small"; return SC_ERR_BAD_SIZE; }
     SC_HIP(I, hipSetDevice(I->gpu));
     int rc = download_field(I, result(I), U_out);
     if (rc) return rc;

@@ -49,9 +49,25 @@ bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipSt
 int  residual_max_blocks();
 void launch_residual(Field U, Field F, double *d_partials, double *d_out, hipStream_t s);
 
-// multigrid transfer operators
-void launch_restrict_residual(Field Uf, Field Ff, Field Fc, hipStream_t s);   // Fc = 4 * FW(Ff - A Uf)
-void launch_prolong_add(Field Uc, Field Uf, hipStream_t s);                    // Uf += P Uc (interior)
+// ---------------------------------------------------------------- multigrid (sc_mg_kernels.hip)
+// One grid direction of a level pair.  Level l has n interior points at unit spacing (in
+// level units) except the LAST gap, from point n to the Dirichlet boundary, which is alpha
+// (0.5 <= alpha <= 1.5).  That one irregular interval lets any ROI size coarsen without
+// moving the boundary: coarse points sit on the even fine points 2,4,..,2*nc.
+struct MGDim {
+    int n, nc;        // interior points on this level / on the next coarser one
+    float alpha;      // last gap of this level
+    float cw_last;    // stencil weight of the inner neighbour at the last point: 2/(1+alpha)
+    float d_last;     // diagonal contribution at the last point: 2/alpha (regular: 2)
+    float tw1, tw2;   // interpolation weights of the fine tail points 2nc+1, 2nc+2 (0 if absent)
+    float inv_last;   // 1 / (row sum of the transposed interpolation at coarse point nc)
+};
+struct MGGeom { MGDim x, y; };
+
+void launch_rb_half_gen(Field U, Field F, int color, float omega, MGGeom g, hipStream_t s);
+void launch_residual_field(Field U, Field F, Field R, MGGeom g, hipStream_t s); // R = F - A U (double arithmetic)
+void launch_restrict(Field R, Field Fc, MGGeom g, hipStream_t s);               // Fc = 4 * normalised P^T R
+void launch_prolong_add(Field Uc, Field Uf, MGGeom g, unsigned *d_maxcorr, hipStream_t s); // Uf += P Uc
 void launch_fill_zero(Field U, hipStream_t s);
 
 } // namespace sc

@@ -14,7 +14,9 @@ struct DevBuf {
 };
 
 struct MGLevel {
-    Field U, F, T; // solution/correction, RHS, scratch (ping-pong partner)
+    Field U, F, T;   // correction, RHS, scratch (residual field); level 0 aliases the instance fields
+    MGGeom g;        // geometry of this level and of its transfer to the next coarser one
+    float omega = 1.f; // SOR factor used when this is the coarsest level
 };
 
 struct Instance {
@@ -43,6 +45,8 @@ struct Instance {
     double *d_partials = nullptr;
     double *d_red = nullptr;
     double *h_red = nullptr;     // pinned
+    unsigned *d_maxcorr = nullptr;
+    unsigned *h_maxcorr = nullptr; // pinned
     hipEvent_t ev[8]{};
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     size_t arena_bytes = 0;

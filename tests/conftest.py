@@ -1,0 +1,61 @@
+import gzip
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _decode_bgr(name):
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(Image.open(os.path.join(GOLDEN, name)).convert("RGB"))[:, :, ::-1])
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def c1_inputs():
+    """Config 1: airplane -> sky, all-255 mask, centre (800,150)
+    (seamlessClone-python-binding/SeamlessClone_test.py:8-22).  BGR like cv2.imread."""
+    sky = _decode_bgr("sky.jpg")
+    air = _decode_bgr("airplane.jpg")
+    mask = np.full(air.shape[:2], 255, np.uint8)
+    return dict(dst=sky, patch=air, mask=mask, cx=800, cy=150)
+
+
+@pytest.fixture(scope="session")
+def golden_blend_rgb():
+    """The reference's one committed output (lossy JPEG), decoded, RGB order."""
+    from PIL import Image
+    return np.asarray(Image.open(os.path.join(GOLDEN, "blendedMat_0.jpg")).convert("RGB")).astype(np.int16)
+
+
+def jpeg_roundtrip_rgb(bgr, quality=95):
+    """cv2.imwrite(.jpg) defaults of OpenCV 3.4: quality 95, 4:2:0 -- reproduced with PIL."""
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(buf, "JPEG", quality=quality, subsampling=2)
+    buf.seek(0)
+    return np.asarray(Image.open(buf)).astype(np.int16)
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """One library instance on GPU 0 for the whole GPU session (fails loudly without a GPU)."""
+    from seamlesscloneoptimization_amd import capi
+    inst = capi.Instance(0)
+    yield inst
+    inst.destroy()
