@@ -219,6 +219,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     DevBuf *bufs[] = { &I->d_face, &I->d_body_roi, &I->d_mask, &I->d_M, &I->d_U0, &I->d_U1, &I->d_F };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
+    if (I->mg_partial.p) (void)hipFree(I->mg_partial.p);
     if (I->d_rect) (void)hipFree(I->d_rect);
     if (I->d_partials) (void)hipFree(I->d_partials);
     if (I->d_red) (void)hipFree(I->d_red);
@@ -572,12 +573,13 @@ int sc_hip_field_time_sweeps(void *p, int method, int launches, int spl, float o
     Instance *I = get(p);
     if (!I || !I->F.p || !ms_per_launch || launches < 1) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));
-    if (spl < 1) spl = 1;
-    int rc = run_sweeps(I, method, spl, omega, spl); // warm-up launch
+    const int d = fused_depth(method, spl);
+    const int per = d > 0 ? d : 1;                      // sweeps one "launch group" performs
+    int rc = run_sweeps(I, method, per, omega, spl);    // warm-up
     if (rc) return rc;
     I->info.sweep_launches = 0;
     SC_HIP(I, hipEventRecord(I->ev_k0, I->stream));
-    rc = run_sweeps(I, method, launches * spl, omega, spl);
+    rc = run_sweeps(I, method, launches * per, omega, spl);
     if (rc) return rc;
     SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
     SC_HIP(I, hipStreamSynchronize(I->stream));

@@ -44,6 +44,7 @@ void launch_rb_half(Field U, Field F, int color, float omega, hipStream_t s);
 // fused temporally-blocked kernels (sc_sweep_tb.hip); return false when the shape is unsupported
 bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s);
 bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipStream_t s);
+int  tb_max_depth(int method);
 
 // residual: d_out[0] = sum r^2, d_out[1] = sum lap^2 (double); d_partials holds >= 2*max_blocks doubles
 int  residual_max_blocks();
@@ -67,7 +68,9 @@ struct MGGeom { MGDim x, y; };
 void launch_rb_half_gen(Field U, Field F, int color, float omega, MGGeom g, hipStream_t s);
 void launch_residual_field(Field U, Field F, Field R, MGGeom g, hipStream_t s); // R = F - A U (double arithmetic)
 void launch_restrict(Field R, Field Fc, MGGeom g, hipStream_t s);               // Fc = 4 * normalised P^T R
-void launch_prolong_add(Field Uc, Field Uf, MGGeom g, unsigned *d_maxcorr, hipStream_t s); // Uf += P Uc
+int  prolong_blocks(int nx, int ny, int C);
+// Uf += P Uc; with d_partial (>= prolong_blocks floats) also *d_maxcorr = bits of max |P Uc|
+void launch_prolong_add(Field Uc, Field Uf, MGGeom g, float *d_partial, unsigned *d_maxcorr, hipStream_t s);
 void launch_fill_zero(Field U, hipStream_t s);
 
 } // namespace sc

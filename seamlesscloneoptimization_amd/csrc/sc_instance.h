@@ -38,6 +38,7 @@ struct Instance {
     bool result_in_U1 = false;
     // multigrid hierarchy (level 0 aliases U0/U1/F)
     std::vector<DevBuf> mg_bufs;
+    DevBuf mg_partial;    // per-block maxima of the level-0 correction
     std::vector<MGLevel> mg;
     // reductions / mailboxes
     int *d_rect = nullptr;
@@ -68,6 +69,7 @@ int setup_fields(Instance *I, int W, int H, int C);
 // solver drivers (sc_solver.cpp) -- operate on I->U0/U1/F, leave the answer in result(I)
 int solve(Instance *I);
 int run_sweeps(Instance *I, int method, int sweeps, float omega, int sweeps_per_launch);
+int fused_depth(int method, int sweeps_per_launch); // 0 = plain kernels
 int eval_residual(Instance *I, double out[2]);
 Field &result(Instance *I);
 float optimal_omega(int W, int H);

@@ -159,37 +159,81 @@ __device__ __forceinline__ void interp_1d(const MGDim &d, int i, int &I0, int &I
     }
 }
 
-__global__ __launch_bounds__(256) void k_prolong_add(Field Uc, Field Uf, MGGeom g, unsigned *__restrict__ maxcorr)
+// Thread = 4 consecutive fine points of one row (float4 read-modify-write of Uf).  With MAXC the
+// largest |correction| of the launch is reduced wave64 shuffle -> LDS -> one plain store per
+// block into `partial`, folded by k_max_final (a single atomic word would serialise ~10^5 waves).
+template <bool MAXC>
+__global__ __launch_bounds__(256) void k_prolong_add(Field Uc, Field Uf, MGGeom g, float *__restrict__ partial)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 256 + 4 * lane;
+    const int y = blockIdx.y * 4 + wv + 1;
     const int c = blockIdx.z;
-    float corr = 0.f;
-    if (x <= g.x.n && y <= g.y.n) {
-        int I0, I1, J0, J1;
-        float wx0, wx1, wy0, wy1;
-        interp_1d(g.x, x, I0, I1, wx0, wx1);
+    float m = 0.f;
+    if (y <= g.y.n && x <= g.x.n) {
+        int J0, J1;
+        float wy0, wy1;
         interp_1d(g.y, y, J0, J1, wy0, wy1);
-        const float *__restrict__ e = Uc.at(c);
-        const int Pc = Uc.pitch;
-        const float top = wx0 * e[(size_t)J0 * Pc + I0] + wx1 * e[(size_t)J0 * Pc + I1];
-        const float bot = wx0 * e[(size_t)J1 * Pc + I0] + wx1 * e[(size_t)J1 * Pc + I1];
-        corr = wy0 * top + wy1 * bot;
-        float *u = Uf.at(c) + (size_t)y * Uf.pitch + x;
-        *u = *u + corr;
+        const float *__restrict__ e0 = Uc.at(c) + (size_t)J0 * Uc.pitch;
+        const float *__restrict__ e1 = Uc.at(c) + (size_t)J1 * Uc.pitch;
+        float *up = Uf.at(c) + (size_t)y * Uf.pitch + x;
+        float4 u4 = *reinterpret_cast<float4 *>(up);
+        float cr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xi = x + k;
+            cr[k] = 0.f;
+            if (xi >= 1 && xi <= g.x.n) {
+                int I0, I1;
+                float wx0, wx1;
+                interp_1d(g.x, xi, I0, I1, wx0, wx1);
+                const float top = wx0 * e0[I0] + wx1 * e0[I1];
+                const float bot = wx0 * e1[I0] + wx1 * e1[I1];
+                cr[k] = wy0 * top + wy1 * bot;
+            }
+        }
+        if (x + 0 >= 1 && x + 0 <= g.x.n) u4.x = u4.x + cr[0];
+        if (x + 1 <= g.x.n) u4.y = u4.y + cr[1];
+        if (x + 2 <= g.x.n) u4.z = u4.z + cr[2];
+        if (x + 3 <= g.x.n) u4.w = u4.w + cr[3];
+        *reinterpret_cast<float4 *>(up) = u4;
+        if (MAXC) m = fmaxf(fmaxf(fabsf(cr[0]), fabsf(cr[1])), fmaxf(fabsf(cr[2]), fabsf(cr[3])));
     }
-    if (maxcorr) { // wave64 max of |corr|, one atomic per wave (non-negative floats order as uints)
-        float m = fabsf(corr);
+    if (MAXC) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxcorr, __float_as_uint(m));
+        __shared__ float red[4];
+        if (lane == 0) red[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =
+                fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     }
 }
 
-void launch_prolong_add(Field Uc, Field Uf, MGGeom g, unsigned *d_maxcorr, hipStream_t s)
+__global__ __launch_bounds__(256) void k_max_final(const float *__restrict__ partial, int n, unsigned *__restrict__ out)
 {
-    dim3 grid((g.x.n + 63) / 64, (g.y.n + 3) / 4, Uf.C);
-    hipLaunchKernelGGL(k_prolong_add, grid, dim3(256), 0, s, Uc, Uf, g, d_maxcorr);
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, partial[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+int prolong_blocks(int nx, int ny, int C) { return ((nx + 1 + 255) / 256) * ((ny + 3) / 4) * C; }
+
+void launch_prolong_add(Field Uc, Field Uf, MGGeom g, float *d_partial, unsigned *d_maxcorr, hipStream_t s)
+{
+    dim3 grid((g.x.n + 1 + 255) / 256, (g.y.n + 3) / 4, Uf.C);
+    if (d_partial && d_maxcorr) {
+        hipLaunchKernelGGL(k_prolong_add<true>, grid, dim3(256), 0, s, Uc, Uf, g, d_partial);
+        hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, s, d_partial, (int)(grid.x * grid.y * grid.z), d_maxcorr);
+    } else {
+        hipLaunchKernelGGL(k_prolong_add<false>, grid, dim3(256), 0, s, Uc, Uf, g, (float *)nullptr);
+    }
 }
 
 } // namespace sc

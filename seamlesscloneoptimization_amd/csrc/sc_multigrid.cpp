@@ -120,7 +120,8 @@ static int vcycle(Instance *I, size_t l, int pre, int post)
     launch_fill_zero(Lc.U, I->stream);
     if ((rc = vcycle(I, l + 1, pre, post))) return rc;
     Ul = (l == 0) ? result(I) : L.U;
-    launch_prolong_add(Lc.U, Ul, L.g, l == 0 ? I->d_maxcorr : nullptr, I->stream);
+    launch_prolong_add(Lc.U, Ul, L.g, l == 0 ? (float *)I->mg_partial.p : nullptr, l == 0 ? I->d_maxcorr : nullptr,
+                       I->stream);
     if ((rc = smooth(I, l, post))) return rc;
     return SC_OK;
 }
@@ -130,6 +131,7 @@ int mg_solve(Instance *I)
     const sc_solver_opts &o = I->opts;
     int rc = build_levels(I);
     if (rc) return rc;
+    if ((rc = ensure(I, I->mg_partial, sizeof(float) * (size_t)prolong_blocks(I->F.W - 2, I->F.H - 2, I->F.C)))) return rc;
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
     const float utol = o.update_tol > 0.f ? o.update_tol : 0.02f;
     const int budget = o.max_sweeps > 0 ? o.max_sweeps : 30;
@@ -138,7 +140,6 @@ int mg_solve(Instance *I)
     int cyc = 0;
     bool ok = false;
     while (cyc < budget) {
-        SC_HIP(I, hipMemsetAsync(I->d_maxcorr, 0, sizeof(unsigned), I->stream));
         if ((rc = vcycle(I, 0, pre, post))) return rc;
         ++cyc;
         SC_HIP(I, hipGetLastError());

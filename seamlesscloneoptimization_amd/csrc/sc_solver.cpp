@@ -30,47 +30,53 @@ int eval_residual(Instance *I, double out[2])
     return SC_OK;
 }
 
-// `sweeps` full sweeps of `method` on the current field.  sweeps_per_launch > 1 selects the
-// temporally blocked kernels (T sweeps fused in one launch); a remainder < T runs through a
-// shallower launch so the total is exact.
+// sweeps_per_launch semantics (opts / hooks):
+//    0  library default: fused register-blocked kernels at their deepest supported depth
+//    1  one sweep per launch with the plain kernels (k_jacobi; two k_rb_half launches)
+//   -1  fused kernel, depth 1 (one full red-black sweep = both colours in one launch)
+//  >=2  fused kernel, that depth (clamped to what the kernel supports)
+// All variants produce bit-identical fields; a remainder < depth runs through a shallower launch.
+int fused_depth(int method, int spl)
+{
+    const int mx = tb_max_depth(method);
+    if (spl == 1) return 0;             // plain kernels
+    if (spl == 0) return mx;
+    if (spl < 0) return 1;
+    return spl < mx ? spl : mx;
+}
+
 int run_sweeps(Instance *I, int method, int sweeps, float omega, int spl)
 {
     if (sweeps <= 0) return SC_OK;
-    if (spl <= 0) spl = I->opts.sweeps_per_launch;
-    if (spl <= 0) spl = 1;
-    if (method == SC_METHOD_JACOBI) {
-        int left = sweeps;
-        while (left > 0) {
-            int T = std::min(spl, left);
-            bool done = false;
-            if (T > 1) done = launch_jacobi_tb(result(I), other(I), I->F, T, I->stream);
-            if (!done) { T = 1; launch_jacobi(result(I), other(I), I->F, I->stream); }
-            I->result_in_U1 = !I->result_in_U1;
-            I->info.sweep_launches += 1;
-            left -= T;
-        }
-    } else if (method == SC_METHOD_RBGS || method == SC_METHOD_SOR) {
-        float om = 1.0f;
-        if (method == SC_METHOD_SOR) om = (omega > 0.f) ? omega : optimal_omega(I->F.W, I->F.H);
-        int left = sweeps;
-        while (left > 0) {
-            int T = std::min(spl, left);
-            bool done = false;
-            if (spl > 1) {
-                done = launch_rb_tb(result(I), other(I), I->F, T, om, I->stream);
-                if (done) I->result_in_U1 = !I->result_in_U1;
-            }
-            if (!done) {
-                T = 1;
-                launch_rb_half(result(I), I->F, 0, om, I->stream);
-                launch_rb_half(result(I), I->F, 1, om, I->stream);
-            }
-            I->info.sweep_launches += done ? 1 : 2;
-            left -= T;
-        }
-    } else {
+    if (method != SC_METHOD_JACOBI && method != SC_METHOD_RBGS && method != SC_METHOD_SOR) {
         I->err = "run_sweeps: unknown method";
         return SC_ERR_BAD_ARG;
+    }
+    const int depth = fused_depth(method, spl);
+    float om = 1.0f;
+    if (method == SC_METHOD_SOR) om = (omega > 0.f) ? omega : optimal_omega(I->F.W, I->F.H);
+    int left = sweeps;
+    while (left > 0) {
+        int T = std::min(std::max(depth, 1), left);
+        bool done = false;
+        if (depth > 0) {
+            done = (method == SC_METHOD_JACOBI) ? launch_jacobi_tb(result(I), other(I), I->F, T, I->stream)
+                                                : launch_rb_tb(result(I), other(I), I->F, T, om, I->stream);
+            if (done) { I->result_in_U1 = !I->result_in_U1; I->info.sweep_launches += 1; }
+        }
+        if (!done) {
+            T = 1;
+            if (method == SC_METHOD_JACOBI) {
+                launch_jacobi(result(I), other(I), I->F, I->stream);
+                I->result_in_U1 = !I->result_in_U1;
+                I->info.sweep_launches += 1;
+            } else {
+                launch_rb_half(result(I), I->F, 0, om, I->stream);
+                launch_rb_half(result(I), I->F, 1, om, I->stream);
+                I->info.sweep_launches += 2;
+            }
+        }
+        left -= T;
     }
     SC_HIP(I, hipGetLastError());
     return SC_OK;

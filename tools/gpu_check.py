@@ -57,17 +57,18 @@ for (W, H) in [(77, 53), (1000, 39), (1026, 770), (2048, 2048)]:
     i = inst.info(); s = pkg.compare.image_diff_stats(want, body)
     print(f"MG {W}x{H} rc {rc} cycles {i.sweeps} ms: mask {i.ms_mask:.3f} pre {i.ms_pre:.3f} solve {i.ms_solve:.3f} post {i.ms_post:.3f} h2d {i.ms_h2d:.3f} d2h {i.ms_d2h:.3f}", pkg.compare.format_stats(s), flush=True)
     check(f"MG clone {W}x{H} within 1", s["max"] <= 1 and rc == 0)
-# timing of single-sweep kernels at 2048^2
+# timing of sweep kernels
 for (W, H) in [(2048, 2048), (4096, 4096)]:
     rng = np.random.default_rng(1)
     U = rng.normal(100, 30, (3, H, W)).astype(np.float32); F = rng.normal(0, 10, (3, H, W)).astype(np.float32)
     inst.field_load(U, F)
-    for method, name in [(0, "jacobi"), (1, "rbgs")]:
-        ms = inst.field_time_sweeps(method, 50, 1, 1.0)
-        unknowns = (W-2)*(H-2)*3
-        by = 12 * unknowns if method == 0 else 12 * unknowns  # per launch: jacobi full sweep; rb_half = half sweep, charged 6B/unknown
-        if method == 1: by = by / 2
-        print(f"{name} {W}x{H}: {ms*1e3:.1f} us/launch -> {by/ms/1e9:.2f} TB/s algorithmic", flush=True)
+    unknowns = (W-2)*(H-2)*3
+    for method, name, spls in [(0, "jacobi", (1, -1, 2, 3, 4)), (1, "rbgs", (1, -1, 2))]:
+        for spl in spls:
+            ms = inst.field_time_sweeps(method, 50, spl, 1.0)
+            sweeps_per_launch = 0.5 if (method == 1 and spl == 1) else abs(spl)
+            by = 12 * unknowns * sweeps_per_launch
+            print(f"{name} spl={spl} {W}x{H}: {ms*1e3:.1f} us/launch -> {by/ms/1e9:.2f} TB/s algorithmic", flush=True)
 inst.destroy()
 print("ALL OK" if ok else "SOME FAILED")
 sys.exit(0 if ok else 1)
