@@ -1,0 +1,61 @@
+"""Command line with the reference's argv (seamlessClone-CUDA/seamlessClone_main.cu:69-94):
+
+    python -m seamlesscloneoptimization_amd.cli src.yml dst.yml mask.yml centerX centerY gpu [--out result.bmp]
+
+src = patch ("face"), dst = destination ("body"), mask: OpenCV FileStorage yml, node "data"
+(seamlessClone_imp.cu:226-237).  Prints the line the reference prints with bSync=True
+(seamlessClone_imp.cu:343-346).  Images may also be .bmp/.jpg/.png.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+
+import numpy as np
+
+from . import capi, compare, ymlio
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="seamlessClone_main")
+    ap.add_argument("src"); ap.add_argument("dst"); ap.add_argument("mask")
+    ap.add_argument("centerX", type=int); ap.add_argument("centerY", type=int); ap.add_argument("gpu", type=int)
+    ap.add_argument("--out", help="write the blended image (.bmp or .yml)")
+    ap.add_argument("--method", default="mg", choices=["mg", "sor", "rbgs", "jacobi"])
+    ap.add_argument("--reference-warmup", action="store_true",
+                    help="clone twice in place like the reference binary (seamlessClone_imp.cu:303-318)")
+    a = ap.parse_args(argv)
+    src, dst, mask = compare._load(a.src), compare._load(a.dst), compare._load(a.mask)
+    if mask.ndim == 3:
+        mask = np.ascontiguousarray(mask[:, :, 0])
+    print("mat shape: %d, %d, %d" % (src.shape[1], src.shape[0], 3))
+    print("mat shape: %d, %d, %d" % (dst.shape[1], dst.shape[0], 3))
+    print("mat shape: %d, %d, %d" % (mask.shape[1], mask.shape[0], 1))
+    inst = capi.Instance(a.gpu)
+    try:
+        opts = {"method": {"mg": 3, "sor": 2, "rbgs": 1, "jacobi": 0}[a.method],
+                "reference_warmup": int(a.reference_warmup)}
+        if a.method != "mg":
+            opts.update(tol=2e-5, max_sweeps=1000000, check_every=64)
+        inst.set_solver(**opts)
+        body = np.array(dst, np.uint8, copy=True, order="C")
+        inst.run(np.ascontiguousarray(src), body, np.ascontiguousarray(mask), a.centerX, a.centerY, sync=True)
+        body2 = np.array(dst, np.uint8, copy=True, order="C")      # timed run after the warm-up, as the reference does
+        inst.run(np.ascontiguousarray(src), body2, np.ascontiguousarray(mask), a.centerX, a.centerY, sync=True)
+        i = inst.info()
+        print("Compute stage performance time= %.3f msec, patch size=%dx%d" % (i.ms_device_total, i.W, i.H))
+        print("total device memory used: %d" % i.device_bytes)
+        print("transfers: H2D %.3f msec, D2H %.3f msec; solver %s: %d cycles/sweeps"
+              % (i.ms_h2d, i.ms_d2h, a.method, i.sweeps))
+    finally:
+        inst.destroy()
+    if a.out:
+        if a.out.endswith((".yml", ".yml.gz")):
+            ymlio.write_yml(a.out, body, name="result")
+        else:
+            ymlio.write_bmp(a.out, body)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -73,4 +73,14 @@ int  prolong_blocks(int nx, int ny, int C);
 void launch_prolong_add(Field Uc, Field Uf, MGGeom g, float *d_partial, unsigned *d_maxcorr, hipStream_t s);
 void launch_fill_zero(Field U, hipStream_t s);
 
+// bottom of the V-cycle fused into one launch (one workgroup per channel)
+constexpr int MG_BOTTOM_MAX_LEVELS = 12;
+constexpr int MG_BOTTOM_POINTS = 128 * 128;   // levels with <= this many unknowns per plane go to the bottom kernel
+struct MGBottomLevel { Field U, F, T; MGGeom g; float omega; };
+struct MGBottomArgs {
+    int nlevels, pre, post, coarse_sweeps;
+    MGBottomLevel lv[MG_BOTTOM_MAX_LEVELS];
+};
+void launch_mg_bottom(const MGBottomArgs &a, int C, hipStream_t s);
+
 } // namespace sc

@@ -40,6 +40,7 @@ struct Instance {
     std::vector<DevBuf> mg_bufs;
     DevBuf mg_partial;    // per-block maxima of the level-0 correction
     std::vector<MGLevel> mg;
+    size_t mg_bottom = 0;  // first level run by the fused bottom kernel (== mg.size(): none)
     // reductions / mailboxes
     int *d_rect = nullptr;
     int *h_rect = nullptr;       // pinned

@@ -236,4 +236,138 @@ void launch_prolong_add(Field Uc, Field Uf, MGGeom g, float *d_partial, unsigned
     }
 }
 
+// ---- bottom of the V-cycle in ONE launch -----------------------------------------------------
+// Every level small enough (<= MG_BOTTOM_POINTS unknowns per plane) is processed by a single
+// 1024-thread workgroup per channel: smoothing, residual, restriction, coarsest solve,
+// prolongation and post-smoothing run as block-strided loops separated by __syncthreads(), so
+// the ~100 tiny launches those levels would need collapse into one.  Only this workgroup
+// touches its channel's planes, so workgroup-scope visibility is all that is required.
+__device__ __forceinline__ float gen_gs(const float *__restrict__ u, const float *__restrict__ f, int P, int x, int y,
+                                        const MGGeom &g)
+{
+    const float cw = (x == g.x.n) ? g.x.cw_last : 1.0f, dx = (x == g.x.n) ? g.x.d_last : 2.0f;
+    const float cn = (y == g.y.n) ? g.y.cw_last : 1.0f, dy = (y == g.y.n) ? g.y.d_last : 2.0f;
+    const float *p = u + (size_t)y * P + x;
+    return (((cw * p[-1] + p[1]) + (cn * p[-P] + p[P])) - f[(size_t)y * P + x]) / (dx + dy);
+}
+
+__device__ void bt_rb_half(float *u, const float *f, int P, const MGGeom &g, int color, float omega, bool sor)
+{
+    const int hx = (g.x.n + 1) / 2; // colour columns per row (upper bound)
+    for (int i = threadIdx.x; i < hx * g.y.n; i += blockDim.x) {
+        const int y = 1 + i / hx;
+        const int x = 1 + 2 * (i - (y - 1) * hx) + ((1 + y + color) & 1);
+        if (x > g.x.n) continue;
+        const float gs = gen_gs(u, f, P, x, y, g);
+        float *p = u + (size_t)y * P + x;
+        *p = sor ? (*p + omega * (gs - *p)) : gs;
+    }
+    __syncthreads();
+}
+
+__device__ void bt_residual(const float *u, const float *f, float *r, int P, const MGGeom &g)
+{
+    for (int i = threadIdx.x; i < g.x.n * g.y.n; i += blockDim.x) {
+        const int y = 1 + i / g.x.n, x = 1 + (i - (y - 1) * g.x.n);
+        const double cw = (x == g.x.n) ? (double)g.x.cw_last : 1.0, dx = (x == g.x.n) ? (double)g.x.d_last : 2.0;
+        const double cn = (y == g.y.n) ? (double)g.y.cw_last : 1.0, dy = (y == g.y.n) ? (double)g.y.d_last : 2.0;
+        const float *p = u + (size_t)y * P + x;
+        const double s = ((cw * (double)p[-1] + (double)p[1]) + (cn * (double)p[-P] + (double)p[P])) - (dx + dy) * (double)p[0];
+        r[(size_t)y * P + x] = (float)((double)f[(size_t)y * P + x] - s);
+    }
+    __syncthreads();
+}
+
+__device__ void bt_restrict_zero(const float *r, int P, float *fc, float *uc, int Pc, const MGGeom &g)
+{
+    for (int i = threadIdx.x; i < g.x.nc * g.y.nc; i += blockDim.x) {
+        const int J = 1 + i / g.x.nc, I = 1 + (i - (J - 1) * g.x.nc);
+        float wx[4], wy[4], ix, iy;
+        restrict_weights(g.x, I, wx, ix);
+        restrict_weights(g.y, J, wy, iy);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int y = 2 * J - 1 + a;
+            if (wy[a] == 0.f || y > g.y.n) continue;
+            float rowacc = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int x = 2 * I - 1 + b;
+                if (wx[b] == 0.f || x > g.x.n) continue;
+                rowacc += wx[b] * r[(size_t)y * P + x];
+            }
+            acc += wy[a] * rowacc;
+        }
+        fc[(size_t)J * Pc + I] = 4.0f * (acc * (ix * iy));
+        uc[(size_t)J * Pc + I] = 0.f;
+    }
+    __syncthreads();
+}
+
+__device__ void bt_prolong(const float *e, int Pc, float *u, int P, const MGGeom &g)
+{
+    for (int i = threadIdx.x; i < g.x.n * g.y.n; i += blockDim.x) {
+        const int y = 1 + i / g.x.n, x = 1 + (i - (y - 1) * g.x.n);
+        int I0, I1, J0, J1;
+        float wx0, wx1, wy0, wy1;
+        interp_1d(g.x, x, I0, I1, wx0, wx1);
+        interp_1d(g.y, y, J0, J1, wy0, wy1);
+        const float top = wx0 * e[(size_t)J0 * Pc + I0] + wx1 * e[(size_t)J0 * Pc + I1];
+        const float bot = wx0 * e[(size_t)J1 * Pc + I0] + wx1 * e[(size_t)J1 * Pc + I1];
+        float *p = u + (size_t)y * P + x;
+        *p = *p + (wy0 * top + wy1 * bot);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
+{
+    const int c = blockIdx.x;
+    const int L = a.nlevels;
+    // the top bottom-level correction starts from zero (interior only; ring/pads are zero already)
+    {
+        const MGBottomLevel &t = a.lv[0];
+        float *u = t.U.at(c);
+        for (int i = threadIdx.x; i < t.g.x.n * t.g.y.n; i += blockDim.x) {
+            const int y = 1 + i / t.g.x.n, x = 1 + (i - (y - 1) * t.g.x.n);
+            u[(size_t)y * t.U.pitch + x] = 0.f;
+        }
+        __syncthreads();
+    }
+    for (int l = 0; l + 1 < L; ++l) {
+        const MGBottomLevel &v = a.lv[l];
+        const MGBottomLevel &w = a.lv[l + 1];
+        float *u = v.U.at(c);
+        const float *f = v.F.at(c);
+        for (int s = 0; s < a.pre; ++s) {
+            bt_rb_half(u, f, v.U.pitch, v.g, 0, 1.0f, false);
+            bt_rb_half(u, f, v.U.pitch, v.g, 1, 1.0f, false);
+        }
+        bt_residual(u, f, v.T.at(c), v.U.pitch, v.g);
+        bt_restrict_zero(v.T.at(c), v.U.pitch, w.F.at(c), w.U.at(c), w.U.pitch, v.g);
+    }
+    {
+        const MGBottomLevel &v = a.lv[L - 1];
+        for (int s = 0; s < a.coarse_sweeps; ++s) {
+            bt_rb_half(v.U.at(c), v.F.at(c), v.U.pitch, v.g, 0, v.omega, true);
+            bt_rb_half(v.U.at(c), v.F.at(c), v.U.pitch, v.g, 1, v.omega, true);
+        }
+    }
+    for (int l = L - 2; l >= 0; --l) {
+        const MGBottomLevel &v = a.lv[l];
+        const MGBottomLevel &w = a.lv[l + 1];
+        bt_prolong(w.U.at(c), w.U.pitch, v.U.at(c), v.U.pitch, v.g);
+        for (int s = 0; s < a.post; ++s) {
+            bt_rb_half(v.U.at(c), v.F.at(c), v.U.pitch, v.g, 0, 1.0f, false);
+            bt_rb_half(v.U.at(c), v.F.at(c), v.U.pitch, v.g, 1, 1.0f, false);
+        }
+    }
+}
+
+void launch_mg_bottom(const MGBottomArgs &a, int C, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mg_bottom, dim3(C), dim3(1024), 0, s, a);
+}
+
 } // namespace sc

@@ -41,6 +41,30 @@ static Field level_field(void *p, int W, int H, int C)
     return f;
 }
 
+// first level handled by the fused bottom kernel (never level 0: it uses the exact kernels)
+static size_t bottom_start(Instance *I)
+{
+    for (size_t l = 1; l < I->mg.size(); ++l)
+        if ((long)I->mg[l].g.x.n * I->mg[l].g.y.n <= MG_BOTTOM_POINTS && I->mg.size() - l <= MG_BOTTOM_MAX_LEVELS)
+            return l;
+    return I->mg.size();
+}
+
+static int run_bottom(Instance *I, size_t l0, int pre, int post)
+{
+    MGBottomArgs a;
+    a.nlevels = (int)(I->mg.size() - l0);
+    a.pre = pre; a.post = post;
+    const MGLevel &last = I->mg.back();
+    a.coarse_sweeps = std::max(8, std::min(64, 2 * std::max(last.g.x.n, last.g.y.n)));
+    for (int i = 0; i < a.nlevels; ++i) {
+        const MGLevel &L = I->mg[l0 + i];
+        a.lv[i].U = L.U; a.lv[i].F = L.F; a.lv[i].T = L.T; a.lv[i].g = L.g; a.lv[i].omega = L.omega;
+    }
+    launch_mg_bottom(a, I->F.C, I->stream);
+    return SC_OK;
+}
+
 static int build_levels(Instance *I)
 {
     const int W = I->F.W, H = I->F.H, C = I->F.C;
@@ -79,10 +103,12 @@ static int build_levels(Instance *I)
         L.T = level_field(I->mg_bufs[3 * l + 2].p, Wl, Hl, C);
         // rings and pads of F/U must be zero; ensure() zero-fills fresh memory, but a reused
         // larger buffer may hold stale data from another ROI size
+        SC_HIP(I, hipMemsetAsync(L.U.p, 0, L.U.bytes(), I->stream));
         SC_HIP(I, hipMemsetAsync(L.F.p, 0, L.F.bytes(), I->stream));
         SC_HIP(I, hipMemsetAsync(L.T.p, 0, L.T.bytes(), I->stream));
     }
     I->mg[0].F = I->F;
+    I->mg_bottom = bottom_start(I);
     return SC_OK;
 }
 
@@ -102,6 +128,7 @@ static int vcycle(Instance *I, size_t l, int pre, int post)
 {
     MGLevel &L = I->mg[l];
     int rc;
+    if (l > 0 && l == I->mg_bottom) return run_bottom(I, l, pre, post);
     if (l + 1 == I->mg.size()) { // coarsest: SOR with the level's optimal factor
         const int n = std::max(8, std::min(64, 2 * std::max(L.g.x.n, L.g.y.n)));
         if (l == 0) return run_sweeps(I, SC_METHOD_SOR, n, L.omega, 1);
@@ -117,7 +144,7 @@ static int vcycle(Instance *I, size_t l, int pre, int post)
     Field Tl = (l == 0) ? (I->result_in_U1 ? I->U0 : I->U1) : L.T;
     launch_residual_field(Ul, L.F, Tl, L.g, I->stream);
     launch_restrict(Tl, Lc.F, L.g, I->stream);
-    launch_fill_zero(Lc.U, I->stream);
+    if (l + 1 != I->mg_bottom) launch_fill_zero(Lc.U, I->stream); // the bottom kernel zeroes its own top level
     if ((rc = vcycle(I, l + 1, pre, post))) return rc;
     Ul = (l == 0) ? result(I) : L.U;
     launch_prolong_add(Lc.U, Ul, L.g, l == 0 ? (float *)I->mg_partial.p : nullptr, l == 0 ? I->d_maxcorr : nullptr,

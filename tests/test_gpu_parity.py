@@ -224,6 +224,44 @@ def test_device_resident_run_equals_host_run(hip, oracles):
     assert info.ms_device_total > 0 and info.ms_solve > 0
 
 
+def test_instance_reuse_across_roi_sizes_is_stateless(hip, oracles):
+    """Grow-only buffers are reused across ROI shapes: a big clone followed by a small one must
+    give exactly what a fresh instance gives (stale coarse-level rings once broke this)."""
+    from seamlesscloneoptimization_amd import capi
+    o, _ = oracles
+    big = o.synth_inputs(700, 500, margin=32)
+    small = o.synth_inputs(130, 41, margin=32)
+    b = big[0].copy(); hip.run(big[1], b, big[2], big[3], big[4])
+    got = small[0].copy(); hip.run(small[1], got, small[2], small[3], small[4])
+    fresh = capi.Instance(0)
+    try:
+        want = small[0].copy(); fresh.run(small[1], want, small[2], small[3], small[4])
+    finally:
+        fresh.destroy()
+    assert np.array_equal(got, want)
+    ref = o.seamless_clone(small[0], small[1], small[2], small[3], small[4])
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1
+
+
+def test_cli_with_the_reference_yml_inputs(tmp_path, golden_dir, c1_inputs, oracles, capsys):
+    """README.md:59-63 workflow: yml in -> clone -> BMP out -> vs.py statistics."""
+    import gzip, shutil
+    from seamlesscloneoptimization_amd import cli, compare, ymlio
+    o, _ = oracles
+    for n in ("src.yml", "src_mask.yml"):
+        with gzip.open(os.path.join(golden_dir, n + ".gz"), "rb") as f, open(tmp_path / n, "wb") as g:
+            shutil.copyfileobj(f, g)
+    ymlio.write_yml(tmp_path / "dst.yml", c1_inputs["dst"], name="dst")       # dst.yml is a missing blob upstream
+    out = tmp_path / "ucRGB_Output.bmp"
+    assert cli.main([str(tmp_path / "src.yml"), str(tmp_path / "dst.yml"), str(tmp_path / "src_mask.yml"),
+                     "800", "150", "0", "--out", str(out)]) == 0
+    text = capsys.readouterr().out
+    assert "Compute stage performance time=" in text and "patch size=298x192" in text
+    want = o.seamless_clone(c1_inputs["dst"], c1_inputs["patch"], c1_inputs["mask"], 800, 150)
+    ymlio.write_bmp(tmp_path / "opencv.bmp", want)
+    assert compare.main([str(tmp_path / "opencv.bmp"), str(out)]) == 0
+
+
 def test_error_codes(hip, oracles):
     from seamlesscloneoptimization_amd import capi
     o, _ = oracles
