@@ -71,7 +71,7 @@ def cpu_baseline(dst, patch, mask, cx, cy, gpu_out, budget_s):
     for _ in range(reps):
         oc.seamless_clone(dst, patch, mask, cx, cy, 1, False)
     dt = (time.perf_counter() - t0) / reps
-    nthr = oc.max_threads()
+    nthr = max(1, min(oc.max_threads(), len(os.sched_getaffinity(0)), 16))  # the GPU box gives 16 cores per GPU
     t0 = time.perf_counter()
     ref = oc.seamless_clone(dst, patch, mask, cx, cy, nthr, True)  # exact-denominator variant, all cores
     dt_all = time.perf_counter() - t0
@@ -136,12 +136,14 @@ def main():
     # ---- roofline of the dominant sweep kernel: HIP events on the library's stream, over a
     #      region of back-to-back launches on the very fields the clone just used
     unknowns = (W - 2) * (H - 2) * 3
-    spl = max(1, args.sweeps_per_launch)
+    spl = args.sweeps_per_launch            # 0: library default = fused kernels at their deepest depth
+    rb_depth = {0: 2, 1: 0, -1: 1}.get(spl, min(spl, 2))        # sweeps per launch of the red-black kernel
+    j_depth = {0: 4, 1: 0, -1: 1}.get(spl, min(spl, 4))
     ms_rb = inst.field_time_sweeps(capi.SC_METHOD_RBGS, args.kernel_launches, spl, 1.0)
     ms_j = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, args.kernel_launches, spl, 1.0)
-    rb_launch_sweeps = 0.5 if spl == 1 else float(spl)   # spl==1: one colour per launch
-    rb_bytes = 12.0 * unknowns * rb_launch_sweeps
-    j_bytes = 12.0 * unknowns * spl
+    ms_j1 = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, args.kernel_launches, 1, 1.0)
+    rb_bytes = 12.0 * unknowns * (0.5 if rb_depth == 0 else rb_depth)   # plain kernel: one colour per launch
+    j_bytes = 12.0 * unknowns * max(j_depth, 1)
 
     def roof(name, bytes_per_launch, ms, note):
         ach = bytes_per_launch / (ms * 1e-3) / 1e9
@@ -149,12 +151,20 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "us_per_launch": round(ms * 1e3, 2),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch), "note": note}
 
-    rb_name = "k_rb_half (red-black half sweep, level 0)" if spl == 1 else f"k_rb_tb<{spl}> (fused red-black sweeps)"
-    j_name = "k_jacobi (LDS-tiled 5-point)" if spl == 1 else f"k_jacobi_tb<{spl}>"
+    rb_name = "k_rb_half (one colour, in place)" if rb_depth == 0 else \
+        f"k_rb_tb<{rb_depth},8,8> ({rb_depth} fused red-black sweeps per launch, register blocked)"
+    j_name = "k_jacobi (LDS-tiled 5-point, 1 sweep)" if j_depth == 0 else \
+        f"k_jacobi_tb<{j_depth},8,8> ({j_depth} fused Jacobi sweeps per launch, register blocked)"
+    cache_note = ("working set %.0f MB %s the 256 MB Infinity Cache" %
+                  (unknowns * 12 / 1e6, "fits" if unknowns * 12 < 256e6 else "exceeds"))
     roofline = roof(rb_name, rb_bytes, ms_rb,
-                    "dominant kernel of the timed clone; 12 B/unknown/channel/full sweep (SURVEY 8d); "
-                    "2048^2 working set (151 MB) sits in the 256 MB Infinity Cache")
-    roofline_j = roof(j_name, j_bytes, ms_j, "the Jacobi stencil named by the north-star, same field")
+                    "dominant kernel of the timed clone (multigrid smoother, level 0); algorithmic bytes = "
+                    "12 B/unknown/channel/sweep x sweeps per launch (SURVEY 8d), so >1.0 is 'effective' bandwidth "
+                    "from temporal blocking; " + cache_note)
+    roofline_j = roof(j_name, j_bytes, ms_j, "the Jacobi stencil named by the north-star, same field; effective "
+                      "bandwidth (temporal blocking); " + cache_note)
+    roofline_j1 = roof("k_jacobi (LDS-tiled 5-point, 1 sweep per launch)", 12.0 * unknowns, ms_j1,
+                       "single-sweep Jacobi: algorithmic == actual traffic; " + cache_note)
 
     total_pix = comm.sum(float(W * H)) * args.steps
     value = total_pix / elapsed / 1e6
@@ -169,7 +179,7 @@ def main():
                    "cycles_or_sweeps": int(info.sweeps)},
         "stages_ms": {"mask": round(info.ms_mask, 4), "pre": round(info.ms_pre, 4), "solve": round(info.ms_solve, 4),
                       "post": round(info.ms_post, 4), "device_total": round(info.ms_device_total, 4)},
-        "roofline": roofline, "roofline_jacobi": roofline_j,
+        "roofline": roofline, "roofline_jacobi": roofline_j, "roofline_jacobi_single_sweep": roofline_j1,
     }
     if comm.rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(dst, patch, mask, cx, cy, out, args.cpu_seconds)

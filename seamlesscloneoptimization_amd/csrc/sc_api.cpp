@@ -41,6 +41,47 @@ int ensure(Instance *I, DevBuf &b, size_t bytes)
     return SC_OK;
 }
 
+int ensure_pinned(Instance *I, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return SC_OK;
+    size_t ncap = bytes > 2 * b.cap ? bytes : 2 * b.cap;
+    ncap = (ncap + 4095) & ~(size_t)4095;
+    if (b.p) {
+        SC_HIP(I, hipStreamSynchronize(I->stream));
+        SC_HIP(I, hipHostFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    SC_HIP(I, hipHostMalloc(&b.p, ncap, hipHostMallocDefault));
+    b.cap = ncap;
+    return SC_OK;
+}
+
+static bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// rows x row_bytes from caller memory (pitch hpitch) to device memory (pitch dpitch).
+// Pageable sources are packed into the instance's pinned staging first.
+static int upload_rows(Instance *I, DevBuf &stage, void *d, size_t dpitch, const uint8_t *h, size_t hpitch,
+                       size_t row_bytes, int rows)
+{
+    if (rows <= 0 || row_bytes == 0) return SC_OK;
+    if (is_pinned(h)) {
+        SC_HIP(I, hipMemcpy2DAsync(d, dpitch, h, hpitch, row_bytes, rows, hipMemcpyHostToDevice, I->stream));
+        return SC_OK;
+    }
+    int rc = ensure_pinned(I, stage, row_bytes * (size_t)rows);
+    if (rc) return rc;
+    uint8_t *s = (uint8_t *)stage.p;
+    if (hpitch == row_bytes) memcpy(s, h, row_bytes * (size_t)rows);
+    else for (int y = 0; y < rows; ++y) memcpy(s + (size_t)y * row_bytes, h + (size_t)y * hpitch, row_bytes);
+    SC_HIP(I, hipMemcpy2DAsync(d, dpitch, s, row_bytes, row_bytes, rows, hipMemcpyHostToDevice, I->stream));
+    return SC_OK;
+}
+
 static Field make_field(void *p, int W, int H, int C)
 {
     Field f;
@@ -199,6 +240,7 @@ void *my_seamlessclone_api_imp_create_instance(int gpu_id)
     ok = ok && hipMalloc((void **)&I->d_red, 2 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_maxcorr, sizeof(unsigned)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_maxcorr, sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
+    ok = ok && mg_bottom_prepare() == hipSuccess;   // opt in to >64 KiB dynamic LDS for the bottom kernel
     for (int i = 0; ok && i < 8; ++i) ok = hipEventCreate(&I->ev[i]) == hipSuccess;
     ok = ok && hipEventCreate(&I->ev_k0) == hipSuccess && hipEventCreate(&I->ev_k1) == hipSuccess;
     if (!ok) {
@@ -227,6 +269,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->h_maxcorr) (void)hipHostFree(I->h_maxcorr);
     if (I->h_rect) (void)hipHostFree(I->h_rect);
     if (I->h_red) (void)hipHostFree(I->h_red);
+    for (DevBuf *b : { &I->h_face, &I->h_body, &I->h_mask, &I->h_out }) if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < 8; ++i) if (I->ev[i]) (void)hipEventDestroy(I->ev[i]);
     if (I->ev_k0) (void)hipEventDestroy(I->ev_k0);
     if (I->ev_k1) (void)hipEventDestroy(I->ev_k1);
@@ -355,7 +398,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     const int dms = round_up(mc, 256);
     if ((rc = ensure(I, I->d_mask, (size_t)dms * mr))) return rc;
     SC_HIP(I, hipEventRecord(I->ev[0], I->stream));
-    SC_HIP(I, hipMemcpy2DAsync(I->d_mask.p, dms, mask, ms, mc, mr, hipMemcpyHostToDevice, I->stream));
+    if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
     SC_HIP(I, hipEventRecord(I->ev[1], I->stream));
     Geo g;
     if ((rc = device_bbox(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, cx, cy, g))) return rc;
@@ -365,31 +408,35 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     const int dfs = round_up(3 * g.W, 256);
     if ((rc = ensure(I, I->d_face, (size_t)dfs * g.H))) return rc;
     if ((rc = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return rc;
-    SC_HIP(I, hipMemcpy2DAsync(I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H,
-                               hipMemcpyHostToDevice, I->stream));
-    SC_HIP(I, hipMemcpy2DAsync(I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H,
-                               hipMemcpyHostToDevice, I->stream));
+    if ((rc = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return rc;
+    if ((rc = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return rc;
     SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
     const int passes = I->opts.reference_warmup ? 2 : 1;
     rc = device_clone(I, (const uint8_t *)I->d_mask.p, dms, (const uint8_t *)I->d_face.p, dfs,
                       (uint8_t *)I->d_body_roi.p, dfs, g, passes);
     if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
-    // --- interior straight into the caller's image
-    if (g.W > 2 && g.H > 2)
-        SC_HIP(I, hipMemcpy2DAsync(body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1), bs,
-                                   (const uint8_t *)I->d_body_roi.p + dfs + 3, dfs, 3 * (size_t)(g.W - 2), g.H - 2,
-                                   hipMemcpyDeviceToHost, I->stream));
-    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
-    bool must_sync = bSync;
-    if (!must_sync) {
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, body) != hipSuccess || attr.type != hipMemoryTypeHost) {
-            (void)hipGetLastError();
-            must_sync = true; // pageable destination: complete before returning
+    // --- interior back into the caller's image: pinned destinations receive the DMA directly,
+    //     pageable ones go through the pinned staging and a row-wise memcpy
+    const size_t ob = 3 * (size_t)(g.W - 2);
+    const int orows = g.H - 2;
+    uint8_t *dst_org = body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1);
+    const bool body_pinned = is_pinned(body);
+    if (orows > 0 && ob > 0) {
+        if (body_pinned) {
+            SC_HIP(I, hipMemcpy2DAsync(dst_org, bs, (const uint8_t *)I->d_body_roi.p + dfs + 3, dfs, ob, orows,
+                                       hipMemcpyDeviceToHost, I->stream));
+        } else {
+            int prc = ensure_pinned(I, I->h_out, ob * (size_t)orows);
+            if (prc) return prc;
+            SC_HIP(I, hipMemcpy2DAsync(I->h_out.p, ob, (const uint8_t *)I->d_body_roi.p + dfs + 3, dfs, ob, orows,
+                                       hipMemcpyDeviceToHost, I->stream));
         }
     }
-    if (must_sync) {
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    if (bSync || !body_pinned) {
         SC_HIP(I, hipStreamSynchronize(I->stream));
+        if (!body_pinned)
+            for (int y = 0; y < orows; ++y) memcpy(dst_org + (size_t)y * bs, (const uint8_t *)I->h_out.p + (size_t)y * ob, ob);
         finish_timing(I, true);
     }
     return rc;

@@ -45,6 +45,12 @@ void launch_rb_half(Field U, Field F, int color, float omega, hipStream_t s);
 bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s);
 bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipStream_t s);
 int  tb_max_depth(int method);
+struct MGGeom;
+constexpr int TBM_PLAIN = 0, TBM_PROLONG = 1, TBM_ZEROIN = 4;   // mode of launch_rb_tb_gen
+bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s);
+int  launch_rb_tb_prolong0(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, Field E, float *partial, hipStream_t s);
+int  tb_blocks_level0(int W, int H, int C, int sweeps);
+void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_t s);
 
 // residual: d_out[0] = sum r^2, d_out[1] = sum lap^2 (double); d_partials holds >= 2*max_blocks doubles
 int  residual_max_blocks();
@@ -68,19 +74,22 @@ struct MGGeom { MGDim x, y; };
 void launch_rb_half_gen(Field U, Field F, int color, float omega, MGGeom g, hipStream_t s);
 void launch_residual_field(Field U, Field F, Field R, MGGeom g, hipStream_t s); // R = F - A U (double arithmetic)
 void launch_restrict(Field R, Field Fc, MGGeom g, hipStream_t s);               // Fc = 4 * normalised P^T R
+void launch_residual_restrict(Field U, Field F, Field Fc, MGGeom g, hipStream_t s); // both, fused (no residual field)
 int  prolong_blocks(int nx, int ny, int C);
 // Uf += P Uc; with d_partial (>= prolong_blocks floats) also *d_maxcorr = bits of max |P Uc|
 void launch_prolong_add(Field Uc, Field Uf, MGGeom g, float *d_partial, unsigned *d_maxcorr, hipStream_t s);
 void launch_fill_zero(Field U, hipStream_t s);
 
-// bottom of the V-cycle fused into one launch (one workgroup per channel)
+// bottom of the V-cycle fused into one launch (one workgroup per channel, levels LDS resident)
 constexpr int MG_BOTTOM_MAX_LEVELS = 12;
-constexpr int MG_BOTTOM_POINTS = 128 * 128;   // levels with <= this many unknowns per plane go to the bottom kernel
-struct MGBottomLevel { Field U, F, T; MGGeom g; float omega; };
+constexpr int MG_BOTTOM_LDS_BYTES = 152 * 1024;   // of the CU's 160 KiB
+struct MGBottomLevel { MGGeom g; float omega; int offU, offF, pitch; };   // LDS offsets / row pitch in floats
 struct MGBottomArgs {
-    int nlevels, pre, post, coarse_sweeps;
+    int nlevels, pre, post, coarse_sweeps, lds_floats;
+    Field Ftop, Utop;       // HBM planes of the first bottom level: RHS in, correction out
     MGBottomLevel lv[MG_BOTTOM_MAX_LEVELS];
 };
+hipError_t mg_bottom_prepare();
 void launch_mg_bottom(const MGBottomArgs &a, int C, hipStream_t s);
 
 } // namespace sc

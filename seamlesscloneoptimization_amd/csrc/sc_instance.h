@@ -29,6 +29,9 @@ struct Instance {
 
     // staging copies for host-pointer runs
     DevBuf d_face, d_body_roi, d_mask;
+    // page-locked host staging (grow-only): pageable caller images are packed here row by row so
+    // each image crosses PCIe as ONE DMA instead of one slow pageable 2-D copy
+    DevBuf h_face, h_body, h_mask, h_out;
     // ROI mask after 3x erode
     DevBuf d_M;
     int mpitch = 0;

@@ -44,20 +44,45 @@ __device__ __forceinline__ double wave_sum_d(double v)
 // global atomics, :927-963).  Here: per-lane scan of BB_ROWS rows, wave64 shuffle reduction,
 // LDS across the 4 waves, one set of 4 global atomics per block that saw a set pixel.
 // rect = {x_min, x_max, y_min, y_max}, host-seeded with {mw-1, 0, mh-1, 0} (:1006).
-constexpr int BB_ROWS = 16;
+// Each lane scans 16-byte chunks (uint4 loads from the 16-B aligned address at or below the
+// row start; bytes outside [1, mw-2] are masked off) of BB_ROWS rows, so a 2050^2 mask is read
+// by ~200 workgroups with 8 independent 16-B loads in flight per lane.
+constexpr int BB_ROWS = 8;
+
+__device__ __forceinline__ unsigned nonzero_bytes(unsigned w)
+{
+    return (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u; // bit 7 of every non-zero byte
+}
 
 __global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
                                                    int *__restrict__ rect)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int yb = blockIdx.y * BB_ROWS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x * 64 + lane;
+    const int yb = (blockIdx.y * 4 + wave) * BB_ROWS;
     int minx = INT_MAX, maxx = -1, miny = INT_MAX, maxy = -1;
-    if (x >= 1 && x < mw - 1) {
-#pragma unroll 4
-        for (int r = 0; r < BB_ROWS; ++r) {
-            const int y = yb + r;
-            if (y >= 1 && y < mh - 1 && mask[(size_t)y * mstep + x] != 0) {
-                minx = x; maxx = x;
+#pragma unroll
+    for (int r = 0; r < BB_ROWS; ++r) {
+        const int y = yb + r;
+        if (y < 1 || y >= mh - 1) continue;
+        const uint8_t *row = mask + (size_t)y * mstep;
+        const int a0 = (int)((uintptr_t)row & 15);
+        const int xb = chunk * 16 - a0;               // x of byte 0 of this chunk
+        if (xb >= mw - 1 || xb + 15 < 1) continue;
+        const uint4 v = *reinterpret_cast<const uint4 *>(row + xb);
+        const unsigned w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned m = nonzero_bytes(w[k]);
+            const int x0 = xb + 4 * k;
+            if (x0 < 1 || x0 + 3 > mw - 2) {          // partial dword at the row ends: drop invalid bytes
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (x0 + b < 1 || x0 + b > mw - 2) m &= ~(0x80u << (8 * b));
+            }
+            if (m) {
+                const int lo = x0 + ((__ffs((int)m) - 1) >> 3), hi = x0 + ((31 - __clz((int)m)) >> 3);
+                minx = min(minx, lo); maxx = max(maxx, hi);
                 miny = min(miny, y); maxy = max(maxy, y);
             }
         }
@@ -65,7 +90,6 @@ __global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ m
     minx = wave_min_i(minx); maxx = wave_max_i(maxx);
     miny = wave_min_i(miny); maxy = wave_max_i(maxy);
     __shared__ int red[4][4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) { red[wave][0] = minx; red[wave][1] = maxx; red[wave][2] = miny; red[wave][3] = maxy; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -82,7 +106,8 @@ __global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ m
 
 void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s)
 {
-    dim3 grid((mw + 255) / 256, (mh + BB_ROWS - 1) / BB_ROWS);
+    const int chunks = (mw + 15 + 15) / 16;   // +15: a row may start up to 15 bytes into its first chunk
+    dim3 grid((chunks + 63) / 64, (mh + 4 * BB_ROWS - 1) / (4 * BB_ROWS));
     hipLaunchKernelGGL(k_mask_bbox, grid, dim3(256), 0, s, mask, mw, mh, mstep, d_rect);
 }
 
@@ -141,51 +166,97 @@ void launch_mask_erode3(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int m
 // (:1937,:1940,:1944,:1947) only feed gdX/gdY at the last column/row, which no interior
 // divergence reads, so they vanish here.
 // ------------------------------------------------------------------------------------------
+// Tile = 64 x 16 pixels per 256-thread block.  The interleaved u8 rows of both images (tile +
+// 1-px halo, 198 bytes per row) are staged in LDS with aligned dword loads -- the ROI origin has
+// arbitrary byte alignment -- and every pixel then reads its 5-point neighbourhood as LDS bytes;
+// the three float fields are written with lane-contiguous (coalesced) stores.
+constexpr int PP_TW = 64, PP_TH = 16;
+constexpr int PP_ROWB = 3 * (PP_TW + 2) + 6;            // bytes kept per staged row (+ alignment slack)
+constexpr int PP_ROWD = (PP_ROWB + 3) / 4;              // dwords per staged row
+
+__device__ __forceinline__ void pp_stage(const uint8_t *__restrict__ img, int step, int W, int H, int tx0, int ty0,
+                                         unsigned (*sm)[PP_ROWD], int *org)
+{
+    // row ry of the tile holds image row ty0-1+ry; its LDS byte 0 is the 4-B aligned address at or
+    // below pixel (tx0-1).  Only dwords that contain a byte of a pixel inside [0,W) are loaded.
+    for (int i = threadIdx.x; i < (PP_TH + 2) * PP_ROWD; i += 256) {
+        const int ry = i / PP_ROWD, k = i - ry * PP_ROWD;
+        const int y = ty0 - 1 + ry;
+        unsigned v = 0;
+        int a = 0;
+        if (y >= 0 && y < H) {
+            const uint8_t *row = img + (size_t)y * step;
+            const uint8_t *first = row + 3 * (tx0 - 1);
+            a = (int)((uintptr_t)first & 3);
+            const uint8_t *p = first - a + 4 * k;               // aligned dword k of this row
+            if (p + 3 >= row && p < row + 3 * W) v = *reinterpret_cast<const unsigned *>(p);
+        }
+        if (k == 0) org[ry] = a;
+        sm[ry][k] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ body, int bstep,
                                                     const uint8_t *__restrict__ face, int fstep,
                                                     const uint8_t *__restrict__ M, int mpitch,
                                                     Field U0, Field U1, Field F)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ unsigned sb[PP_TH + 2][PP_ROWD], sp[PP_TH + 2][PP_ROWD];
+    __shared__ int ob[PP_TH + 2], op[PP_TH + 2];
     const int W = U0.W, H = U0.H;
-    if (x >= W || y >= H) return;
-    const uint8_t *b = body + (size_t)y * bstep + 3 * x;
-    const uint8_t *p = face + (size_t)y * fstep + 3 * x;
-    const bool interior = (x >= 1) && (x <= W - 2) && (y >= 1) && (y <= H - 2);
-    float m = 0.f, ml = 0.f, mu = 0.f;
-    if (interior) {
-        const uint8_t *mp = M + (size_t)y * mpitch + x;
-        m = (float)mp[0] * (1.0f / 255.0f);
-        ml = (float)mp[-1] * (1.0f / 255.0f);
-        mu = (float)mp[-mpitch] * (1.0f / 255.0f);
-    }
-    const size_t o = (size_t)y * U0.pitch + x;
+    const int tx0 = blockIdx.x * PP_TW, ty0 = blockIdx.y * PP_TH;
+    pp_stage(body, bstep, W, H, tx0, ty0, sb, ob);
+    pp_stage(face, fstep, W, H, tx0, ty0, sp, op);
+    __syncthreads();
+    const int lx = threadIdx.x & 63, x = tx0 + lx;
+    if (x >= W) return;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float b0 = (float)b[c];
-        float lap = 0.0f;
+    for (int k = 0; k < PP_TH / 4; ++k) {
+        const int ly = (threadIdx.x >> 6) + 4 * k, y = ty0 + ly;
+        if (y >= H) break;
+        const int ry = ly + 1;                                  // tile row of y
+        // byte offsets of pixel x in rows y-1, y, y+1 of both staged tiles
+        const uint8_t *bu = reinterpret_cast<const uint8_t *>(sb[ry - 1]) + ob[ry - 1] + 3 * (lx + 1);
+        const uint8_t *b0 = reinterpret_cast<const uint8_t *>(sb[ry]) + ob[ry] + 3 * (lx + 1);
+        const uint8_t *bd = reinterpret_cast<const uint8_t *>(sb[ry + 1]) + ob[ry + 1] + 3 * (lx + 1);
+        const uint8_t *pu = reinterpret_cast<const uint8_t *>(sp[ry - 1]) + op[ry - 1] + 3 * (lx + 1);
+        const uint8_t *p0 = reinterpret_cast<const uint8_t *>(sp[ry]) + op[ry] + 3 * (lx + 1);
+        const uint8_t *pd = reinterpret_cast<const uint8_t *>(sp[ry + 1]) + op[ry + 1] + 3 * (lx + 1);
+        const bool interior = (x >= 1) && (x <= W - 2) && (y >= 1) && (y <= H - 2);
+        float m = 0.f, ml = 0.f, mu = 0.f;
         if (interior) {
-            const float bl = (float)b[c - 3], br = (float)b[c + 3];
-            const float bu = (float)b[c - bstep], bd = (float)b[c + bstep];
-            const float p0 = (float)p[c], pl = (float)p[c - 3], pr = (float)p[c + 3];
-            const float pu = (float)p[c - fstep], pd = (float)p[c + fstep];
-            const float gx = (1.0f - m) * (br - b0) + m * (pr - p0);
-            const float gxl = (1.0f - ml) * (b0 - bl) + ml * (p0 - pl);
-            const float gy = (1.0f - m) * (bd - b0) + m * (pd - p0);
-            const float gyu = (1.0f - mu) * (b0 - bu) + mu * (p0 - pu);
-            lap = (gx - gxl) + (gy - gyu);
+            const uint8_t *mp = M + (size_t)y * mpitch + x;
+            m = (float)mp[0] * (1.0f / 255.0f);
+            ml = (float)mp[-1] * (1.0f / 255.0f);
+            mu = (float)mp[-mpitch] * (1.0f / 255.0f);
         }
-        U0.at(c)[o] = b0;
-        U1.at(c)[o] = b0;
-        F.at(c)[o] = lap;
+        const size_t o = (size_t)y * U0.pitch + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float bc = (float)b0[c];
+            float lap = 0.0f;
+            if (interior) {
+                const float bl = (float)b0[c - 3], br = (float)b0[c + 3];
+                const float bup = (float)bu[c], bdn = (float)bd[c];
+                const float pc = (float)p0[c], pl = (float)p0[c - 3], pr = (float)p0[c + 3];
+                const float pup = (float)pu[c], pdn = (float)pd[c];
+                const float gx = (1.0f - m) * (br - bc) + m * (pr - pc);
+                const float gxl = (1.0f - ml) * (bc - bl) + ml * (pc - pl);
+                const float gy = (1.0f - m) * (bdn - bc) + m * (pdn - pc);
+                const float gyu = (1.0f - mu) * (bc - bup) + mu * (pc - pup);
+                lap = (gx - gxl) + (gy - gyu);
+            }
+            U0.at(c)[o] = bc;
+            U1.at(c)[o] = bc;
+            F.at(c)[o] = lap;
+        }
     }
 }
 
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s)
 {
-    dim3 grid((U0.W + 63) / 64, (U0.H + 3) / 4);
+    dim3 grid((U0.W + PP_TW - 1) / PP_TW, (U0.H + PP_TH - 1) / PP_TH);
     hipLaunchKernelGGL(k_preprocess, grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
 }
 

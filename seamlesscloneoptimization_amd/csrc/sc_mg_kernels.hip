@@ -7,6 +7,7 @@
 // (seamlessClone_imp.cpp:1814-1896).  The multigrid converges to that system's solution for
 // any ROI size; its components are checked against oracle/mg_np.py.
 #include "sc_common.h"
+#include "sc_mg_device.h"
 
 namespace sc {
 
@@ -106,13 +107,6 @@ void launch_residual_field(Field U, Field F, Field R, MGGeom g, hipStream_t s)
 // ---- restriction: Fc = 4 * (row-normalised transpose of the interpolation) applied to R ----
 // Coarse point I gathers fine points 2I-1, 2I, 2I+1 with weights 1/2, 1, 1/2; the last coarse
 // point takes the (up to two) tail points with their interpolation weights instead.
-__device__ __forceinline__ void restrict_weights(const MGDim &d, int I, float w[4], float &inv)
-{
-    w[0] = 0.5f; w[1] = 1.0f;
-    if (I < d.nc) { w[2] = 0.5f; w[3] = 0.0f; inv = 0.5f; }
-    else          { w[2] = d.tw1; w[3] = d.tw2; inv = d.inv_last; }
-}
-
 __global__ __launch_bounds__(256) void k_restrict(Field R, Field Fc, MGGeom g)
 {
     const int I = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
@@ -147,18 +141,74 @@ void launch_restrict(Field R, Field Fc, MGGeom g, hipStream_t s)
     hipLaunchKernelGGL(k_restrict, grid, dim3(256), 0, s, R, Fc, g);
 }
 
-// ---- prolongation + correction: Uf += P Uc on the fine interior ------------------------------
-__device__ __forceinline__ void interp_1d(const MGDim &d, int i, int &I0, int &I1, float &w0, float &w1)
+// ---- fused residual + restriction (one pass over U and F, no residual field in HBM) ---------
+// Coarse tile 64 x 8 per 256-thread block.  Phase 1 stages the fine U tile (+1 halo) in LDS with
+// aligned float4 loads; phase 2 forms the fine residuals (double arithmetic) into a second LDS
+// tile, reading F straight from HBM exactly once; phase 3 applies the normalised transposed
+// interpolation.  Replaces k_residual_field + k_restrict (which wrote and re-read a full field).
+constexpr int RR_CW = 64, RR_CH = 8;
+constexpr int RR_FW = 2 * RR_CW + 8, RR_FH = 2 * RR_CH + 4;   // 136 x 20 fine values
+
+__global__ __launch_bounds__(256) void k_residual_restrict(Field U, Field F, Field Fc, MGGeom g)
 {
-    if (i <= 2 * d.nc) {
-        if ((i & 1) == 0) { I0 = i >> 1; I1 = I0; w0 = 1.0f; w1 = 0.0f; }
-        else { I0 = (i - 1) >> 1; I1 = I0 + 1; w0 = 0.5f; w1 = 0.5f; }
-    } else {
-        I0 = d.nc; I1 = d.nc; w1 = 0.0f;
-        w0 = (i - 2 * d.nc == 1) ? d.tw1 : d.tw2;
+    __shared__ __attribute__((aligned(16))) float su[RR_FH][RR_FW];
+    __shared__ float sr[RR_FH][RR_FW];
+    const int c = blockIdx.z;
+    const int I0 = blockIdx.x * RR_CW, J0 = blockIdx.y * RR_CH;   // coarse points I0+1.., J0+1..
+    const int XS = 2 * I0, YS = 2 * J0;                             // fine origin of the tiles
+    const int H = U.H, P = U.pitch;
+    const float *__restrict__ u = U.at(c);
+    for (int i = threadIdx.x; i < RR_FH * (RR_FW / 4); i += 256) {
+        const int ry = i / (RR_FW / 4), q = i - ry * (RR_FW / 4);
+        const int y = YS + ry, x = XS + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < H && x < P) v = *reinterpret_cast<const float4 *>(u + (size_t)y * P + x);
+        *reinterpret_cast<float4 *>(&su[ry][4 * q]) = v;
+    }
+    __syncthreads();
+    const float *__restrict__ f = F.at(c);
+    for (int i = threadIdx.x; i < (RR_FH - 2) * (RR_FW - 6); i += 256) {
+        const int ry = 1 + i / (RR_FW - 6), cx = 1 + (i - (ry - 1) * (RR_FW - 6));
+        const int y = YS + ry, x = XS + cx;
+        float res = 0.f;
+        if (x <= g.x.n && y <= g.y.n) {
+            const double cw = (x == g.x.n) ? (double)g.x.cw_last : 1.0, dx = (x == g.x.n) ? (double)g.x.d_last : 2.0;
+            const double cn = (y == g.y.n) ? (double)g.y.cw_last : 1.0, dy = (y == g.y.n) ? (double)g.y.d_last : 2.0;
+            const double s = ((cw * (double)su[ry][cx - 1] + (double)su[ry][cx + 1]) +
+                              (cn * (double)su[ry - 1][cx] + (double)su[ry + 1][cx])) - (dx + dy) * (double)su[ry][cx];
+            res = (float)((double)f[(size_t)y * P + x] - s);
+        }
+        sr[ry][cx] = res;
+    }
+    __syncthreads();
+    const int li = threadIdx.x & 63, lj = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int Jl = lj + 4 * k;
+        const int I = I0 + 1 + li, J = J0 + 1 + Jl;
+        if (I > g.x.nc || J > g.y.nc) continue;
+        float wx[4], wy[4], ix, iy;
+        restrict_weights(g.x, I, wx, ix);
+        restrict_weights(g.y, J, wy, iy);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float rowacc = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rowacc += wx[b] * sr[2 * Jl + 1 + a][2 * li + 1 + b];
+            acc += wy[a] * rowacc;
+        }
+        Fc.at(c)[(size_t)J * Fc.pitch + I] = 4.0f * (acc * (ix * iy));
     }
 }
 
+void launch_residual_restrict(Field U, Field F, Field Fc, MGGeom g, hipStream_t s)
+{
+    dim3 grid((g.x.nc + RR_CW - 1) / RR_CW, (g.y.nc + RR_CH - 1) / RR_CH, U.C);
+    hipLaunchKernelGGL(k_residual_restrict, grid, dim3(256), 0, s, U, F, Fc, g);
+}
+
+// ---- prolongation + correction: Uf += P Uc on the fine interior ------------------------------
 // Thread = 4 consecutive fine points of one row (float4 read-modify-write of Uf).  With MAXC the
 // largest |correction| of the launch is reduced wave64 shuffle -> LDS -> one plain store per
 // block into `partial`, folded by k_max_final (a single atomic word would serialise ~10^5 waves).
@@ -223,6 +273,11 @@ __global__ __launch_bounds__(256) void k_max_final(const float *__restrict__ par
     if (threadIdx.x == 0) *out = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
+void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, s, d_partial, n, d_out);
+}
+
 int prolong_blocks(int nx, int ny, int C) { return ((nx + 1 + 255) / 256) * ((ny + 3) / 4) * C; }
 
 void launch_prolong_add(Field Uc, Field Uf, MGGeom g, float *d_partial, unsigned *d_maxcorr, hipStream_t s)
@@ -236,49 +291,46 @@ void launch_prolong_add(Field Uc, Field Uf, MGGeom g, float *d_partial, unsigned
     }
 }
 
-// ---- bottom of the V-cycle in ONE launch -----------------------------------------------------
-// Every level small enough (<= MG_BOTTOM_POINTS unknowns per plane) is processed by a single
-// 1024-thread workgroup per channel: smoothing, residual, restriction, coarsest solve,
-// prolongation and post-smoothing run as block-strided loops separated by __syncthreads(), so
-// the ~100 tiny launches those levels would need collapse into one.  Only this workgroup
-// touches its channel's planes, so workgroup-scope visibility is all that is required.
-__device__ __forceinline__ float gen_gs(const float *__restrict__ u, const float *__restrict__ f, int P, int x, int y,
-                                        const MGGeom &g)
+// ---- bottom of the V-cycle in ONE launch, LDS resident ----------------------------------------
+// Every level from `first` down whose planes fit the CU's LDS together (U and F per level; the
+// residual is formed on the fly inside the restriction) is processed by one 1024-thread
+// workgroup per channel: the top RHS is read from HBM once, all smoothing / restriction /
+// coarsest solve / prolongation runs on LDS with one s_barrier per phase, and only the top
+// correction is written back.  This collapses the ~100 tiny launches those levels would need.
+__device__ __forceinline__ float lds_gs(const float *u, const float *f, int P, int x, int y, const MGGeom &g)
 {
     const float cw = (x == g.x.n) ? g.x.cw_last : 1.0f, dx = (x == g.x.n) ? g.x.d_last : 2.0f;
     const float cn = (y == g.y.n) ? g.y.cw_last : 1.0f, dy = (y == g.y.n) ? g.y.d_last : 2.0f;
-    const float *p = u + (size_t)y * P + x;
-    return (((cw * p[-1] + p[1]) + (cn * p[-P] + p[P])) - f[(size_t)y * P + x]) / (dx + dy);
+    const float *p = u + y * P + x;
+    return (((cw * p[-1] + p[1]) + (cn * p[-P] + p[P])) - f[y * P + x]) / (dx + dy);
 }
 
-__device__ void bt_rb_half(float *u, const float *f, int P, const MGGeom &g, int color, float omega, bool sor)
+__device__ __forceinline__ void lds_rb_half(float *u, const float *f, int P, const MGGeom &g, int color, float omega,
+                                            bool sor)
 {
-    const int hx = (g.x.n + 1) / 2; // colour columns per row (upper bound)
+    const int hx = (g.x.n + 1) / 2;
     for (int i = threadIdx.x; i < hx * g.y.n; i += blockDim.x) {
         const int y = 1 + i / hx;
         const int x = 1 + 2 * (i - (y - 1) * hx) + ((1 + y + color) & 1);
         if (x > g.x.n) continue;
-        const float gs = gen_gs(u, f, P, x, y, g);
-        float *p = u + (size_t)y * P + x;
+        const float gs = lds_gs(u, f, P, x, y, g);
+        float *p = u + y * P + x;
         *p = sor ? (*p + omega * (gs - *p)) : gs;
     }
     __syncthreads();
 }
 
-__device__ void bt_residual(const float *u, const float *f, float *r, int P, const MGGeom &g)
+// residual at one fine point, double arithmetic (see k_residual_field)
+__device__ __forceinline__ float lds_res(const float *u, const float *f, int P, int x, int y, const MGGeom &g)
 {
-    for (int i = threadIdx.x; i < g.x.n * g.y.n; i += blockDim.x) {
-        const int y = 1 + i / g.x.n, x = 1 + (i - (y - 1) * g.x.n);
-        const double cw = (x == g.x.n) ? (double)g.x.cw_last : 1.0, dx = (x == g.x.n) ? (double)g.x.d_last : 2.0;
-        const double cn = (y == g.y.n) ? (double)g.y.cw_last : 1.0, dy = (y == g.y.n) ? (double)g.y.d_last : 2.0;
-        const float *p = u + (size_t)y * P + x;
-        const double s = ((cw * (double)p[-1] + (double)p[1]) + (cn * (double)p[-P] + (double)p[P])) - (dx + dy) * (double)p[0];
-        r[(size_t)y * P + x] = (float)((double)f[(size_t)y * P + x] - s);
-    }
-    __syncthreads();
+    const double cw = (x == g.x.n) ? (double)g.x.cw_last : 1.0, dx = (x == g.x.n) ? (double)g.x.d_last : 2.0;
+    const double cn = (y == g.y.n) ? (double)g.y.cw_last : 1.0, dy = (y == g.y.n) ? (double)g.y.d_last : 2.0;
+    const float *p = u + y * P + x;
+    const double s = ((cw * (double)p[-1] + (double)p[1]) + (cn * (double)p[-P] + (double)p[P])) - (dx + dy) * (double)p[0];
+    return (float)((double)f[y * P + x] - s);
 }
 
-__device__ void bt_restrict_zero(const float *r, int P, float *fc, float *uc, int Pc, const MGGeom &g)
+__device__ __forceinline__ void lds_restrict(const float *u, const float *f, int P, float *fc, int Pc, const MGGeom &g)
 {
     for (int i = threadIdx.x; i < g.x.nc * g.y.nc; i += blockDim.x) {
         const int J = 1 + i / g.x.nc, I = 1 + (i - (J - 1) * g.x.nc);
@@ -295,17 +347,16 @@ __device__ void bt_restrict_zero(const float *r, int P, float *fc, float *uc, in
             for (int b = 0; b < 4; ++b) {
                 const int x = 2 * I - 1 + b;
                 if (wx[b] == 0.f || x > g.x.n) continue;
-                rowacc += wx[b] * r[(size_t)y * P + x];
+                rowacc += wx[b] * lds_res(u, f, P, x, y, g);
             }
             acc += wy[a] * rowacc;
         }
-        fc[(size_t)J * Pc + I] = 4.0f * (acc * (ix * iy));
-        uc[(size_t)J * Pc + I] = 0.f;
+        fc[J * Pc + I] = 4.0f * (acc * (ix * iy));
     }
     __syncthreads();
 }
 
-__device__ void bt_prolong(const float *e, int Pc, float *u, int P, const MGGeom &g)
+__device__ __forceinline__ void lds_prolong(const float *e, int Pc, float *u, int P, const MGGeom &g)
 {
     for (int i = threadIdx.x; i < g.x.n * g.y.n; i += blockDim.x) {
         const int y = 1 + i / g.x.n, x = 1 + (i - (y - 1) * g.x.n);
@@ -313,61 +364,75 @@ __device__ void bt_prolong(const float *e, int Pc, float *u, int P, const MGGeom
         float wx0, wx1, wy0, wy1;
         interp_1d(g.x, x, I0, I1, wx0, wx1);
         interp_1d(g.y, y, J0, J1, wy0, wy1);
-        const float top = wx0 * e[(size_t)J0 * Pc + I0] + wx1 * e[(size_t)J0 * Pc + I1];
-        const float bot = wx0 * e[(size_t)J1 * Pc + I0] + wx1 * e[(size_t)J1 * Pc + I1];
-        float *p = u + (size_t)y * P + x;
-        *p = *p + (wy0 * top + wy1 * bot);
+        const float top = wx0 * e[J0 * Pc + I0] + wx1 * e[J0 * Pc + I1];
+        const float bot = wx0 * e[J1 * Pc + I0] + wx1 * e[J1 * Pc + I1];
+        u[y * P + x] += wy0 * top + wy1 * bot;
     }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int c = blockIdx.x;
     const int L = a.nlevels;
-    // the top bottom-level correction starts from zero (interior only; ring/pads are zero already)
-    {
+    for (int i = threadIdx.x; i < a.lds_floats; i += blockDim.x) lds[i] = 0.f;   // zero corrections, rings, pads
+    __syncthreads();
+    {   // top RHS: HBM -> LDS
         const MGBottomLevel &t = a.lv[0];
-        float *u = t.U.at(c);
+        const float *__restrict__ fg = a.Ftop.at(c);
+        float *f = lds + t.offF;
         for (int i = threadIdx.x; i < t.g.x.n * t.g.y.n; i += blockDim.x) {
             const int y = 1 + i / t.g.x.n, x = 1 + (i - (y - 1) * t.g.x.n);
-            u[(size_t)y * t.U.pitch + x] = 0.f;
+            f[y * t.pitch + x] = fg[(size_t)y * a.Ftop.pitch + x];
         }
         __syncthreads();
     }
     for (int l = 0; l + 1 < L; ++l) {
         const MGBottomLevel &v = a.lv[l];
         const MGBottomLevel &w = a.lv[l + 1];
-        float *u = v.U.at(c);
-        const float *f = v.F.at(c);
         for (int s = 0; s < a.pre; ++s) {
-            bt_rb_half(u, f, v.U.pitch, v.g, 0, 1.0f, false);
-            bt_rb_half(u, f, v.U.pitch, v.g, 1, 1.0f, false);
+            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, 1.0f, false);
+            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, 1.0f, false);
         }
-        bt_residual(u, f, v.T.at(c), v.U.pitch, v.g);
-        bt_restrict_zero(v.T.at(c), v.U.pitch, w.F.at(c), w.U.at(c), w.U.pitch, v.g);
+        lds_restrict(lds + v.offU, lds + v.offF, v.pitch, lds + w.offF, w.pitch, v.g);
     }
     {
         const MGBottomLevel &v = a.lv[L - 1];
         for (int s = 0; s < a.coarse_sweeps; ++s) {
-            bt_rb_half(v.U.at(c), v.F.at(c), v.U.pitch, v.g, 0, v.omega, true);
-            bt_rb_half(v.U.at(c), v.F.at(c), v.U.pitch, v.g, 1, v.omega, true);
+            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, v.omega, true);
+            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, v.omega, true);
         }
     }
     for (int l = L - 2; l >= 0; --l) {
         const MGBottomLevel &v = a.lv[l];
         const MGBottomLevel &w = a.lv[l + 1];
-        bt_prolong(w.U.at(c), w.U.pitch, v.U.at(c), v.U.pitch, v.g);
+        lds_prolong(lds + w.offU, w.pitch, lds + v.offU, v.pitch, v.g);
         for (int s = 0; s < a.post; ++s) {
-            bt_rb_half(v.U.at(c), v.F.at(c), v.U.pitch, v.g, 0, 1.0f, false);
-            bt_rb_half(v.U.at(c), v.F.at(c), v.U.pitch, v.g, 1, 1.0f, false);
+            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, 1.0f, false);
+            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, 1.0f, false);
+        }
+    }
+    {   // top correction: LDS -> HBM (interior; ring and pads of the global plane stay zero)
+        const MGBottomLevel &t = a.lv[0];
+        float *__restrict__ ug = a.Utop.at(c);
+        const float *u = lds + t.offU;
+        for (int i = threadIdx.x; i < t.g.x.n * t.g.y.n; i += blockDim.x) {
+            const int y = 1 + i / t.g.x.n, x = 1 + (i - (y - 1) * t.g.x.n);
+            ug[(size_t)y * a.Utop.pitch + x] = u[y * t.pitch + x];
         }
     }
 }
 
+hipError_t mg_bottom_prepare()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_mg_bottom), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               MG_BOTTOM_LDS_BYTES);
+}
+
 void launch_mg_bottom(const MGBottomArgs &a, int C, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mg_bottom, dim3(C), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_mg_bottom, dim3(C), dim3(1024), (size_t)a.lds_floats * sizeof(float), s, a);
 }
 
 } // namespace sc

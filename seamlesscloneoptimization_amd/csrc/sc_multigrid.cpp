@@ -41,12 +41,20 @@ static Field level_field(void *p, int W, int H, int C)
     return f;
 }
 
-// first level handled by the fused bottom kernel (never level 0: it uses the exact kernels)
+// LDS floats level l needs inside the bottom kernel: U and F planes, odd row pitch
+static int bottom_pitch(const MGLevel &L) { return (L.g.x.n + 2) | 1; }
+static long bottom_floats(const MGLevel &L) { return 2L * bottom_pitch(L) * (L.g.y.n + 2); }
+
+// first level handled by the fused bottom kernel: the first l >= 1 from which all remaining
+// levels fit the LDS budget together (never level 0: it runs the exact kernels)
 static size_t bottom_start(Instance *I)
 {
-    for (size_t l = 1; l < I->mg.size(); ++l)
-        if ((long)I->mg[l].g.x.n * I->mg[l].g.y.n <= MG_BOTTOM_POINTS && I->mg.size() - l <= MG_BOTTOM_MAX_LEVELS)
-            return l;
+    for (size_t l = 1; l < I->mg.size(); ++l) {
+        if (I->mg.size() - l > (size_t)MG_BOTTOM_MAX_LEVELS) continue;
+        long tot = 0;
+        for (size_t k = l; k < I->mg.size(); ++k) tot += bottom_floats(I->mg[k]);
+        if (tot * (long)sizeof(float) <= (long)MG_BOTTOM_LDS_BYTES) return l;
+    }
     return I->mg.size();
 }
 
@@ -57,10 +65,18 @@ static int run_bottom(Instance *I, size_t l0, int pre, int post)
     a.pre = pre; a.post = post;
     const MGLevel &last = I->mg.back();
     a.coarse_sweeps = std::max(8, std::min(64, 2 * std::max(last.g.x.n, last.g.y.n)));
+    int off = 0;
     for (int i = 0; i < a.nlevels; ++i) {
         const MGLevel &L = I->mg[l0 + i];
-        a.lv[i].U = L.U; a.lv[i].F = L.F; a.lv[i].T = L.T; a.lv[i].g = L.g; a.lv[i].omega = L.omega;
+        a.lv[i].g = L.g; a.lv[i].omega = L.omega;
+        a.lv[i].pitch = bottom_pitch(L);
+        const int plane = a.lv[i].pitch * (L.g.y.n + 2);
+        a.lv[i].offU = off; a.lv[i].offF = off + plane;
+        off += 2 * plane;
     }
+    a.lds_floats = off;
+    a.Ftop = I->mg[l0].F;
+    a.Utop = I->mg[l0].U;
     launch_mg_bottom(a, I->F.C, I->stream);
     return SC_OK;
 }
@@ -112,12 +128,22 @@ static int build_levels(Instance *I)
     return SC_OK;
 }
 
-static int smooth(Instance *I, size_t l, int n)
+// Smoothing of a coarse level (l >= 1) with the fused general kernel; U <-> T ping-pong, both
+// carry zero rings.  mode (first launch only): TBM_ZEROIN = the current correction is all zero
+// (nothing is read), TBM_PROLONG = add the interpolated correction of level l+1 while loading.
+static int smooth_gen(Instance *I, size_t l, int n, int mode, Field E)
 {
-    if (n <= 0) return SC_OK;
-    if (l == 0) return run_sweeps(I, SC_METHOD_RBGS, n, 1.0f, I->opts.sweeps_per_launch);
     MGLevel &L = I->mg[l];
-    for (int s = 0; s < n; ++s) {
+    int left = n;
+    while (left > 0) {
+        const int T = std::min(2, left);
+        if (!launch_rb_tb_gen(L.U, L.T, L.F, T, L.g, mode, E, I->stream)) break;
+        std::swap(L.U, L.T);
+        mode = TBM_PLAIN;
+        left -= T;
+    }
+    if (left > 0 && mode != TBM_PLAIN) return SC_ERR_BAD_ARG; // cannot happen: depths 1 and 2 always exist
+    for (int s = 0; s < left; ++s) {
         launch_rb_half_gen(L.U, L.F, 0, 1.0f, L.g, I->stream);
         launch_rb_half_gen(L.U, L.F, 1, 1.0f, L.g, I->stream);
     }
@@ -129,27 +155,51 @@ static int vcycle(Instance *I, size_t l, int pre, int post)
     MGLevel &L = I->mg[l];
     int rc;
     if (l > 0 && l == I->mg_bottom) return run_bottom(I, l, pre, post);
-    if (l + 1 == I->mg.size()) { // coarsest: SOR with the level's optimal factor
+    if (l + 1 == I->mg.size()) { // coarsest level outside the bottom kernel: SOR with its optimal factor
         const int n = std::max(8, std::min(64, 2 * std::max(L.g.x.n, L.g.y.n)));
         if (l == 0) return run_sweeps(I, SC_METHOD_SOR, n, L.omega, 1);
+        launch_fill_zero(L.U, I->stream);
         for (int s = 0; s < n; ++s) {
             launch_rb_half_gen(L.U, L.F, 0, L.omega, L.g, I->stream);
             launch_rb_half_gen(L.U, L.F, 1, L.omega, L.g, I->stream);
         }
         return SC_OK;
     }
-    if ((rc = smooth(I, l, pre))) return rc;
     MGLevel &Lc = I->mg[l + 1];
-    Field Ul = (l == 0) ? result(I) : L.U;
-    Field Tl = (l == 0) ? (I->result_in_U1 ? I->U0 : I->U1) : L.T;
-    launch_residual_field(Ul, L.F, Tl, L.g, I->stream);
-    launch_restrict(Tl, Lc.F, L.g, I->stream);
-    if (l + 1 != I->mg_bottom) launch_fill_zero(Lc.U, I->stream); // the bottom kernel zeroes its own top level
+    // ---- pre-smoothing (levels >= 1 start from a zero correction)
+    if (l == 0) {
+        if ((rc = run_sweeps(I, SC_METHOD_RBGS, pre, 1.0f, I->opts.sweeps_per_launch))) return rc;
+    } else if (pre > 0) {
+        if ((rc = smooth_gen(I, l, pre, TBM_ZEROIN, Field{}))) return rc;
+    } else {
+        launch_fill_zero(L.U, I->stream);
+    }
+    // ---- residual + restriction in one pass, coarse problem
+    launch_residual_restrict(l == 0 ? result(I) : L.U, L.F, Lc.F, L.g, I->stream);
     if ((rc = vcycle(I, l + 1, pre, post))) return rc;
-    Ul = (l == 0) ? result(I) : L.U;
-    launch_prolong_add(Lc.U, Ul, L.g, l == 0 ? (float *)I->mg_partial.p : nullptr, l == 0 ? I->d_maxcorr : nullptr,
-                       I->stream);
-    if ((rc = smooth(I, l, post))) return rc;
+    // ---- prolongation fused into the first post-smoothing launch
+    if (l == 0) {
+        const int T = std::min(2, post);
+        int nb = 0;
+        if (T > 0 && I->opts.sweeps_per_launch != 1) {
+            Field &in = result(I);
+            Field &out = I->result_in_U1 ? I->U0 : I->U1;
+            nb = launch_rb_tb_prolong0(in, out, I->F, T, L.g, Lc.U, (float *)I->mg_partial.p, I->stream);
+        }
+        if (nb > 0) {
+            I->result_in_U1 = !I->result_in_U1;
+            I->info.sweep_launches += 1;
+            launch_max_final((const float *)I->mg_partial.p, nb, I->d_maxcorr, I->stream);
+            if ((rc = run_sweeps(I, SC_METHOD_RBGS, post - T, 1.0f, I->opts.sweeps_per_launch))) return rc;
+        } else {
+            launch_prolong_add(Lc.U, result(I), L.g, (float *)I->mg_partial.p, I->d_maxcorr, I->stream);
+            if ((rc = run_sweeps(I, SC_METHOD_RBGS, post, 1.0f, I->opts.sweeps_per_launch))) return rc;
+        }
+    } else if (post > 0) {
+        if ((rc = smooth_gen(I, l, post, TBM_PROLONG, Lc.U))) return rc;
+    } else {
+        launch_prolong_add(Lc.U, L.U, L.g, nullptr, nullptr, I->stream);
+    }
     return SC_OK;
 }
 
@@ -158,7 +208,10 @@ int mg_solve(Instance *I)
     const sc_solver_opts &o = I->opts;
     int rc = build_levels(I);
     if (rc) return rc;
-    if ((rc = ensure(I, I->mg_partial, sizeof(float) * (size_t)prolong_blocks(I->F.W - 2, I->F.H - 2, I->F.C)))) return rc;
+    {
+        const int nb = std::max(prolong_blocks(I->F.W - 2, I->F.H - 2, I->F.C), tb_blocks_level0(I->F.W, I->F.H, I->F.C, 1));
+        if ((rc = ensure(I, I->mg_partial, sizeof(float) * (size_t)nb))) return rc;
+    }
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
     const float utol = o.update_tol > 0.f ? o.update_tol : 0.02f;
     const int budget = o.max_sweeps > 0 ? o.max_sweeps : 30;

@@ -14,6 +14,7 @@
 // HBM traffic per launch ~ (4 B + 4 B)/efficiency + 4 B per unknown for T sweeps, against
 // 12 B x T algorithmic -- hence "effective" bandwidth above the HBM roof for T > 1.
 #include "sc_common.h"
+#include "sc_mg_device.h"
 
 namespace sc {
 
@@ -31,8 +32,16 @@ __device__ __forceinline__ void tb_load(const float *__restrict__ p, int P, int 
 }
 
 // ---------------------------------------------------------------------------- red-black
-template <int T, int NW, int R, bool SOR>
-__global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field F, float omega)
+// GEN = general-coefficient variant for the multigrid coarse levels (MGDim: modified stencil at
+// the last column / row, division by the true diagonal); GEN = false is the exact level-0 form.
+// FLAGS (multigrid fusions): TB_PROLONG adds the interpolated coarse correction P*E to U while
+// loading it (replaces k_prolong_add), TB_MAXC also reduces max|P*E| per block into `partial`,
+// TB_ZEROIN treats Uin as all-zero without reading it (first smoothing of a coarse correction).
+constexpr int TB_PROLONG = 1, TB_MAXC = 2, TB_ZEROIN = 4;
+
+template <int T, int NW, int R, bool SOR, bool GEN, int FLAGS>
+__global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field F, float omega, MGGeom g, Field E,
+                                                   float *__restrict__ partial)
 {
     constexpr int HY = 2 * T, RH = NW * R;
     static_assert(2 * T <= TB_HX, "column halo too small for this depth");
@@ -44,10 +53,101 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
     const int ry = blockIdx.y * (RH - 2 * HY) - HY;
     const int y0 = ry + wv * R;
     float4 u[R], f[R];
-    tb_load<R>(Uin.at(c), P, H, x, y0, u);
+    if (FLAGS & TB_ZEROIN) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        tb_load<R>(Uin.at(c), P, H, x, y0, u);
+    }
     tb_load<R>(F.at(c), P, H, x, y0, f);
     const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
     const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
+    if (FLAGS & TB_PROLONG) {
+        // u += P*E: bilinear interpolation of the coarse correction (MGDim tail weights at the end)
+        const float *__restrict__ e = E.at(c);
+        const int Pc = E.pitch;
+        float m = 0.f;
+        // Fast path (everything away from the irregular last interval): x is a multiple of 4 and
+        // y0 is even, so the lane's 4 x R fine points interpolate from 3 coarse columns x/2..x/2+2
+        // and R/2+1 coarse rows -- (R/2+1) x (float2 + float) loads instead of 16 per fine row.
+        const bool fast = (R % 2 == 0) && ((y0 & 1) == 0) && x >= 0 && x + 4 <= 2 * g.x.nc && y0 >= 0 &&
+                          y0 + R <= 2 * g.y.nc;
+        if (fast) {
+            const int c0 = x >> 1, J = y0 >> 1;
+            float4 row[R / 2 + 1];
+#pragma unroll
+            for (int j = 0; j <= R / 2; ++j) {
+                const float *er = e + (size_t)(J + j) * Pc + c0;
+                const float2 ab = *reinterpret_cast<const float2 *>(er);
+                const float cc = er[2];
+                row[j] = make_float4(ab.x, 0.5f * ab.x + 0.5f * ab.y, ab.y, 0.5f * ab.y + 0.5f * cc);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + r;
+                float4 cr = row[r / 2];
+                if (r & 1) {
+                    const float4 nx = row[r / 2 + 1];
+                    cr = make_float4(0.5f * cr.x + 0.5f * nx.x, 0.5f * cr.y + 0.5f * nx.y, 0.5f * cr.z + 0.5f * nx.z,
+                                     0.5f * cr.w + 0.5f * nx.w);
+                }
+                if (y < 1 || y > H - 2) continue;
+                if (x0ok) { u[r].x = u[r].x + cr.x; m = fmaxf(m, fabsf(cr.x)); }
+                if (x1ok) { u[r].y = u[r].y + cr.y; m = fmaxf(m, fabsf(cr.y)); }
+                if (x2ok) { u[r].z = u[r].z + cr.z; m = fmaxf(m, fabsf(cr.z)); }
+                if (x3ok) { u[r].w = u[r].w + cr.w; m = fmaxf(m, fabsf(cr.w)); }
+            }
+        } else {
+            int I0[4], I1[4];
+            float wa[4], wb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xi = min(max(x + k, 1), g.x.n);
+                interp_1d(g.x, xi, I0[k], I1[k], wa[k], wb[k]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + r;
+                if (y < 1 || y > H - 2) continue;
+                int J0, J1;
+                float wy0, wy1;
+                interp_1d(g.y, y, J0, J1, wy0, wy1);
+                const float *e0 = e + (size_t)J0 * Pc, *e1 = e + (size_t)J1 * Pc;
+                float cr[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float top = wa[k] * e0[I0[k]] + wb[k] * e0[I1[k]];
+                    const float bot = wa[k] * e1[I0[k]] + wb[k] * e1[I1[k]];
+                    cr[k] = wy0 * top + wy1 * bot;
+                }
+                if (x0ok) { u[r].x = u[r].x + cr[0]; m = fmaxf(m, fabsf(cr[0])); }
+                if (x1ok) { u[r].y = u[r].y + cr[1]; m = fmaxf(m, fabsf(cr[1])); }
+                if (x2ok) { u[r].z = u[r].z + cr[2]; m = fmaxf(m, fabsf(cr[2])); }
+                if (x3ok) { u[r].w = u[r].w + cr[3]; m = fmaxf(m, fabsf(cr[3])); }
+            }
+        }
+        if (FLAGS & TB_MAXC) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            __shared__ float red[NW];
+            if (lane == 0) red[wv] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float mm = red[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red[w]);
+                partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = mm;
+            }
+        }
+    }
+    // general coefficients (compile away when !GEN)
+    const float cw0 = (GEN && x + 0 == g.x.n) ? g.x.cw_last : 1.0f, dx0 = (GEN && x + 0 == g.x.n) ? g.x.d_last : 2.0f;
+    const float cw1 = (GEN && x + 1 == g.x.n) ? g.x.cw_last : 1.0f, dx1 = (GEN && x + 1 == g.x.n) ? g.x.d_last : 2.0f;
+    const float cw2 = (GEN && x + 2 == g.x.n) ? g.x.cw_last : 1.0f, dx2 = (GEN && x + 2 == g.x.n) ? g.x.d_last : 2.0f;
+    const float cw3 = (GEN && x + 3 == g.x.n) ? g.x.cw_last : 1.0f, dx3 = (GEN && x + 3 == g.x.n) ? g.x.d_last : 2.0f;
+#define SC_TB_GS(L, R_, A, B, FF, CW, DX)                                                    \
+    (GEN ? ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - (FF)) / ((DX) + dy)                   \
+         : 0.25f * ((((L) + (R_)) + ((A) + (B))) - (FF)))
     edge[0][wv][0][lane] = u[0];
     edge[0][wv][1][lane] = u[R - 1];
     __syncthreads();
@@ -64,13 +164,16 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
             const float4 a = (r == 0) ? up : u[r - 1];
             const float4 b = (r == R - 1) ? dn : u[r + 1];
             float4 cur = u[r];
+            const float cn = (GEN && y == g.y.n) ? g.y.cw_last : 1.0f;
+            const float dy = (GEN && y == g.y.n) ? g.y.d_last : 2.0f;
+            (void)cn; (void)dy;
             // x is a multiple of 4, so the colour of component k depends on (y + k) only: the
             // branch below is wave-uniform
             if (((y + color) & 1) == 0) {
                 float l = __shfl_up(cur.w, 1, 64);
                 if (lane == 0) l = 0.f;
-                const float g0 = 0.25f * (((l + cur.y) + (a.x + b.x)) - f[r].x);
-                const float g2 = 0.25f * (((cur.y + cur.w) + (a.z + b.z)) - f[r].z);
+                const float g0 = SC_TB_GS(l, cur.y, a.x, b.x, f[r].x, cw0, dx0);
+                const float g2 = SC_TB_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, dx2);
                 const float n0 = SOR ? (cur.x + omega * (g0 - cur.x)) : g0;
                 const float n2 = SOR ? (cur.z + omega * (g2 - cur.z)) : g2;
                 if (yok && x0ok) cur.x = n0;
@@ -78,8 +181,8 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
             } else {
                 float rr = __shfl_down(cur.x, 1, 64);
                 if (lane == 63) rr = 0.f;
-                const float g1 = 0.25f * (((cur.x + cur.z) + (a.y + b.y)) - f[r].y);
-                const float g3 = 0.25f * (((cur.z + rr) + (a.w + b.w)) - f[r].w);
+                const float g1 = SC_TB_GS(cur.x, cur.z, a.y, b.y, f[r].y, cw1, dx1);
+                const float g3 = SC_TB_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, dx3);
                 const float n1 = SOR ? (cur.y + omega * (g1 - cur.y)) : g1;
                 const float n3 = SOR ? (cur.w + omega * (g3 - cur.w)) : g3;
                 if (yok && x1ok) cur.y = n1;
@@ -102,6 +205,8 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
         if (yr >= HY && yr < RH - HY && y >= 0 && y < H) *reinterpret_cast<float4 *>(out + (size_t)y * P + x) = u[r];
     }
 }
+
+#undef SC_TB_GS
 
 // ---------------------------------------------------------------------------- Jacobi
 template <int T, int NW, int R>
@@ -169,22 +274,61 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
 // ---------------------------------------------------------------------------- launchers
 constexpr int TB_NW = 8, TB_R = 8;
 
-template <int T, bool SOR>
-static void launch_rb_t(Field Uin, Field Uout, Field F, float omega, hipStream_t s)
+template <int T, int NW, bool SOR, bool GEN, int FLAGS>
+static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom &g, Field E, float *partial, hipStream_t s)
 {
-    constexpr int RH = TB_NW * TB_R, HY = 2 * T;
+    constexpr int RH = NW * TB_R, HY = 2 * T;
     dim3 grid((Uin.W + (256 - 2 * TB_HX) - 1) / (256 - 2 * TB_HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
-    hipLaunchKernelGGL((k_rb_tb<T, TB_NW, TB_R, SOR>), grid, dim3(TB_NW * 64), 0, s, Uin, Uout, F, omega);
+    hipLaunchKernelGGL((k_rb_tb<T, NW, TB_R, SOR, GEN, FLAGS>), grid, dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
+    return (int)(grid.x * grid.y * grid.z);
 }
 
 bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipStream_t s)
 {
     const bool sor = omega != 1.0f;
+    MGGeom g{};
+    Field e{};
     switch (sweeps) {
-    case 1: sor ? launch_rb_t<1, true>(Uin, Uout, F, omega, s) : launch_rb_t<1, false>(Uin, Uout, F, omega, s); return true;
-    case 2: sor ? launch_rb_t<2, true>(Uin, Uout, F, omega, s) : launch_rb_t<2, false>(Uin, Uout, F, omega, s); return true;
+    case 1: sor ? launch_rb_t<1, TB_NW, true, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s) : launch_rb_t<1, TB_NW, false, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s); return true;
+    case 2: sor ? launch_rb_t<2, TB_NW, true, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s) : launch_rb_t<2, TB_NW, false, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s); return true;
     default: return false;
     }
+}
+
+// Level-0 post-smoothing fused with the prolongation of the coarse correction E and the
+// max|correction| reduction (Gauss-Seidel, exact level-0 stencil).  Returns the number of
+// partial maxima written (0: unsupported depth).
+int launch_rb_tb_prolong0(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, Field E, float *partial, hipStream_t s)
+{
+    if (sweeps == 1) return launch_rb_t<1, TB_NW, false, false, TB_PROLONG | TB_MAXC>(Uin, Uout, F, 1.0f, g, E, partial, s);
+    if (sweeps == 2) return launch_rb_t<2, TB_NW, false, false, TB_PROLONG | TB_MAXC>(Uin, Uout, F, 1.0f, g, E, partial, s);
+    return 0;
+}
+
+int tb_blocks_level0(int W, int H, int C, int sweeps)
+{
+    const int RH = TB_NW * TB_R, HY = 2 * sweeps;
+    return ((W + (256 - 2 * TB_HX) - 1) / (256 - 2 * TB_HX)) * ((H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * C;
+}
+
+// coarse multigrid levels: Gauss-Seidel only (omega = 1); smaller workgroups on small levels so
+// the grid still spreads over the chip.  mode: 0 plain, TB_ZEROIN, TB_PROLONG (with E).
+bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s)
+{
+    const bool big = (long)Uin.W * Uin.H >= 700L * 700L;
+#define SC_GEN_CASE(TT, MODE)                                                                                       \
+    (big ? launch_rb_t<TT, 8, false, true, MODE>(Uin, Uout, F, 1.0f, g, E, nullptr, s)                             \
+         : launch_rb_t<TT, 4, false, true, MODE>(Uin, Uout, F, 1.0f, g, E, nullptr, s))
+    if (sweeps == 1) {
+        if (mode == 0) SC_GEN_CASE(1, 0); else if (mode == TB_ZEROIN) SC_GEN_CASE(1, TB_ZEROIN); else SC_GEN_CASE(1, TB_PROLONG);
+        return true;
+    }
+    if (sweeps == 2) {
+        if (mode == 0) SC_GEN_CASE(2, 0); else if (mode == TB_ZEROIN) SC_GEN_CASE(2, TB_ZEROIN); else SC_GEN_CASE(2, TB_PROLONG);
+        return true;
+    }
+#undef SC_GEN_CASE
+    return false;
 }
 
 template <int T>
