@@ -104,7 +104,10 @@ def main():
         args.gpus = comm.world
     import numpy as np
 
-    inst = capi.Instance(comm.local_rank)
+    ndev = capi.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no MI355X visible (there is no CPU fallback)")
+    inst = capi.Instance(comm.local_rank % ndev)   # % ndev only matters when rehearsing N ranks on a 1-GPU box
     opts = dict(method=METHODS[args.method])
     if args.method == "sor":
         opts.update(tol=2e-5, max_sweeps=200000, check_every=64)
@@ -145,10 +148,23 @@ def main():
     rb_bytes = 12.0 * unknowns * (0.5 if rb_depth == 0 else rb_depth)   # plain kernel: one colour per launch
     j_bytes = 12.0 * unknowns * max(j_depth, 1)
 
-    def roof(name, bytes_per_launch, ms, note):
+    def pmc_traffic(symbol):
+        """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+        WRITE_SIZE, tools/pmc_traffic.py); null when no pass exists for this ROI size."""
+        path = os.path.join(ROOT, "profiles", f"pmc_traffic_roi{args.roi}.json")
+        try:
+            ks = json.load(open(path))["kernels"]
+        except Exception:
+            return None
+        for k, v in ks.items():
+            if symbol in k:
+                return v["traffic_bytes_per_launch"]
+        return None
+
+    def roof(name, symbol, bytes_per_launch, ms, note):
         ach = bytes_per_launch / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "us_per_launch": round(ms * 1e3, 2),
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(symbol), "us_per_launch": round(ms * 1e3, 2),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch), "note": note}
 
     rb_name = "k_rb_half (one colour, in place)" if rb_depth == 0 else \
@@ -157,13 +173,15 @@ def main():
         f"k_jacobi_tb<{j_depth},8,8> ({j_depth} fused Jacobi sweeps per launch, register blocked)"
     cache_note = ("working set %.0f MB %s the 256 MB Infinity Cache" %
                   (unknowns * 12 / 1e6, "fits" if unknowns * 12 < 256e6 else "exceeds"))
-    roofline = roof(rb_name, rb_bytes, ms_rb,
+    rb_sym = "k_rb_half<" if rb_depth == 0 else f"k_rb_tb<{rb_depth}, 8, 8, false, false, 0>"
+    j_sym = "k_jacobi(" if j_depth == 0 else f"k_jacobi_tb<{j_depth}, 8, 8>"
+    roofline = roof(rb_name, rb_sym, rb_bytes, ms_rb,
                     "dominant kernel of the timed clone (multigrid smoother, level 0); algorithmic bytes = "
                     "12 B/unknown/channel/sweep x sweeps per launch (SURVEY 8d), so >1.0 is 'effective' bandwidth "
                     "from temporal blocking; " + cache_note)
-    roofline_j = roof(j_name, j_bytes, ms_j, "the Jacobi stencil named by the north-star, same field; effective "
+    roofline_j = roof(j_name, j_sym, j_bytes, ms_j, "the Jacobi stencil named by the north-star, same field; effective "
                       "bandwidth (temporal blocking); " + cache_note)
-    roofline_j1 = roof("k_jacobi (LDS-tiled 5-point, 1 sweep per launch)", 12.0 * unknowns, ms_j1,
+    roofline_j1 = roof("k_jacobi (LDS-tiled 5-point, 1 sweep per launch)", "k_jacobi(", 12.0 * unknowns, ms_j1,
                        "single-sweep Jacobi: algorithmic == actual traffic; " + cache_note)
 
     total_pix = comm.sum(float(W * H)) * args.steps

@@ -96,10 +96,10 @@ SC_API void *my_seamlessclone_api_imp_create_instance(int gpu_id);
 
 /* seamlessclone_cuda.h:6-21 / seamlessClone_imp.cu:265-352.
  * face = patch (CV_8UC3), body = destination (CV_8UC3, modified in place), mask (CV_8UC1,
- * same size as face).  Host pointers.  bSync=true waits for completion before returning
- * (and fills the timing fields); bSync=false returns after enqueueing when `body` is
- * page-locked, otherwise it still completes before returning (the result must land in
- * caller memory).  Returns SC_OK or a negative SC_ERR_*. */
+ * same size as face).  Host pointers (pageable or page-locked).  The call completes before it
+ * returns whatever bSync says, because the result has to land in caller memory (the reference
+ * is synchronous here as well: D2H + host splice, seamlessClone_imp.cpp:471-483); bSync is kept
+ * for signature compatibility.  Returns SC_OK or a negative SC_ERR_*. */
 SC_API int my_seamlessclone_api_imp_run(void *instance,
                                  const uint8_t *face, int face_cols, int face_rows, int face_step,
                                  uint8_t *body, int body_cols, int body_rows, int body_step,

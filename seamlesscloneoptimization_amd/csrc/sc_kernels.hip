@@ -11,6 +11,7 @@
 // written so the oracle can check the sweeps bit for bit.
 #include "sc_common.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace sc {
 
@@ -292,8 +293,9 @@ void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s)
 // 256-float row as 64 float4), LDS row = [3 pad | left halo | 256 | right halo | 3 pad] so the
 // body stays 16-B aligned for ds_read_b128.  Left/right neighbours inside the row come from the
 // adjacent lanes (wave shuffles); only lane 0 / 63 read the halo columns from LDS.
-constexpr int JT_TW = 256, JT_TH = 16, JT_LDW = JT_TW + 8;
+constexpr int JT_TW = 256, JT_LDW = JT_TW + 8;
 
+template <int JT_TH>
 __global__ __launch_bounds__(256) void k_jacobi(Field Uin, Field Uout, Field F)
 {
     __shared__ __attribute__((aligned(16))) float t[JT_TH + 2][JT_LDW];
@@ -339,10 +341,23 @@ __global__ __launch_bounds__(256) void k_jacobi(Field Uin, Field Uout, Field F)
     }
 }
 
+// Tile height 16: measured on MI355X at 2048^2 / 4096^2 (tools/tune_jacobi.py) 16 rows ->
+// 5.67 / 5.37 TB/s, 32 -> 4.5 / 4.0, 64 -> 2.7 / 2.7: the load-barrier-compute structure wants
+// many small resident tiles more than it wants a thinner halo.  SC_JT_TH overrides for tuning.
 void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s)
 {
-    dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + JT_TH - 1) / JT_TH, Uin.C);
-    hipLaunchKernelGGL(k_jacobi, grid, dim3(256), 0, s, Uin, Uout, F);
+    static const int forced = [] { const char *e = getenv("SC_JT_TH"); return e ? atoi(e) : 0; }();
+    int th = forced ? forced : 16;
+    if (th == 64) {
+        dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + 63) / 64, Uin.C);
+        hipLaunchKernelGGL(k_jacobi<64>, grid, dim3(256), 0, s, Uin, Uout, F);
+    } else if (th == 32) {
+        dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + 31) / 32, Uin.C);
+        hipLaunchKernelGGL(k_jacobi<32>, grid, dim3(256), 0, s, Uin, Uout, F);
+    } else {
+        dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + 15) / 16, Uin.C);
+        hipLaunchKernelGGL(k_jacobi<16>, grid, dim3(256), 0, s, Uin, Uout, F);
+    }
 }
 
 // One colour of a red-black Gauss-Seidel / SOR sweep, in place.  A colour-c point reads only
