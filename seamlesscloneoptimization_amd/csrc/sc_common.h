@@ -39,11 +39,11 @@ void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_o
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s);
 void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s);
 
-void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s);
-void launch_rb_half(Field U, Field F, int color, float omega, hipStream_t s);
+void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag = false);
+void launch_rb_half(Field U, Field F, int color, float omega, hipStream_t s, bool tag = false);
 // fused temporally-blocked kernels (sc_sweep_tb.hip); return false when the shape is unsupported
-bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s);
-bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipStream_t s);
+bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s, bool tag = false);
+bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipStream_t s, bool tag = false);
 int  tb_max_depth(int method);
 struct MGGeom;
 constexpr int TBM_PLAIN = 0, TBM_PROLONG = 1, TBM_ZEROIN = 4;   // mode of launch_rb_tb_gen

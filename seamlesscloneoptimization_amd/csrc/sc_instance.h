@@ -39,6 +39,7 @@ struct Instance {
     DevBuf d_U0, d_U1, d_F;
     Field U0, U1, F;      // current views into the buffers above
     bool result_in_U1 = false;
+    bool bench_tag = false;   // sc_hip_field_time_sweeps: launch the second-symbol instantiations
     // multigrid hierarchy (level 0 aliases U0/U1/F)
     std::vector<DevBuf> mg_bufs;
     DevBuf mg_partial;    // per-block maxima of the level-0 correction

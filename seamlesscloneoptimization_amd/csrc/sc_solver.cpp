@@ -60,19 +60,19 @@ int run_sweeps(Instance *I, int method, int sweeps, float omega, int spl)
         int T = std::min(std::max(depth, 1), left);
         bool done = false;
         if (depth > 0) {
-            done = (method == SC_METHOD_JACOBI) ? launch_jacobi_tb(result(I), other(I), I->F, T, I->stream)
-                                                : launch_rb_tb(result(I), other(I), I->F, T, om, I->stream);
+            done = (method == SC_METHOD_JACOBI) ? launch_jacobi_tb(result(I), other(I), I->F, T, I->stream, I->bench_tag)
+                                                : launch_rb_tb(result(I), other(I), I->F, T, om, I->stream, I->bench_tag);
             if (done) { I->result_in_U1 = !I->result_in_U1; I->info.sweep_launches += 1; }
         }
         if (!done) {
             T = 1;
             if (method == SC_METHOD_JACOBI) {
-                launch_jacobi(result(I), other(I), I->F, I->stream);
+                launch_jacobi(result(I), other(I), I->F, I->stream, I->bench_tag);
                 I->result_in_U1 = !I->result_in_U1;
                 I->info.sweep_launches += 1;
             } else {
-                launch_rb_half(result(I), I->F, 0, om, I->stream);
-                launch_rb_half(result(I), I->F, 1, om, I->stream);
+                launch_rb_half(result(I), I->F, 0, om, I->stream, I->bench_tag);
+                launch_rb_half(result(I), I->F, 1, om, I->stream, I->bench_tag);
                 I->info.sweep_launches += 2;
             }
         }

@@ -86,27 +86,58 @@ def c4(inst):
     emit({"config": "c4 4096x4096 full clone (multigrid)", "cycles": i.sweeps, "device_ms": round(i.ms_device_total, 3), "Mpix/s": round(4096 * 4096 / (i.ms_device_total * 1e-3) / 1e6, 1)})
 
 def c5(inst):
-    """batch of 64 independent 1024x1024 clones (here: all 64 on one GPU, device resident)."""
-    imgs = []
-    for k in range(8):   # 8 distinct images reused 8x each keeps host generation time small
-        dst, patch, mask, cx, cy = synth(1024, 100 + k)
-        imgs.append((inst.to_device(patch), patch.shape[:2], inst.to_device(dst), inst.to_device(dst), dst, inst.to_device(mask), mask.shape[:2], cx, cy))
-    def one(k):
-        f, fs, b0, b, dst, m, ms, cx, cy = imgs[k % 8]
-        inst.copy_d2d_async(b, b0, dst.nbytes)
-        inst.run_device(f, fs, b, dst.shape[:2], m, ms, cx, cy, sync=False)
-    for k in range(8): one(k)
-    inst.sync(); t0 = time.perf_counter()
-    for k in range(64): one(k)
-    inst.sync(); dt = time.perf_counter() - t0
-    emit({"config": "c5 64 independent 1024x1024 clones on ONE GPU (8 per GPU when sharded over 8)", "ms_total": round(dt * 1e3, 3),
-          "ms_per_clone": round(dt / 64 * 1e3, 4), "Mpix/s": round(64 * 1024 * 1024 / dt / 1e6, 1), "cycles": inst.info().sweeps})
-    for t in imgs:
-        for p in (t[0], t[2], t[3], t[5]): inst.free(p)
+    """batch of 64 independent 1024x1024 clones on ONE GPU, device resident, 1..8 concurrent streams."""
+    from seamlesscloneoptimization_amd.batch import StreamPool
+    hosts = [synth(1024, 100 + k) for k in range(8)]     # 8 distinct images reused 8x each
+    for streams in (1, 2, 4, 8):
+        pool = StreamPool(0, streams)
+        jobs = []
+        for k in range(64):
+            dst, patch, mask, cx, cy = hosts[k % 8]
+            owner = pool.instances[k % streams]
+            jobs.append(dict(f=owner.to_device(patch), fs=patch.shape[:2], b0=owner.to_device(dst), b=owner.to_device(dst),
+                             n=dst.nbytes, bs=dst.shape[:2], m=owner.to_device(mask), ms=mask.shape[:2], cx=cx, cy=cy))
+        def one(i, j):
+            i.copy_d2d_async(j["b"], j["b0"], j["n"])
+            i.run_device(j["f"], j["fs"], j["b"], j["bs"], j["m"], j["ms"], j["cx"], j["cy"], sync=False)
+        pool.map(one, jobs[:8]); pool.sync()
+        t0 = time.perf_counter()
+        pool.map(one, jobs); pool.sync()
+        dt = time.perf_counter() - t0
+        emit({"config": "c5 64 independent 1024x1024 clones on ONE GPU (8 per GPU when sharded over 8)", "streams": streams,
+              "ms_total": round(dt * 1e3, 3), "ms_per_clone": round(dt / 64 * 1e3, 4), "Mpix/s": round(64 * 1024 * 1024 / dt / 1e6, 1)})
+        for j in jobs:
+            for key in ("f", "b0", "b", "m"): pool.instances[0].free(j[key])
+        pool.close()
+
+def c3s(inst):
+    """flagship 2048^2 clone with 1..4 concurrent streams (independent images)."""
+    from seamlesscloneoptimization_amd.batch import StreamPool
+    hosts = [synth(2048, 200 + k) for k in range(4)]
+    for streams in (1, 2, 4):
+        pool = StreamPool(0, streams)
+        jobs = []
+        for k in range(16):
+            dst, patch, mask, cx, cy = hosts[k % 4]
+            owner = pool.instances[k % streams]
+            jobs.append(dict(f=owner.to_device(patch), fs=patch.shape[:2], b0=owner.to_device(dst), b=owner.to_device(dst),
+                             n=dst.nbytes, bs=dst.shape[:2], m=owner.to_device(mask), ms=mask.shape[:2], cx=cx, cy=cy))
+        def one(i, j):
+            i.copy_d2d_async(j["b"], j["b0"], j["n"])
+            i.run_device(j["f"], j["fs"], j["b"], j["bs"], j["m"], j["ms"], j["cx"], j["cy"], sync=False)
+        pool.map(one, jobs[:4]); pool.sync()
+        t0 = time.perf_counter()
+        pool.map(one, jobs); pool.sync()
+        dt = time.perf_counter() - t0
+        emit({"config": "2048x2048 clones, concurrent streams on one GPU", "streams": streams, "ms_per_clone": round(dt / 16 * 1e3, 4),
+              "Mpix/s": round(16 * 2048 * 2048 / dt / 1e6, 1)})
+        for j in jobs:
+            for key in ("f", "b0", "b", "m"): pool.instances[0].free(j[key])
+        pool.close()
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]
     inst = capi.Instance(0)
     for w in which:
-        {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5}[w](inst)
+        {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5, "c3s": c3s}[w](inst)
     inst.destroy()
