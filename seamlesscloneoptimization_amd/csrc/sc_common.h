@@ -51,6 +51,11 @@ bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &
 int  launch_rb_tb_prolong0(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, Field E, float *partial, hipStream_t s);
 int  tb_blocks_level0(int W, int H, int C, int sweeps);
 void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_t s);
+// whole level-0 part of a V-cycle in one launch (sc_cycle0.hip): [prolong E] + `sweeps` RBGS sweeps +
+// residual + restriction into Fc.  Returns #partials written, 0 without prolong, -1 if unsupported.
+int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
+                   float *partial, hipStream_t s);
+int  cycle0_blocks(int W, int H, int C, int sweeps);
 
 // residual: d_out[0] = sum r^2, d_out[1] = sum lap^2 (double); d_partials holds >= 2*max_blocks doubles
 int  residual_max_blocks();

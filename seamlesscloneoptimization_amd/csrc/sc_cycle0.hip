@@ -1,0 +1,273 @@
+// sc_cycle0.hip -- the whole level-0 part of a multigrid V-cycle in ONE launch (gfx950).
+//
+// k_cycle0<T, NW, R, PRO> reads U and the RHS once and, with the field held in registers
+// (same register-blocked layout as sc_sweep_tb.hip), performs
+//     [PRO]  U += P*E  (bilinear prolongation of the coarse correction) and the per-block
+//            max|P*E| used by the stop rule,
+//     T      red-black Gauss-Seidel sweeps (post-smoothing of this cycle and pre-smoothing of the
+//            next one back to back: T = post + pre; the first launch of a solve has T = pre),
+//     then   the residual (double arithmetic) and its full-weighting restriction to the coarse RHS,
+// and writes U and the coarse RHS once.  Against the three-kernel form (smoother, residual +
+// restriction, prolongation + smoother: ~39 B of HBM traffic per unknown and cycle) this moves
+// ~17 B.  Level 0 only: exact 5-point stencil, regular spacing (alpha = 1), where the restriction
+// is the plain 1/4-1/2-1/4 tensor stencil up to a normalisation factor at the last coarse
+// row/column (MGDim::inv_last).
+//
+// Halo: values at depth d from the region edge are exact for d half-steps; the residual needs one
+// more ring and the restriction a second one, so the exact output tile is the region minus
+// HX = 12 columns (3 float4 lanes) and HY = 2T+2 rows on every side.  HY is even so that coarse
+// rows (even fine rows) pair up inside each lane's R-row band.
+#include "sc_common.h"
+#include "sc_wave.h"
+#include "sc_mg_device.h"
+
+namespace sc {
+
+constexpr int C0_HXQ = 3;               // halo lanes (float4) per side
+constexpr int C0_HX = 4 * C0_HXQ;
+
+template <int R>
+__device__ __forceinline__ void c0_load(const float *__restrict__ p, int P, int H, int x, int y0, float4 (&v)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int y = y0 + r;
+        v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H && x >= 0 && x < P) v[r] = *reinterpret_cast<const float4 *>(p + (size_t)y * P + x);
+    }
+}
+
+template <int T, int NW, int R, bool PRO>
+__global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
+                                                    float *__restrict__ partial)
+{
+    constexpr int HY = 2 * T + 2, RH = NW * R;
+    static_assert(2 * T + 2 <= C0_HX, "column halo too small");
+    static_assert(R % 2 == 0, "bands must hold whole coarse-row pairs");
+    __shared__ float4 edge[2][NW][2][64];
+    __shared__ float2 hedge[NW][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.z;
+    const int W = Uin.W, H = Uin.H, P = Uin.pitch;
+    const int x = blockIdx.x * (256 - 2 * C0_HX) - C0_HX + 4 * lane;
+    const int y0 = blockIdx.y * (RH - 2 * HY) - HY + wv * R;       // even
+    float4 u[R], f[R];
+    c0_load<R>(Uin.at(c), P, H, x, y0, u);
+    if (!PRO) c0_load<R>(F.at(c), P, H, x, y0, f);   // with PRO the RHS is fetched after the prolongation (VGPR pressure)
+    const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
+    const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
+
+    // ------------------------------------------------------------------ prolongation
+    if (PRO) {
+        const float *__restrict__ e = E.at(c);
+        const int Pc = E.pitch;
+        float m = 0.f;
+        const bool fast = x >= 0 && x + 4 <= 2 * g.x.nc && y0 >= 0 && y0 + R <= 2 * g.y.nc;
+        if (fast) {
+            const int c0 = x >> 1, J = y0 >> 1;
+            float4 row[R / 2 + 1];
+#pragma unroll
+            for (int j = 0; j <= R / 2; ++j) {
+                const float *er = e + (size_t)(J + j) * Pc + c0;
+                const float2 ab = *reinterpret_cast<const float2 *>(er);
+                const float cc = er[2];
+                row[j] = make_float4(ab.x, 0.5f * ab.x + 0.5f * ab.y, ab.y, 0.5f * ab.y + 0.5f * cc);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + r;
+                float4 cr = row[r / 2];
+                if (r & 1) {
+                    const float4 nx = row[r / 2 + 1];
+                    cr = make_float4(0.5f * cr.x + 0.5f * nx.x, 0.5f * cr.y + 0.5f * nx.y, 0.5f * cr.z + 0.5f * nx.z,
+                                     0.5f * cr.w + 0.5f * nx.w);
+                }
+                if (y < 1 || y > H - 2) continue;
+                if (x0ok) { u[r].x = u[r].x + cr.x; m = fmaxf(m, fabsf(cr.x)); }
+                if (x1ok) { u[r].y = u[r].y + cr.y; m = fmaxf(m, fabsf(cr.y)); }
+                if (x2ok) { u[r].z = u[r].z + cr.z; m = fmaxf(m, fabsf(cr.z)); }
+                if (x3ok) { u[r].w = u[r].w + cr.w; m = fmaxf(m, fabsf(cr.w)); }
+            }
+        } else {
+            int I0[4], I1[4];
+            float wa[4], wb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xi = min(max(x + k, 1), g.x.n);
+                interp_1d(g.x, xi, I0[k], I1[k], wa[k], wb[k]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + r;
+                if (y < 1 || y > H - 2) continue;
+                int J0, J1;
+                float wy0, wy1;
+                interp_1d(g.y, y, J0, J1, wy0, wy1);
+                const float *e0 = e + (size_t)J0 * Pc, *e1 = e + (size_t)J1 * Pc;
+                float cr[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float top = wa[k] * e0[I0[k]] + wb[k] * e0[I1[k]];
+                    const float bot = wa[k] * e1[I0[k]] + wb[k] * e1[I1[k]];
+                    cr[k] = wy0 * top + wy1 * bot;
+                }
+                if (x0ok) { u[r].x = u[r].x + cr[0]; m = fmaxf(m, fabsf(cr[0])); }
+                if (x1ok) { u[r].y = u[r].y + cr[1]; m = fmaxf(m, fabsf(cr[1])); }
+                if (x2ok) { u[r].z = u[r].z + cr[2]; m = fmaxf(m, fabsf(cr[2])); }
+                if (x3ok) { u[r].w = u[r].w + cr[3]; m = fmaxf(m, fabsf(cr[3])); }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        __shared__ float red[NW];
+        if (lane == 0) red[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mm = red[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red[w]);
+            partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = mm;
+        }
+    }
+
+    if (PRO) c0_load<R>(F.at(c), P, H, x, y0, f);
+
+    // ------------------------------------------------------------------ T red-black sweeps
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    edge[0][wv][0][lane] = u[0];
+    edge[0][wv][1][lane] = u[R - 1];
+    __syncthreads();
+#pragma unroll
+    for (int step = 0; step < 2 * T; ++step) {
+        const int buf = step & 1, color = step & 1;
+        const float4 up = (wv > 0) ? edge[buf][wv - 1][1][lane] : zero;
+        const float4 dn = (wv < NW - 1) ? edge[buf][wv + 1][0][lane] : zero;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int y = y0 + r;
+            const bool yok = (y >= 1) && (y <= H - 2);
+            const float4 a = (r == 0) ? up : u[r - 1];
+            const float4 b = (r == R - 1) ? dn : u[r + 1];
+            float4 cur = u[r];
+            if (((y + color) & 1) == 0) {      // wave-uniform: x is a multiple of 4
+                float l = wave_from_left(cur.w);
+                if (lane == 0) l = 0.f;
+                const float n0 = 0.25f * (((l + cur.y) + (a.x + b.x)) - f[r].x);
+                const float n2 = 0.25f * (((cur.y + cur.w) + (a.z + b.z)) - f[r].z);
+                if (yok && x0ok) cur.x = n0;
+                if (yok && x2ok) cur.z = n2;
+            } else {
+                float rr = wave_from_right(cur.x);
+                if (lane == 63) rr = 0.f;
+                const float n1 = 0.25f * (((cur.x + cur.z) + (a.y + b.y)) - f[r].y);
+                const float n3 = 0.25f * (((cur.z + rr) + (a.w + b.w)) - f[r].w);
+                if (yok && x1ok) cur.y = n1;
+                if (yok && x3ok) cur.w = n3;
+            }
+            u[r] = cur;
+        }
+        edge[buf ^ 1][wv][0][lane] = u[0];
+        edge[buf ^ 1][wv][1][lane] = u[R - 1];
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ residual + restriction
+    {
+        constexpr int buf = (2 * T) & 1;       // the edges written after the last half-step
+        const float4 up = (wv > 0) ? edge[buf][wv - 1][1][lane] : zero;
+        const float4 dn = (wv < NW - 1) ? edge[buf][wv + 1][0][lane] : zero;
+        float h0[R], h1[R];                    // horizontally filtered residual at coarse columns x and x+2
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int y = y0 + r;
+            const bool yok = (y >= 1) && (y <= H - 2);
+            const float4 a = (r == 0) ? up : u[r - 1];
+            const float4 b = (r == R - 1) ? dn : u[r + 1];
+            const float4 cur = u[r];
+            float l = wave_from_left(cur.w), rr = wave_from_right(cur.x);
+            if (lane == 0) l = 0.f;
+            if (lane == 63) rr = 0.f;
+            float4 res = zero;
+#define SC_C0_RES(L, R_, A, B, CC, FF) \
+    (float)((double)(FF) - ((((double)(L) + (double)(R_)) + ((double)(A) + (double)(B))) - 4.0 * (double)(CC)))
+            if (yok && x0ok) res.x = SC_C0_RES(l, cur.y, a.x, b.x, cur.x, f[r].x);
+            if (yok && x1ok) res.y = SC_C0_RES(cur.x, cur.z, a.y, b.y, cur.y, f[r].y);
+            if (yok && x2ok) res.z = SC_C0_RES(cur.y, cur.w, a.z, b.z, cur.z, f[r].z);
+            if (yok && x3ok) res.w = SC_C0_RES(cur.z, rr, a.w, b.w, cur.w, f[r].w);
+#undef SC_C0_RES
+            float rl = wave_from_left(res.w);
+            if (lane == 0) rl = 0.f;
+            h0[r] = (0.5f * rl + res.x) + 0.5f * res.y;
+            h1[r] = (0.5f * res.y + res.z) + 0.5f * res.w;
+        }
+        hedge[wv][lane] = make_float2(h0[R - 1], h1[R - 1]);
+        __syncthreads();
+        const float2 hup = (wv > 0) ? hedge[wv - 1][lane] : make_float2(0.f, 0.f);
+        const bool lane_out = (lane >= C0_HXQ) && (lane < 64 - C0_HXQ);
+        const int I = x >> 1;                                  // coarse column of fine x (x even)
+        float *__restrict__ fc = Fc.at(c);
+        const float fx0 = (I == g.x.nc) ? 2.0f * g.x.inv_last : 1.0f;
+        const float fx1 = (I + 1 == g.x.nc) ? 2.0f * g.x.inv_last : 1.0f;
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            const int yr = wv * R + r, y = y0 + r;
+            const int J = y >> 1;
+            if (!lane_out || yr < HY || yr >= RH - HY || J < 1 || J > g.y.nc) continue;
+            const float m0 = (r == 0) ? hup.x : h0[r - 1], m1 = (r == 0) ? hup.y : h1[r - 1];
+            const float v0 = (0.5f * m0 + h0[r]) + 0.5f * h0[r + 1];
+            const float v1 = (0.5f * m1 + h1[r]) + 0.5f * h1[r + 1];
+            const float fy = (J == g.y.nc) ? 2.0f * g.y.inv_last : 1.0f;
+            float *o = fc + (size_t)J * Fc.pitch + I;
+            if (I >= 1 && I <= g.x.nc) o[0] = v0 * (fx0 * fy);
+            if (I + 1 >= 1 && I + 1 <= g.x.nc) o[1] = v1 * (fx1 * fy);
+        }
+    }
+
+    // ------------------------------------------------------------------ write back the exact inner tile
+    if (lane < C0_HXQ || lane >= 64 - C0_HXQ || x >= P || x >= W) return;
+    float *__restrict__ out = Uout.at(c);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int yr = wv * R + r, y = y0 + r;
+        if (yr >= HY && yr < RH - HY && y >= 0 && y < H) *reinterpret_cast<float4 *>(out + (size_t)y * P + x) = u[r];
+    }
+}
+
+constexpr int C0_NW = 8, C0_R = 8;
+
+template <int T, bool PRO>
+static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s)
+{
+    constexpr int RH = C0_NW * C0_R, HY = 2 * T + 2;
+    dim3 grid((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
+    hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO>), grid, dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E, g, partial);
+    return (int)(grid.x * grid.y * grid.z);
+}
+
+// sweeps = T red-black GS sweeps; prolong: add P*E first and write per-block max|P*E| to `partial`.
+// Returns the number of partial maxima written (0 without prolong), or -1 for an unsupported depth.
+int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
+                  float *partial, hipStream_t s)
+{
+    if (prolong) {
+        switch (sweeps) {
+        case 2: return launch_c0<2, true>(Uin, Uout, F, Fc, E, g, partial, s);
+        case 3: return launch_c0<3, true>(Uin, Uout, F, Fc, E, g, partial, s);
+        case 4: return launch_c0<4, true>(Uin, Uout, F, Fc, E, g, partial, s);
+        default: return -1;
+        }
+    }
+    switch (sweeps) {
+    case 1: launch_c0<1, false>(Uin, Uout, F, Fc, E, g, partial, s); return 0;
+    case 2: launch_c0<2, false>(Uin, Uout, F, Fc, E, g, partial, s); return 0;
+    default: return -1;
+    }
+}
+
+int cycle0_blocks(int W, int H, int C, int sweeps)
+{
+    const int RH = C0_NW * C0_R, HY = 2 * sweeps + 2;
+    return ((W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * C;
+}
+
+} // namespace sc

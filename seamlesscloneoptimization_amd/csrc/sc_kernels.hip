@@ -10,6 +10,7 @@
 // Compiled with -ffp-contract=off: every float expression below is evaluated exactly as
 // written so the oracle can check the sweeps bit for bit.
 #include "sc_common.h"
+#include "sc_wave.h"
 #include <limits.h>
 #include <stdlib.h>
 
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_jacobi(Field Uin, Field Uout, Field F)
         const float4 c4 = *reinterpret_cast<const float4 *>(&t[ry + 1][4 + 4 * lane]);
         const float4 u4 = *reinterpret_cast<const float4 *>(&t[ry][4 + 4 * lane]);
         const float4 d4 = *reinterpret_cast<const float4 *>(&t[ry + 2][4 + 4 * lane]);
-        float l = __shfl_up(c4.w, 1, 64), r = __shfl_down(c4.x, 1, 64);
+        float l = wave_from_left(c4.w), r = wave_from_right(c4.x);
         if (lane == 0) l = t[ry + 1][3];
         if (lane == 63) r = t[ry + 1][4 + JT_TW];
         const float4 f4 = *reinterpret_cast<const float4 *>(f + (size_t)y * P + x);
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void k_rb_half(Field U, Field F, int color, fl
     const float4 u4 = *reinterpret_cast<const float4 *>(row - P + x);
     const float4 d4 = *reinterpret_cast<const float4 *>(row + P + x);
     const float4 f4 = *reinterpret_cast<const float4 *>(F.at(c) + (size_t)y * P + x);
-    float l = __shfl_up(c4.w, 1, 64), r = __shfl_down(c4.x, 1, 64);
+    float l = wave_from_left(c4.w), r = wave_from_right(c4.x);
     if (lane == 0) l = (x > 0) ? row[x - 1] : 0.f;
     if (lane == 63) r = (x + 4 < P) ? row[x + 4] : 0.f;
     float4 o = c4;
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void k_residual(Field U, Field F, double *__re
         const float4 u4 = *reinterpret_cast<const float4 *>(row - P + x);
         const float4 d4 = *reinterpret_cast<const float4 *>(row + P + x);
         const float4 f4 = *reinterpret_cast<const float4 *>(F.at(c) + (size_t)y * P + x);
-        float l = __shfl_up(c4.w, 1, 64), r = __shfl_down(c4.x, 1, 64);
+        float l = wave_from_left(c4.w), r = wave_from_right(c4.x);
         if (lane == 0) l = (x > 0) ? row[x - 1] : 0.f;
         if (lane == 63) r = (x + 4 < P) ? row[x + 4] : 0.f;
 #define SC_RES(CC, L, R, UU, DD, FF, XI)                                          \

@@ -7,6 +7,7 @@
 // (seamlessClone_imp.cpp:1814-1896).  The multigrid converges to that system's solution for
 // any ROI size; its components are checked against oracle/mg_np.py.
 #include "sc_common.h"
+#include "sc_wave.h"
 #include "sc_mg_device.h"
 
 namespace sc {
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(256) void k_rb_half_gen(Field U, Field F, int color
     const float4 u4 = *reinterpret_cast<const float4 *>(row - P + x);
     const float4 d4 = *reinterpret_cast<const float4 *>(row + P + x);
     const float4 f4 = *reinterpret_cast<const float4 *>(F.at(c) + (size_t)y * P + x);
-    float l = __shfl_up(c4.w, 1, 64), r = __shfl_down(c4.x, 1, 64);
+    float l = wave_from_left(c4.w), r = wave_from_right(c4.x);
     if (lane == 0) l = (x > 0) ? row[x - 1] : 0.f;
     if (lane == 63) r = (x + 4 < P) ? row[x + 4] : 0.f;
     const float cn = (y == g.y.n) ? g.y.cw_last : 1.0f;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void k_residual_field(Field U, Field F, Field 
     const float4 u4 = *reinterpret_cast<const float4 *>(row - P + x);
     const float4 d4 = *reinterpret_cast<const float4 *>(row + P + x);
     const float4 f4 = *reinterpret_cast<const float4 *>(F.at(c) + (size_t)y * P + x);
-    float l = __shfl_up(c4.w, 1, 64), r = __shfl_down(c4.x, 1, 64);
+    float l = wave_from_left(c4.w), r = wave_from_right(c4.x);
     if (lane == 0) l = (x > 0) ? row[x - 1] : 0.f;
     if (lane == 63) r = (x + 4 < P) ? row[x + 4] : 0.f;
     const double cn = (y == g.y.n) ? (double)g.y.cw_last : 1.0;

@@ -209,7 +209,8 @@ int mg_solve(Instance *I)
     int rc = build_levels(I);
     if (rc) return rc;
     {
-        const int nb = std::max(prolong_blocks(I->F.W - 2, I->F.H - 2, I->F.C), tb_blocks_level0(I->F.W, I->F.H, I->F.C, 1));
+        const int nb = std::max(std::max(prolong_blocks(I->F.W - 2, I->F.H - 2, I->F.C), tb_blocks_level0(I->F.W, I->F.H, I->F.C, 1)),
+                                cycle0_blocks(I->F.W, I->F.H, I->F.C, 1));
         if ((rc = ensure(I, I->mg_partial, sizeof(float) * (size_t)nb))) return rc;
     }
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
@@ -219,6 +220,49 @@ int mg_solve(Instance *I)
     // writes its interior, and both buffers carry the same ring, so it stays a valid partner
     int cyc = 0;
     bool ok = false;
+    // Fused level-0 form: one launch per cycle does [prolongation +] post-smoothing of this cycle,
+    // pre-smoothing of the next, residual and restriction (sc_cycle0.hip).  The first launch has no
+    // correction to add; after the last one the field has simply had `pre` extra sweeps.
+    const bool fused0 = o.sweeps_per_launch != 1 && I->mg.size() >= 2 && pre >= 1 && pre <= 2 && post >= 1 &&
+                        pre + post <= 4;
+    if (fused0) {
+        Field none{};
+        launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
+                      I->stream);
+        I->result_in_U1 = !I->result_in_U1;
+        I->info.sweep_launches += 1;
+        while (cyc < budget) {
+            if ((rc = vcycle(I, 1, pre, post))) return rc;
+            const int nb = launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
+                                         I->mg[0].g, post + pre, true, (float *)I->mg_partial.p, I->stream);
+            if (nb <= 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
+            I->result_in_U1 = !I->result_in_U1;
+            I->info.sweep_launches += 1;
+            launch_max_final((const float *)I->mg_partial.p, nb, I->d_maxcorr, I->stream);
+            ++cyc;
+            SC_HIP(I, hipGetLastError());
+            // The first two corrections of a solve are never below the stop threshold unless the
+            // initial guess was already the answer, and every check costs a host round trip
+            // (~35 us of idle GPU), so checking starts with the third cycle.
+            if (cyc < 3 && cyc < budget && o.tol <= 0.f) continue;
+            SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
+            SC_HIP(I, hipStreamSynchronize(I->stream));
+            float m;
+            unsigned bits = *I->h_maxcorr;
+            memcpy(&m, &bits, sizeof(float));
+            if (o.tol > 0.f) {
+                double r[2];
+                if ((rc = eval_residual(I, r))) return rc;
+                const double rel = (r[1] > 0.0) ? std::sqrt(r[0] / r[1]) : std::sqrt(r[0]);
+                I->info.rel_residual = rel;
+                if (rel <= (double)o.tol) { ok = true; break; }
+            }
+            if (m <= utol) { ok = true; break; }
+        }
+        I->info.sweeps = cyc;
+        I->info.converged = ok ? 1 : 0;
+        return ok ? SC_OK : SC_ERR_NOT_CONVERGED;
+    }
     while (cyc < budget) {
         if ((rc = vcycle(I, 0, pre, post))) return rc;
         ++cyc;

@@ -14,6 +14,7 @@
 // HBM traffic per launch ~ (4 B + 4 B)/efficiency + 4 B per unknown for T sweeps, against
 // 12 B x T algorithmic -- hence "effective" bandwidth above the HBM roof for T > 1.
 #include "sc_common.h"
+#include "sc_wave.h"
 #include "sc_mg_device.h"
 
 namespace sc {
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
             // x is a multiple of 4, so the colour of component k depends on (y + k) only: the
             // branch below is wave-uniform
             if (((y + color) & 1) == 0) {
-                float l = __shfl_up(cur.w, 1, 64);
+                float l = wave_from_left(cur.w);
                 if (lane == 0) l = 0.f;
                 const float g0 = SC_TB_GS(l, cur.y, a.x, b.x, f[r].x, cw0, dx0);
                 const float g2 = SC_TB_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, dx2);
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
                 if (yok && x0ok) cur.x = n0;
                 if (yok && x2ok) cur.z = n2;
             } else {
-                float rr = __shfl_down(cur.x, 1, 64);
+                float rr = wave_from_right(cur.x);
                 if (lane == 63) rr = 0.f;
                 const float g1 = SC_TB_GS(cur.x, cur.z, a.y, b.y, f[r].y, cw1, dx1);
                 const float g3 = SC_TB_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, dx3);
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
             const bool yok = (y >= 1) && (y <= H - 2);
             const float4 cur = u[r];
             const float4 b = (r == R - 1) ? dn : u[r + 1];
-            float l = __shfl_up(cur.w, 1, 64), rr = __shfl_down(cur.x, 1, 64);
+            float l = wave_from_left(cur.w), rr = wave_from_right(cur.x);
             if (lane == 0) l = 0.f;
             if (lane == 63) rr = 0.f;
             float4 nw = cur;
@@ -275,12 +276,12 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
 // ---------------------------------------------------------------------------- launchers
 constexpr int TB_NW = 8, TB_R = 8;
 
-template <int T, int NW, bool SOR, bool GEN, int FLAGS>
+template <int T, int NW, bool SOR, bool GEN, int FLAGS, int R = TB_R>
 static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom &g, Field E, float *partial, hipStream_t s)
 {
-    constexpr int RH = NW * TB_R, HY = 2 * T;
+    constexpr int RH = NW * R, HY = 2 * T;
     dim3 grid((Uin.W + (256 - 2 * TB_HX) - 1) / (256 - 2 * TB_HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
-    hipLaunchKernelGGL((k_rb_tb<T, NW, TB_R, SOR, GEN, FLAGS>), grid, dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
+    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS>), grid, dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
     return (int)(grid.x * grid.y * grid.z);
 }
 
@@ -321,9 +322,10 @@ int tb_blocks_level0(int W, int H, int C, int sweeps)
 bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s)
 {
     const bool big = (long)Uin.W * Uin.H >= 700L * 700L;
+// small levels: 8 waves x 4 rows (same 256 x 32 region as 4 x 8, half the serial work per lane)
 #define SC_GEN_CASE(TT, MODE)                                                                                       \
     (big ? launch_rb_t<TT, 8, false, true, MODE>(Uin, Uout, F, 1.0f, g, E, nullptr, s)                             \
-         : launch_rb_t<TT, 4, false, true, MODE>(Uin, Uout, F, 1.0f, g, E, nullptr, s))
+         : launch_rb_t<TT, 8, false, true, MODE, 4>(Uin, Uout, F, 1.0f, g, E, nullptr, s))
     if (sweeps == 1) {
         if (mode == 0) SC_GEN_CASE(1, 0); else if (mode == TB_ZEROIN) SC_GEN_CASE(1, TB_ZEROIN); else SC_GEN_CASE(1, TB_PROLONG);
         return true;
