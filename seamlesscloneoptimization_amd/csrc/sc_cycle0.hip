@@ -149,20 +149,20 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             const float4 a = (r == 0) ? up : u[r - 1];
             const float4 b = (r == R - 1) ? dn : u[r + 1];
             float4 cur = u[r];
-            if (((y + color) & 1) == 0) {      // wave-uniform: x is a multiple of 4
+            if (((r + color) & 1) == 0) {      // compile time: x is a multiple of 4 and y0 is even
                 float l = wave_from_left(cur.w);
                 if (lane == 0) l = 0.f;
                 const float n0 = 0.25f * (((l + cur.y) + (a.x + b.x)) - f[r].x);
                 const float n2 = 0.25f * (((cur.y + cur.w) + (a.z + b.z)) - f[r].z);
-                if (yok && x0ok) cur.x = n0;
-                if (yok && x2ok) cur.z = n2;
+                cur.x = (yok & x0ok) ? n0 : cur.x;
+                cur.z = (yok & x2ok) ? n2 : cur.z;
             } else {
                 float rr = wave_from_right(cur.x);
                 if (lane == 63) rr = 0.f;
                 const float n1 = 0.25f * (((cur.x + cur.z) + (a.y + b.y)) - f[r].y);
                 const float n3 = 0.25f * (((cur.z + rr) + (a.w + b.w)) - f[r].w);
-                if (yok && x1ok) cur.y = n1;
-                if (yok && x3ok) cur.w = n3;
+                cur.y = (yok & x1ok) ? n1 : cur.y;
+                cur.w = (yok & x3ok) ? n3 : cur.w;
             }
             u[r] = cur;
         }
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             float4 res = zero;
 #define SC_C0_RES(L, R_, A, B, CC, FF) \
     (float)((double)(FF) - ((((double)(L) + (double)(R_)) + ((double)(A) + (double)(B))) - 4.0 * (double)(CC)))
-            if (yok && x0ok) res.x = SC_C0_RES(l, cur.y, a.x, b.x, cur.x, f[r].x);
-            if (yok && x1ok) res.y = SC_C0_RES(cur.x, cur.z, a.y, b.y, cur.y, f[r].y);
-            if (yok && x2ok) res.z = SC_C0_RES(cur.y, cur.w, a.z, b.z, cur.z, f[r].z);
-            if (yok && x3ok) res.w = SC_C0_RES(cur.z, rr, a.w, b.w, cur.w, f[r].w);
+            res.x = (yok & x0ok) ? SC_C0_RES(l, cur.y, a.x, b.x, cur.x, f[r].x) : 0.f;
+            res.y = (yok & x1ok) ? SC_C0_RES(cur.x, cur.z, a.y, b.y, cur.y, f[r].y) : 0.f;
+            res.z = (yok & x2ok) ? SC_C0_RES(cur.y, cur.w, a.z, b.z, cur.z, f[r].z) : 0.f;
+            res.w = (yok & x3ok) ? SC_C0_RES(cur.z, rr, a.w, b.w, cur.w, f[r].w) : 0.f;
 #undef SC_C0_RES
             float rl = wave_from_left(res.w);
             if (lane == 0) rl = 0.f;

@@ -169,17 +169,17 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
             const float cn = (GEN && y == g.y.n) ? g.y.cw_last : 1.0f;
             const float dy = (GEN && y == g.y.n) ? g.y.d_last : 2.0f;
             (void)cn; (void)dy;
-            // x is a multiple of 4, so the colour of component k depends on (y + k) only: the
-            // branch below is wave-uniform
-            if (((y + color) & 1) == 0) {
+            // x is a multiple of 4 and y0 is even (tile origins and halos are even), so the colour
+            // of component k of row r is known at compile time
+            if (((r + color) & 1) == 0) {
                 float l = wave_from_left(cur.w);
                 if (lane == 0) l = 0.f;
                 const float g0 = SC_TB_GS(l, cur.y, a.x, b.x, f[r].x, cw0, dx0);
                 const float g2 = SC_TB_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, dx2);
                 const float n0 = SOR ? (cur.x + omega * (g0 - cur.x)) : g0;
                 const float n2 = SOR ? (cur.z + omega * (g2 - cur.z)) : g2;
-                if (yok && x0ok) cur.x = n0;
-                if (yok && x2ok) cur.z = n2;
+                cur.x = (yok & x0ok) ? n0 : cur.x;
+                cur.z = (yok & x2ok) ? n2 : cur.z;
             } else {
                 float rr = wave_from_right(cur.x);
                 if (lane == 63) rr = 0.f;
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
                 const float g3 = SC_TB_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, dx3);
                 const float n1 = SOR ? (cur.y + omega * (g1 - cur.y)) : g1;
                 const float n3 = SOR ? (cur.w + omega * (g3 - cur.w)) : g3;
-                if (yok && x1ok) cur.y = n1;
-                if (yok && x3ok) cur.w = n3;
+                cur.y = (yok & x1ok) ? n1 : cur.y;
+                cur.w = (yok & x3ok) ? n3 : cur.w;
             }
             u[r] = cur;
         }
@@ -251,10 +251,10 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
             const float n1 = 0.25f * (((cur.x + cur.z) + (prev.y + b.y)) - f[r].y);
             const float n2 = 0.25f * (((cur.y + cur.w) + (prev.z + b.z)) - f[r].z);
             const float n3 = 0.25f * (((cur.z + rr) + (prev.w + b.w)) - f[r].w);
-            if (yok && x0ok) nw.x = n0;
-            if (yok && x1ok) nw.y = n1;
-            if (yok && x2ok) nw.z = n2;
-            if (yok && x3ok) nw.w = n3;
+            nw.x = (yok & x0ok) ? n0 : nw.x;
+            nw.y = (yok & x1ok) ? n1 : nw.y;
+            nw.z = (yok & x2ok) ? n2 : nw.z;
+            nw.w = (yok & x3ok) ? n3 : nw.w;
             prev = cur;
             u[r] = nw;
         }
