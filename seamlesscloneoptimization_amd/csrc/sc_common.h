@@ -77,9 +77,7 @@ struct MGDim {
 struct MGGeom { MGDim x, y; };
 
 void launch_rb_half_gen(Field U, Field F, int color, float omega, MGGeom g, hipStream_t s);
-void launch_residual_field(Field U, Field F, Field R, MGGeom g, hipStream_t s); // R = F - A U (double arithmetic)
-void launch_restrict(Field R, Field Fc, MGGeom g, hipStream_t s);               // Fc = 4 * normalised P^T R
-void launch_residual_restrict(Field U, Field F, Field Fc, MGGeom g, hipStream_t s); // both, fused (no residual field)
+void launch_residual_restrict(Field U, Field F, Field Fc, MGGeom g, hipStream_t s); // Fc = 4 * normalised P^T (F - A U)
 int  prolong_blocks(int nx, int ny, int C);
 // Uf += P Uc; with d_partial (>= prolong_blocks floats) also *d_maxcorr = bits of max |P Uc|
 void launch_prolong_add(Field Uc, Field Uf, MGGeom g, float *d_partial, unsigned *d_maxcorr, hipStream_t s);

@@ -61,92 +61,14 @@ void launch_rb_half_gen(Field U, Field F, int color, float omega, MGGeom g, hipS
         hipLaunchKernelGGL(k_rb_half_gen<true>, grid, dim3(256), 0, s, U, F, color, omega, g);
 }
 
-// ---- residual field R = F - A U, evaluated in double from the float32 values ---------------
-// (float32 evaluation cancels catastrophically on smooth error: at 2048^2 it leaves ~1 grey
-// level of smooth error invisible; the double evaluation is exact for float inputs.)
-__global__ __launch_bounds__(256) void k_residual_field(Field U, Field F, Field R, MGGeom g)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = blockIdx.z;
-    const int W = U.W, H = U.H, P = U.pitch;
-    const int x = blockIdx.x * 256 + 4 * lane;
-    const int y = blockIdx.y * 4 + wv;
-    if (y < 1 || y > H - 2 || x >= P) return;
-    const float *__restrict__ row = U.at(c) + (size_t)y * P;
-    const float4 c4 = *reinterpret_cast<const float4 *>(row + x);
-    const float4 u4 = *reinterpret_cast<const float4 *>(row - P + x);
-    const float4 d4 = *reinterpret_cast<const float4 *>(row + P + x);
-    const float4 f4 = *reinterpret_cast<const float4 *>(F.at(c) + (size_t)y * P + x);
-    float l = wave_from_left(c4.w), r = wave_from_right(c4.x);
-    if (lane == 0) l = (x > 0) ? row[x - 1] : 0.f;
-    if (lane == 63) r = (x + 4 < P) ? row[x + 4] : 0.f;
-    const double cn = (y == g.y.n) ? (double)g.y.cw_last : 1.0;
-    const double dy = (y == g.y.n) ? (double)g.y.d_last : 2.0;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#define SC_RESF(dst, XI, CC, L, R_, UU, DD, FF)                                                     \
-    if ((XI) >= 1 && (XI) <= W - 2) {                                                               \
-        const double cw = ((XI) == g.x.n) ? (double)g.x.cw_last : 1.0;                              \
-        const double dx = ((XI) == g.x.n) ? (double)g.x.d_last : 2.0;                               \
-        const double s = ((cw * (double)(L) + (double)(R_)) + (cn * (double)(UU) + (double)(DD))) - \
-                         (dx + dy) * (double)(CC);                                                  \
-        dst = (float)((double)(FF) - s);                                                            \
-    }
-    SC_RESF(o.x, x + 0, c4.x, l, c4.y, u4.x, d4.x, f4.x)
-    SC_RESF(o.y, x + 1, c4.y, c4.x, c4.z, u4.y, d4.y, f4.y)
-    SC_RESF(o.z, x + 2, c4.z, c4.y, c4.w, u4.z, d4.z, f4.z)
-    SC_RESF(o.w, x + 3, c4.w, c4.z, r, u4.w, d4.w, f4.w)
-#undef SC_RESF
-    *reinterpret_cast<float4 *>(R.at(c) + (size_t)y * P + x) = o;
-}
-
-void launch_residual_field(Field U, Field F, Field R, MGGeom g, hipStream_t s)
-{
-    dim3 grid((U.W + 255) / 256, (U.H + 3) / 4, U.C);
-    hipLaunchKernelGGL(k_residual_field, grid, dim3(256), 0, s, U, F, R, g);
-}
-
-// ---- restriction: Fc = 4 * (row-normalised transpose of the interpolation) applied to R ----
-// Coarse point I gathers fine points 2I-1, 2I, 2I+1 with weights 1/2, 1, 1/2; the last coarse
-// point takes the (up to two) tail points with their interpolation weights instead.
-__global__ __launch_bounds__(256) void k_restrict(Field R, Field Fc, MGGeom g)
-{
-    const int I = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
-    const int J = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
-    const int c = blockIdx.z;
-    if (I > g.x.nc || J > g.y.nc) return;
-    float wx[4], wy[4], ix, iy;
-    restrict_weights(g.x, I, wx, ix);
-    restrict_weights(g.y, J, wy, iy);
-    const float *__restrict__ r = R.at(c);
-    const int P = R.pitch;
-    float acc = 0.f;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int y = 2 * J - 1 + a;
-        if (wy[a] == 0.f || y > g.y.n) continue;
-        float rowacc = 0.f;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int x = 2 * I - 1 + b;
-            if (wx[b] == 0.f || x > g.x.n) continue;
-            rowacc += wx[b] * r[(size_t)y * P + x];
-        }
-        acc += wy[a] * rowacc;
-    }
-    Fc.at(c)[(size_t)J * Fc.pitch + I] = 4.0f * (acc * (ix * iy));
-}
-
-void launch_restrict(Field R, Field Fc, MGGeom g, hipStream_t s)
-{
-    dim3 grid((g.x.nc + 63) / 64, (g.y.nc + 3) / 4, R.C);
-    hipLaunchKernelGGL(k_restrict, grid, dim3(256), 0, s, R, Fc, g);
-}
-
 // ---- fused residual + restriction (one pass over U and F, no residual field in HBM) ---------
+// Fc = 4 * (row-normalised transpose of the interpolation) applied to R = F - A U.
+// The residual is evaluated in double from the float32 values: float32 evaluation cancels
+// catastrophically on smooth error (at 2048^2 it leaves ~1 grey level of smooth error invisible),
+// the double evaluation is exact for float inputs.
 // Coarse tile 64 x 8 per 256-thread block.  Phase 1 stages the fine U tile (+1 halo) in LDS with
-// aligned float4 loads; phase 2 forms the fine residuals (double arithmetic) into a second LDS
-// tile, reading F straight from HBM exactly once; phase 3 applies the normalised transposed
-// interpolation.  Replaces k_residual_field + k_restrict (which wrote and re-read a full field).
+// aligned float4 loads; phase 2 forms the fine residuals into a second LDS tile, reading F
+// straight from HBM exactly once; phase 3 applies the normalised transposed interpolation.
 constexpr int RR_CW = 64, RR_CH = 8;
 constexpr int RR_FW = 2 * RR_CW + 8, RR_FH = 2 * RR_CH + 4;   // 136 x 20 fine values
 

@@ -35,6 +35,21 @@ def c1(inst):
           "device_ms": round(i.ms_device_total, 4), "h2d_ms": round(i.ms_h2d, 4), "d2h_ms": round(i.ms_d2h, 4), "cycles": i.sweeps,
           "roi": [i.W, i.H], "Mpix/s": round(i.W * i.H / dt / 1e6, 2), "reference_V100_ms": 1.905, "reference_T4_ms": 2.613})
 
+def host(inst):
+    """PCIe-inclusive rate of the drop-in call itself: pageable numpy images through my_seamlessclone_api_imp_run."""
+    for roi in (1024, 2048):
+        dst, patch, mask, cx, cy = synth(roi, 0)
+        body = dst.copy(); inst.run(patch, body, mask, cx, cy)
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            inst.run(patch, body, mask, cx, cy, sync=True)     # body re-used: same transfer volume, fewer cycles do not matter here
+        dt = (time.perf_counter() - t0) / n
+        body = dst.copy(); inst.run(patch, body, mask, cx, cy); i = inst.info()
+        emit({"config": f"host path {roi}x{roi} ROI (pageable images, H2D + clone + D2H per call)", "ms_per_call_repeat": round(dt * 1e3, 3),
+              "fresh_call": {"h2d_ms": round(i.ms_h2d, 3), "device_ms": round(i.ms_device_total, 3), "d2h_ms": round(i.ms_d2h, 3)},
+              "Mpix/s_pcie_inclusive": round(roi * roi / (i.ms_h2d + i.ms_device_total + i.ms_d2h) / 1e3, 1)})
+
 def load_clone_fields(inst, roi):
     dst, patch, mask, cx, cy = synth(roi, 0)
     inst.build_rhs(patch, dst, mask, cx, cy)       # leaves U0=U1=dst ROI, F=lap on the device
@@ -139,5 +154,5 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]
     inst = capi.Instance(0)
     for w in which:
-        {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5, "c3s": c3s}[w](inst)
+        {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5, "c3s": c3s, "host": host}[w](inst)
     inst.destroy()
