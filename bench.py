@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 # The HIP library must be loaded before anything pulls in torch's bundled ROCm runtime.
 from seamlesscloneoptimization_amd import capi  # noqa: E402
+capi.load()   # bind /opt/rocm's HIP runtime now; torch (gloo only, N>1) is imported later inside Comm()
 from seamlesscloneoptimization_amd.batch import Comm, StreamPool, timed_region  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
