@@ -220,78 +220,151 @@ void launch_prolong_add(Field Uc, Field Uf, MGGeom g, float *d_partial, unsigned
 // workgroup per channel: the top RHS is read from HBM once, all smoothing / restriction /
 // coarsest solve / prolongation runs on LDS with one s_barrier per phase, and only the top
 // correction is written back.  This collapses the ~100 tiny launches those levels would need.
-__device__ __forceinline__ float lds_gs(const float *u, const float *f, int P, int x, int y, const MGGeom &g)
+// Index mapping inside the bottom kernel: a linear index over rows of power-of-two padded width
+// (shift/mask instead of an integer division per point), and the four possible diagonals (regular / last column / last row /
+// corner) are inverted once per call instead of dividing per point.
+struct BtInv { float rr, lr, rl, ll; };   // 1/(dx+dy): regular, last col, last row, both
+__device__ __forceinline__ BtInv bt_inv(const MGGeom &g)
+{
+    BtInv v;
+    v.rr = 0.25f;
+    v.lr = 1.0f / (g.x.d_last + 2.0f);
+    v.rl = 1.0f / (2.0f + g.y.d_last);
+    v.ll = 1.0f / (g.x.d_last + g.y.d_last);
+    return v;
+}
+
+__device__ __forceinline__ int pow2_shift(int n) { return n <= 1 ? 0 : 32 - __clz(n - 1); }   // 2^shift >= n
+
+// Phase boundary.  WAVE = the phase is executed by ONE wavefront (the tiny levels): DS operations
+// of a wave are processed in order, so draining lgkmcnt and stopping compiler reordering is
+// enough -- no s_barrier, which is what the tiny levels' ~45 phases would otherwise wait on.
+template <bool WAVE>
+__device__ __forceinline__ void bt_sync()
+{
+    if (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <bool WAVE>
+__device__ __forceinline__ void lds_rb_half(float *u, const float *f, int P, const MGGeom &g, int color, float omega,
+                                            bool sor)
+{
+    const BtInv iv = bt_inv(g);
+    const int hx = (g.x.n + 1) >> 1, sh = pow2_shift(hx), total = g.y.n << sh;
+    const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, nthr = WAVE ? 64 : (int)blockDim.x;
+    for (int i = tid; i < total; i += nthr) {
+        const int y = 1 + (i >> sh);
+        const int x = 1 + ((1 + y + color) & 1) + 2 * (i & ((1 << sh) - 1));
+        if (x > g.x.n) continue;
+        const bool ylast = (y == g.y.n), xlast = (x == g.x.n);
+        const float cn = ylast ? g.y.cw_last : 1.0f, cw = xlast ? g.x.cw_last : 1.0f;
+        const float inv = xlast ? (ylast ? iv.ll : iv.lr) : (ylast ? iv.rl : iv.rr);
+        float *p = u + y * P + x;
+        const float gs = (((cw * p[-1] + p[1]) + (cn * p[-P] + p[P])) - f[y * P + x]) * inv;
+        *p = sor ? (*p + omega * (gs - *p)) : gs;
+    }
+    bt_sync<WAVE>();
+}
+
+// residual at one fine point (float: the levels in here are small and well conditioned; the
+// double evaluation matters on the fine levels handled by k_cycle0 / k_residual_restrict)
+__device__ __forceinline__ float lds_res(const float *u, const float *f, int P, int x, int y, const MGGeom &g)
 {
     const float cw = (x == g.x.n) ? g.x.cw_last : 1.0f, dx = (x == g.x.n) ? g.x.d_last : 2.0f;
     const float cn = (y == g.y.n) ? g.y.cw_last : 1.0f, dy = (y == g.y.n) ? g.y.d_last : 2.0f;
     const float *p = u + y * P + x;
-    return (((cw * p[-1] + p[1]) + (cn * p[-P] + p[P])) - f[y * P + x]) / (dx + dy);
+    const float s = ((cw * p[-1] + p[1]) + (cn * p[-P] + p[P])) - (dx + dy) * p[0];
+    return f[y * P + x] - s;
 }
 
-__device__ __forceinline__ void lds_rb_half(float *u, const float *f, int P, const MGGeom &g, int color, float omega,
-                                            bool sor)
-{
-    const int hx = (g.x.n + 1) / 2;
-    for (int i = threadIdx.x; i < hx * g.y.n; i += blockDim.x) {
-        const int y = 1 + i / hx;
-        const int x = 1 + 2 * (i - (y - 1) * hx) + ((1 + y + color) & 1);
-        if (x > g.x.n) continue;
-        const float gs = lds_gs(u, f, P, x, y, g);
-        float *p = u + y * P + x;
-        *p = sor ? (*p + omega * (gs - *p)) : gs;
-    }
-    __syncthreads();
-}
-
-// residual at one fine point, double arithmetic (see k_residual_field)
-__device__ __forceinline__ float lds_res(const float *u, const float *f, int P, int x, int y, const MGGeom &g)
-{
-    const double cw = (x == g.x.n) ? (double)g.x.cw_last : 1.0, dx = (x == g.x.n) ? (double)g.x.d_last : 2.0;
-    const double cn = (y == g.y.n) ? (double)g.y.cw_last : 1.0, dy = (y == g.y.n) ? (double)g.y.d_last : 2.0;
-    const float *p = u + y * P + x;
-    const double s = ((cw * (double)p[-1] + (double)p[1]) + (cn * (double)p[-P] + (double)p[P])) - (dx + dy) * (double)p[0];
-    return (float)((double)f[y * P + x] - s);
-}
-
+template <bool WAVE>
 __device__ __forceinline__ void lds_restrict(const float *u, const float *f, int P, float *fc, int Pc, const MGGeom &g)
 {
-    for (int i = threadIdx.x; i < g.x.nc * g.y.nc; i += blockDim.x) {
-        const int J = 1 + i / g.x.nc, I = 1 + (i - (J - 1) * g.x.nc);
-        float wx[4], wy[4], ix, iy;
-        restrict_weights(g.x, I, wx, ix);
-        restrict_weights(g.y, J, wy, iy);
-        float acc = 0.f;
+    const int sh = pow2_shift(g.x.nc), total = g.y.nc << sh;
+    const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, nthr = WAVE ? 64 : (int)blockDim.x;
+    for (int i = tid; i < total; i += nthr) {
+        const int J = 1 + (i >> sh), I = 1 + (i & ((1 << sh) - 1));
+        if (I > g.x.nc) continue;
+        {
+            float wy[4], iy, wx[4], ix;
+            restrict_weights(g.y, J, wy, iy);
+            restrict_weights(g.x, I, wx, ix);
+            float acc = 0.f;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int y = 2 * J - 1 + a;
-            if (wy[a] == 0.f || y > g.y.n) continue;
-            float rowacc = 0.f;
+            for (int a = 0; a < 4; ++a) {
+                const int y = 2 * J - 1 + a;
+                if (wy[a] == 0.f || y > g.y.n) continue;
+                float rowacc = 0.f;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int x = 2 * I - 1 + b;
-                if (wx[b] == 0.f || x > g.x.n) continue;
-                rowacc += wx[b] * lds_res(u, f, P, x, y, g);
+                for (int b = 0; b < 4; ++b) {
+                    const int x = 2 * I - 1 + b;
+                    if (wx[b] == 0.f || x > g.x.n) continue;
+                    rowacc += wx[b] * lds_res(u, f, P, x, y, g);
+                }
+                acc += wy[a] * rowacc;
             }
-            acc += wy[a] * rowacc;
+            fc[J * Pc + I] = 4.0f * (acc * (ix * iy));
         }
-        fc[J * Pc + I] = 4.0f * (acc * (ix * iy));
     }
-    __syncthreads();
+    bt_sync<WAVE>();
 }
 
+template <bool WAVE>
 __device__ __forceinline__ void lds_prolong(const float *e, int Pc, float *u, int P, const MGGeom &g)
 {
-    for (int i = threadIdx.x; i < g.x.n * g.y.n; i += blockDim.x) {
-        const int y = 1 + i / g.x.n, x = 1 + (i - (y - 1) * g.x.n);
-        int I0, I1, J0, J1;
-        float wx0, wx1, wy0, wy1;
-        interp_1d(g.x, x, I0, I1, wx0, wx1);
-        interp_1d(g.y, y, J0, J1, wy0, wy1);
-        const float top = wx0 * e[J0 * Pc + I0] + wx1 * e[J0 * Pc + I1];
-        const float bot = wx0 * e[J1 * Pc + I0] + wx1 * e[J1 * Pc + I1];
-        u[y * P + x] += wy0 * top + wy1 * bot;
+    const int sh = pow2_shift(g.x.n), total = g.y.n << sh;
+    const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, nthr = WAVE ? 64 : (int)blockDim.x;
+    for (int i = tid; i < total; i += nthr) {
+        const int y = 1 + (i >> sh), x = 1 + (i & ((1 << sh) - 1));
+        if (x > g.x.n) continue;
+        {
+            int J0, J1, I0, I1;
+            float wy0, wy1, wx0, wx1;
+            interp_1d(g.y, y, J0, J1, wy0, wy1);
+            interp_1d(g.x, x, I0, I1, wx0, wx1);
+            const float top = wx0 * e[J0 * Pc + I0] + wx1 * e[J0 * Pc + I1];
+            const float bot = wx0 * e[J1 * Pc + I0] + wx1 * e[J1 * Pc + I1];
+            u[y * P + x] += wy0 * top + wy1 * bot;
+        }
     }
-    __syncthreads();
+    bt_sync<WAVE>();
+}
+
+// levels [l0, L) of the V-cycle: descent, coarsest solve, ascent (level l0's own prolongation is the caller's)
+template <bool WAVE>
+__device__ __forceinline__ void bt_subcycle(float *lds, const MGBottomArgs &a, int l0, int l1)
+{
+    const int L = a.nlevels;
+    for (int l = l0; l < l1 && l + 1 < L; ++l) {
+        const MGBottomLevel &v = a.lv[l];
+        const MGBottomLevel &w = a.lv[l + 1];
+        for (int s = 0; s < a.pre; ++s) {
+            lds_rb_half<WAVE>(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, 1.0f, false);
+            lds_rb_half<WAVE>(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, 1.0f, false);
+        }
+        lds_restrict<WAVE>(lds + v.offU, lds + v.offF, v.pitch, lds + w.offF, w.pitch, v.g);
+    }
+}
+
+template <bool WAVE>
+__device__ __forceinline__ void bt_ascent(float *lds, const MGBottomArgs &a, int l0, int l1)
+{
+    for (int l = l1 - 1; l >= l0; --l) {
+        if (l + 1 >= a.nlevels) continue;
+        const MGBottomLevel &v = a.lv[l];
+        const MGBottomLevel &w = a.lv[l + 1];
+        lds_prolong<WAVE>(lds + w.offU, w.pitch, lds + v.offU, v.pitch, v.g);
+        for (int s = 0; s < a.post; ++s) {
+            lds_rb_half<WAVE>(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, 1.0f, false);
+            lds_rb_half<WAVE>(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, 1.0f, false);
+        }
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
@@ -305,45 +378,40 @@ __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
         const MGBottomLevel &t = a.lv[0];
         const float *__restrict__ fg = a.Ftop.at(c);
         float *f = lds + t.offF;
-        for (int i = threadIdx.x; i < t.g.x.n * t.g.y.n; i += blockDim.x) {
-            const int y = 1 + i / t.g.x.n, x = 1 + (i - (y - 1) * t.g.x.n);
-            f[y * t.pitch + x] = fg[(size_t)y * a.Ftop.pitch + x];
-        }
+        for (int y = 1 + (threadIdx.x >> 6); y <= t.g.y.n; y += 16)
+            for (int x = 1 + (threadIdx.x & 63); x <= t.g.x.n; x += 64) f[y * t.pitch + x] = fg[(size_t)y * a.Ftop.pitch + x];
         __syncthreads();
     }
-    for (int l = 0; l + 1 < L; ++l) {
-        const MGBottomLevel &v = a.lv[l];
-        const MGBottomLevel &w = a.lv[l + 1];
-        for (int s = 0; s < a.pre; ++s) {
-            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, 1.0f, false);
-            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, 1.0f, false);
+    // levels [0, ls): all 16 waves with block barriers; levels [ls, L): wave 0 alone (<= 4 colour
+    // points per lane), the other waves wait at ONE barrier for the whole sub-cycle
+    int ls = L;
+    while (ls > 0 && ((a.lv[ls - 1].g.x.n + 1) >> 1) * a.lv[ls - 1].g.y.n <= 256) --ls;
+    const int lb = ls < L - 1 ? ls : L - 1;            // block-mode levels are [0, lb)
+    bt_subcycle<false>(lds, a, 0, lb);
+    const MGBottomLevel &cv = a.lv[L - 1];
+    if (ls < L) {
+        if ((threadIdx.x >> 6) == 0) {
+            bt_subcycle<true>(lds, a, lb, L - 1);
+            for (int s = 0; s < a.coarse_sweeps; ++s) {
+                lds_rb_half<true>(lds + cv.offU, lds + cv.offF, cv.pitch, cv.g, 0, cv.omega, true);
+                lds_rb_half<true>(lds + cv.offU, lds + cv.offF, cv.pitch, cv.g, 1, cv.omega, true);
+            }
+            bt_ascent<true>(lds, a, lb, L - 1);
         }
-        lds_restrict(lds + v.offU, lds + v.offF, v.pitch, lds + w.offF, w.pitch, v.g);
-    }
-    {
-        const MGBottomLevel &v = a.lv[L - 1];
+        __syncthreads();
+    } else {                                            // even the coarsest level is large (thin ROIs)
         for (int s = 0; s < a.coarse_sweeps; ++s) {
-            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, v.omega, true);
-            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, v.omega, true);
+            lds_rb_half<false>(lds + cv.offU, lds + cv.offF, cv.pitch, cv.g, 0, cv.omega, true);
+            lds_rb_half<false>(lds + cv.offU, lds + cv.offF, cv.pitch, cv.g, 1, cv.omega, true);
         }
     }
-    for (int l = L - 2; l >= 0; --l) {
-        const MGBottomLevel &v = a.lv[l];
-        const MGBottomLevel &w = a.lv[l + 1];
-        lds_prolong(lds + w.offU, w.pitch, lds + v.offU, v.pitch, v.g);
-        for (int s = 0; s < a.post; ++s) {
-            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, 1.0f, false);
-            lds_rb_half(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, 1.0f, false);
-        }
-    }
+    bt_ascent<false>(lds, a, 0, lb);
     {   // top correction: LDS -> HBM (interior; ring and pads of the global plane stay zero)
         const MGBottomLevel &t = a.lv[0];
         float *__restrict__ ug = a.Utop.at(c);
         const float *u = lds + t.offU;
-        for (int i = threadIdx.x; i < t.g.x.n * t.g.y.n; i += blockDim.x) {
-            const int y = 1 + i / t.g.x.n, x = 1 + (i - (y - 1) * t.g.x.n);
-            ug[(size_t)y * a.Utop.pitch + x] = u[y * t.pitch + x];
-        }
+        for (int y = 1 + (threadIdx.x >> 6); y <= t.g.y.n; y += 16)
+            for (int x = 1 + (threadIdx.x & 63); x <= t.g.x.n; x += 64) ug[(size_t)y * a.Utop.pitch + x] = u[y * t.pitch + x];
     }
 }
 
