@@ -192,6 +192,31 @@ def test_c1_reference_golden_jpeg_through_the_c_abi(hip, c1_inputs, golden_blend
     assert d[roi].mean() < 0.05 and (d[roi] > 0).mean() < 0.03 and d.mean() < 0.002
 
 
+def test_frozen_golden_vectors_on_the_gpu(hip, golden_dir, c1_inputs):
+    """The committed golden vectors (tests/golden/*.npz) through the C ABI."""
+    ex = np.load(os.path.join(golden_dir, "c1_expected.npz"))
+    c = c1_inputs
+    body = c["dst"].copy()
+    hip.run(c["patch"], body, c["mask"], 800, 150)
+    assert np.abs(body[54:54 + 192, 651:651 + 298].astype(int) - ex["roi_bgr"].astype(int)).max() <= 1
+    hip.set_solver(reference_warmup=1)
+    body = c["dst"].copy()
+    hip.run(c["patch"], body, c["mask"], 800, 150)
+    hip.set_solver(reference_warmup=0)
+    assert np.abs(body[54:54 + 192, 651:651 + 298].astype(int) - ex["roi_twice_bgr"].astype(int)).max() <= 1
+    syn = np.load(os.path.join(golden_dir, "synthetic_cases.npz"))
+    for name in ("r16x12", "r33x17", "e40x37"):
+        dst, patch, mask = syn[name + "_dst"], syn[name + "_patch"], syn[name + "_mask"]
+        cx, cy = (int(v) for v in syn[name + "_center"])
+        geo, M = hip.mask_stage(mask, cx, cy)
+        assert np.array_equal(M, syn[name + "_eroded"])
+        _, B, lap = hip.build_rhs(patch, dst, mask, cx, cy)
+        assert np.array_equal(lap.transpose(1, 2, 0), syn[name + "_lap_f32"])          # bit exact
+        body = dst.copy()
+        hip.run(patch, body, mask, cx, cy)
+        assert np.abs(body.astype(int) - syn[name + "_out"].astype(int)).max() <= 1
+
+
 def test_python_class_end_to_end(c1_inputs, oracles):
     from seamlesscloneoptimization_amd import SeamlessClone, compare
     o, _ = oracles

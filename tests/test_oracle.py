@@ -151,3 +151,29 @@ def test_edge_cases():
     # all-zero-eroded mask => pure dst gradients => the clone returns dst (up to truncation)
     out = oc.seamless_clone(dst, patch[:8, :9].copy(), np.full((8, 9), 255, np.uint8), cx, cy, 1, True)
     assert np.abs(out.astype(int) - dst.astype(int)).max() <= 1
+
+
+def test_frozen_golden_vectors(golden_dir, c1_inputs):
+    """Frozen oracle outputs (tests/golden/make_golden.py): both restatements must keep reproducing them."""
+    ex = np.load(os.path.join(golden_dir, "c1_expected.npz"))
+    c = c1_inputs
+    out, info = o.seamless_clone(c["dst"], c["patch"], c["mask"], 800, 150, return_all=True)
+    g = ex["geo"]
+    assert list(g) == [1, 1, 298, 192, 651, 54]
+    assert np.array_equal(out[54:54 + 192, 651:651 + 298], ex["roi_bgr"])
+    assert np.array_equal(info["g"].astype(np.float32), ex["rhs_g_f32"])
+    assert int(info["geo"]["M"].astype(np.int64).sum()) == int(ex["eroded_mask_sum"])
+    got_c = oc.seamless_clone(c["dst"], c["patch"], c["mask"], 800, 150, 2, True)
+    assert np.abs(got_c[54:54 + 192, 651:651 + 298].astype(int) - ex["roi_bgr"].astype(int)).max() <= 1
+    syn = np.load(os.path.join(golden_dir, "synthetic_cases.npz"))
+    for name in ("r16x12", "r33x17", "e40x37"):
+        dst, patch, mask = syn[name + "_dst"], syn[name + "_patch"], syn[name + "_mask"]
+        cx, cy = (int(v) for v in syn[name + "_center"])
+        res, inf = o.seamless_clone(dst, patch, mask, cx, cy, return_all=True)
+        assert np.array_equal(res, syn[name + "_out"])
+        assert np.array_equal(inf["lap"].astype(np.float32), syn[name + "_lap_f32"])
+        assert np.array_equal(inf["geo"]["M"], syn[name + "_eroded"])
+        geo, M = oc.mask_stage(mask, cx, cy)
+        B, lap = oc.build_rhs(dst, patch, geo, M)
+        assert np.array_equal(M, syn[name + "_eroded"]) and np.array_equal(lap.transpose(1, 2, 0), syn[name + "_lap_f32"])
+        assert np.abs(oc.seamless_clone(dst, patch, mask, cx, cy, 1, True).astype(int) - syn[name + "_out"].astype(int)).max() <= 1
