@@ -58,12 +58,17 @@ enum sc_method {
 
 typedef struct sc_solver_opts {
     int   method;            /* enum sc_method                                              */
-    int   max_sweeps;        /* sweeps (JACOBI/RBGS/SOR) or V-cycles (MULTIGRID) budget     */
+    int   max_sweeps;        /* sweeps (JACOBI/RBGS/SOR) or V-cycles (MULTIGRID) budget; MULTIGRID
+                                reports SC_ERR_NOT_CONVERGED when the budget ends first         */
     float tol;               /* stop when ||lap - A u||_2 / ||lap||_2 <= tol; <=0: run
                                 exactly max_sweeps                                         */
     int   check_every;       /* sweeps between residual checks (tol>0)                      */
-    float omega;             /* SOR relaxation; <=0 -> 2/(1+sin(pi/max(w,h)+1)) style optimum */
-    int   sweeps_per_launch; /* temporal blocking depth of the sweep kernel; 0 = library default */
+    float omega;             /* SOR relaxation; <=0 -> optimum for the rectangle,
+                                2/(1+sqrt(1-rho^2)), rho = (cos(pi/(w+1))+cos(pi/(h+1)))/2            */
+    int   sweeps_per_launch; /* 0: library default (register-blocked fused kernels, deepest depth);
+                                1: one sweep per launch with the plain kernels; -1: fused kernel, depth 1;
+                                >=2: fused kernel at that depth (Jacobi <=4, red-black <=2).  All variants
+                                give bit-identical fields.                                          */
     int   reference_warmup;  /* 1: clone twice in place, as the reference's run() does
                                 (warm-up + 1, seamlessClone_imp.cu:303-318)                */
     int   mg_pre, mg_post;   /* multigrid smoothing sweeps per level (0 = default 2/2)      */
@@ -83,7 +88,7 @@ typedef struct sc_run_info {
     float  ms_h2d, ms_mask, ms_pre, ms_solve, ms_post, ms_d2h; /* hipEvent times on the instance stream */
     float  ms_device_total;         /* mask + pre + solve + post                            */
     int    sweep_launches;          /* launches of the dominant sweep kernel in the last run */
-    float  ms_sweep_kernels;        /* hipEvent time spent in them (only when profiling enabled) */
+    float  last_update;             /* MULTIGRID: max |coarse-grid correction| of the last checked cycle (grey levels) */
     size_t device_bytes;            /* arena bytes owned by the instance                    */
 } sc_run_info;
 

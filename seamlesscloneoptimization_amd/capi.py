@@ -47,7 +47,7 @@ class RunInfo(C.Structure):
                 ("sweeps", C.c_int), ("converged", C.c_int), ("rel_residual", C.c_double),
                 ("ms_h2d", C.c_float), ("ms_mask", C.c_float), ("ms_pre", C.c_float), ("ms_solve", C.c_float),
                 ("ms_post", C.c_float), ("ms_d2h", C.c_float), ("ms_device_total", C.c_float),
-                ("sweep_launches", C.c_int), ("ms_sweep_kernels", C.c_float), ("device_bytes", C.c_size_t)]
+                ("sweep_launches", C.c_int), ("last_update", C.c_float), ("device_bytes", C.c_size_t)]
 
 
 class SeamlessCloneError(RuntimeError):

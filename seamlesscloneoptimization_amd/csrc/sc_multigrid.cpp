@@ -250,6 +250,7 @@ int mg_solve(Instance *I)
             float m;
             unsigned bits = *I->h_maxcorr;
             memcpy(&m, &bits, sizeof(float));
+            I->info.last_update = m;
             if (o.tol > 0.f) {
                 double r[2];
                 if ((rc = eval_residual(I, r))) return rc;
@@ -273,6 +274,7 @@ int mg_solve(Instance *I)
         float m;
         unsigned bits = *I->h_maxcorr;
         memcpy(&m, &bits, sizeof(float));
+        I->info.last_update = m;
         if (o.tol > 0.f) { // optional residual-based stop
             double r[2];
             if ((rc = eval_residual(I, r))) return rc;

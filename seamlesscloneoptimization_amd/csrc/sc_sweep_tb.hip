@@ -14,6 +14,7 @@
 // HBM traffic per launch ~ (4 B + 4 B)/efficiency + 4 B per unknown for T sweeps, against
 // 12 B x T algorithmic -- hence "effective" bandwidth above the HBM roof for T > 1.
 #include "sc_common.h"
+#include <stdlib.h>
 #include "sc_wave.h"
 #include "sc_mg_device.h"
 
@@ -321,7 +322,8 @@ int tb_blocks_level0(int W, int H, int C, int sweeps)
 // the grid still spreads over the chip.  mode: 0 plain, TB_ZEROIN, TB_PROLONG (with E).
 bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s)
 {
-    const bool big = (long)Uin.W * Uin.H >= 700L * 700L;
+    static const long big_side = [] { const char *e = getenv("SC_BIG_SIDE"); return e ? atol(e) : 700L; }();
+    const bool big = (long)Uin.W * Uin.H >= big_side * big_side;
 // small levels: 8 waves x 4 rows (same 256 x 32 region as 4 x 8, half the serial work per lane)
 #define SC_GEN_CASE(TT, MODE)                                                                                       \
     (big ? launch_rb_t<TT, 8, false, true, MODE>(Uin, Uout, F, 1.0f, g, E, nullptr, s)                             \
