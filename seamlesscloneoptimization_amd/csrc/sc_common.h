@@ -56,6 +56,8 @@ void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_
 int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
                    float *partial, hipStream_t s);
 int  cycle0_blocks(int W, int H, int C, int sweeps);
+// coarse level: zero-guess pre-smoothing + residual + restriction fused (Uout = smoothed correction, Fc = next RHS)
+bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s);
 
 // residual: d_out[0] = sum r^2, d_out[1] = sum lap^2 (double); d_partials holds >= 2*max_blocks doubles
 int  residual_max_blocks();

@@ -37,7 +37,10 @@ __device__ __forceinline__ void c0_load(const float *__restrict__ p, int P, int 
     }
 }
 
-template <int T, int NW, int R, bool PRO>
+// GEN    = coarse multigrid level: general stencil coefficients at the last column / row (MGDim)
+//          and the interpolation-tail weights in the restriction of the last coarse column / row.
+// ZEROIN = the incoming correction is identically zero and is not read (first visit of a level).
+template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN>
 __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
                                                     float *__restrict__ partial)
 {
@@ -45,14 +48,19 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
     static_assert(2 * T + 2 <= C0_HX, "column halo too small");
     static_assert(R % 2 == 0, "bands must hold whole coarse-row pairs");
     __shared__ float4 edge[2][NW][2][64];
-    __shared__ float2 hedge[NW][64];
+    __shared__ float2 hedge[2][NW][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.z;
     const int W = Uin.W, H = Uin.H, P = Uin.pitch;
     const int x = blockIdx.x * (256 - 2 * C0_HX) - C0_HX + 4 * lane;
     const int y0 = blockIdx.y * (RH - 2 * HY) - HY + wv * R;       // even
     float4 u[R], f[R];
-    c0_load<R>(Uin.at(c), P, H, x, y0, u);
+    if (ZEROIN) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        c0_load<R>(Uin.at(c), P, H, x, y0, u);
+    }
     if (!PRO) c0_load<R>(F.at(c), P, H, x, y0, f);   // with PRO the RHS is fetched after the prolongation (VGPR pressure)
     const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
     const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
@@ -133,6 +141,14 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
     if (PRO) c0_load<R>(F.at(c), P, H, x, y0, f);
 
     // ------------------------------------------------------------------ T red-black sweeps
+    // general coefficients (compile away when !GEN)
+    const float cw0 = (GEN && x + 0 == g.x.n) ? g.x.cw_last : 1.0f, dx0 = (GEN && x + 0 == g.x.n) ? g.x.d_last : 2.0f;
+    const float cw1 = (GEN && x + 1 == g.x.n) ? g.x.cw_last : 1.0f, dx1 = (GEN && x + 1 == g.x.n) ? g.x.d_last : 2.0f;
+    const float cw2 = (GEN && x + 2 == g.x.n) ? g.x.cw_last : 1.0f, dx2 = (GEN && x + 2 == g.x.n) ? g.x.d_last : 2.0f;
+    const float cw3 = (GEN && x + 3 == g.x.n) ? g.x.cw_last : 1.0f, dx3 = (GEN && x + 3 == g.x.n) ? g.x.d_last : 2.0f;
+#define SC_C0_GS(L, R_, A, B, FF, CW, DX)                                                    \
+    (GEN ? ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - (FF)) / ((DX) + dy)                   \
+         : 0.25f * ((((L) + (R_)) + ((A) + (B))) - (FF)))
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     edge[0][wv][0][lane] = u[0];
     edge[0][wv][1][lane] = u[R - 1];
@@ -149,18 +165,21 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             const float4 a = (r == 0) ? up : u[r - 1];
             const float4 b = (r == R - 1) ? dn : u[r + 1];
             float4 cur = u[r];
+            const float cn = (GEN && y == g.y.n) ? g.y.cw_last : 1.0f;
+            const float dy = (GEN && y == g.y.n) ? g.y.d_last : 2.0f;
+            (void)cn; (void)dy;
             if (((r + color) & 1) == 0) {      // compile time: x is a multiple of 4 and y0 is even
                 float l = wave_from_left(cur.w);
                 if (lane == 0) l = 0.f;
-                const float n0 = 0.25f * (((l + cur.y) + (a.x + b.x)) - f[r].x);
-                const float n2 = 0.25f * (((cur.y + cur.w) + (a.z + b.z)) - f[r].z);
+                const float n0 = SC_C0_GS(l, cur.y, a.x, b.x, f[r].x, cw0, dx0);
+                const float n2 = SC_C0_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, dx2);
                 cur.x = (yok & x0ok) ? n0 : cur.x;
                 cur.z = (yok & x2ok) ? n2 : cur.z;
             } else {
                 float rr = wave_from_right(cur.x);
                 if (lane == 63) rr = 0.f;
-                const float n1 = 0.25f * (((cur.x + cur.z) + (a.y + b.y)) - f[r].y);
-                const float n3 = 0.25f * (((cur.z + rr) + (a.w + b.w)) - f[r].w);
+                const float n1 = SC_C0_GS(cur.x, cur.z, a.y, b.y, f[r].y, cw1, dx1);
+                const float n3 = SC_C0_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, dx3);
                 cur.y = (yok & x1ok) ? n1 : cur.y;
                 cur.w = (yok & x3ok) ? n3 : cur.w;
             }
@@ -172,10 +191,16 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
     }
 
     // ------------------------------------------------------------------ residual + restriction
+#undef SC_C0_GS
     {
         constexpr int buf = (2 * T) & 1;       // the edges written after the last half-step
         const float4 up = (wv > 0) ? edge[buf][wv - 1][1][lane] : zero;
         const float4 dn = (wv < NW - 1) ? edge[buf][wv + 1][0][lane] : zero;
+        const int I = x >> 1;                                  // coarse column of fine x (x even)
+        // weights of the two fine points right of / below a coarse point: 1/2, 0 in general, the
+        // interpolation-tail weights at the last coarse column / row (MGDim)
+        const float wxa0 = (GEN && I == g.x.nc) ? g.x.tw1 : 0.5f, wxb0 = (GEN && I == g.x.nc) ? g.x.tw2 : 0.0f;
+        const float wxa1 = (GEN && I + 1 == g.x.nc) ? g.x.tw1 : 0.5f, wxb1 = (GEN && I + 1 == g.x.nc) ? g.x.tw2 : 0.0f;
         float h0[R], h1[R];                    // horizontally filtered residual at coarse columns x and x+2
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -187,24 +212,35 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             float l = wave_from_left(cur.w), rr = wave_from_right(cur.x);
             if (lane == 0) l = 0.f;
             if (lane == 63) rr = 0.f;
-            float4 res = zero;
-#define SC_C0_RES(L, R_, A, B, CC, FF) \
-    (float)((double)(FF) - ((((double)(L) + (double)(R_)) + ((double)(A) + (double)(B))) - 4.0 * (double)(CC)))
-            res.x = (yok & x0ok) ? SC_C0_RES(l, cur.y, a.x, b.x, cur.x, f[r].x) : 0.f;
-            res.y = (yok & x1ok) ? SC_C0_RES(cur.x, cur.z, a.y, b.y, cur.y, f[r].y) : 0.f;
-            res.z = (yok & x2ok) ? SC_C0_RES(cur.y, cur.w, a.z, b.z, cur.z, f[r].z) : 0.f;
-            res.w = (yok & x3ok) ? SC_C0_RES(cur.z, rr, a.w, b.w, cur.w, f[r].w) : 0.f;
+            const double cn = (GEN && y == g.y.n) ? (double)g.y.cw_last : 1.0;
+            const double dy = (GEN && y == g.y.n) ? (double)g.y.d_last : 2.0;
+            float4 res;
+#define SC_C0_RES(L, R_, A, B, CC, FF, CW, DX)                                                              \
+    (float)((double)(FF) - ((((double)(CW) * (double)(L) + (double)(R_)) + (cn * (double)(A) + (double)(B))) - \
+                            ((double)(DX) + dy) * (double)(CC)))
+            res.x = (yok & x0ok) ? SC_C0_RES(l, cur.y, a.x, b.x, cur.x, f[r].x, cw0, dx0) : 0.f;
+            res.y = (yok & x1ok) ? SC_C0_RES(cur.x, cur.z, a.y, b.y, cur.y, f[r].y, cw1, dx1) : 0.f;
+            res.z = (yok & x2ok) ? SC_C0_RES(cur.y, cur.w, a.z, b.z, cur.z, f[r].z, cw2, dx2) : 0.f;
+            res.w = (yok & x3ok) ? SC_C0_RES(cur.z, rr, a.w, b.w, cur.w, f[r].w, cw3, dx3) : 0.f;
 #undef SC_C0_RES
             float rl = wave_from_left(res.w);
             if (lane == 0) rl = 0.f;
-            h0[r] = (0.5f * rl + res.x) + 0.5f * res.y;
-            h1[r] = (0.5f * res.y + res.z) + 0.5f * res.w;
+            if (GEN) {
+                float rn = wave_from_right(res.x);
+                if (lane == 63) rn = 0.f;
+                h0[r] = ((0.5f * rl + res.x) + wxa0 * res.y) + wxb0 * res.z;
+                h1[r] = ((0.5f * res.y + res.z) + wxa1 * res.w) + wxb1 * rn;
+            } else {
+                h0[r] = (0.5f * rl + res.x) + 0.5f * res.y;
+                h1[r] = (0.5f * res.y + res.z) + 0.5f * res.w;
+            }
         }
-        hedge[wv][lane] = make_float2(h0[R - 1], h1[R - 1]);
+        hedge[0][wv][lane] = make_float2(h0[R - 1], h1[R - 1]);
+        if (GEN) hedge[1][wv][lane] = make_float2(h0[0], h1[0]);
         __syncthreads();
-        const float2 hup = (wv > 0) ? hedge[wv - 1][lane] : make_float2(0.f, 0.f);
+        const float2 hup = (wv > 0) ? hedge[0][wv - 1][lane] : make_float2(0.f, 0.f);
+        const float2 hdn = (GEN && wv < NW - 1) ? hedge[1][wv + 1][lane] : make_float2(0.f, 0.f);
         const bool lane_out = (lane >= C0_HXQ) && (lane < 64 - C0_HXQ);
-        const int I = x >> 1;                                  // coarse column of fine x (x even)
         float *__restrict__ fc = Fc.at(c);
         const float fx0 = (I == g.x.nc) ? 2.0f * g.x.inv_last : 1.0f;
         const float fx1 = (I + 1 == g.x.nc) ? 2.0f * g.x.inv_last : 1.0f;
@@ -214,8 +250,17 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             const int J = y >> 1;
             if (!lane_out || yr < HY || yr >= RH - HY || J < 1 || J > g.y.nc) continue;
             const float m0 = (r == 0) ? hup.x : h0[r - 1], m1 = (r == 0) ? hup.y : h1[r - 1];
-            const float v0 = (0.5f * m0 + h0[r]) + 0.5f * h0[r + 1];
-            const float v1 = (0.5f * m1 + h1[r]) + 0.5f * h1[r + 1];
+            float v0, v1;
+            if (GEN) {
+                const float wya = (J == g.y.nc) ? g.y.tw1 : 0.5f, wyb = (J == g.y.nc) ? g.y.tw2 : 0.0f;
+                const float p0 = (r + 2 < R) ? h0[(r + 2 < R) ? r + 2 : 0] : hdn.x;
+                const float p1 = (r + 2 < R) ? h1[(r + 2 < R) ? r + 2 : 0] : hdn.y;
+                v0 = ((0.5f * m0 + h0[r]) + wya * h0[r + 1]) + wyb * p0;
+                v1 = ((0.5f * m1 + h1[r]) + wya * h1[r + 1]) + wyb * p1;
+            } else {
+                v0 = (0.5f * m0 + h0[r]) + 0.5f * h0[r + 1];
+                v1 = (0.5f * m1 + h1[r]) + 0.5f * h1[r + 1];
+            }
             const float fy = (J == g.y.nc) ? 2.0f * g.y.inv_last : 1.0f;
             float *o = fc + (size_t)J * Fc.pitch + I;
             if (I >= 1 && I <= g.x.nc) o[0] = v0 * (fx0 * fy);
@@ -240,7 +285,8 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
 {
     constexpr int RH = C0_NW * C0_R, HY = 2 * T + 2;
     dim3 grid((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
-    hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO>), grid, dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E, g, partial);
+    hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false>), grid, dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E, g,
+                       partial);
     return (int)(grid.x * grid.y * grid.z);
 }
 
@@ -268,6 +314,26 @@ int cycle0_blocks(int W, int H, int C, int sweeps)
 {
     const int RH = C0_NW * C0_R, HY = 2 * sweeps + 2;
     return ((W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * C;
+}
+
+// Coarse levels (l >= 1): pre-smoothing from a zero correction + residual + restriction in one
+// launch.  Uout receives the smoothed correction, Fc the next level's RHS.
+template <int T, int R>
+static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_t s)
+{
+    constexpr int RH = C0_NW * R, HY = 2 * T + 2;
+    Field none{};
+    dim3 grid((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX), (F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), F.C);
+    hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true>), grid, dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
+                       Uout, F, Fc, none, g, (float *)nullptr);
+}
+
+bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s)
+{
+    const bool big = (long)F.W * F.H >= 700L * 700L;
+    if (sweeps == 1) { big ? launch_cn<1, 8>(Uout, F, Fc, g, s) : launch_cn<1, 4>(Uout, F, Fc, g, s); return true; }
+    if (sweeps == 2) { big ? launch_cn<2, 8>(Uout, F, Fc, g, s) : launch_cn<2, 4>(Uout, F, Fc, g, s); return true; }
+    return false;
 }
 
 } // namespace sc

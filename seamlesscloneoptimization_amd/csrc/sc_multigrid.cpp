@@ -166,16 +166,20 @@ static int vcycle(Instance *I, size_t l, int pre, int post)
         return SC_OK;
     }
     MGLevel &Lc = I->mg[l + 1];
-    // ---- pre-smoothing (levels >= 1 start from a zero correction)
+    // ---- pre-smoothing (levels >= 1 start from a zero correction), residual + restriction
+    bool restricted = false;
     if (l == 0) {
         if ((rc = run_sweeps(I, SC_METHOD_RBGS, pre, 1.0f, I->opts.sweeps_per_launch))) return rc;
+    } else if (pre > 0 && I->opts.sweeps_per_launch != 1 &&
+               launch_cycle_coarse(L.T, L.F, Lc.F, L.g, pre, I->stream)) {
+        std::swap(L.U, L.T);      // one launch did all three
+        restricted = true;
     } else if (pre > 0) {
         if ((rc = smooth_gen(I, l, pre, TBM_ZEROIN, Field{}))) return rc;
     } else {
         launch_fill_zero(L.U, I->stream);
     }
-    // ---- residual + restriction in one pass, coarse problem
-    launch_residual_restrict(l == 0 ? result(I) : L.U, L.F, Lc.F, L.g, I->stream);
+    if (!restricted) launch_residual_restrict(l == 0 ? result(I) : L.U, L.F, Lc.F, L.g, I->stream);
     if ((rc = vcycle(I, l + 1, pre, post))) return rc;
     // ---- prolongation fused into the first post-smoothing launch
     if (l == 0) {
