@@ -155,7 +155,7 @@ def main():
     unknowns = (W - 2) * (H - 2) * 3
     spl = args.sweeps_per_launch            # 0: library default = fused kernels at their deepest depth
     rb_depth = {0: 2, 1: 0, -1: 1}.get(spl, min(spl, 2))        # sweeps per launch of the red-black kernel
-    j_depth = {0: 4, 1: 0, -1: 1}.get(spl, min(spl, 4))
+    j_depth = {0: 8, 1: 0, -1: 1, 5: 4, 7: 6}.get(spl, min(spl, 8))
     ms_rb = inst.field_time_sweeps(capi.SC_METHOD_RBGS, args.kernel_launches, spl, 1.0)
     ms_j = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, args.kernel_launches, spl, 1.0)
     ms_j1 = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, args.kernel_launches, 1, 1.0)
@@ -190,7 +190,7 @@ def main():
     # the isolated launches below run the same kernels under a second symbol (template tag) so the
     # rocprofv3 statistics of this command keep them apart from the concurrent in-clone launches
     rb_sym = "k_rb_half<false, 1>" if rb_depth == 0 else f"k_rb_tb<{rb_depth}, 8, 8, false, false, 8>"
-    j_sym = "k_jacobi<16, 1>" if j_depth == 0 else f"k_jacobi_tb<{j_depth}, 8, 8, 1>"
+    j_sym = "k_jacobi<16, 1>" if j_depth == 0 else f"k_jacobi_tb<{j_depth}, 8, 8, 1, {1 if j_depth <= 4 else 2}>"
     roofline = roof(rb_name, rb_sym, rb_bytes, ms_rb,
                     "dominant kernel of the timed clone (multigrid smoother, level 0); algorithmic bytes = "
                     "12 B/unknown/channel/sweep x sweeps per launch (SURVEY 8d), so >1.0 is 'effective' bandwidth "

@@ -67,7 +67,7 @@ typedef struct sc_solver_opts {
                                 2/(1+sqrt(1-rho^2)), rho = (cos(pi/(w+1))+cos(pi/(h+1)))/2            */
     int   sweeps_per_launch; /* 0: library default (register-blocked fused kernels, deepest depth);
                                 1: one sweep per launch with the plain kernels; -1: fused kernel, depth 1;
-                                >=2: fused kernel at that depth (Jacobi <=4, red-black <=2).  All variants
+                                >=2: fused kernel at that depth (Jacobi 1-4, 6, 8; red-black 1-2).  All variants
                                 give bit-identical fields.                                          */
     int   reference_warmup;  /* 1: clone twice in place, as the reference's run() does
                                 (warm-up + 1, seamlessClone_imp.cu:303-318)                */

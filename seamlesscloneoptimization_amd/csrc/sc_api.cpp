@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 
 using namespace sc;
 
@@ -63,6 +64,30 @@ static bool is_pinned(const void *p)
     return attr.type == hipMemoryTypeHost;
 }
 
+// Row-wise host copy between a caller image and the pinned staging.  Large images are split
+// over a few short-lived threads: a single core moves ~14 GB/s, which would make the packing
+// (not PCIe, not the GPU) the longest part of a 2048^2 call.
+static void copy_rows(uint8_t *dst, size_t dpitch, const uint8_t *src, size_t spitch, size_t row_bytes, int rows)
+{
+    const size_t total = row_bytes * (size_t)rows;
+    int nthr = total >= (size_t)(4u << 20) ? 4 : 1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && (unsigned)nthr > hw) nthr = (int)hw;
+    auto work = [=](int t) {
+        const int y0 = (int)((long)rows * t / nthr), y1 = (int)((long)rows * (t + 1) / nthr);
+        if (dpitch == row_bytes && spitch == row_bytes) {
+            memcpy(dst + (size_t)y0 * row_bytes, src + (size_t)y0 * row_bytes, row_bytes * (size_t)(y1 - y0));
+            return;
+        }
+        for (int y = y0; y < y1; ++y) memcpy(dst + (size_t)y * dpitch, src + (size_t)y * spitch, row_bytes);
+    };
+    if (nthr == 1) { work(0); return; }
+    std::thread th[3];
+    for (int t = 1; t < nthr; ++t) th[t - 1] = std::thread(work, t);
+    work(0);
+    for (int t = 1; t < nthr; ++t) th[t - 1].join();
+}
+
 // rows x row_bytes from caller memory (pitch hpitch) to device memory (pitch dpitch).
 // hipMemcpy2DAsync issues one DMA per row (~6 us each, measured with rocprofv3: 384 copies per
 // 298x192 clone), so pageable sources are packed into the pinned staging AT THE DEVICE PITCH and
@@ -81,7 +106,7 @@ static int upload_rows(Instance *I, DevBuf &stage, void *d, size_t dpitch, const
     int rc = ensure_pinned(I, stage, dpitch * (size_t)rows);
     if (rc) return rc;
     uint8_t *s = (uint8_t *)stage.p;
-    for (int y = 0; y < rows; ++y) memcpy(s + (size_t)y * dpitch, h + (size_t)y * hpitch, row_bytes);
+    copy_rows(s, dpitch, h, hpitch, row_bytes, rows);
     SC_HIP(I, hipMemcpyAsync(d, s, dpitch * (size_t)(rows - 1) + row_bytes, hipMemcpyHostToDevice, I->stream));
     return SC_OK;
 }
@@ -434,8 +459,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     // the result has to land in caller memory, so the call completes before returning whatever
     // bSync says (the reference is effectively synchronous too: its D2H + host splice, imp.cpp:471)
     SC_HIP(I, hipStreamSynchronize(I->stream));
-    for (int y = 0; y < orows; ++y)
-        memcpy(dst_org + (size_t)y * bs, (const uint8_t *)I->h_out.p + (size_t)(y + 1) * dfs + 3, ob);
+    if (orows > 0 && ob > 0) copy_rows(dst_org, (size_t)bs, (const uint8_t *)I->h_out.p + dfs + 3, (size_t)dfs, ob, orows);
     (void)bSync;
     finish_timing(I, true);
     return rc;
@@ -619,7 +643,8 @@ int sc_hip_field_time_sweeps(void *p, int method, int launches, int spl, float o
     Instance *I = get(p);
     if (!I || !I->F.p || !ms_per_launch || launches < 1) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));
-    const int d = fused_depth(method, spl);
+    int d = fused_depth(method, spl);
+    if (method == SC_METHOD_JACOBI && (d == 5 || d == 7)) d -= 1;   // instantiated depths: 1-4, 6, 8
     const int per = d > 0 ? d : 1;                      // sweeps one "launch group" performs
     I->bench_tag = true;                                // same code under a second symbol (see k_jacobi)
     int rc = run_sweeps(I, method, per, omega, spl);    // warm-up

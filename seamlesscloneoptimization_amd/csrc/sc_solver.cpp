@@ -38,10 +38,10 @@ int eval_residual(Instance *I, double out[2])
 // All variants produce bit-identical fields; a remainder < depth runs through a shallower launch.
 int fused_depth(int method, int spl)
 {
-    const int mx = tb_max_depth(method);
     if (spl == 1) return 0;             // plain kernels
-    if (spl == 0) return mx;
+    if (spl == 0) return tb_max_depth(method);
     if (spl < 0) return 1;
+    const int mx = tb_hard_max_depth(method);
     return spl < mx ? spl : mx;
 }
 
@@ -57,12 +57,14 @@ int run_sweeps(Instance *I, int method, int sweeps, float omega, int spl)
     if (method == SC_METHOD_SOR) om = (omega > 0.f) ? omega : optimal_omega(I->F.W, I->F.H);
     int left = sweeps;
     while (left > 0) {
-        int T = std::min(std::max(depth, 1), left);
+        int T = 1;
         bool done = false;
-        if (depth > 0) {
-            done = (method == SC_METHOD_JACOBI) ? launch_jacobi_tb(result(I), other(I), I->F, T, I->stream, I->bench_tag)
-                                                : launch_rb_tb(result(I), other(I), I->F, T, om, I->stream, I->bench_tag);
-            if (done) { I->result_in_U1 = !I->result_in_U1; I->info.sweep_launches += 1; }
+        // deepest instantiated depth <= min(depth, left) (the launchers return false, without
+        // launching, for a depth that is not instantiated)
+        for (int t = std::min(depth, left); t >= 1 && !done; --t) {
+            done = (method == SC_METHOD_JACOBI) ? launch_jacobi_tb(result(I), other(I), I->F, t, I->stream, I->bench_tag)
+                                                : launch_rb_tb(result(I), other(I), I->F, t, om, I->stream, I->bench_tag);
+            if (done) { T = t; I->result_in_U1 = !I->result_in_U1; I->info.sweep_launches += 1; }
         }
         if (!done) {
             T = 1;

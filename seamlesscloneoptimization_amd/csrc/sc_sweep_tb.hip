@@ -212,16 +212,17 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
 #undef SC_TB_GS
 
 // ---------------------------------------------------------------------------- Jacobi
-template <int T, int NW, int R, int TAG>
+// HXQ = halo float4 lanes per side: 1 (4 columns, T <= 4) or 2 (8 columns, T <= 8)
+template <int T, int NW, int R, int TAG, int HXQ>
 __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Field F)
 {
-    constexpr int HY = T, RH = NW * R;
-    static_assert(T <= TB_HX, "column halo too small for this depth");
+    constexpr int HY = T, RH = NW * R, HX = 4 * HXQ;
+    static_assert(T <= HX, "column halo too small for this depth");
     __shared__ float4 edge[2][NW][2][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.z;
     const int W = Uin.W, H = Uin.H, P = Uin.pitch;
-    const int x = blockIdx.x * (256 - 2 * TB_HX) - TB_HX + 4 * lane;
+    const int x = blockIdx.x * (256 - 2 * HX) - HX + 4 * lane;
     const int ry = blockIdx.y * (RH - 2 * HY) - HY;
     const int y0 = ry + wv * R;
     float4 u[R], f[R];
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
             __syncthreads();
         }
     }
-    if (lane == 0 || lane == 63 || x >= P || x >= W) return;
+    if (lane < HXQ || lane >= 64 - HXQ || x >= P || x >= W) return;
     float *__restrict__ out = Uout.at(c);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -343,10 +344,11 @@ bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &
 template <int T>
 static void launch_jacobi_t(Field Uin, Field Uout, Field F, hipStream_t s, bool tag)
 {
+    constexpr int HXQ = T <= 4 ? 1 : 2, HX = 4 * HXQ;
     constexpr int RH = TB_NW * TB_R, HY = T;
-    dim3 grid((Uin.W + (256 - 2 * TB_HX) - 1) / (256 - 2 * TB_HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
-    if (tag) hipLaunchKernelGGL((k_jacobi_tb<T, TB_NW, TB_R, 1>), grid, dim3(TB_NW * 64), 0, s, Uin, Uout, F);
-    else hipLaunchKernelGGL((k_jacobi_tb<T, TB_NW, TB_R, 0>), grid, dim3(TB_NW * 64), 0, s, Uin, Uout, F);
+    dim3 grid((Uin.W + (256 - 2 * HX) - 1) / (256 - 2 * HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
+    if (tag) hipLaunchKernelGGL((k_jacobi_tb<T, TB_NW, TB_R, 1, HXQ>), grid, dim3(TB_NW * 64), 0, s, Uin, Uout, F);
+    else hipLaunchKernelGGL((k_jacobi_tb<T, TB_NW, TB_R, 0, HXQ>), grid, dim3(TB_NW * 64), 0, s, Uin, Uout, F);
 }
 
 bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s, bool tag)
@@ -356,10 +358,14 @@ bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s,
     case 2: launch_jacobi_t<2>(Uin, Uout, F, s, tag); return true;
     case 3: launch_jacobi_t<3>(Uin, Uout, F, s, tag); return true;
     case 4: launch_jacobi_t<4>(Uin, Uout, F, s, tag); return true;
+    case 6: launch_jacobi_t<6>(Uin, Uout, F, s, tag); return true;
+    case 8: launch_jacobi_t<8>(Uin, Uout, F, s, tag); return true;
     default: return false;
     }
 }
 
-int tb_max_depth(int method) { return method == SC_METHOD_JACOBI ? 4 : 2; }
+// default depth (sweeps_per_launch = 0) and the deepest instantiated one
+int tb_max_depth(int method) { return method == SC_METHOD_JACOBI ? 8 : 2; }
+int tb_hard_max_depth(int method) { return method == SC_METHOD_JACOBI ? 8 : 2; }
 
 } // namespace sc

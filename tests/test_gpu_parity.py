@@ -89,10 +89,10 @@ def test_fused_register_blocked_sweeps_bit_exact(hip, oracles, W, H):
     rng = np.random.default_rng(W * 7 + H)
     U = rng.normal(100, 50, (3, H, W)).astype(np.float32)
     F = rng.normal(0, 30, (3, H, W)).astype(np.float32)
-    want_j = {n: oc.jacobi(U, F, n) for n in (1, 4, 7)}
+    want_j = {n: oc.jacobi(U, F, n) for n in (1, 4, 7, 17)}
     want_g = {n: oc.rbgs(U, F, n, 1.0) for n in (1, 2, 5)}
     want_s = {n: oc.rbgs(U, F, n, 1.7) for n in (2, 5)}
-    for spl in (0, -1, 2, 3, 4):
+    for spl in (0, -1, 2, 3, 4, 6, 8):
         for n, want in want_j.items():
             hip.field_load(U, F); hip.field_sweep(capi.SC_METHOD_JACOBI, n, 1.0, spl)
             assert np.array_equal(hip.field_store(), want), ("jacobi", spl, n)

@@ -59,8 +59,8 @@ def c2(inst):
     """single 512x512 ROI, 3-channel float, 1000 Jacobi sweeps."""
     load_clone_fields(inst, 512)
     unknowns = 510 * 510 * 3
-    for spl, name in [(1, "k_jacobi, 1 sweep/launch"), (0, "k_jacobi_tb<4>, 4 sweeps/launch")]:
-        depth = 1 if spl == 1 else 4
+    for spl, name in [(1, "k_jacobi, 1 sweep/launch"), (4, "k_jacobi_tb<4>, 4 sweeps/launch"), (0, "k_jacobi_tb<8>, 8 sweeps/launch (default)")]:
+        depth = {1: 1, 4: 4, 0: 8}[spl]
         inst.field_sweep(capi.SC_METHOD_JACOBI, 8, 1.0, spl)
         ms = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, 1000 // depth, spl, 1.0) * (1000 // depth)
         emit({"config": "c2 512x512 ROI, 1000 Jacobi sweeps", "kernel": name, "ms_per_1000_sweeps": round(ms, 3),
@@ -89,7 +89,8 @@ def c4(inst):
     load_clone_fields(inst, 4096)
     unknowns = 4094 * 4094 * 3
     for method, mname, spl, depth, name in [(capi.SC_METHOD_JACOBI, "jacobi", 1, 1, "k_jacobi"), (capi.SC_METHOD_JACOBI, "jacobi", -1, 1, "k_jacobi_tb<1>"),
-                                            (capi.SC_METHOD_JACOBI, "jacobi", 0, 4, "k_jacobi_tb<4>"), (capi.SC_METHOD_RBGS, "rbgs", -1, 1, "k_rb_tb<1>"),
+                                            (capi.SC_METHOD_JACOBI, "jacobi", 4, 4, "k_jacobi_tb<4>"), (capi.SC_METHOD_JACOBI, "jacobi", 0, 8, "k_jacobi_tb<8>"),
+                                            (capi.SC_METHOD_RBGS, "rbgs", -1, 1, "k_rb_tb<1>"),
                                             (capi.SC_METHOD_RBGS, "rbgs", 0, 2, "k_rb_tb<2>")]:
         ms = inst.field_time_sweeps(method, 100, spl, 1.0)
         by = 12.0 * unknowns * depth
