@@ -154,7 +154,7 @@ def main():
     #      region of back-to-back launches on the very fields the clone just used
     unknowns = (W - 2) * (H - 2) * 3
     spl = args.sweeps_per_launch            # 0: library default = fused kernels at their deepest depth
-    rb_depth = {0: 2, 1: 0, -1: 1}.get(spl, min(spl, 2))        # sweeps per launch of the red-black kernel
+    rb_depth = {0: 4, 1: 0, -1: 1}.get(spl, min(spl, 4))        # sweeps per launch of the red-black kernel
     j_depth = {0: 8, 1: 0, -1: 1, 5: 4, 7: 6}.get(spl, min(spl, 8))
     ms_rb = inst.field_time_sweeps(capi.SC_METHOD_RBGS, args.kernel_launches, spl, 1.0)
     ms_j = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, args.kernel_launches, spl, 1.0)
@@ -189,12 +189,24 @@ def main():
                   (unknowns * 12 / 1e6, "fits" if unknowns * 12 < 256e6 else "exceeds"))
     # the isolated launches below run the same kernels under a second symbol (template tag) so the
     # rocprofv3 statistics of this command keep them apart from the concurrent in-clone launches
-    rb_sym = "k_rb_half<false, 1>" if rb_depth == 0 else f"k_rb_tb<{rb_depth}, 8, 8, false, false, 8>"
+    rb_sym = "k_rb_half<false, 1>" if rb_depth == 0 else f"k_rb_tb<{rb_depth}, 8, 8, false, false, 8, {1 if rb_depth <= 2 else 2}>"
     j_sym = "k_jacobi<16, 1>" if j_depth == 0 else f"k_jacobi_tb<{j_depth}, 8, 8, 1, {1 if j_depth <= 4 else 2}>"
-    roofline = roof(rb_name, rb_sym, rb_bytes, ms_rb,
-                    "dominant kernel of the timed clone (multigrid smoother, level 0); algorithmic bytes = "
-                    "12 B/unknown/channel/sweep x sweeps per launch (SURVEY 8d), so >1.0 is 'effective' bandwidth "
-                    "from temporal blocking; " + cache_note)
+    roofline_rb = roof(rb_name, rb_sym, rb_bytes, ms_rb,
+                       "red-black GS/SOR sweeps alone; algorithmic bytes = 12 B/unknown/channel/sweep x sweeps per launch "
+                       "(SURVEY 8d), so >1.0 is 'effective' bandwidth from temporal blocking; " + cache_note)
+    # the dominant kernel of the timed clone: the fused level-0 multigrid cycle.  Algorithmic bytes per
+    # unknown and channel = the SURVEY 8d figures of the operations it fuses: 4 red-black sweeps (4 x 12 B),
+    # residual (8 B read) + restricted RHS (1/4 x 4 B written), prolongation (1/4 x 4 B read + 4 B read + 4 B written)
+    c0_bytes = (4 * 12.0 + 8.0 + 1.0 + 9.0) * unknowns
+    if args.method == "mg":
+        ms_c0 = inst.time_cycle0(args.kernel_launches)
+        roofline = roof("k_cycle0<4,8,8,PRO> (prolongation + 4 red-black sweeps + residual + restriction, one launch)",
+                        "k_cycle0<4, 8, 8, true, false, false, 1>", c0_bytes, ms_c0,
+                        "dominant kernel of the timed clone (whole level-0 part of a V-cycle); algorithmic bytes = sum of the "
+                        "SURVEY 8d figures of the fused operations = 66 B/unknown/channel, so >1.0 is 'effective' bandwidth; "
+                        + cache_note)
+    else:
+        roofline = roofline_rb
     roofline_j = roof(j_name, j_sym, j_bytes, ms_j, "the Jacobi stencil named by the north-star, same field; effective "
                       "bandwidth (temporal blocking); " + cache_note)
     roofline_j1 = roof("k_jacobi (LDS-tiled 5-point, 1 sweep per launch)", "k_jacobi<16, 1>", 12.0 * unknowns, ms_j1,
@@ -215,7 +227,8 @@ def main():
                    "cycles_or_sweeps": int(info.sweeps)},
         "single_clone_stages_ms": {"mask": round(info.ms_mask, 4), "pre": round(info.ms_pre, 4), "solve": round(info.ms_solve, 4),
                       "post": round(info.ms_post, 4), "device_total": round(info.ms_device_total, 4)},
-        "roofline": roofline, "roofline_jacobi": roofline_j, "roofline_jacobi_single_sweep": roofline_j1,
+        "roofline": roofline, "roofline_red_black": roofline_rb, "roofline_jacobi": roofline_j,
+        "roofline_jacobi_single_sweep": roofline_j1,
     }
     if comm.rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(dst, patch, mask, cx, cy, out, args.cpu_seconds)

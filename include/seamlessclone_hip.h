@@ -171,6 +171,10 @@ SC_API int sc_hip_field_store(void *instance, float *U_out, size_t capacity_floa
 SC_API int sc_hip_field_time_sweeps(void *instance, int method, int launches, int sweeps_per_launch, float omega,
                              float *ms_per_launch);
 
+/* isolated timing of the fused level-0 multigrid cycle kernel on the state left by the last
+ * MULTIGRID run (values are discarded; bench.py roofline) */
+SC_API int sc_hip_time_cycle0(void *instance, int launches, float *ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,6 +138,8 @@ def load():
     L.sc_hip_field_store.restype = C.c_int
     L.sc_hip_field_time_sweeps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)]
     L.sc_hip_field_time_sweeps.restype = C.c_int
+    L.sc_hip_time_cycle0.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.sc_hip_time_cycle0.restype = C.c_int
     _lib = L
     return L
 
@@ -306,6 +308,15 @@ class Instance:
         self._check(self.L.sc_hip_field_time_sweeps(self.h, int(method), int(launches), int(sweeps_per_launch),
                                                     float(omega), C.byref(ms)))
         return float(ms.value)
+
+
+def _time_cycle0(self, launches: int = 100) -> float:
+    ms = C.c_float(0)
+    self._check(self.L.sc_hip_time_cycle0(self.h, int(launches), C.byref(ms)))
+    return float(ms.value)
+
+
+Instance.time_cycle0 = _time_cycle0
 
 
 def device_count() -> int:

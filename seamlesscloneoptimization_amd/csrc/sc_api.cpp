@@ -661,4 +661,28 @@ int sc_hip_field_time_sweeps(void *p, int method, int launches, int spl, float o
     return SC_OK;
 }
 
+// Isolated timing of the level-0 cycle kernel (prolongation + 4 red-black sweeps + residual +
+// restriction) on the fields and hierarchy the last MULTIGRID run left on the device.  The values
+// it produces are discarded; only the launch duration matters (bench.py roofline).
+int sc_hip_time_cycle0(void *p, int launches, float *ms_per_launch)
+{
+    Instance *I = get(p);
+    if (!I || !ms_per_launch || launches < 1) return SC_ERR_BAD_ARG;
+    if (!I->F.p || I->mg.size() < 2 || !I->mg_partial.p) { I->err = "time_cycle0: run a multigrid clone first"; return SC_ERR_BAD_ARG; }
+    SC_HIP(I, hipSetDevice(I->gpu));
+    auto once = [&]() {
+        launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, 4, true,
+                      (float *)I->mg_partial.p, I->stream, true);
+        I->result_in_U1 = !I->result_in_U1;
+    };
+    once();
+    SC_HIP(I, hipEventRecord(I->ev_k0, I->stream));
+    for (int i = 0; i < launches; ++i) once();
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    *ms_per_launch = ev_ms(I->ev_k0, I->ev_k1) / (float)launches;
+    return SC_OK;
+}
+
 } // extern "C"

@@ -40,7 +40,7 @@ __device__ __forceinline__ void c0_load(const float *__restrict__ p, int P, int 
 // GEN    = coarse multigrid level: general stencil coefficients at the last column / row (MGDim)
 //          and the interpolation-tail weights in the restriction of the last coarse column / row.
 // ZEROIN = the incoming correction is identically zero and is not read (first visit of a level).
-template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN>
+template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG: second symbol for isolated timing
 __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
                                                     float *__restrict__ partial)
 {
@@ -280,21 +280,22 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
 
 constexpr int C0_NW = 8, C0_R = 8;
 
-template <int T, bool PRO>
+template <int T, bool PRO, int TAG = 0>
 static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s)
 {
     constexpr int RH = C0_NW * C0_R, HY = 2 * T + 2;
     dim3 grid((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
-    hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false>), grid, dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E, g,
-                       partial);
+    hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false, TAG>), grid, dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E,
+                       g, partial);
     return (int)(grid.x * grid.y * grid.z);
 }
 
 // sweeps = T red-black GS sweeps; prolong: add P*E first and write per-block max|P*E| to `partial`.
 // Returns the number of partial maxima written (0 without prolong), or -1 for an unsupported depth.
 int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                  float *partial, hipStream_t s)
+                  float *partial, hipStream_t s, bool tag)
 {
+    if (tag && prolong && sweeps == 4) return launch_c0<4, true, 1>(Uin, Uout, F, Fc, E, g, partial, s);
     if (prolong) {
         switch (sweeps) {
         case 2: return launch_c0<2, true>(Uin, Uout, F, Fc, E, g, partial, s);

@@ -42,17 +42,17 @@ __device__ __forceinline__ void tb_load(const float *__restrict__ p, int P, int 
 constexpr int TB_PROLONG = 1, TB_MAXC = 2, TB_ZEROIN = 4;
 constexpr int TB_TAG = 8;   // no effect on the code: a second symbol for the isolated roofline launches (see k_jacobi)
 
-template <int T, int NW, int R, bool SOR, bool GEN, int FLAGS>
+template <int T, int NW, int R, bool SOR, bool GEN, int FLAGS, int HXQ = 1>
 __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field F, float omega, MGGeom g, Field E,
                                                    float *__restrict__ partial)
 {
-    constexpr int HY = 2 * T, RH = NW * R;
-    static_assert(2 * T <= TB_HX, "column halo too small for this depth");
+    constexpr int HY = 2 * T, RH = NW * R, HX = 4 * HXQ;   // HXQ halo lanes per side: 4 columns each
+    static_assert(2 * T <= HX, "column halo too small for this depth");
     __shared__ float4 edge[2][NW][2][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.z;
     const int W = Uin.W, H = Uin.H, P = Uin.pitch;
-    const int x = blockIdx.x * (256 - 2 * TB_HX) - TB_HX + 4 * lane;
+    const int x = blockIdx.x * (256 - 2 * HX) - HX + 4 * lane;
     const int ry = blockIdx.y * (RH - 2 * HY) - HY;
     const int y0 = ry + wv * R;
     float4 u[R], f[R];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
         }
     }
     // write back the exact inner tile (ring rows/columns are copied through unchanged)
-    if (lane == 0 || lane == 63 || x >= P || x >= W) return;
+    if (lane < HXQ || lane >= 64 - HXQ || x >= P || x >= W) return;
     float *__restrict__ out = Uout.at(c);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -281,9 +281,10 @@ constexpr int TB_NW = 8, TB_R = 8;
 template <int T, int NW, bool SOR, bool GEN, int FLAGS, int R = TB_R>
 static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom &g, Field E, float *partial, hipStream_t s)
 {
+    constexpr int HXQ = 2 * T <= 4 ? 1 : 2, HX = 4 * HXQ;
     constexpr int RH = NW * R, HY = 2 * T;
-    dim3 grid((Uin.W + (256 - 2 * TB_HX) - 1) / (256 - 2 * TB_HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
-    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS>), grid, dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
+    dim3 grid((Uin.W + (256 - 2 * HX) - 1) / (256 - 2 * HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
+    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS, HXQ>), grid, dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
     return (int)(grid.x * grid.y * grid.z);
 }
 
@@ -295,10 +296,13 @@ bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipSt
     if (tag && !sor) {
         if (sweeps == 1) { launch_rb_t<1, TB_NW, false, false, TB_TAG>(Uin, Uout, F, omega, g, e, nullptr, s); return true; }
         if (sweeps == 2) { launch_rb_t<2, TB_NW, false, false, TB_TAG>(Uin, Uout, F, omega, g, e, nullptr, s); return true; }
+        if (sweeps == 4) { launch_rb_t<4, TB_NW, false, false, TB_TAG>(Uin, Uout, F, omega, g, e, nullptr, s); return true; }
     }
     switch (sweeps) {
     case 1: sor ? launch_rb_t<1, TB_NW, true, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s) : launch_rb_t<1, TB_NW, false, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s); return true;
     case 2: sor ? launch_rb_t<2, TB_NW, true, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s) : launch_rb_t<2, TB_NW, false, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s); return true;
+    case 3: sor ? launch_rb_t<3, TB_NW, true, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s) : launch_rb_t<3, TB_NW, false, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s); return true;
+    case 4: sor ? launch_rb_t<4, TB_NW, true, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s) : launch_rb_t<4, TB_NW, false, false, 0>(Uin, Uout, F, omega, g, e, nullptr, s); return true;
     default: return false;
     }
 }
@@ -365,7 +369,7 @@ bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s,
 }
 
 // default depth (sweeps_per_launch = 0) and the deepest instantiated one
-int tb_max_depth(int method) { return method == SC_METHOD_JACOBI ? 8 : 2; }
-int tb_hard_max_depth(int method) { return method == SC_METHOD_JACOBI ? 8 : 2; }
+int tb_max_depth(int method) { return method == SC_METHOD_JACOBI ? 8 : 4; }
+int tb_hard_max_depth(int method) { return method == SC_METHOD_JACOBI ? 8 : 4; }
 
 } // namespace sc
