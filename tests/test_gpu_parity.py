@@ -247,6 +247,30 @@ def test_clone_various_shapes_within_one(hip, oracles, W, H, ellipse):
     assert s["max"] <= 1 and s["percent"] < 0.1, compare.format_stats(s)
 
 
+def test_random_shapes_fuzz(hip, oracles):
+    """40 seeded random ROI shapes (odd/even sizes, thin strips, sizes straddling tile and level
+    boundaries, rectangular masks away from the patch border): every one within +-1 of the oracle."""
+    from seamlesscloneoptimization_amd import compare
+    o, _ = oracles
+    rng = np.random.default_rng(20261003)
+    worst = 0
+    for case in range(40):
+        W = int(rng.choice([rng.integers(3, 40), rng.integers(40, 300), rng.integers(225, 270), rng.integers(460, 520)]))
+        H = int(rng.choice([rng.integers(3, 40), rng.integers(40, 200), rng.integers(40, 64), rng.integers(100, 130)]))
+        dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=case, seed_patch=100 + case, margin=24)
+        if case % 3 == 0 and W > 12 and H > 12:           # inner rectangle instead of the full patch
+            mask = np.zeros_like(mask)
+            x0, y0 = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+            mask[y0:H + 2 - int(rng.integers(1, 4)), x0:W + 2 - int(rng.integers(1, 4))] = 255
+        want = o.seamless_clone(dst, patch, mask, cx, cy)
+        body = dst.copy()
+        assert hip.run(patch, body, mask, cx, cy) == 0, (case, W, H)
+        s = compare.image_diff_stats(want, body)
+        assert s["max"] <= 1, (case, W, H, compare.format_stats(s))
+        worst = max(worst, s["percent"])
+    assert worst < 1.0
+
+
 def test_device_resident_run_equals_host_run(hip, oracles):
     o, _ = oracles
     dst, patch, mask, cx, cy = o.synth_inputs(200, 150, margin=64)
