@@ -74,7 +74,11 @@ typedef struct sc_solver_opts {
     int   mg_pre, mg_post;   /* multigrid smoothing sweeps per level (0 = default 2/2)      */
     float update_tol;        /* MULTIGRID stop rule: finish once the largest coarse-grid
                                 correction applied to the ROI in a V-cycle is <= update_tol grey
-                                levels (default 0.02; the remaining error is ~20x smaller).
+                                levels.  The error left is ~18x smaller (contraction 0.055 per
+                                cycle).  Default 0.25: 3-4 cycles, error ~0.01 grey levels, i.e.
+                                max |delta| 1 on <0.2 % of channels vs the exact solution -- the
+                                level of the reference's own float32 deviation from OpenCV (0.16 %
+                                at 2400x1552, PDF p3).  0.02 costs one more cycle (<0.02 %).
                                 The float32 residual norm stalls earlier and is only reported. */
     int   reserved[5];
 } sc_solver_opts;

@@ -218,7 +218,7 @@ int mg_solve(Instance *I)
         if ((rc = ensure(I, I->mg_partial, sizeof(float) * (size_t)nb))) return rc;
     }
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
-    const float utol = o.update_tol > 0.f ? o.update_tol : 0.02f;
+    const float utol = o.update_tol > 0.f ? o.update_tol : 0.25f;
     const int budget = o.max_sweeps > 0 ? o.max_sweeps : 30;
     // the level-0 scratch is the ping-pong partner of the solution; the residual field only
     // writes its interior, and both buffers carry the same ring, so it stays a valid partner

@@ -169,7 +169,7 @@ def test_c1_clone_matches_oracle_within_one(hip, oracles, c1_inputs):
         body = c["dst"].copy()
         assert hip.run(c["patch"], body, c["mask"], c["cx"], c["cy"], sync=True) == 0
         s = compare.image_diff_stats(want, body)
-        assert s["max"] <= 1 and s["percent"] < 0.01, compare.format_stats(s)
+        assert s["max"] <= 1 and s["percent"] < 0.05, compare.format_stats(s)
         info = hip.info()
         assert (info.x0, info.y0, info.W, info.H, info.ltx, info.lty) == (1, 1, 298, 192, 651, 54)
         assert np.array_equal(body[:54], c["dst"][:54]) and np.array_equal(body[:, :651], c["dst"][:, :651])
@@ -244,7 +244,7 @@ def test_clone_various_shapes_within_one(hip, oracles, W, H, ellipse):
     body = dst.copy()
     assert hip.run(patch, body, mask, cx, cy, sync=True) == 0
     s = compare.image_diff_stats(want, body)
-    assert s["max"] <= 1 and s["percent"] < 0.1, compare.format_stats(s)
+    assert s["max"] <= 1 and s["percent"] < 0.5, compare.format_stats(s)
 
 
 def test_random_shapes_fuzz(hip, oracles):
@@ -351,7 +351,7 @@ def test_4096_roi_against_the_c_oracle(hip, oracles):
     info = hip.info()
     assert (info.W, info.H) == (4096, 4096) and info.converged == 1 and info.sweeps <= 10
     s = compare.image_diff_stats(want, body)
-    assert s["max"] <= 1 and s["percent"] < 0.2, compare.format_stats(s)
+    assert s["max"] <= 1 and s["percent"] < 0.5, compare.format_stats(s)
 
 
 def test_native_cli_binary(tmp_path, golden_dir, c1_inputs, oracles):
@@ -436,7 +436,7 @@ def test_full_size_properties_2048(hip, oracles):
     body = dst.copy()
     assert hip.run(patch, body, mask, cx, cy, sync=True) == 0
     info = hip.info()
-    assert (info.W, info.H) == (W, H) and info.converged == 1 and info.sweeps <= 10
+    assert (info.W, info.H) == (W, H) and info.converged == 1 and info.sweeps <= 6
     r2, f2 = hip.field_residual()
     assert np.sqrt(r2 / f2) < 1e-4
     U = hip.field_store()
@@ -444,7 +444,13 @@ def test_full_size_properties_2048(hip, oracles):
     assert np.array_equal(U[:, 0, :], ring[:, 0, :]) and np.array_equal(U[:, :, -1], ring[:, :, -1])
     want = o.seamless_clone(dst, patch, mask, cx, cy)
     s = compare.image_diff_stats(want, body)
-    assert s["max"] <= 1 and s["percent"] < 0.1, compare.format_stats(s)
+    assert s["max"] <= 1 and s["percent"] < 0.5, compare.format_stats(s)
+    # one more cycle (update_tol 0.02) tightens the agreement by the contraction factor
+    hip.set_solver(update_tol=0.02)
+    body2 = dst.copy(); hip.run(patch, body2, mask, cx, cy)
+    hip.set_solver(update_tol=hip.default_opts().update_tol)
+    s2 = compare.image_diff_stats(want, body2)
+    assert s2["max"] <= 1 and s2["percent"] < 0.05, compare.format_stats(s2)
     # 1000 Jacobi sweeps at 512^2 (config 2) stay bit-exact with the CPU sweeps
     rng = np.random.default_rng(2)
     U0 = rng.normal(100, 40, (3, 512, 512)).astype(np.float32); F = rng.normal(0, 20, (3, 512, 512)).astype(np.float32)
