@@ -1,6 +1,7 @@
 // sc_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the seamless-clone hot path:
-// mask stage, fused pre-process, single-sweep Jacobi / red-black smoothers, residual norm,
-// multigrid transfer operators and the fused post-process.  wave = 64 lanes throughout.
+// mask stage, fused pre-process, single-sweep Jacobi / red-black smoothers, residual norm and
+// the fused post-process.  wave = 64 lanes throughout.  (Register-blocked multi-sweep kernels:
+// sc_sweep_tb.hip; multigrid cycle kernels: sc_cycle0.hip, sc_mg_kernels.hip.)
 //
 // Reference behaviour (what, not how): seamlessClone-CUDA/seamlessClone_imp.cpp
 //   mask stage   :892-1071     pre-process :1920-2018     post-process :2078-2103
