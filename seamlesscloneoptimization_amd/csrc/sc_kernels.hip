@@ -164,7 +164,7 @@ void launch_mask_erode3(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int m
 // ------------------------------------------------------------------------------------------
 // fused pre-process: ROI crop + u8->f32 + forward-difference gradients of dst ROI and patch +
 // mask blend + backward-difference divergence  (seamlessClone_imp.cpp:1920-2018 in one pass,
-// no gdX/gdY round trip).  Writes the Dirichlet/initial field U0 = U1 = dst ROI and the
+// no gdX/gdY round trip).  Writes the Dirichlet/initial field U0 = dst ROI and the
 // un-folded stencil RHS F = lap (0 on the ring).  The reflect-101 branches of the reference
 // (:1937,:1940,:1944,:1947) only feed gdX/gdY at the last column/row, which no interior
 // divergence reads, so they vanish here.
@@ -249,9 +249,8 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
                 const float gyu = (1.0f - mu) * (bc - bup) + mu * (pc - pup);
                 lap = (gx - gxl) + (gy - gyu);
             }
-            U0.at(c)[o] = bc;
-            U1.at(c)[o] = bc;
-            F.at(c)[o] = lap;
+            U0.at(c)[o] = bc;      // U1 needs no initialisation: every sweep kernel writes its whole
+            F.at(c)[o] = lap;      // output plane, ring included, before anything reads it
         }
     }
 }
