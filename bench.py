@@ -80,7 +80,17 @@ def cpu_baseline(dst, patch, mask, cx, cy, gpu_out, budget_s):
     ref = oc.seamless_clone(dst, patch, mask, cx, cy, nthr, True)  # exact-denominator variant, all cores
     dt_all = time.perf_counter() - t0
     d = np.abs(ref.astype(np.int16) - gpu_out.astype(np.int16))
+    # apples-to-apples for the fixed-iteration stencil config (512^2 ROI, 1000 Jacobi sweeps):
+    # the same sweeps in C on one core, 200 timed and scaled to 1000
+    rng = np.random.default_rng(5)
+    Uj = rng.normal(100, 40, (3, 512, 512)).astype(np.float32)
+    Fj = rng.normal(0, 20, (3, 512, 512)).astype(np.float32)
+    t0 = time.perf_counter()
+    oc.jacobi(Uj, Fj, 200)
+    tj = (time.perf_counter() - t0) * 5.0
     return {
+        "jacobi_512x512_1000_sweeps": {"ms": round(tj * 1e3, 1), "Gpix_updates_per_s": round(510 * 510 * 1000 / tj / 1e9, 3),
+                                       "cores": 1, "note": "CPU counterpart of tools/bench_configs.py c2 (GPU: 1.2 ms)"},
         "value": round(W * H / dt / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
         "sample": f"{reps} timed + 1 warm-up full clones of the same {W}x{H} ROI, C restatement of "
                   f"cv::seamlessClone (DST-direct, float32 tables), {dt * 1e3:.0f} ms each",
