@@ -185,14 +185,14 @@ static int check_roi(Instance *I, const Geo &g, int bc, int br)
 }
 
 // erode -> pre-process -> solve -> post-process on device-resident ROI origins
-static int device_clone(Instance *I, const uint8_t *d_mask, int ms, const uint8_t *face_org, int fstep,
+static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, const uint8_t *face_org, int fstep,
                         uint8_t *body_org, int bstep, const Geo &g, int passes)
 {
     int rc;
     I->mpitch = round_up(g.W, 64);
     if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
     if ((rc = setup_fields(I, g.W, g.H, 3))) return rc;
-    launch_mask_erode3(d_mask, ms, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    launch_mask_erode3(d_mask, ms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
     SC_HIP(I, hipEventRecord(I->ev[4], I->stream));
     int solve_rc = SC_OK;
     for (int pass = 0; pass < passes; ++pass) {
@@ -441,7 +441,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     if ((rc = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return rc;
     SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
     const int passes = I->opts.reference_warmup ? 2 : 1;
-    rc = device_clone(I, (const uint8_t *)I->d_mask.p, dms, (const uint8_t *)I->d_face.p, dfs,
+    rc = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p, dfs,
                       (uint8_t *)I->d_body_roi.p, dfs, g, passes);
     if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
     // --- interior back into the caller's image.  One linear D2H of the compact ROI buffer into
@@ -482,7 +482,7 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     if ((rc = check_roi(I, g, bc, br))) return rc;
     SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
     const int passes = I->opts.reference_warmup ? 2 : 1;
-    rc = device_clone(I, d_mask, ms, d_face + (size_t)g.y0 * fs + 3 * g.x0, fs,
+    rc = device_clone(I, d_mask, ms, mr, d_face + (size_t)g.y0 * fs + 3 * g.x0, fs,
                       d_body + (size_t)g.lty * bs + 3 * g.ltx, bs, g, passes);
     if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
     SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
@@ -513,7 +513,7 @@ int sc_hip_mask_stage(void *p, const uint8_t *mask, int mc, int mr, int ms, int 
     geo[0] = g.x0; geo[1] = g.y0; geo[2] = g.W; geo[3] = g.H; geo[4] = g.ltx; geo[5] = g.lty;
     I->mpitch = round_up(g.W, 64);
     if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
-    launch_mask_erode3((const uint8_t *)I->d_mask.p, dms, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    launch_mask_erode3((const uint8_t *)I->d_mask.p, dms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
     SC_HIP(I, hipGetLastError());
     if (M_out) {
         if (M_capacity < (size_t)g.W * g.H) return SC_ERR_BAD_SIZE;

@@ -117,48 +117,80 @@ void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rec
 // Crop to the bounding box + three 3x3 erodes (seamlessClone_imp.cpp:1052-1062, kernel
 // :892-925) fused into one pass.  Each reference pass outputs 255 iff all nine inputs are 255
 // and forces the ROI frame to 0, so three passes equal: "ring(x,y) >= 3 and the 7x7 window is
-// all 255" -- evaluated separably (7-wide AND along x, then along y) on an LDS tile + 3 halo.
-constexpr int ER_TW = 64, ER_TH = 16;
+// all 255".  Outputs with ring < 3 are 0 whatever the window holds, and for ring >= 3 the window
+// lies inside the ROI, so nothing outside the ROI ever matters.
+//
+// Word formulation: a lane owns one 32-bit word (4 pixels) of the output column-wise and slides
+// down ER_STRIP rows.  Per source row it fetches the 12 bytes x-3 .. x+8 (four aligned dwords +
+// v_alignbyte, the ROI origin has arbitrary byte alignment), turns them into "== 255" flag bytes,
+// ANDs the seven byte-shifted views (horizontal 7-window for all four pixels at once) and keeps the
+// last seven such words in registers for the vertical AND.
+constexpr int ER_STRIP = 16;
 
-__global__ __launch_bounds__(256) void k_mask_erode3(const uint8_t *__restrict__ mask, int mstep, Geo g,
-                                                     uint8_t *__restrict__ M, int mpitch)
+__device__ __forceinline__ unsigned is255_flags(unsigned w)   // 0x80 in every byte that equals 255
 {
-    __shared__ uint8_t a[ER_TH + 6][ER_TW + 8];
-    __shared__ uint8_t b[ER_TH + 6][ER_TW];
-    const int tx0 = blockIdx.x * ER_TW, ty0 = blockIdx.y * ER_TH;
-    for (int i = threadIdx.x; i < (ER_TH + 6) * (ER_TW + 6); i += 256) {
-        const int ry = i / (ER_TW + 6), rx = i - ry * (ER_TW + 6);
-        const int x = tx0 + rx - 3, y = ty0 + ry - 3;
-        uint8_t v = 0;
-        if (x >= 0 && x < g.W && y >= 0 && y < g.H) v = mask[(size_t)(y + g.y0) * mstep + (x + g.x0)] == 255;
-        a[ry][rx] = v;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < (ER_TH + 6) * ER_TW; i += 256) {
-        const int ry = i / ER_TW, rx = i - ry * ER_TW;
-        uint8_t v = a[ry][rx];
+    const unsigned t = ~w;                                     // zero byte <=> source byte == 255
+    return ~((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t)) & 0x80808080u;
+}
+
+__global__ __launch_bounds__(256) void k_mask_erode3(const uint8_t *__restrict__ mask, int mstep, size_t mask_bytes,
+                                                     Geo g, uint8_t *__restrict__ M, int mpitch)
+{
+    // aligned dwords that overlap the mask buffer [mask, mask + mask_bytes): nothing outside is touched
+    const uintptr_t lo = (uintptr_t)mask & ~(uintptr_t)3, hi = ((uintptr_t)mask + mask_bytes - 1) & ~(uintptr_t)3;
+    const int xw = blockIdx.x * 64 + (threadIdx.x & 63);       // word column
+    const int x = 4 * xw;
+    const int ys = (blockIdx.y * 4 + (threadIdx.x >> 6)) * ER_STRIP;
+    if (x >= g.W || ys >= g.H) return;
+    unsigned h[7];                                             // horizontal results of rows y-3 .. y+3
 #pragma unroll
-        for (int k = 1; k < 7; ++k) v &= a[ry][rx + k];
-        b[ry][rx] = v;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ER_TH * ER_TW; i += 256) {
-        const int ry = i / ER_TW, rx = i - ry * ER_TW;
-        const int x = tx0 + rx, y = ty0 + ry;
-        if (x < g.W && y < g.H) {
-            uint8_t v = b[ry][rx];
+    for (int k = 0; k < 7; ++k) h[k] = 0;
+    // per-pixel ring-in-x mask for the four bytes of this word
+    unsigned xring = 0;
 #pragma unroll
-            for (int k = 1; k < 7; ++k) v &= b[ry + k][rx];
-            const int ring = min(min(x, g.W - 1 - x), min(y, g.H - 1 - y));
-            M[(size_t)y * mpitch + x] = (v && ring >= 3) ? 255 : 0;
+    for (int j = 0; j < 4; ++j)
+        if (x + j >= 3 && x + j <= g.W - 4) xring |= 0x80u << (8 * j);
+    auto hrow = [&](int y) -> unsigned {
+        if (y < 0 || y >= g.H) return 0u;
+        const uint8_t *s = mask + (size_t)(y + g.y0) * mstep + (g.x0 + x - 3);
+        const int a = (int)((uintptr_t)s & 3);
+        const unsigned *p = reinterpret_cast<const unsigned *>(s - a);
+        unsigned d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uintptr_t q = (uintptr_t)(p + k);
+            d[k] = (q >= lo && q <= hi) ? p[k] : 0u;
         }
+        const unsigned d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+        const unsigned fa = is255_flags(__builtin_amdgcn_alignbyte(d1, d0, a));    // bytes x-3 .. x
+        const unsigned fb = is255_flags(__builtin_amdgcn_alignbyte(d2, d1, a));    // bytes x+1 .. x+4
+        const unsigned fc = is255_flags(__builtin_amdgcn_alignbyte(d3, d2, a));    // bytes x+5 .. x+8
+        // byte j of the result = AND of flag bytes j .. j+6 of the 12-byte window
+        return fa & __builtin_amdgcn_alignbyte(fb, fa, 1) & __builtin_amdgcn_alignbyte(fb, fa, 2) &
+               __builtin_amdgcn_alignbyte(fb, fa, 3) & fb & __builtin_amdgcn_alignbyte(fc, fb, 1) &
+               __builtin_amdgcn_alignbyte(fc, fb, 2);
+    };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h[k + 1] = hrow(ys - 3 + k);    // rows ys-3 .. ys+2
+    for (int r = 0; r < ER_STRIP; ++r) {
+        const int y = ys + r;
+        if (y >= g.H) break;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) h[k] = h[k + 1];
+        h[6] = hrow(y + 3);
+        unsigned v = h[0] & h[1] & h[2] & h[3] & h[4] & h[5] & h[6] & xring;
+        if (y < 3 || y > g.H - 4) v = 0;
+        v = (v >> 7) * 255u;                                    // 0x80 flags -> 0xff bytes
+        *reinterpret_cast<unsigned *>(M + (size_t)y * mpitch + x) = v;
     }
 }
 
-void launch_mask_erode3(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int mpitch, hipStream_t s)
+void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, uint8_t *M, int mpitch, hipStream_t s)
 {
-    dim3 grid((g.W + ER_TW - 1) / ER_TW, (g.H + ER_TH - 1) / ER_TH);
-    hipLaunchKernelGGL(k_mask_erode3, grid, dim3(256), 0, s, mask, mstep, g, M, mpitch);
+    dim3 grid(((g.W + 3) / 4 + 63) / 64, (g.H + 4 * ER_STRIP - 1) / (4 * ER_STRIP));
+    // last row may be shorter than the step: count only what the caller guarantees
+    const size_t bytes = (size_t)mstep * (mask_rows - 1) + (size_t)(g.x0 + g.W + 1);
+    hipLaunchKernelGGL(k_mask_erode3, grid, dim3(256), 0, s, mask, mstep, bytes, g, M, mpitch);
 }
 
 // ------------------------------------------------------------------------------------------
