@@ -46,6 +46,7 @@ bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s,
 bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipStream_t s, bool tag = false);
 int  tb_max_depth(int method);
 int  tb_hard_max_depth(int method);
+long tb_big_side();
 struct MGGeom;
 constexpr int TBM_PLAIN = 0, TBM_PROLONG = 1, TBM_ZEROIN = 4;   // mode of launch_rb_tb_gen
 bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s);

@@ -331,7 +331,7 @@ static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_
 
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s)
 {
-    const bool big = (long)F.W * F.H >= 700L * 700L;
+    const bool big = (long)F.W * F.H >= tb_big_side() * tb_big_side();
     if (sweeps == 1) { big ? launch_cn<1, 8>(Uout, F, Fc, g, s) : launch_cn<1, 4>(Uout, F, Fc, g, s); return true; }
     if (sweeps == 2) { big ? launch_cn<2, 8>(Uout, F, Fc, g, s) : launch_cn<2, 4>(Uout, F, Fc, g, s); return true; }
     return false;

@@ -142,9 +142,6 @@ __global__ __launch_bounds__(256) void k_mask_erode3(const uint8_t *__restrict__
     const int x = 4 * xw;
     const int ys = (blockIdx.y * 4 + (threadIdx.x >> 6)) * ER_STRIP;
     if (x >= g.W || ys >= g.H) return;
-    unsigned h[7];                                             // horizontal results of rows y-3 .. y+3
-#pragma unroll
-    for (int k = 0; k < 7; ++k) h[k] = 0;
     // per-pixel ring-in-x mask for the four bytes of this word
     unsigned xring = 0;
 #pragma unroll
@@ -170,18 +167,18 @@ __global__ __launch_bounds__(256) void k_mask_erode3(const uint8_t *__restrict__
                __builtin_amdgcn_alignbyte(fb, fa, 3) & fb & __builtin_amdgcn_alignbyte(fc, fb, 1) &
                __builtin_amdgcn_alignbyte(fc, fb, 2);
     };
+    // all ER_STRIP + 6 horizontal words first (independent loads in flight together), then the
+    // vertical 7-row ANDs
+    unsigned hh[ER_STRIP + 6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) h[k + 1] = hrow(ys - 3 + k);    // rows ys-3 .. ys+2
+    for (int k = 0; k < ER_STRIP + 6; ++k) hh[k] = hrow(ys - 3 + k);
+#pragma unroll
     for (int r = 0; r < ER_STRIP; ++r) {
         const int y = ys + r;
-        if (y >= g.H) break;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) h[k] = h[k + 1];
-        h[6] = hrow(y + 3);
-        unsigned v = h[0] & h[1] & h[2] & h[3] & h[4] & h[5] & h[6] & xring;
+        unsigned v = hh[r] & hh[r + 1] & hh[r + 2] & hh[r + 3] & hh[r + 4] & hh[r + 5] & hh[r + 6] & xring;
         if (y < 3 || y > g.H - 4) v = 0;
         v = (v >> 7) * 255u;                                    // 0x80 flags -> 0xff bytes
-        *reinterpret_cast<unsigned *>(M + (size_t)y * mpitch + x) = v;
+        if (y < g.H) *reinterpret_cast<unsigned *>(M + (size_t)y * mpitch + x) = v;
     }
 }
 

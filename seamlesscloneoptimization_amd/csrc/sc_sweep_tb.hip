@@ -323,12 +323,21 @@ int tb_blocks_level0(int W, int H, int C, int sweeps)
     return ((W + (256 - 2 * TB_HX) - 1) / (256 - 2 * TB_HX)) * ((H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * C;
 }
 
+// Side above which a coarse level would use 8-row bands (fewer, larger workgroups).  Measured on
+// MI355X (bench.py, 2048^2 and 4096^2 ROIs): 4-row bands win at every coarse-level size -- they
+// stay under 128 VGPRs (2 workgroups per CU) and halve the serial work per lane -- so the default
+// never selects the 8-row form; SC_BIG_SIDE overrides for tuning runs.
+long tb_big_side()
+{
+    static const long v = [] { const char *e = getenv("SC_BIG_SIDE"); return e ? atol(e) : 1000000L; }();
+    return v;
+}
+
 // coarse multigrid levels: Gauss-Seidel only (omega = 1); smaller workgroups on small levels so
 // the grid still spreads over the chip.  mode: 0 plain, TB_ZEROIN, TB_PROLONG (with E).
 bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s)
 {
-    static const long big_side = [] { const char *e = getenv("SC_BIG_SIDE"); return e ? atol(e) : 700L; }();
-    const bool big = (long)Uin.W * Uin.H >= big_side * big_side;
+    const bool big = (long)Uin.W * Uin.H >= tb_big_side() * tb_big_side();
 // small levels: 8 waves x 4 rows (same 256 x 32 region as 4 x 8, half the serial work per lane)
 #define SC_GEN_CASE(TT, MODE)                                                                                       \
     (big ? launch_rb_t<TT, 8, false, true, MODE>(Uin, Uout, F, 1.0f, g, E, nullptr, s)                             \
