@@ -337,14 +337,15 @@ __device__ __forceinline__ void lds_prolong(const float *e, int Pc, float *u, in
 }
 
 // levels [l0, L) of the V-cycle: descent, coarsest solve, ascent (level l0's own prolongation is the caller's)
+// `lv` points at the level descriptors staged in LDS (indexing the kernel-argument array with a
+// run-time level number costs a dependent scalar-memory round trip per field)
 template <bool WAVE>
-__device__ __forceinline__ void bt_subcycle(float *lds, const MGBottomArgs &a, int l0, int l1)
+__device__ __forceinline__ void bt_subcycle(float *lds, const MGBottomLevel *lv, int L, int pre, int l0, int l1)
 {
-    const int L = a.nlevels;
     for (int l = l0; l < l1 && l + 1 < L; ++l) {
-        const MGBottomLevel &v = a.lv[l];
-        const MGBottomLevel &w = a.lv[l + 1];
-        for (int s = 0; s < a.pre; ++s) {
+        const MGBottomLevel v = lv[l];
+        const MGBottomLevel w = lv[l + 1];
+        for (int s = 0; s < pre; ++s) {
             lds_rb_half<WAVE>(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, 1.0f, false);
             lds_rb_half<WAVE>(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, 1.0f, false);
         }
@@ -353,14 +354,14 @@ __device__ __forceinline__ void bt_subcycle(float *lds, const MGBottomArgs &a, i
 }
 
 template <bool WAVE>
-__device__ __forceinline__ void bt_ascent(float *lds, const MGBottomArgs &a, int l0, int l1)
+__device__ __forceinline__ void bt_ascent(float *lds, const MGBottomLevel *lv, int L, int post, int l0, int l1)
 {
     for (int l = l1 - 1; l >= l0; --l) {
-        if (l + 1 >= a.nlevels) continue;
-        const MGBottomLevel &v = a.lv[l];
-        const MGBottomLevel &w = a.lv[l + 1];
+        if (l + 1 >= L) continue;
+        const MGBottomLevel v = lv[l];
+        const MGBottomLevel w = lv[l + 1];
         lds_prolong<WAVE>(lds + w.offU, w.pitch, lds + v.offU, v.pitch, v.g);
-        for (int s = 0; s < a.post; ++s) {
+        for (int s = 0; s < post; ++s) {
             lds_rb_half<WAVE>(lds + v.offU, lds + v.offF, v.pitch, v.g, 0, 1.0f, false);
             lds_rb_half<WAVE>(lds + v.offU, lds + v.offF, v.pitch, v.g, 1, 1.0f, false);
         }
@@ -370,33 +371,38 @@ __device__ __forceinline__ void bt_ascent(float *lds, const MGBottomArgs &a, int
 __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ MGBottomLevel lv[MG_BOTTOM_MAX_LEVELS];
     const int c = blockIdx.x;
     const int L = a.nlevels;
+    if (threadIdx.x < MG_BOTTOM_MAX_LEVELS) lv[threadIdx.x] = a.lv[threadIdx.x];
     for (int i = threadIdx.x; i < a.lds_floats; i += blockDim.x) lds[i] = 0.f;   // zero corrections, rings, pads
     __syncthreads();
+    const MGBottomLevel t = lv[0];
     {   // top RHS: HBM -> LDS
-        const MGBottomLevel &t = a.lv[0];
         const float *__restrict__ fg = a.Ftop.at(c);
         float *f = lds + t.offF;
-        for (int y = 1 + (threadIdx.x >> 6); y <= t.g.y.n; y += 16)
-            for (int x = 1 + (threadIdx.x & 63); x <= t.g.x.n; x += 64) f[y * t.pitch + x] = fg[(size_t)y * a.Ftop.pitch + x];
+        const int sh = pow2_shift(t.g.x.n), total = t.g.y.n << sh;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int y = 1 + (i >> sh), x = 1 + (i & ((1 << sh) - 1));
+            if (x <= t.g.x.n) f[y * t.pitch + x] = fg[(size_t)y * a.Ftop.pitch + x];
+        }
         __syncthreads();
     }
-    // levels [0, ls): all 16 waves with block barriers; levels [ls, L): wave 0 alone (<= 4 colour
+    // levels [0, lb): all 16 waves with block barriers; levels [ls, L): wave 0 alone (<= 4 colour
     // points per lane), the other waves wait at ONE barrier for the whole sub-cycle
     int ls = L;
-    while (ls > 0 && ((a.lv[ls - 1].g.x.n + 1) >> 1) * a.lv[ls - 1].g.y.n <= 256) --ls;
+    while (ls > 0 && ((lv[ls - 1].g.x.n + 1) >> 1) * lv[ls - 1].g.y.n <= 256) --ls;
     const int lb = ls < L - 1 ? ls : L - 1;            // block-mode levels are [0, lb)
-    bt_subcycle<false>(lds, a, 0, lb);
-    const MGBottomLevel &cv = a.lv[L - 1];
+    bt_subcycle<false>(lds, lv, L, a.pre, 0, lb);
+    const MGBottomLevel cv = lv[L - 1];
     if (ls < L) {
         if ((threadIdx.x >> 6) == 0) {
-            bt_subcycle<true>(lds, a, lb, L - 1);
+            bt_subcycle<true>(lds, lv, L, a.pre, lb, L - 1);
             for (int s = 0; s < a.coarse_sweeps; ++s) {
                 lds_rb_half<true>(lds + cv.offU, lds + cv.offF, cv.pitch, cv.g, 0, cv.omega, true);
                 lds_rb_half<true>(lds + cv.offU, lds + cv.offF, cv.pitch, cv.g, 1, cv.omega, true);
             }
-            bt_ascent<true>(lds, a, lb, L - 1);
+            bt_ascent<true>(lds, lv, L, a.post, lb, L - 1);
         }
         __syncthreads();
     } else {                                            // even the coarsest level is large (thin ROIs)
@@ -405,13 +411,15 @@ __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
             lds_rb_half<false>(lds + cv.offU, lds + cv.offF, cv.pitch, cv.g, 1, cv.omega, true);
         }
     }
-    bt_ascent<false>(lds, a, 0, lb);
+    bt_ascent<false>(lds, lv, L, a.post, 0, lb);
     {   // top correction: LDS -> HBM (interior; ring and pads of the global plane stay zero)
-        const MGBottomLevel &t = a.lv[0];
         float *__restrict__ ug = a.Utop.at(c);
         const float *u = lds + t.offU;
-        for (int y = 1 + (threadIdx.x >> 6); y <= t.g.y.n; y += 16)
-            for (int x = 1 + (threadIdx.x & 63); x <= t.g.x.n; x += 64) ug[(size_t)y * a.Utop.pitch + x] = u[y * t.pitch + x];
+        const int sh = pow2_shift(t.g.x.n), total = t.g.y.n << sh;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int y = 1 + (i >> sh), x = 1 + (i & ((1 << sh) - 1));
+            if (x <= t.g.x.n) ug[(size_t)y * a.Utop.pitch + x] = u[y * t.pitch + x];
+        }
     }
 }
 
