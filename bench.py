@@ -7,8 +7,9 @@
 A "step" is one pass of the hot path over one batch: `--batch` (default 4) independent
 NORMAL_CLONEs of a 2048x2048 ROI per GPU (mask stage + fused pre-process + Poisson solve to +-1
 grey-level parity + fused post-process), each through the C ABI with its three images already
-resident in HBM (sc_hip_run_device), issued from `--streams` (default 4) library instances = HIP
-streams so one clone's latency-bound phases overlap another's bandwidth-bound ones.  Every rank
+resident in HBM (sc_hip_run_device), issued by the library's native pool (sc_hip_pool_run: `--streams`,
+default 4, instances = HIP streams, one C++ worker thread each) so one clone's latency-bound phases
+overlap another's bandwidth-bound ones.  Every rank
 owns its own synthetic images (weak scaling: independent images, no data-path collective);
 value = total ROI Mpix / max-over-ranks wall time.  Each destination is restored from a pristine
 device copy before every clone (inside the timed region) so no clone starts from an
@@ -32,7 +33,7 @@ sys.path.insert(0, ROOT)
 # The HIP library must be loaded before anything pulls in torch's bundled ROCm runtime.
 from seamlesscloneoptimization_amd import capi  # noqa: E402
 capi.load()   # bind /opt/rocm's HIP runtime now; torch (gloo only, N>1) is imported later inside Comm()
-from seamlesscloneoptimization_amd.batch import Comm, StreamPool, timed_region  # noqa: E402
+from seamlesscloneoptimization_amd.batch import Comm, timed_region  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
@@ -130,28 +131,38 @@ def main():
         opts.update(sweeps_per_launch=args.sweeps_per_launch)
     streams = max(1, min(args.streams, args.batch))
     # % ndev only matters when rehearsing N ranks on a 1-GPU box
-    pool = StreamPool(comm.local_rank % ndev, streams, **opts)
+    pool = capi.Pool(comm.local_rank % ndev, streams, **opts)      # native C++ workers, one per HIP stream
     inst = pool.instances[0]
 
     W = H = args.roi
     jobs = []
+    cjobs = pool.make_jobs(args.batch)          # one C job per image: D2D restore + device-resident clone
     for b in range(args.batch):
         dst, patch, mask, cx, cy = synth(args.roi, comm.rank * args.batch + b)
-        owner = pool.instances[b % streams]
-        jobs.append(dict(host=(dst, patch, mask, cx, cy), f=owner.to_device(patch), fs=patch.shape[:2],
-                         b0=owner.to_device(dst), b=owner.to_device(dst), n=dst.nbytes, bs=dst.shape[:2],
-                         m=owner.to_device(mask), ms=mask.shape[:2], cx=cx, cy=cy))
+        j = dict(host=(dst, patch, mask, cx, cy), f=inst.to_device(patch), fs=patch.shape[:2],
+                 b0=inst.to_device(dst), b=inst.to_device(dst), n=dst.nbytes, bs=dst.shape[:2],
+                 m=inst.to_device(mask), ms=mask.shape[:2], cx=cx, cy=cy)
+        jobs.append(j)
+        c = cjobs[b]
+        c.face, c.face_cols, c.face_rows, c.face_step = j["f"], patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+        c.body, c.body_cols, c.body_rows, c.body_step = j["b"], dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+        c.mask, c.mask_cols, c.mask_rows, c.mask_step = j["m"], mask.shape[1], mask.shape[0], mask.shape[1]
+        c.centerX, c.centerY, c.body_restore = cx, cy, j["b0"]
 
     def clone(i, j, sync=False):
         i.copy_d2d_async(j["b"], j["b0"], j["n"])
         i.run_device(j["f"], j["fs"], j["b"], j["bs"], j["m"], j["ms"], j["cx"], j["cy"], sync=sync)
 
     def step():
-        pool.map(clone, jobs)
+        pool.run(cjobs, device_resident=True)   # returns when the whole batch is complete
+
+    def sync_all():
+        for i in pool.instances:
+            i.sync()
 
     for _ in range(args.warmup):
         step()
-    elapsed = timed_region(comm, pool.sync, lambda: [step() for _ in range(args.steps)])
+    elapsed = timed_region(comm, sync_all, lambda: [step() for _ in range(args.steps)])
     dst, patch, mask, cx, cy = jobs[0]["host"]
     out = inst.from_device(jobs[0]["b"], dst.shape)
     if not all(i.info().converged for i in pool.instances) or np.array_equal(out, dst):

@@ -175,6 +175,25 @@ SC_API int sc_hip_field_store(void *instance, float *U_out, size_t capacity_floa
 SC_API int sc_hip_field_time_sweeps(void *instance, int method, int launches, int sweeps_per_launch, float omega,
                              float *ms_per_launch);
 
+/* ---- native batch driver: K instances (HIP streams) on one GPU, one host thread each ----------
+ * Clones are independent; several in flight hide one another's latency-bound phases.  Jobs are
+ * pulled from a shared counter, each runs exactly once, sc_hip_pool_run returns when all are done. */
+typedef struct sc_batch_job {
+    const uint8_t *face; int face_cols, face_rows, face_step;
+    uint8_t *body;       int body_cols, body_rows, body_step;
+    const uint8_t *mask; int mask_cols, mask_rows, mask_step;
+    int centerX, centerY;
+    const uint8_t *body_restore;   /* device-resident batches only: if non-NULL, body is refreshed from
+                                      this device image (body_step * body_rows bytes) before the clone */
+    int rc;                        /* out: SC_OK or SC_ERR_* of this job */
+} sc_batch_job;
+SC_API void *sc_hip_pool_create(int gpu_id, int streams);
+SC_API void  sc_hip_pool_destroy(void *pool);
+SC_API int   sc_hip_pool_size(void *pool);
+SC_API void *sc_hip_pool_instance(void *pool, int k);          /* instance k, e.g. for sc_hip_get_info */
+SC_API int   sc_hip_pool_set_solver(void *pool, const sc_solver_opts *opts);
+SC_API int   sc_hip_pool_run(void *pool, sc_batch_job *jobs, int n, int device_resident);
+
 /* isolated timing of the fused level-0 multigrid cycle kernel on the state left by the last
  * MULTIGRID run (values are discarded; bench.py roofline) */
 SC_API int sc_hip_time_cycle0(void *instance, int launches, float *ms_per_launch);

@@ -50,6 +50,13 @@ class RunInfo(C.Structure):
                 ("sweep_launches", C.c_int), ("last_update", C.c_float), ("device_bytes", C.c_size_t)]
 
 
+class BatchJob(C.Structure):
+    _fields_ = [("face", C.c_void_p), ("face_cols", C.c_int), ("face_rows", C.c_int), ("face_step", C.c_int),
+                ("body", C.c_void_p), ("body_cols", C.c_int), ("body_rows", C.c_int), ("body_step", C.c_int),
+                ("mask", C.c_void_p), ("mask_cols", C.c_int), ("mask_rows", C.c_int), ("mask_step", C.c_int),
+                ("centerX", C.c_int), ("centerY", C.c_int), ("body_restore", C.c_void_p), ("rc", C.c_int)]
+
+
 class SeamlessCloneError(RuntimeError):
     def __init__(self, code, msg=""):
         self.code = code
@@ -138,6 +145,18 @@ def load():
     L.sc_hip_field_store.restype = C.c_int
     L.sc_hip_field_time_sweeps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)]
     L.sc_hip_field_time_sweeps.restype = C.c_int
+    L.sc_hip_pool_create.argtypes = [C.c_int, C.c_int]
+    L.sc_hip_pool_create.restype = C.c_void_p
+    L.sc_hip_pool_destroy.argtypes = [C.c_void_p]
+    L.sc_hip_pool_destroy.restype = None
+    L.sc_hip_pool_size.argtypes = [C.c_void_p]
+    L.sc_hip_pool_size.restype = C.c_int
+    L.sc_hip_pool_instance.argtypes = [C.c_void_p, C.c_int]
+    L.sc_hip_pool_instance.restype = C.c_void_p
+    L.sc_hip_pool_set_solver.argtypes = [C.c_void_p, C.POINTER(SolverOpts)]
+    L.sc_hip_pool_set_solver.restype = C.c_int
+    L.sc_hip_pool_run.argtypes = [C.c_void_p, C.POINTER(BatchJob), C.c_int, C.c_int]
+    L.sc_hip_pool_run.restype = C.c_int
     L.sc_hip_time_cycle0.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.sc_hip_time_cycle0.restype = C.c_int
     _lib = L
@@ -317,6 +336,69 @@ def _time_cycle0(self, launches: int = 100) -> float:
 
 
 Instance.time_cycle0 = _time_cycle0
+
+
+class _Borrowed(Instance):
+    """An instance owned by a native pool: same methods, no destroy."""
+
+    def __init__(self, L, handle, gpu_id):          # noqa: D401 - no create call
+        self.L, self.h, self.gpu_id = L, handle, gpu_id
+
+    def destroy(self):
+        self.h = None
+
+
+class Pool:
+    """The library's native batch driver (csrc/sc_pool.cpp): K instances = K HIP streams on one GPU,
+    one C++ worker thread each, jobs pulled from a shared counter."""
+
+    def __init__(self, gpu_id: int = 0, streams: int = 4, **solver):
+        self.L = load()
+        self.h = self.L.sc_hip_pool_create(int(gpu_id), int(streams))
+        if not self.h:
+            raise SeamlessCloneError(SC_ERR_HIP, f"cannot create a pool on GPU {gpu_id} (no CPU fallback)")
+        self.gpu_id = gpu_id
+        self.instances = [_Borrowed(self.L, self.L.sc_hip_pool_instance(self.h, k), gpu_id)
+                          for k in range(self.L.sc_hip_pool_size(self.h))]
+        if solver:
+            o = self.instances[0].get_solver()
+            for k, v in solver.items():
+                setattr(o, k, v)
+            rc = self.L.sc_hip_pool_set_solver(self.h, C.byref(o))
+            if rc != SC_OK:
+                raise SeamlessCloneError(rc, "bad solver options")
+
+    @staticmethod
+    def make_jobs(n: int):
+        return (BatchJob * n)()
+
+    def run(self, jobs, device_resident: bool):
+        rc = self.L.sc_hip_pool_run(self.h, jobs, len(jobs), 1 if device_resident else 0)
+        if rc != SC_OK:
+            raise SeamlessCloneError(rc, "a batch job failed (see jobs[i].rc)")
+
+    def run_host(self, items):
+        """items: (face, body, mask, cx, cy) numpy tuples; bodies are blended in place."""
+        jobs = self.make_jobs(len(items))
+        for j, (face, body, mask, cx, cy) in zip(jobs, items):
+            f, b, m = _img(face), _img(body), _img(mask)
+            (j.face, j.face_cols, j.face_rows, j.face_step) = f
+            (j.body, j.body_cols, j.body_rows, j.body_step) = b
+            (j.mask, j.mask_cols, j.mask_rows, j.mask_step) = m
+            j.centerX, j.centerY, j.body_restore = int(cx), int(cy), None
+        self.run(jobs, device_resident=False)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sc_hip_pool_destroy(self.h)
+            self.h = None
+            self.instances = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_count() -> int:

@@ -1,0 +1,167 @@
+// sc_pool.cpp -- native batch driver: K library instances (= K HIP streams) on one GPU, each driven
+// by its own host thread, pulling independent clone jobs from a shared counter.
+//
+// The reference has no batch or multi-stream mode (one instance, one stream, seamlessClone_imp.cu:
+// 239-263).  Clones are independent and a single clone leaves the GPU idle in its latency-bound
+// phases (coarse multigrid levels, the bounding-box read-back), so several in flight raise
+// throughput (2048^2 ROI: 5.3 -> 9 Gpix/s with four).  This is the C++ equivalent of
+// seamlesscloneoptimization_amd/batch.py:StreamPool, behind the same C ABI.
+#include "sc_instance.h"
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+using namespace sc;
+
+namespace {
+
+struct Pool {
+    uint32_t magic = 0x5C10E002u;
+    int gpu = 0;
+    std::vector<void *> inst;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    // current batch
+    sc_batch_job *jobs = nullptr;
+    int njobs = 0, device_resident = 0;
+    std::atomic<int> next{ 0 };
+    int generation = 0, finished_workers = 0;
+    bool stop = false;
+};
+
+void run_job(void *inst, sc_batch_job &j, int device_resident)
+{
+    if (device_resident) {
+        if (j.body_restore) {
+            const int rc = sc_hip_memcpy_d2d_async(inst, j.body, j.body_restore, (size_t)j.body_step * j.body_rows);
+            if (rc != SC_OK) { j.rc = rc; return; }
+        }
+        j.rc = sc_hip_run_device(inst, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows,
+                                 j.body_step, j.mask, j.mask_cols, j.mask_rows, j.mask_step, j.centerX, j.centerY, false);
+    } else {
+        j.rc = my_seamlessclone_api_imp_run(inst, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols,
+                                            j.body_rows, j.body_step, j.mask, j.mask_cols, j.mask_rows, j.mask_step,
+                                            j.centerX, j.centerY, 0, true);
+    }
+}
+
+void worker(Pool *P, int k)
+{
+    int seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(P->mu);
+            P->cv_work.wait(lk, [&] { return P->stop || P->generation != seen; });
+            if (P->stop) return;
+            seen = P->generation;
+        }
+        for (;;) {
+            const int i = P->next.fetch_add(1);
+            if (i >= P->njobs) break;
+            run_job(P->inst[k], P->jobs[i], P->device_resident);
+        }
+        my_seamlessclone_api_imp_sync(P->inst[k]);          // the batch is complete when run() returns
+        {
+            std::lock_guard<std::mutex> lk(P->mu);
+            if (++P->finished_workers == (int)P->workers.size()) P->cv_done.notify_all();
+        }
+    }
+}
+
+Pool *get_pool(void *p)
+{
+    Pool *P = (Pool *)p;
+    return (P && P->magic == 0x5C10E002u) ? P : nullptr;
+}
+
+} // namespace
+
+extern "C" {
+
+void *sc_hip_pool_create(int gpu_id, int streams)
+{
+    if (streams < 1) streams = 1;
+    if (streams > 16) streams = 16;
+    Pool *P = new (std::nothrow) Pool();
+    if (!P) return nullptr;
+    P->gpu = gpu_id;
+    for (int k = 0; k < streams; ++k) {
+        void *inst = my_seamlessclone_api_imp_create_instance(gpu_id);
+        if (!inst) {
+            for (void *i : P->inst) my_seamlessclone_api_imp_destroy(i);
+            delete P;
+            return nullptr;
+        }
+        P->inst.push_back(inst);
+    }
+    for (int k = 0; k < streams; ++k) P->workers.emplace_back(worker, P, k);
+    return P;
+}
+
+void sc_hip_pool_destroy(void *p)
+{
+    Pool *P = get_pool(p);
+    if (!P) return;
+    {
+        std::lock_guard<std::mutex> lk(P->mu);
+        P->stop = true;
+    }
+    P->cv_work.notify_all();
+    for (std::thread &t : P->workers) t.join();
+    for (void *i : P->inst) my_seamlessclone_api_imp_destroy(i);
+    P->magic = 0;
+    delete P;
+}
+
+int sc_hip_pool_size(void *p)
+{
+    Pool *P = get_pool(p);
+    return P ? (int)P->inst.size() : 0;
+}
+
+void *sc_hip_pool_instance(void *p, int k)
+{
+    Pool *P = get_pool(p);
+    if (!P || k < 0 || k >= (int)P->inst.size()) return nullptr;
+    return P->inst[k];
+}
+
+int sc_hip_pool_set_solver(void *p, const sc_solver_opts *opts)
+{
+    Pool *P = get_pool(p);
+    if (!P || !opts) return SC_ERR_BAD_ARG;
+    for (void *i : P->inst) {
+        const int rc = sc_hip_set_solver(i, opts);
+        if (rc != SC_OK) return rc;
+    }
+    return SC_OK;
+}
+
+// Runs all jobs (any order, each exactly once) and returns when every one has completed on the GPU.
+// Return value: SC_OK, or the first failing job's code (each job's own code is in jobs[i].rc).
+int sc_hip_pool_run(void *p, sc_batch_job *jobs, int n, int device_resident)
+{
+    Pool *P = get_pool(p);
+    if (!P || (n > 0 && !jobs) || n < 0) return SC_ERR_BAD_ARG;
+    if (n == 0) return SC_OK;
+    {
+        std::lock_guard<std::mutex> lk(P->mu);
+        P->jobs = jobs; P->njobs = n; P->device_resident = device_resident;
+        P->next.store(0);
+        P->finished_workers = 0;
+        ++P->generation;
+    }
+    P->cv_work.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(P->mu);
+        P->cv_done.wait(lk, [&] { return P->finished_workers == (int)P->workers.size(); });
+    }
+    for (int i = 0; i < n; ++i)
+        if (jobs[i].rc != SC_OK && jobs[i].rc != SC_ERR_NOT_CONVERGED) return jobs[i].rc;
+    return SC_OK;
+}
+
+} // extern "C"

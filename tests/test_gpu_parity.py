@@ -399,6 +399,47 @@ def test_stream_pool_matches_sequential(oracles):
     pool.close()
 
 
+def test_native_pool_matches_sequential(oracles):
+    """sc_hip_pool_run (C++ worker threads, one instance/stream each): host batches and device-resident
+    batches with restore give exactly the sequential results; a failing job reports its own code."""
+    from seamlesscloneoptimization_amd import capi
+    o, _ = oracles
+    items = [o.synth_inputs(150 + 24 * k, 100 + 10 * k, seed_dst=40 + k, seed_patch=60 + k, margin=32) for k in range(7)]
+    seq = capi.Instance(0)
+    want = []
+    for dst, patch, mask, cx, cy in items:
+        b = dst.copy(); seq.run(patch, b, mask, cx, cy); want.append(b)
+    seq.destroy()
+    pool = capi.Pool(0, 3)
+    assert len(pool.instances) == 3
+    for _ in range(2):
+        bodies = [it[0].copy() for it in items]
+        pool.run_host([(it[1], b, it[2], it[3], it[4]) for it, b in zip(items, bodies)])
+        assert all(np.array_equal(b, w) for b, w in zip(bodies, want))
+    # device-resident with restore
+    inst = pool.instances[0]
+    jobs = pool.make_jobs(len(items))
+    keep = []
+    for j, (dst, patch, mask, cx, cy) in zip(jobs, items):
+        f, b0, b, m = inst.to_device(patch), inst.to_device(dst), inst.to_device(np.zeros_like(dst)), inst.to_device(mask)
+        keep.append((f, b0, b, m, dst.shape))
+        j.face, j.face_cols, j.face_rows, j.face_step = f, patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+        j.body, j.body_cols, j.body_rows, j.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+        j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
+        j.centerX, j.centerY, j.body_restore = cx, cy, b0
+    pool.run(jobs, device_resident=True)
+    for (f, b0, b, m, shape), w in zip(keep, want):
+        assert np.array_equal(inst.from_device(b, shape), w)
+    jobs[2].centerX = 1                                     # ROI leaves the image -> that job fails, others run
+    with pytest.raises(capi.SeamlessCloneError) as e:
+        pool.run(jobs, device_resident=True)
+    assert e.value.code == capi.SC_ERR_ROI_OOB and jobs[2].rc == capi.SC_ERR_ROI_OOB and jobs[3].rc == 0
+    for f, b0, b, m, _ in keep:
+        for p in (f, b0, b, m):
+            inst.free(p)
+    pool.close()
+
+
 def test_error_codes(hip, oracles):
     from seamlesscloneoptimization_amd import capi
     o, _ = oracles
