@@ -204,14 +204,14 @@ def main():
 
     rb_name = "k_rb_half (one colour, in place)" if rb_depth == 0 else \
         f"k_rb_tb<{rb_depth},8,8> ({rb_depth} fused red-black sweeps per launch, register blocked)"
-    j_name = "k_jacobi (LDS-tiled 5-point, 1 sweep)" if j_depth == 0 else \
+    j_name = "k_jacobi_roll (register-rolling 5-point, 1 sweep)" if j_depth == 0 else \
         f"k_jacobi_tb<{j_depth},8,8> ({j_depth} fused Jacobi sweeps per launch, register blocked)"
     cache_note = ("working set %.0f MB %s the 256 MB Infinity Cache" %
                   (unknowns * 12 / 1e6, "fits" if unknowns * 12 < 256e6 else "exceeds"))
     # the isolated launches below run the same kernels under a second symbol (template tag) so the
     # rocprofv3 statistics of this command keep them apart from the concurrent in-clone launches
     rb_sym = "k_rb_half<false, 1>" if rb_depth == 0 else f"k_rb_tb<{rb_depth}, 8, 8, false, false, 8, {1 if rb_depth <= 2 else 2}>"
-    j_sym = "k_jacobi<16, 1>" if j_depth == 0 else f"k_jacobi_tb<{j_depth}, 8, 8, 1, {1 if j_depth <= 4 else 2}>"
+    j_sym = "k_jacobi_roll<4, 1>" if j_depth == 0 else f"k_jacobi_tb<{j_depth}, 8, 8, 1, {1 if j_depth <= 4 else 2}>"
     roofline_rb = roof(rb_name, rb_sym, rb_bytes, ms_rb,
                        "red-black GS/SOR sweeps alone; algorithmic bytes = 12 B/unknown/channel/sweep x sweeps per launch "
                        "(SURVEY 8d), so >1.0 is 'effective' bandwidth from temporal blocking; " + cache_note)
@@ -230,7 +230,7 @@ def main():
         roofline = roofline_rb
     roofline_j = roof(j_name, j_sym, j_bytes, ms_j, "the Jacobi stencil named by the north-star, same field; effective "
                       "bandwidth (temporal blocking); " + cache_note)
-    roofline_j1 = roof("k_jacobi (LDS-tiled 5-point, 1 sweep per launch)", "k_jacobi<16, 1>", 12.0 * unknowns, ms_j1,
+    roofline_j1 = roof("k_jacobi_roll<4> (5-point sweep, rows rolling through registers, 1 sweep per launch)", "k_jacobi_roll<4, 1>", 12.0 * unknowns, ms_j1,
                        "single-sweep Jacobi: algorithmic == actual traffic; " + cache_note)
 
     total_pix = comm.sum(float(W * H * args.batch)) * args.steps

@@ -26,14 +26,19 @@ namespace sc {
 constexpr int C0_HXQ = 3;               // halo lanes (float4) per side
 constexpr int C0_HX = 4 * C0_HXQ;
 
+// R rows of one lane's float4 column.  Addresses are clamped into the plane instead of tested: a
+// test around each load would put it in its own branch region with a wait behind it, and the R
+// rows would be fetched one memory latency after the other instead of all at once.  What a clamped
+// lane / row receives is never used: the ring is fixed and every update and residual is masked to
+// the interior, so out-of-range values only ever flow into other out-of-range values.
 template <int R>
 __device__ __forceinline__ void c0_load(const float *__restrict__ p, int P, int H, int x, int y0, float4 (&v)[R])
 {
+    const int xc = min(max(x, 0), P - 4);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int y = y0 + r;
-        v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < H && x >= 0 && x < P) v[r] = *reinterpret_cast<const float4 *>(p + (size_t)y * P + x);
+        const int yc = min(max(y0 + r, 0), H - 1);
+        v[r] = *reinterpret_cast<const float4 *>(p + (size_t)yc * P + xc);
     }
 }
 
@@ -61,7 +66,21 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
     } else {
         c0_load<R>(Uin.at(c), P, H, x, y0, u);
     }
-    if (!PRO) c0_load<R>(F.at(c), P, H, x, y0, f);   // with PRO the RHS is fetched after the prolongation (VGPR pressure)
+    // coarse rows of the prolongation (fast path), requested together with U; lanes / rows outside
+    // the regular part of the coarse grid read a clamped address and take the general path below
+    float2 eab[PRO ? R / 2 + 1 : 1];
+    float ecc[PRO ? R / 2 + 1 : 1];
+    if (PRO) {
+        const float *__restrict__ e = E.at(c);
+        const int cx = min(max(x >> 1, 0), E.pitch - 4), J = y0 >> 1;
+#pragma unroll
+        for (int j = 0; j <= R / 2; ++j) {
+            const float *er = e + (size_t)min(max(J + j, 0), E.H - 1) * E.pitch + cx;
+            eab[j] = *reinterpret_cast<const float2 *>(er);
+            ecc[j] = er[2];
+        }
+    }
+    if (!PRO) c0_load<R>(F.at(c), P, H, x, y0, f);   // with PRO the RHS is fetched after the prolongation
     const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
     const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
 
@@ -72,13 +91,11 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
         float m = 0.f;
         const bool fast = x >= 0 && x + 4 <= 2 * g.x.nc && y0 >= 0 && y0 + R <= 2 * g.y.nc;
         if (fast) {
-            const int c0 = x >> 1, J = y0 >> 1;
             float4 row[R / 2 + 1];
 #pragma unroll
             for (int j = 0; j <= R / 2; ++j) {
-                const float *er = e + (size_t)(J + j) * Pc + c0;
-                const float2 ab = *reinterpret_cast<const float2 *>(er);
-                const float cc = er[2];
+                const float2 ab = eab[j];
+                const float cc = ecc[j];
                 row[j] = make_float4(ab.x, 0.5f * ab.x + 0.5f * ab.y, ab.y, 0.5f * ab.y + 0.5f * cc);
             }
 #pragma unroll
@@ -125,6 +142,7 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
                 if (x3ok) { u[r].w = u[r].w + cr[3]; m = fmaxf(m, fabsf(cr[3])); }
             }
         }
+        c0_load<R>(F.at(c), P, H, x, y0, f);   // after the prolongation (VGPR pressure), in flight during the reduction
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         __shared__ float red[NW];
@@ -137,8 +155,6 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = mm;
         }
     }
-
-    if (PRO) c0_load<R>(F.at(c), P, H, x, y0, f);
 
     // ------------------------------------------------------------------ T red-black sweeps
     // general coefficients (compile away when !GEN)

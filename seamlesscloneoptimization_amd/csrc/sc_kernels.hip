@@ -346,9 +346,17 @@ __global__ __launch_bounds__(256) void k_jacobi(Field Uin, Field Uout, Field F)
         if (lane == 0) t[ry][3] = (yok && tx0 > 0) ? uin[(size_t)y * P + tx0 - 1] : 0.f;
         if (lane == 63) t[ry][4 + JT_TW] = (yok && tx0 + JT_TW < P) ? uin[(size_t)y * P + tx0 + JT_TW] : 0.f;
     }
+    // the right-hand side does not depend on the tile: fetch it before the barrier so its latency
+    // overlaps the tile load instead of following it
+    const float *__restrict__ f = F.at(c);
+    float4 fr[JT_TH / 4];
+#pragma unroll
+    for (int k = 0; k < JT_TH / 4; ++k) {
+        const int y = ty0 + wv + 4 * k;
+        fr[k] = (y < H && x < P) ? *reinterpret_cast<const float4 *>(f + (size_t)y * P + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
     if (x >= P) return;
-    const float *__restrict__ f = F.at(c);
     float *__restrict__ uout = Uout.at(c);
 #pragma unroll
     for (int k = 0; k < JT_TH / 4; ++k) {
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(256) void k_jacobi(Field Uin, Field Uout, Field F)
         float l = wave_from_left(c4.w), r = wave_from_right(c4.x);
         if (lane == 0) l = t[ry + 1][3];
         if (lane == 63) r = t[ry + 1][4 + JT_TW];
-        const float4 f4 = *reinterpret_cast<const float4 *>(f + (size_t)y * P + x);
+        const float4 f4 = fr[k];
         const bool yi = (y >= 1) && (y <= H - 2);
         float4 o = c4;
         if (yi) {
@@ -373,24 +381,87 @@ __global__ __launch_bounds__(256) void k_jacobi(Field Uin, Field Uout, Field F)
     }
 }
 
-// Tile height 16: measured on MI355X at 2048^2 / 4096^2 (tools/tune_jacobi.py) 16 rows ->
-// 5.67 / 5.37 TB/s, 32 -> 4.5 / 4.0, 64 -> 2.7 / 2.7: the load-barrier-compute structure wants
-// many small resident tiles more than it wants a thinner halo.  SC_JT_TH overrides for tuning.
+// Jacobi without LDS: every wave owns a 256-column x S-row segment and walks down it with the rows
+// y-1, y, y+1 in registers.  No barrier, so the S-row loop is one straight instruction stream the
+// compiler can software-pipeline (all loads of the unrolled body issue before the first use).
+// Left/right neighbours come from the adjacent lanes (DPP); lanes 0 and 63 fetch the one column
+// outside the segment from memory (an L2 hit: the neighbouring wave streams that line anyway).
+template <int S, int TAG>
+__global__ __launch_bounds__(256) void k_jacobi_roll(Field Uin, Field Uout, Field F)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.z;
+    const int W = Uin.W, H = Uin.H, P = Uin.pitch;
+    const int x = blockIdx.x * 256 + 4 * lane;
+    const int ya = (blockIdx.y * 4 + wv) * S;
+    if (x >= P || ya >= H) return;
+    const float *__restrict__ uin = Uin.at(c);
+    const float *__restrict__ f = F.at(c);
+    float *__restrict__ uout = Uout.at(c);
+    // Rows ya-1 .. ya+S, the right-hand sides and the two outside columns are all requested up front.
+    // Row and column indices are clamped instead of tested: a clamped value only ever feeds a ring
+    // or out-of-range output, which is passed through / not stored, and the loads stay branch-free.
+    float4 u[S + 2], fr[S];
+    float e[S];
+#pragma unroll
+    for (int k = 0; k < S + 2; ++k) {
+        const int y = min(max(ya + k - 1, 0), H - 1);
+        u[k] = *reinterpret_cast<const float4 *>(uin + (size_t)y * P + x);
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const int y = min(ya + k, H - 1);
+        fr[k] = *reinterpret_cast<const float4 *>(f + (size_t)y * P + x);
+        e[k] = 0.f;
+    }
+    if (lane == 0 || lane == 63) {
+        const int ex = lane == 0 ? max(x - 1, 0) : min(x + 4, P - 1);
+#pragma unroll
+        for (int k = 0; k < S; ++k) e[k] = uin[(size_t)min(ya + k, H - 1) * P + ex];
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const int y = ya + k;
+        const float4 c4 = u[k + 1], u4 = u[k], d4 = u[k + 2], f4 = fr[k];
+        float l = wave_from_left(c4.w), r = wave_from_right(c4.x);
+        l = lane == 0 ? e[k] : l;
+        r = lane == 63 ? e[k] : r;
+        const bool yi = (y >= 1) && (y <= H - 2);
+        float4 o;
+        o.x = (yi && x + 0 >= 1 && x + 0 <= W - 2) ? 0.25f * (((l + c4.y) + (u4.x + d4.x)) - f4.x) : c4.x;
+        o.y = (yi && x + 1 <= W - 2) ? 0.25f * (((c4.x + c4.z) + (u4.y + d4.y)) - f4.y) : c4.y;
+        o.z = (yi && x + 2 <= W - 2) ? 0.25f * (((c4.y + c4.w) + (u4.z + d4.z)) - f4.z) : c4.z;
+        o.w = (yi && x + 3 <= W - 2) ? 0.25f * (((c4.z + r) + (u4.w + d4.w)) - f4.w) : c4.w;
+        if (y < H) *reinterpret_cast<float4 *>(uout + (size_t)y * P + x) = o;
+    }
+}
+
+// Default: the register-rolling kernel with 4-row segments.  Measured on MI355X at 2048^2 / 4096^2
+// (tools/tune_jacobi.py): roll S=4 6.2 / 5.75 TB/s, S=8 6.0 / 5.7, S=16 5.85 / 5.5; LDS tile of 16 rows
+// 5.7 / 5.45, 32 rows 4.8 / 4.6, 64 rows 3.2 / 3.3.  A bare out = a + b kernel with the same tiling and
+// a one-row halo (tools/stream_probe.hip) reaches 6.9 / 5.9 TB/s on the same data, so the sweep runs
+// at 90 / 97 % of what this GPU streams; dropping the two outside-column loads would close most of the
+// rest (measured 6.7 TB/s without them).  SC_JT_TH=<16|32|64> selects the LDS-tiled kernel and
+// SC_JROLL=<4|8|12|16> another segment height, for tuning.
 void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag)
 {
-    static const int forced = [] { const char *e = getenv("SC_JT_TH"); return e ? atoi(e) : 0; }();
-    int th = forced ? forced : 16;
-    if (th == 64) {
-        dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + 63) / 64, Uin.C);
-        hipLaunchKernelGGL((k_jacobi<64, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
-    } else if (th == 32) {
-        dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + 31) / 32, Uin.C);
-        hipLaunchKernelGGL((k_jacobi<32, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
-    } else {
-        dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + 15) / 16, Uin.C);
-        if (tag) hipLaunchKernelGGL((k_jacobi<16, 1>), grid, dim3(256), 0, s, Uin, Uout, F);
+    static const int lds_th = [] { const char *e = getenv("SC_JT_TH"); return e ? atoi(e) : 0; }();
+    static const int roll = [] { const char *e = getenv("SC_JROLL"); return e ? atoi(e) : 4; }();
+    if (lds_th) {
+        const int th = lds_th == 64 ? 64 : (lds_th == 32 ? 32 : 16);
+        dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + th - 1) / th, Uin.C);
+        if (th == 64) hipLaunchKernelGGL((k_jacobi<64, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
+        else if (th == 32) hipLaunchKernelGGL((k_jacobi<32, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
         else hipLaunchKernelGGL((k_jacobi<16, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
+        return;
     }
+    const int S = (roll == 8 || roll == 12 || roll == 16) ? roll : 4;
+    dim3 grid((Uin.W + 255) / 256, (Uin.H + 4 * S - 1) / (4 * S), Uin.C);
+    if (S == 8) hipLaunchKernelGGL((k_jacobi_roll<8, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
+    else if (S == 12) hipLaunchKernelGGL((k_jacobi_roll<12, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
+    else if (S == 16) hipLaunchKernelGGL((k_jacobi_roll<16, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
+    else if (tag) hipLaunchKernelGGL((k_jacobi_roll<4, 1>), grid, dim3(256), 0, s, Uin, Uout, F);
+    else hipLaunchKernelGGL((k_jacobi_roll<4, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
 }
 
 // One colour of a red-black Gauss-Seidel / SOR sweep, in place.  A colour-c point reads only

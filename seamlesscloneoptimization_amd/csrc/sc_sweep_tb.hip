@@ -22,14 +22,18 @@ namespace sc {
 
 constexpr int TB_HX = 4; // column halo (one float4)
 
+// R rows of one lane's float4 column, all requested at once.  Addresses are clamped into the plane
+// rather than tested (a test around each load serialises the R fetches behind R waits); a clamped
+// lane / row holds a value that is never used, because the ring is fixed and every update is masked
+// to the interior, so out-of-range values only flow into other out-of-range values.
 template <int R>
 __device__ __forceinline__ void tb_load(const float *__restrict__ p, int P, int H, int x, int y0, float4 (&v)[R])
 {
+    const int xc = min(max(x, 0), P - 4);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int y = y0 + r;
-        v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < H && x >= 0 && x < P) v[r] = *reinterpret_cast<const float4 *>(p + (size_t)y * P + x);
+        const int yc = min(max(y0 + r, 0), H - 1);
+        v[r] = *reinterpret_cast<const float4 *>(p + (size_t)yc * P + xc);
     }
 }
 
@@ -63,6 +67,20 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
         tb_load<R>(Uin.at(c), P, H, x, y0, u);
     }
     tb_load<R>(F.at(c), P, H, x, y0, f);
+    // coarse rows of the prolongation's fast path, requested together with U and F
+    constexpr bool PROL = (FLAGS & TB_PROLONG) != 0 && (R % 2 == 0);
+    float2 eab[PROL ? R / 2 + 1 : 1];
+    float ecc[PROL ? R / 2 + 1 : 1];
+    if (PROL) {
+        const float *__restrict__ e = E.at(c);
+        const int cx = min(max(x >> 1, 0), E.pitch - 4), J = y0 >> 1;
+#pragma unroll
+        for (int j = 0; j <= R / 2; ++j) {
+            const float *er = e + (size_t)min(max(J + j, 0), E.H - 1) * E.pitch + cx;
+            eab[j] = *reinterpret_cast<const float2 *>(er);
+            ecc[j] = er[2];
+        }
+    }
     const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
     const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
     if (FLAGS & TB_PROLONG) {
@@ -76,13 +94,11 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
         const bool fast = (R % 2 == 0) && ((y0 & 1) == 0) && x >= 0 && x + 4 <= 2 * g.x.nc && y0 >= 0 &&
                           y0 + R <= 2 * g.y.nc;
         if (fast) {
-            const int c0 = x >> 1, J = y0 >> 1;
             float4 row[R / 2 + 1];
 #pragma unroll
             for (int j = 0; j <= R / 2; ++j) {
-                const float *er = e + (size_t)(J + j) * Pc + c0;
-                const float2 ab = *reinterpret_cast<const float2 *>(er);
-                const float cc = er[2];
+                const float2 ab = eab[PROL ? j : 0];
+                const float cc = ecc[PROL ? j : 0];
                 row[j] = make_float4(ab.x, 0.5f * ab.x + 0.5f * ab.y, ab.y, 0.5f * ab.y + 0.5f * cc);
             }
 #pragma unroll
