@@ -54,11 +54,15 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
     static_assert(R % 2 == 0, "bands must hold whole coarse-row pairs");
     __shared__ float4 edge[2][NW][2][64];
     __shared__ float2 hedge[2][NW][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR: row tests become scalar
     const int W = Uin.W, H = Uin.H, P = Uin.pitch;
-    const int x = blockIdx.x * (256 - 2 * C0_HX) - C0_HX + 4 * lane;
-    const int y0 = blockIdx.y * (RH - 2 * HY) - HY + wv * R;       // even
+    // 1-D launch; the tile this workgroup owns is chosen so that neighbouring tiles share an XCD (L2)
+    const int nbx = (W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX), nby = (H + (RH - 2 * HY) - 1) / (RH - 2 * HY);
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int bx = tile % nbx, by = (tile / nbx) % nby, c = tile / (nbx * nby);
+    const int x = bx * (256 - 2 * C0_HX) - C0_HX + 4 * lane;
+    const int y0 = by * (RH - 2 * HY) - HY + wv * R;       // even
     float4 u[R], f[R];
     if (ZEROIN) {
 #pragma unroll
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             float mm = red[0];
 #pragma unroll
             for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red[w]);
-            partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = mm;
+            partial[tile] = mm;
         }
     }
 
@@ -186,14 +190,12 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             (void)cn; (void)dy;
             if (((r + color) & 1) == 0) {      // compile time: x is a multiple of 4 and y0 is even
                 float l = wave_from_left(cur.w);
-                if (lane == 0) l = 0.f;
                 const float n0 = SC_C0_GS(l, cur.y, a.x, b.x, f[r].x, cw0, dx0);
                 const float n2 = SC_C0_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, dx2);
                 cur.x = (yok & x0ok) ? n0 : cur.x;
                 cur.z = (yok & x2ok) ? n2 : cur.z;
             } else {
                 float rr = wave_from_right(cur.x);
-                if (lane == 63) rr = 0.f;
                 const float n1 = SC_C0_GS(cur.x, cur.z, a.y, b.y, f[r].y, cw1, dx1);
                 const float n3 = SC_C0_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, dx3);
                 cur.y = (yok & x1ok) ? n1 : cur.y;
@@ -226,8 +228,6 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             const float4 b = (r == R - 1) ? dn : u[r + 1];
             const float4 cur = u[r];
             float l = wave_from_left(cur.w), rr = wave_from_right(cur.x);
-            if (lane == 0) l = 0.f;
-            if (lane == 63) rr = 0.f;
             const double cn = (GEN && y == g.y.n) ? (double)g.y.cw_last : 1.0;
             const double dy = (GEN && y == g.y.n) ? (double)g.y.d_last : 2.0;
             float4 res;
@@ -240,10 +240,8 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             res.w = (yok & x3ok) ? SC_C0_RES(cur.z, rr, a.w, b.w, cur.w, f[r].w, cw3, dx3) : 0.f;
 #undef SC_C0_RES
             float rl = wave_from_left(res.w);
-            if (lane == 0) rl = 0.f;
             if (GEN) {
                 float rn = wave_from_right(res.x);
-                if (lane == 63) rn = 0.f;
                 h0[r] = ((0.5f * rl + res.x) + wxa0 * res.y) + wxb0 * res.z;
                 h1[r] = ((0.5f * res.y + res.z) + wxa1 * res.w) + wxb1 * rn;
             } else {
@@ -300,10 +298,10 @@ template <int T, bool PRO, int TAG = 0>
 static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s)
 {
     constexpr int RH = C0_NW * C0_R, HY = 2 * T + 2;
-    dim3 grid((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
-    hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false, TAG>), grid, dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E,
+    const int blocks = ((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
+    hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false, TAG>), dim3(blocks), dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E,
                        g, partial);
-    return (int)(grid.x * grid.y * grid.z);
+    return blocks;
 }
 
 // sweeps = T red-black GS sweeps; prolong: add P*E first and write per-block max|P*E| to `partial`.
@@ -340,8 +338,8 @@ static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_
 {
     constexpr int RH = C0_NW * R, HY = 2 * T + 2;
     Field none{};
-    dim3 grid((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX), (F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), F.C);
-    hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true>), grid, dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
+    const int blocks = ((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * F.C;
+    hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true>), dim3(blocks), dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
                        Uout, F, Fc, none, g, (float *)nullptr);
 }
 

@@ -389,11 +389,15 @@ __global__ __launch_bounds__(256) void k_jacobi(Field Uin, Field Uout, Field F)
 template <int S, int TAG>
 __global__ __launch_bounds__(256) void k_jacobi_roll(Field Uin, Field Uout, Field F)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = Uin.W, H = Uin.H, P = Uin.pitch;
-    const int x = blockIdx.x * 256 + 4 * lane;
-    const int ya = (blockIdx.y * 4 + wv) * S;
+    // 1-D launch; vertically adjacent workgroups (they share two rows) are given to the same XCD
+    const int nbx = (W + 255) / 256, nby = (H + 4 * S - 1) / (4 * S);
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int by = tile % nby, bx = (tile / nby) % nbx, c = tile / (nbx * nby);    // column strips: by runs fastest
+    const int x = bx * 256 + 4 * lane;
+    const int ya = (by * 4 + wv) * S;
     if (x >= P || ya >= H) return;
     const float *__restrict__ uin = Uin.at(c);
     const float *__restrict__ f = F.at(c);
@@ -456,7 +460,7 @@ void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag)
         return;
     }
     const int S = (roll == 8 || roll == 12 || roll == 16) ? roll : 4;
-    dim3 grid((Uin.W + 255) / 256, (Uin.H + 4 * S - 1) / (4 * S), Uin.C);
+    const dim3 grid(((Uin.W + 255) / 256) * ((Uin.H + 4 * S - 1) / (4 * S)) * Uin.C);
     if (S == 8) hipLaunchKernelGGL((k_jacobi_roll<8, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
     else if (S == 12) hipLaunchKernelGGL((k_jacobi_roll<12, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
     else if (S == 16) hipLaunchKernelGGL((k_jacobi_roll<16, 0>), grid, dim3(256), 0, s, Uin, Uout, F);

@@ -53,11 +53,15 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
     constexpr int HY = 2 * T, RH = NW * R, HX = 4 * HXQ;   // HXQ halo lanes per side: 4 columns each
     static_assert(2 * T <= HX, "column halo too small for this depth");
     __shared__ float4 edge[2][NW][2][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR: row tests become scalar
     const int W = Uin.W, H = Uin.H, P = Uin.pitch;
-    const int x = blockIdx.x * (256 - 2 * HX) - HX + 4 * lane;
-    const int ry = blockIdx.y * (RH - 2 * HY) - HY;
+    // 1-D launch; neighbouring tiles are given to the same XCD so that they share its L2 (sc_wave.h)
+    const int nbx = (W + (256 - 2 * HX) - 1) / (256 - 2 * HX), nby = (H + (RH - 2 * HY) - 1) / (RH - 2 * HY);
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int bx = tile % nbx, by = (tile / nbx) % nby, c = tile / (nbx * nby);
+    const int x = bx * (256 - 2 * HX) - HX + 4 * lane;
+    const int ry = by * (RH - 2 * HY) - HY;
     const int y0 = ry + wv * R;
     float4 u[R], f[R];
     if (FLAGS & TB_ZEROIN) {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
                 float mm = red[0];
 #pragma unroll
                 for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red[w]);
-                partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = mm;
+                partial[tile] = mm;
             }
         }
     }
@@ -190,7 +194,6 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
             // of component k of row r is known at compile time
             if (((r + color) & 1) == 0) {
                 float l = wave_from_left(cur.w);
-                if (lane == 0) l = 0.f;
                 const float g0 = SC_TB_GS(l, cur.y, a.x, b.x, f[r].x, cw0, dx0);
                 const float g2 = SC_TB_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, dx2);
                 const float n0 = SOR ? (cur.x + omega * (g0 - cur.x)) : g0;
@@ -199,7 +202,6 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
                 cur.z = (yok & x2ok) ? n2 : cur.z;
             } else {
                 float rr = wave_from_right(cur.x);
-                if (lane == 63) rr = 0.f;
                 const float g1 = SC_TB_GS(cur.x, cur.z, a.y, b.y, f[r].y, cw1, dx1);
                 const float g3 = SC_TB_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, dx3);
                 const float n1 = SOR ? (cur.y + omega * (g1 - cur.y)) : g1;
@@ -235,11 +237,15 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
     constexpr int HY = T, RH = NW * R, HX = 4 * HXQ;
     static_assert(T <= HX, "column halo too small for this depth");
     __shared__ float4 edge[2][NW][2][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR: row tests become scalar
     const int W = Uin.W, H = Uin.H, P = Uin.pitch;
-    const int x = blockIdx.x * (256 - 2 * HX) - HX + 4 * lane;
-    const int ry = blockIdx.y * (RH - 2 * HY) - HY;
+    // 1-D launch; neighbouring tiles are given to the same XCD so that they share its L2 (sc_wave.h)
+    const int nbx = (W + (256 - 2 * HX) - 1) / (256 - 2 * HX), nby = (H + (RH - 2 * HY) - 1) / (RH - 2 * HY);
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int bx = tile % nbx, by = (tile / nbx) % nby, c = tile / (nbx * nby);
+    const int x = bx * (256 - 2 * HX) - HX + 4 * lane;
+    const int ry = by * (RH - 2 * HY) - HY;
     const int y0 = ry + wv * R;
     float4 u[R], f[R];
     tb_load<R>(Uin.at(c), P, H, x, y0, u);
@@ -262,8 +268,6 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
             const float4 cur = u[r];
             const float4 b = (r == R - 1) ? dn : u[r + 1];
             float l = wave_from_left(cur.w), rr = wave_from_right(cur.x);
-            if (lane == 0) l = 0.f;
-            if (lane == 63) rr = 0.f;
             float4 nw = cur;
             const float n0 = 0.25f * (((l + cur.y) + (prev.x + b.x)) - f[r].x);
             const float n1 = 0.25f * (((cur.x + cur.z) + (prev.y + b.y)) - f[r].y);
@@ -299,9 +303,9 @@ static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom
 {
     constexpr int HXQ = 2 * T <= 4 ? 1 : 2, HX = 4 * HXQ;
     constexpr int RH = NW * R, HY = 2 * T;
-    dim3 grid((Uin.W + (256 - 2 * HX) - 1) / (256 - 2 * HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
-    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS, HXQ>), grid, dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
-    return (int)(grid.x * grid.y * grid.z);
+    const int blocks = ((Uin.W + (256 - 2 * HX) - 1) / (256 - 2 * HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
+    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS, HXQ>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
+    return blocks;
 }
 
 bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipStream_t s, bool tag)
@@ -375,7 +379,7 @@ static void launch_jacobi_t(Field Uin, Field Uout, Field F, hipStream_t s, bool 
 {
     constexpr int HXQ = T <= 4 ? 1 : 2, HX = 4 * HXQ;
     constexpr int RH = TB_NW * TB_R, HY = T;
-    dim3 grid((Uin.W + (256 - 2 * HX) - 1) / (256 - 2 * HX), (Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY), Uin.C);
+    const dim3 grid(((Uin.W + (256 - 2 * HX) - 1) / (256 - 2 * HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C);
     if (tag) hipLaunchKernelGGL((k_jacobi_tb<T, TB_NW, TB_R, 1, HXQ>), grid, dim3(TB_NW * 64), 0, s, Uin, Uout, F);
     else hipLaunchKernelGGL((k_jacobi_tb<T, TB_NW, TB_R, 0, HXQ>), grid, dim3(TB_NW * 64), 0, s, Uin, Uout, F);
 }

@@ -1,0 +1,17 @@
+"""One clone at a time (no batching) for a kernel-trace timeline: python tools/solo_trace.py [roi] [n]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from seamlesscloneoptimization_amd import capi
+from oracle import oracle_np as o
+roi = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+inst = capi.Instance(0)
+dst, patch, mask, cx, cy = o.synth_inputs(roi, roi, margin=256)
+d_face, d_body, d_mask, d_keep = (inst.to_device(a) for a in (patch, dst, mask, dst))
+for i in range(n):
+    inst.copy_d2d_async(d_body, d_keep, dst.nbytes)
+    inst.run_device(d_face, patch.shape, d_body, dst.shape, d_mask, mask.shape, cx, cy)
+    inst.sync()
+i = inst.info()
+print("device_total %.3f ms  mask %.3f pre %.3f solve %.3f post %.3f cycles %d" % (i.ms_device_total, i.ms_mask, i.ms_pre, i.ms_solve, i.ms_post, i.sweeps))
