@@ -166,8 +166,13 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
     const float cw1 = (GEN && x + 1 == g.x.n) ? g.x.cw_last : 1.0f, dx1 = (GEN && x + 1 == g.x.n) ? g.x.d_last : 2.0f;
     const float cw2 = (GEN && x + 2 == g.x.n) ? g.x.cw_last : 1.0f, dx2 = (GEN && x + 2 == g.x.n) ? g.x.d_last : 2.0f;
     const float cw3 = (GEN && x + 3 == g.x.n) ? g.x.cw_last : 1.0f, dx3 = (GEN && x + 3 == g.x.n) ? g.x.d_last : 2.0f;
-#define SC_C0_GS(L, R_, A, B, FF, CW, DX)                                                    \
-    (GEN ? ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - (FF)) / ((DX) + dy)                   \
+    // reciprocal diagonals, one division per lane and component instead of one per point and half-step:
+    // rdA for regular rows (diagonal dx + 2), rdB for the last row (dx + d_last of the row direction)
+    const float rdA0 = 1.0f / (dx0 + 2.0f), rdA1 = 1.0f / (dx1 + 2.0f), rdA2 = 1.0f / (dx2 + 2.0f), rdA3 = 1.0f / (dx3 + 2.0f);
+    const float rdB0 = GEN ? 1.0f / (dx0 + g.y.d_last) : 0.25f, rdB1 = GEN ? 1.0f / (dx1 + g.y.d_last) : 0.25f;
+    const float rdB2 = GEN ? 1.0f / (dx2 + g.y.d_last) : 0.25f, rdB3 = GEN ? 1.0f / (dx3 + g.y.d_last) : 0.25f;
+#define SC_C0_GS(L, R_, A, B, FF, CW, K)                                                          \
+    (GEN ? ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - (FF)) * (ylast ? rdB##K : rdA##K)        \
          : 0.25f * ((((L) + (R_)) + ((A) + (B))) - (FF)))
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     edge[0][wv][0][lane] = u[0];
@@ -185,19 +190,19 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             const float4 a = (r == 0) ? up : u[r - 1];
             const float4 b = (r == R - 1) ? dn : u[r + 1];
             float4 cur = u[r];
-            const float cn = (GEN && y == g.y.n) ? g.y.cw_last : 1.0f;
-            const float dy = (GEN && y == g.y.n) ? g.y.d_last : 2.0f;
-            (void)cn; (void)dy;
+            const bool ylast = GEN && (y == g.y.n);
+            const float cn = ylast ? g.y.cw_last : 1.0f;
+            (void)cn;
             if (((r + color) & 1) == 0) {      // compile time: x is a multiple of 4 and y0 is even
                 float l = wave_from_left(cur.w);
-                const float n0 = SC_C0_GS(l, cur.y, a.x, b.x, f[r].x, cw0, dx0);
-                const float n2 = SC_C0_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, dx2);
+                const float n0 = SC_C0_GS(l, cur.y, a.x, b.x, f[r].x, cw0, 0);
+                const float n2 = SC_C0_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, 2);
                 cur.x = (yok & x0ok) ? n0 : cur.x;
                 cur.z = (yok & x2ok) ? n2 : cur.z;
             } else {
                 float rr = wave_from_right(cur.x);
-                const float n1 = SC_C0_GS(cur.x, cur.z, a.y, b.y, f[r].y, cw1, dx1);
-                const float n3 = SC_C0_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, dx3);
+                const float n1 = SC_C0_GS(cur.x, cur.z, a.y, b.y, f[r].y, cw1, 1);
+                const float n3 = SC_C0_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, 3);
                 cur.y = (yok & x1ok) ? n1 : cur.y;
                 cur.w = (yok & x3ok) ? n3 : cur.w;
             }

@@ -168,8 +168,13 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
     const float cw1 = (GEN && x + 1 == g.x.n) ? g.x.cw_last : 1.0f, dx1 = (GEN && x + 1 == g.x.n) ? g.x.d_last : 2.0f;
     const float cw2 = (GEN && x + 2 == g.x.n) ? g.x.cw_last : 1.0f, dx2 = (GEN && x + 2 == g.x.n) ? g.x.d_last : 2.0f;
     const float cw3 = (GEN && x + 3 == g.x.n) ? g.x.cw_last : 1.0f, dx3 = (GEN && x + 3 == g.x.n) ? g.x.d_last : 2.0f;
-#define SC_TB_GS(L, R_, A, B, FF, CW, DX)                                                    \
-    (GEN ? ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - (FF)) / ((DX) + dy)                   \
+    // reciprocal diagonals, one division per lane and component instead of one per point and half-step:
+    // rdA for regular rows (diagonal dx + 2), rdB for the last row (dx + d_last of the row direction)
+    const float rdA0 = 1.0f / (dx0 + 2.0f), rdA1 = 1.0f / (dx1 + 2.0f), rdA2 = 1.0f / (dx2 + 2.0f), rdA3 = 1.0f / (dx3 + 2.0f);
+    const float rdB0 = GEN ? 1.0f / (dx0 + g.y.d_last) : 0.25f, rdB1 = GEN ? 1.0f / (dx1 + g.y.d_last) : 0.25f;
+    const float rdB2 = GEN ? 1.0f / (dx2 + g.y.d_last) : 0.25f, rdB3 = GEN ? 1.0f / (dx3 + g.y.d_last) : 0.25f;
+#define SC_TB_GS(L, R_, A, B, FF, CW, K)                                                          \
+    (GEN ? ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - (FF)) * (ylast ? rdB##K : rdA##K)        \
          : 0.25f * ((((L) + (R_)) + ((A) + (B))) - (FF)))
     edge[0][wv][0][lane] = u[0];
     edge[0][wv][1][lane] = u[R - 1];
@@ -187,23 +192,23 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
             const float4 a = (r == 0) ? up : u[r - 1];
             const float4 b = (r == R - 1) ? dn : u[r + 1];
             float4 cur = u[r];
-            const float cn = (GEN && y == g.y.n) ? g.y.cw_last : 1.0f;
-            const float dy = (GEN && y == g.y.n) ? g.y.d_last : 2.0f;
-            (void)cn; (void)dy;
+            const bool ylast = GEN && (y == g.y.n);
+            const float cn = ylast ? g.y.cw_last : 1.0f;
+            (void)cn;
             // x is a multiple of 4 and y0 is even (tile origins and halos are even), so the colour
             // of component k of row r is known at compile time
             if (((r + color) & 1) == 0) {
                 float l = wave_from_left(cur.w);
-                const float g0 = SC_TB_GS(l, cur.y, a.x, b.x, f[r].x, cw0, dx0);
-                const float g2 = SC_TB_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, dx2);
+                const float g0 = SC_TB_GS(l, cur.y, a.x, b.x, f[r].x, cw0, 0);
+                const float g2 = SC_TB_GS(cur.y, cur.w, a.z, b.z, f[r].z, cw2, 2);
                 const float n0 = SOR ? (cur.x + omega * (g0 - cur.x)) : g0;
                 const float n2 = SOR ? (cur.z + omega * (g2 - cur.z)) : g2;
                 cur.x = (yok & x0ok) ? n0 : cur.x;
                 cur.z = (yok & x2ok) ? n2 : cur.z;
             } else {
                 float rr = wave_from_right(cur.x);
-                const float g1 = SC_TB_GS(cur.x, cur.z, a.y, b.y, f[r].y, cw1, dx1);
-                const float g3 = SC_TB_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, dx3);
+                const float g1 = SC_TB_GS(cur.x, cur.z, a.y, b.y, f[r].y, cw1, 1);
+                const float g3 = SC_TB_GS(cur.z, rr, a.w, b.w, f[r].w, cw3, 3);
                 const float n1 = SOR ? (cur.y + omega * (g1 - cur.y)) : g1;
                 const float n3 = SOR ? (cur.w + omega * (g3 - cur.w)) : g3;
                 cur.y = (yok & x1ok) ? n1 : cur.y;
