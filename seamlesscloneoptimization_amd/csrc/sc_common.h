@@ -47,6 +47,7 @@ bool launch_rb_tb(Field Uin, Field Uout, Field F, int sweeps, float omega, hipSt
 int  tb_max_depth(int method);
 int  tb_hard_max_depth(int method);
 long tb_big_side();
+int  tb_gen_rows(int W, int H, int C, int hx, int hy);   // band height (rows per lane) of a coarse-level launch
 struct MGGeom;
 constexpr int TBM_PLAIN = 0, TBM_PROLONG = 1, TBM_ZEROIN = 4;   // mode of launch_rb_tb_gen
 bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s);

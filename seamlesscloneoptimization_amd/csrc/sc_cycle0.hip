@@ -46,7 +46,7 @@ __device__ __forceinline__ void c0_load(const float *__restrict__ p, int P, int 
 //          and the interpolation-tail weights in the restriction of the last coarse column / row.
 // ZEROIN = the incoming correction is identically zero and is not read (first visit of a level).
 template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG: second symbol for isolated timing
-__global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
                                                     float *__restrict__ partial)
 {
     constexpr int HY = 2 * T + 2, RH = NW * R;
@@ -233,12 +233,27 @@ __global__ __launch_bounds__(NW * 64) void k_cycle0(Field Uin, Field Uout, Field
             const float4 b = (r == R - 1) ? dn : u[r + 1];
             const float4 cur = u[r];
             float l = wave_from_left(cur.w), rr = wave_from_right(cur.x);
+            // Level 0 (the only level whose residual has to be accurate: it decides what the solve converges
+            // to) evaluates r = f - sum(neighbour - centre).  Each difference of two neighbouring values is
+            // exact or very nearly so in float32 (Sterbenz: exact when they lie within a factor of two), so
+            // the cancellation that the plain form  f - (sum(neighbours) - 4 centre)  suffers never happens.
+            // The coarse levels solve for corrections; a float32 residual there perturbs the correction by a
+            // relative 1e-7, which the next cycle's level-0 residual sees and removes.
+#ifdef SC_RES_F64
             const double cn = (GEN && y == g.y.n) ? (double)g.y.cw_last : 1.0;
             const double dy = (GEN && y == g.y.n) ? (double)g.y.d_last : 2.0;
-            float4 res;
 #define SC_C0_RES(L, R_, A, B, CC, FF, CW, DX)                                                              \
     (float)((double)(FF) - ((((double)(CW) * (double)(L) + (double)(R_)) + (cn * (double)(A) + (double)(B))) - \
                             ((double)(DX) + dy) * (double)(CC)))
+#else
+            const float cn = (GEN && y == g.y.n) ? g.y.cw_last : 1.0f;
+            const float dy = (GEN && y == g.y.n) ? g.y.d_last : 2.0f;
+            (void)cn; (void)dy;
+#define SC_C0_RES(L, R_, A, B, CC, FF, CW, DX)                                                              \
+    (GEN ? (FF) - ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - ((DX) + dy) * (CC))                            \
+         : (FF) - ((((L) - (CC)) + ((R_) - (CC))) + (((A) - (CC)) + ((B) - (CC)))))
+#endif
+            float4 res;
             res.x = (yok & x0ok) ? SC_C0_RES(l, cur.y, a.x, b.x, cur.x, f[r].x, cw0, dx0) : 0.f;
             res.y = (yok & x1ok) ? SC_C0_RES(cur.x, cur.z, a.y, b.y, cur.y, f[r].y, cw1, dx1) : 0.f;
             res.z = (yok & x2ok) ? SC_C0_RES(cur.y, cur.w, a.z, b.z, cur.z, f[r].z, cw2, dx2) : 0.f;
@@ -350,10 +365,11 @@ static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_
 
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s)
 {
-    const bool big = (long)F.W * F.H >= tb_big_side() * tb_big_side();
-    if (sweeps == 1) { big ? launch_cn<1, 8>(Uout, F, Fc, g, s) : launch_cn<1, 4>(Uout, F, Fc, g, s); return true; }
-    if (sweeps == 2) { big ? launch_cn<2, 8>(Uout, F, Fc, g, s) : launch_cn<2, 4>(Uout, F, Fc, g, s); return true; }
-    return false;
+    if (sweeps != 1 && sweeps != 2) return false;
+    const int R = tb_gen_rows(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
+    if (sweeps == 1) { R == 8 ? launch_cn<1, 8>(Uout, F, Fc, g, s) : R == 6 ? launch_cn<1, 6>(Uout, F, Fc, g, s) : launch_cn<1, 4>(Uout, F, Fc, g, s); }
+    else             { R == 8 ? launch_cn<2, 8>(Uout, F, Fc, g, s) : R == 6 ? launch_cn<2, 6>(Uout, F, Fc, g, s) : launch_cn<2, 4>(Uout, F, Fc, g, s); }
+    return true;
 }
 
 } // namespace sc

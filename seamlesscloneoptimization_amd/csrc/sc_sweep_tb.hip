@@ -360,23 +360,39 @@ long tb_big_side()
 
 // coarse multigrid levels: Gauss-Seidel only (omega = 1); smaller workgroups on small levels so
 // the grid still spreads over the chip.  mode: 0 plain, TB_ZEROIN, TB_PROLONG (with E).
+// Rows per lane (band height) of a coarse-level launch: 8 waves x R rows per workgroup, R in {4, 6, 8}.
+// These launches are latency bound (a workgroup's life is a chain of barriers, not bandwidth), and at
+// ~100 VGPRs two workgroups fit a CU, so what matters is the number of rounds the grid needs over the
+// chip's 512 slots: take the smallest R whose grid fits one round; if none does (large levels) the
+// short 4-row bands won every measurement (tools/bench_configs.py c3/c4).  SC_GEN_R overrides for tuning.
+int tb_gen_rows(int W, int H, int C, int hx, int hy)
+{
+    static const int forced = [] { const char *e = getenv("SC_GEN_R"); return e ? atoi(e) : 0; }();
+    if (forced == 4 || forced == 6 || forced == 8) return forced;
+    if ((long)W * H >= tb_big_side() * tb_big_side()) return 8;
+    const int nbx = (W + (256 - 2 * hx) - 1) / (256 - 2 * hx);
+    for (int R = 4; R <= 8; R += 2) {
+        const int rows = 8 * R - 2 * hy;
+        if (nbx * ((H + rows - 1) / rows) * C <= 512) return R;
+    }
+    return 4;
+}
+
+// coarse multigrid levels: Gauss-Seidel only (omega = 1).  mode: 0 plain, TB_ZEROIN, TB_PROLONG (with E).
 bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s)
 {
-    const bool big = (long)Uin.W * Uin.H >= tb_big_side() * tb_big_side();
-// small levels: 8 waves x 4 rows (same 256 x 32 region as 4 x 8, half the serial work per lane)
-#define SC_GEN_CASE(TT, MODE)                                                                                       \
-    (big ? launch_rb_t<TT, 8, false, true, MODE>(Uin, Uout, F, 1.0f, g, E, nullptr, s)                             \
-         : launch_rb_t<TT, 8, false, true, MODE, 4>(Uin, Uout, F, 1.0f, g, E, nullptr, s))
-    if (sweeps == 1) {
-        if (mode == 0) SC_GEN_CASE(1, 0); else if (mode == TB_ZEROIN) SC_GEN_CASE(1, TB_ZEROIN); else SC_GEN_CASE(1, TB_PROLONG);
-        return true;
-    }
-    if (sweeps == 2) {
-        if (mode == 0) SC_GEN_CASE(2, 0); else if (mode == TB_ZEROIN) SC_GEN_CASE(2, TB_ZEROIN); else SC_GEN_CASE(2, TB_PROLONG);
-        return true;
-    }
+    if (sweeps != 1 && sweeps != 2) return false;
+    const int R = tb_gen_rows(Uin.W, Uin.H, Uin.C, TB_HX, 2 * sweeps);
+#define SC_GEN_R(TT, MODE)                                                                                          \
+    (R == 8 ? launch_rb_t<TT, 8, false, true, MODE, 8>(Uin, Uout, F, 1.0f, g, E, nullptr, s)                        \
+   : R == 6 ? launch_rb_t<TT, 8, false, true, MODE, 6>(Uin, Uout, F, 1.0f, g, E, nullptr, s)                        \
+            : launch_rb_t<TT, 8, false, true, MODE, 4>(Uin, Uout, F, 1.0f, g, E, nullptr, s))
+#define SC_GEN_CASE(TT)                                                                                             \
+    { if (mode == 0) SC_GEN_R(TT, 0); else if (mode == TB_ZEROIN) SC_GEN_R(TT, TB_ZEROIN); else SC_GEN_R(TT, TB_PROLONG); }
+    if (sweeps == 1) SC_GEN_CASE(1) else SC_GEN_CASE(2)
 #undef SC_GEN_CASE
-    return false;
+#undef SC_GEN_R
+    return true;
 }
 
 template <int T>
