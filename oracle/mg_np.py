@@ -129,25 +129,82 @@ def prolong(E, dx: Dim, dy: Dim):
     return out.astype(F32)
 
 
-def vcycle(levels, l, U, F, pre=2, post=2):
+# ---- which level the library's bottom kernel solves directly (mirrors sc_multigrid.cpp: bottom_start, build_fd)
+MG_BOTTOM_LDS_BYTES = 152 * 1024
+MG_BOTTOM_MAX_LEVELS = 12
+
+
+def _bottom_floats(dx: Dim, dy: Dim) -> int:
+    return 2 * ((dx.n + 2) | 1) * (dy.n + 2)
+
+
+def bottom_start(levels) -> int:
+    for l in range(1, len(levels)):
+        if len(levels) - l > MG_BOTTOM_MAX_LEVELS:
+            continue
+        if 4 * sum(_bottom_floats(*levels[k]) for k in range(l, len(levels))) <= MG_BOTTOM_LDS_BYTES:
+            return l
+    return len(levels)
+
+
+def direct_level(levels):
+    """Index of the level solved exactly (fast diagonalisation in LDS), or None."""
+    planes = 0
+    for l in range(bottom_start(levels), len(levels)):
+        dx, dy = levels[l]
+        planes += _bottom_floats(dx, dy)
+        nxp, nyp = (dx.n + 3) // 4 * 4, (dy.n + 3) // 4 * 4
+        if dx.n > 128 or dy.n > 128:
+            continue
+        if 4 * (planes + 2 * nxp * nxp + 2 * nyp * nyp + 3 * nxp * nyp) > MG_BOTTOM_LDS_BYTES:
+            continue
+        return l
+    return None
+
+
+def solve_exact(F, dx: Dim, dy: Dim):
+    """Exact solution of one level's system (zero ring) by a sparse direct solve in float64."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    def t1d(d: Dim):
+        n = d.n
+        main = np.full(n, -2.0); main[-1] = -float(d.d_last)
+        sub = np.ones(n - 1); sup = np.ones(n - 1)
+        if n >= 2:
+            sub[-1] = float(d.cw_last)
+        return sp.diags([sub, main, sup], [-1, 0, 1], format="csr") if n >= 2 else sp.csr_matrix(main.reshape(1, 1))
+    Tx, Ty = t1d(dx), t1d(dy)
+    A = sp.kron(sp.identity(dy.n), Tx) + sp.kron(Ty, sp.identity(dx.n))     # unknowns ordered y-major, x fastest
+    u = spl.spsolve(A.tocsc(), F[1:-1, 1:-1].astype(np.float64).ravel())
+    U = np.zeros_like(F)
+    U[1:-1, 1:-1] = u.reshape(dy.n, dx.n).astype(F32)
+    return U
+
+
+def vcycle(levels, l, U, F, pre=2, post=2, direct=None):
     dx, dy = levels[l]
+    if direct is not None and l == direct:
+        return solve_exact(F, dx, dy)
     if l == len(levels) - 1:
         rho = 0.5 * (np.cos(np.pi / (dx.n + 1.0)) + np.cos(np.pi / (dy.n + 1.0)))
         om = 2.0 / (1.0 + np.sqrt(max(0.0, 1.0 - rho * rho)))
         return rb_gen(U, F, dx, dy, max(8, min(64, 2 * max(dx.n, dy.n))), float(F32(om)))
     U = rb_gen(U, F, dx, dy, pre)
     Fc = restrict(residual_field(U, F, dx, dy), dx, dy)
-    E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post)
+    E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post, direct)
     U = U.copy()
     U += prolong(E, dx, dy)
     return rb_gen(U, F, dx, dy, post)
 
 
-def solve(U0, F, cycles=6):
-    """Multigrid solve of one plane: U0 carries the Dirichlet ring (level 0 is regular)."""
+def solve(U0, F, cycles=6, direct="auto"):
+    """Multigrid solve of one plane: U0 carries the Dirichlet ring (level 0 is regular).
+    direct: "auto" = the level the library solves directly, None = V-cycle down to the coarsest level."""
     H, W = U0.shape
     levels = build_levels(W, H)
-    U = U0.astype(F32, copy=True)
+    d = direct_level(levels) if direct == "auto" else direct
+    U = U0.astype(F32).copy()
     for _ in range(cycles):
-        U = vcycle(levels, 0, U, F)
+        U = vcycle(levels, 0, U, F, direct=d)
     return U

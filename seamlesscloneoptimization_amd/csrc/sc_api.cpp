@@ -291,6 +291,9 @@ void my_seamlessclone_api_imp_destroy(void *p)
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
     if (I->mg_partial.p) (void)hipFree(I->mg_partial.p);
+    if (I->h_partial.p) (void)hipHostFree(I->h_partial.p);
+    if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
+    if (I->h_fd.p) (void)hipHostFree(I->h_fd.p);
     if (I->d_rect) (void)hipFree(I->d_rect);
     if (I->d_partials) (void)hipFree(I->d_partials);
     if (I->d_red) (void)hipFree(I->d_red);

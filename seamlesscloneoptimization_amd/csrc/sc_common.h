@@ -92,11 +92,21 @@ void launch_fill_zero(Field U, hipStream_t s);
 constexpr int MG_BOTTOM_MAX_LEVELS = 12;
 constexpr int MG_BOTTOM_LDS_BYTES = 152 * 1024;   // of the CU's 160 KiB
 struct MGBottomLevel { MGGeom g; float omega; int offU, offF, pitch; };   // LDS offsets / row pitch in floats
+// Direct solve of one bottom level by fast diagonalisation (sc_multigrid.cpp builds the matrices):
+// the level's operator is a tensor sum Tx (x) I + I (x) Ty of two tridiagonal 1-D operators, so with
+// Tx = Vx Lx Vx^-1, Ty = Vy Ly Vy^-1 the solution of A U = F is
+//     U = Vy [ (Vy^-1 F Vx^-T) / (ly_j + lx_i) ] Vx^T      -- four small dense products in LDS.
+// fd_mats (HBM, padded to multiples of 4, zero padded): Mx1[nxp][nxp], My1T[nyp][nyp], My2T[nyp][nyp],
+// Mx2[nxp][nxp], Dinv[nyp][nxp].  fd_level < 0: no direct solve (V-cycle down to the coarsest level).
 struct MGBottomArgs {
     int nlevels, pre, post, coarse_sweeps, lds_floats;
+    int fd_level, fd_nxp, fd_nyp, fd_off;   // level index inside the bottom, padded sizes, LDS offset of the FD region
+    const float *fd_mats;
     Field Ftop, Utop;       // HBM planes of the first bottom level: RHS in, correction out
     MGBottomLevel lv[MG_BOTTOM_MAX_LEVELS];
 };
+__host__ __device__ static inline long fd_mat_floats(int nxp, int nyp) { return 2L * nxp * nxp + 2L * nyp * nyp + (long)nxp * nyp; }
+__host__ __device__ static inline long fd_lds_floats(int nxp, int nyp) { return fd_mat_floats(nxp, nyp) + 2L * nxp * nyp; }
 hipError_t mg_bottom_prepare();
 void launch_mg_bottom(const MGBottomArgs &a, int C, hipStream_t s);
 

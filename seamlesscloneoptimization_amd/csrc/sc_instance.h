@@ -43,8 +43,12 @@ struct Instance {
     // multigrid hierarchy (level 0 aliases U0/U1/F)
     std::vector<DevBuf> mg_bufs;
     DevBuf mg_partial;    // per-block maxima of the level-0 correction
+    DevBuf h_partial;     // pinned copy of the same (small grids are folded on the host: no reduction launch)
     std::vector<MGLevel> mg;
     size_t mg_bottom = 0;  // first level run by the fused bottom kernel (== mg.size(): none)
+    // direct (fast-diagonalisation) solve inside the bottom kernel: level index relative to mg_bottom, or -1
+    int fd_level = -1, fd_nxp = 0, fd_nyp = 0;
+    DevBuf mg_fd, h_fd;    // its matrices: device copy and pinned staging
     // reductions / mailboxes
     int *d_rect = nullptr;
     int *h_rect = nullptr;       // pinned
@@ -69,6 +73,7 @@ int hip_fail(Instance *I, hipError_t e, const char *what);
     } while (0)
 
 int ensure(Instance *I, DevBuf &b, size_t bytes);
+int ensure_pinned(Instance *I, DevBuf &b, size_t bytes);
 int setup_fields(Instance *I, int W, int H, int C);
 
 // solver drivers (sc_solver.cpp) -- operate on I->U0/U1/F, leave the answer in result(I)

@@ -368,6 +368,73 @@ __device__ __forceinline__ void bt_ascent(float *lds, const MGBottomLevel *lv, i
     }
 }
 
+// ---- direct solve of one bottom level by fast diagonalisation (MGBottomArgs, sc_multigrid.cpp) ----
+// out[r][c] = sum_k LT[k][r] * R[k][c]  for r < rows, c < cols (both multiples of 4, zero padded), every
+// operand in LDS with both reads contiguous (the left operand is kept transposed).  A thread owns a
+// 2 x 4 tile: per k one ds_read_b64 + one ds_read_b128 and 8 FMAs.  TRANS writes the tile transposed
+// (the next product needs this result as ITS left operand); SCALE multiplies by scale[r][c].
+template <bool TRANS, bool SCALE>
+__device__ __forceinline__ void fd_product(const float *LT, int pL, const float *R, int pR, int K, int rows, int cols,
+                                           float *out, int pOut, const float *scale)
+{
+    const int tc = cols >> 2, ntiles = (rows >> 1) * tc;
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        const int r0 = (t / tc) << 1, c0 = (t % tc) << 2;
+        float a00 = 0.f, a01 = 0.f, a02 = 0.f, a03 = 0.f, a10 = 0.f, a11 = 0.f, a12 = 0.f, a13 = 0.f;
+        const float *lp = LT + r0, *rp = R + c0;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float2 l = *reinterpret_cast<const float2 *>(lp + k * pL);
+            const float4 r = *reinterpret_cast<const float4 *>(rp + k * pR);
+            a00 = __builtin_fmaf(l.x, r.x, a00); a01 = __builtin_fmaf(l.x, r.y, a01);
+            a02 = __builtin_fmaf(l.x, r.z, a02); a03 = __builtin_fmaf(l.x, r.w, a03);
+            a10 = __builtin_fmaf(l.y, r.x, a10); a11 = __builtin_fmaf(l.y, r.y, a11);
+            a12 = __builtin_fmaf(l.y, r.z, a12); a13 = __builtin_fmaf(l.y, r.w, a13);
+        }
+        if (SCALE) {
+            const float4 s0 = *reinterpret_cast<const float4 *>(scale + r0 * cols + c0);
+            const float4 s1 = *reinterpret_cast<const float4 *>(scale + (r0 + 1) * cols + c0);
+            a00 *= s0.x; a01 *= s0.y; a02 *= s0.z; a03 *= s0.w;
+            a10 *= s1.x; a11 *= s1.y; a12 *= s1.z; a13 *= s1.w;
+        }
+        if (TRANS) {
+            *reinterpret_cast<float2 *>(out + (c0 + 0) * pOut + r0) = make_float2(a00, a10);
+            *reinterpret_cast<float2 *>(out + (c0 + 1) * pOut + r0) = make_float2(a01, a11);
+            *reinterpret_cast<float2 *>(out + (c0 + 2) * pOut + r0) = make_float2(a02, a12);
+            *reinterpret_cast<float2 *>(out + (c0 + 3) * pOut + r0) = make_float2(a03, a13);
+        } else {
+            *reinterpret_cast<float4 *>(out + r0 * pOut + c0) = make_float4(a00, a01, a02, a03);
+            *reinterpret_cast<float4 *>(out + (r0 + 1) * pOut + c0) = make_float4(a10, a11, a12, a13);
+        }
+    }
+    __syncthreads();
+}
+
+// Solves level `v` (RHS plane lds + v.offF, result into lds + v.offU) exactly.  mats: the five matrices
+// already staged in LDS at fd; P0, P1: two nxp x nyp scratch planes behind them.
+__device__ __forceinline__ void fd_solve(float *lds, const MGBottomLevel &v, const float *fd, int nxp, int nyp)
+{
+    const int nx = v.g.x.n, ny = v.g.y.n;
+    const float *Mx1 = fd, *My1T = Mx1 + nxp * nxp, *My2T = My1T + nyp * nyp, *Mx2 = My2T + nyp * nyp, *Dinv = Mx2 + nxp * nxp;
+    float *P0 = const_cast<float *>(Dinv) + nyp * nxp, *P1 = P0 + nxp * nyp;
+    const float *f = lds + v.offF;
+    for (int i = threadIdx.x; i < nxp * nyp; i += blockDim.x) {          // P0 = F^T, zero padded
+        const int x = i / nyp, y = i - x * nyp;
+        P0[i] = (x < nx && y < ny) ? f[(y + 1) * v.pitch + x + 1] : 0.f;
+    }
+    __syncthreads();
+    fd_product<false, false>(P0, nyp, Mx1, nxp, nxp, nyp, nxp, P1, nxp, nullptr);      // G1 = F Vx^-T          [y][i]
+    fd_product<false, true>(My1T, nyp, P1, nxp, nyp, nyp, nxp, P0, nxp, Dinv);         // G2 = (Vy^-1 G1) / (ly + lx)
+    fd_product<true, false>(My2T, nyp, P0, nxp, nyp, nyp, nxp, P1, nyp, nullptr);      // G3^T = (Vy G2)^T      [i][y]
+    fd_product<false, false>(P1, nyp, Mx2, nxp, nxp, nyp, nxp, P0, nxp, nullptr);      // U = G3 Vx^T           [y][x]
+    float *u = lds + v.offU;
+    for (int i = threadIdx.x; i < nx * ny; i += blockDim.x) {
+        const int y = i / nx, x = i - y * nx;
+        u[(y + 1) * v.pitch + x + 1] = P0[y * nxp + x];
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -375,7 +442,15 @@ __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
     const int c = blockIdx.x;
     const int L = a.nlevels;
     if (threadIdx.x < MG_BOTTOM_MAX_LEVELS) lv[threadIdx.x] = a.lv[threadIdx.x];
-    for (int i = threadIdx.x; i < a.lds_floats; i += blockDim.x) lds[i] = 0.f;   // zero corrections, rings, pads
+    const bool fd = a.fd_level >= 0;
+    const int nzero = fd ? a.fd_off : a.lds_floats;
+    for (int i = threadIdx.x; i < nzero; i += blockDim.x) lds[i] = 0.f;   // zero corrections, rings, pads
+    if (fd) {   // stage the direct solver's matrices (16-byte loads; the region is 16-byte aligned and a multiple of 4 floats)
+        const int n4 = (int)(fd_mat_floats(a.fd_nxp, a.fd_nyp) >> 2);
+        const float4 *__restrict__ src = reinterpret_cast<const float4 *>(a.fd_mats);
+        float4 *dst = reinterpret_cast<float4 *>(lds + a.fd_off);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    }
     __syncthreads();
     const MGBottomLevel t = lv[0];
     {   // top RHS: HBM -> LDS
@@ -390,6 +465,13 @@ __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
     }
     // levels [0, lb): all 16 waves with block barriers; levels [ls, L): wave 0 alone (<= 4 colour
     // points per lane), the other waves wait at ONE barrier for the whole sub-cycle
+    if (fd) {
+        // V-cycle levels [0, fd_level) with all waves, level fd_level solved exactly, nothing below it
+        const int lf = a.fd_level;
+        bt_subcycle<false>(lds, lv, lf + 1, a.pre, 0, lf);
+        fd_solve(lds, lv[lf], lds + a.fd_off, a.fd_nxp, a.fd_nyp);
+        bt_ascent<false>(lds, lv, lf + 1, a.post, 0, lf);
+    } else {
     int ls = L;
     while (ls > 0 && ((lv[ls - 1].g.x.n + 1) >> 1) * lv[ls - 1].g.y.n <= 256) --ls;
     const int lb = ls < L - 1 ? ls : L - 1;            // block-mode levels are [0, lb)
@@ -412,6 +494,7 @@ __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
         }
     }
     bt_ascent<false>(lds, lv, L, a.post, 0, lb);
+    }
     {   // top correction: LDS -> HBM (interior; ring and pads of the global plane stay zero)
         float *__restrict__ ug = a.Utop.at(c);
         const float *u = lds + t.offU;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace sc {
 
@@ -58,6 +59,126 @@ static size_t bottom_start(Instance *I)
     return I->mg.size();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct solve of the bottom's first level(s) by fast diagonalisation.
+// A level's operator is  (A u)[y][x] = sum_x' Tx[x][x'] u[y][x'] + sum_y' Ty[y][y'] u[y'][x]  with
+// tridiagonal 1-D parts: rows (1, -2, 1), last row (cw_last, -d_last) (MGDim).  T is not symmetric
+// (the last sub-diagonal is cw_last, the super-diagonal above it 1) but E T E^-1 is, with
+// E = diag(1, .., 1, 1/sqrt(cw_last)); its eigen-decomposition Q L Q^T gives T = V L V^-1 with
+// V = E^-1 Q, V^-1 = Q^T E.  Everything here is double; the device gets float matrices.
+// ---------------------------------------------------------------------------------------------
+// Eigen-decomposition of a symmetric tridiagonal matrix by implicit QL with Wilkinson shifts.
+// d: diagonal (n) -> eigenvalues; e: sub-diagonal, e[i] couples i and i+1 (n-1 used, e[n-1] = 0);
+// zt: n x n, row k = eigenvector k on return (kept transposed so the rotation loop is contiguous).
+static bool tridiag_ql(int n, std::vector<double> &d, std::vector<double> &e, std::vector<double> &zt)
+{
+    zt.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) zt[(size_t)i * n + i] = 1.0;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= 1.1e-16 * dd) break;
+            }
+            if (m != l) {
+                if (++iter > 80) return false;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    r = std::hypot(f, g);
+                    e[i + 1] = r;
+                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+                    s = f / r; c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    p = s * r;
+                    d[i + 1] = g + p;
+                    g = c * r - b;
+                    double *zi = &zt[(size_t)i * n], *zi1 = &zt[(size_t)(i + 1) * n];
+                    for (int k = 0; k < n; ++k) {
+                        f = zi1[k];
+                        zi1[k] = s * zi[k] + c * f;
+                        zi[k] = c * zi[k] - s * f;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    return true;
+}
+
+struct FD1 { int n; std::vector<double> lam, q, ee; };   // q[k*n + i]: component i of eigenvector k; ee: diagonal of E
+
+static bool fd_decompose(const MGDim &g, FD1 &o)
+{
+    const int n = g.n;
+    o.n = n;
+    o.ee.assign(n, 1.0);
+    std::vector<double> d(n, -2.0), e(n, 0.0);
+    for (int i = 0; i + 1 < n; ++i) e[i] = 1.0;
+    d[n - 1] = -(double)g.d_last;
+    if (n >= 2) {
+        e[n - 2] = std::sqrt((double)g.cw_last);          // sqrt(sub * super) = sqrt(cw_last * 1)
+        o.ee[n - 1] = 1.0 / std::sqrt((double)g.cw_last);
+    }
+    if (!tridiag_ql(n, d, e, o.q)) return false;
+    o.lam = d;
+    return true;
+}
+
+// Chooses the bottom level solved directly and uploads its matrices.  I->fd_level = -1 when nothing fits.
+static int build_fd(Instance *I)
+{
+    I->fd_level = -1;
+    static const int fd_on = [] { const char *e = getenv("SC_BOTTOM_FD"); return e ? atoi(e) : 1; }();
+    if (!fd_on || I->mg_bottom >= I->mg.size()) return SC_OK;
+    long planes = 0;
+    for (size_t l = I->mg_bottom; l < I->mg.size(); ++l) {
+        const MGLevel &L = I->mg[l];
+        planes += bottom_floats(L);
+        const int nx = L.g.x.n, ny = L.g.y.n, nxp = round_up(nx, 4), nyp = round_up(ny, 4);
+        if (nx > 128 || ny > 128) continue;
+        if ((planes + fd_lds_floats(nxp, nyp)) * (long)sizeof(float) > (long)MG_BOTTOM_LDS_BYTES) continue;
+        FD1 fx, fy;
+        if (!fd_decompose(L.g.x, fx) || !fd_decompose(L.g.y, fy)) return SC_OK;   // keep the V-cycle bottom
+        const long nf = fd_mat_floats(nxp, nyp);
+        int rc;
+        if ((rc = ensure_pinned(I, I->h_fd, sizeof(float) * (size_t)nf))) return rc;
+        if ((rc = ensure(I, I->mg_fd, sizeof(float) * (size_t)nf))) return rc;
+        float *m = (float *)I->h_fd.p;
+        memset(m, 0, sizeof(float) * (size_t)nf);
+        float *Mx1 = m, *My1T = Mx1 + (size_t)nxp * nxp, *My2T = My1T + (size_t)nyp * nyp, *Mx2 = My2T + (size_t)nyp * nyp,
+              *Dinv = Mx2 + (size_t)nxp * nxp;
+        for (int x = 0; x < nx; ++x)
+            for (int i = 0; i < nx; ++i) {
+                const double q = fx.q[(size_t)i * nx + x];
+                Mx1[(size_t)x * nxp + i] = (float)(q * fx.ee[x]);         // Vx^-1[i][x]
+                Mx2[(size_t)i * nxp + x] = (float)(q / fx.ee[x]);         // Vx[x][i]
+            }
+        for (int y = 0; y < ny; ++y)
+            for (int j = 0; j < ny; ++j) {
+                const double q = fy.q[(size_t)j * ny + y];
+                My1T[(size_t)y * nyp + j] = (float)(q * fy.ee[y]);        // Vy^-1[j][y]
+                My2T[(size_t)j * nyp + y] = (float)(q / fy.ee[y]);        // Vy[y][j]
+            }
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) Dinv[(size_t)j * nxp + i] = (float)(1.0 / (fy.lam[j] + fx.lam[i]));
+        SC_HIP(I, hipMemcpyAsync(I->mg_fd.p, m, sizeof(float) * (size_t)nf, hipMemcpyHostToDevice, I->stream));
+        I->fd_level = (int)(l - I->mg_bottom);
+        I->fd_nxp = nxp; I->fd_nyp = nyp;
+        return SC_OK;
+    }
+    return SC_OK;
+}
+
 static int run_bottom(Instance *I, size_t l0, int pre, int post)
 {
     MGBottomArgs a;
@@ -73,6 +194,14 @@ static int run_bottom(Instance *I, size_t l0, int pre, int post)
         const int plane = a.lv[i].pitch * (L.g.y.n + 2);
         a.lv[i].offU = off; a.lv[i].offF = off + plane;
         off += 2 * plane;
+    }
+    a.fd_level = I->fd_level; a.fd_nxp = I->fd_nxp; a.fd_nyp = I->fd_nyp;
+    a.fd_mats = (const float *)I->mg_fd.p;
+    a.fd_off = 0;
+    if (a.fd_level >= 0) {
+        // levels below the directly solved one are not visited: the FD region takes their place in LDS
+        a.fd_off = (a.lv[a.fd_level].offF + a.lv[a.fd_level].pitch * (I->mg[l0 + a.fd_level].g.y.n + 2) + 3) & ~3;
+        off = a.fd_off + (int)fd_lds_floats(a.fd_nxp, a.fd_nyp);
     }
     a.lds_floats = off;
     a.Ftop = I->mg[l0].F;
@@ -125,7 +254,7 @@ static int build_levels(Instance *I)
     }
     I->mg[0].F = I->F;
     I->mg_bottom = bottom_start(I);
-    return SC_OK;
+    return build_fd(I);
 }
 
 // Smoothing of a coarse level (l >= 1) with the fused general kernel; U <-> T ping-pong, both
@@ -242,18 +371,29 @@ int mg_solve(Instance *I)
             if (nb <= 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
             I->result_in_U1 = !I->result_in_U1;
             I->info.sweep_launches += 1;
-            launch_max_final((const float *)I->mg_partial.p, nb, I->d_maxcorr, I->stream);
             ++cyc;
             SC_HIP(I, hipGetLastError());
             // The first two corrections of a solve are never below the stop threshold unless the
             // initial guess was already the answer, and every check costs a host round trip
             // (~35 us of idle GPU), so checking starts with the third cycle.
             if (cyc < 3 && cyc < budget && o.tol <= 0.f) continue;
-            SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
-            SC_HIP(I, hipStreamSynchronize(I->stream));
-            float m;
-            unsigned bits = *I->h_maxcorr;
-            memcpy(&m, &bits, sizeof(float));
+            // max |correction| = max over the per-workgroup maxima.  A few thousand of them are folded here
+            // on the host (the read-back is needed anyway and a reduction launch costs ~5 us of GPU time);
+            // large grids reduce on the device first.
+            float m = 0.f;
+            if (nb <= 16384) {
+                if ((rc = ensure_pinned(I, I->h_partial, sizeof(float) * (size_t)nb))) return rc;
+                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)nb, hipMemcpyDeviceToHost, I->stream));
+                SC_HIP(I, hipStreamSynchronize(I->stream));
+                const float *hp = (const float *)I->h_partial.p;
+                for (int i = 0; i < nb; ++i) m = hp[i] > m ? hp[i] : m;
+            } else {
+                launch_max_final((const float *)I->mg_partial.p, nb, I->d_maxcorr, I->stream);
+                SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
+                SC_HIP(I, hipStreamSynchronize(I->stream));
+                unsigned bits = *I->h_maxcorr;
+                memcpy(&m, &bits, sizeof(float));
+            }
             I->info.last_update = m;
             if (o.tol > 0.f) {
                 double r[2];
