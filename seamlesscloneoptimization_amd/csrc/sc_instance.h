@@ -13,6 +13,13 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// eigen-decomposition of one 1-D level operator (sc_multigrid.cpp, fast-diagonalisation bottom solve)
+struct FD1 {
+    int n = 0;
+    float cw_last = 0.f, d_last = 0.f;     // together with n: the key
+    std::vector<double> lam, q, ee;          // eigenvalues; q[k*n + i] = component i of eigenvector k; diagonal of E
+};
+
 struct MGLevel {
     Field U, F, T;   // correction, RHS, scratch (residual field); level 0 aliases the instance fields
     MGGeom g;        // geometry of this level and of its transfer to the next coarser one
@@ -49,6 +56,8 @@ struct Instance {
     // direct (fast-diagonalisation) solve inside the bottom kernel: level index relative to mg_bottom, or -1
     int fd_level = -1, fd_nxp = 0, fd_nyp = 0;
     DevBuf mg_fd, h_fd;    // its matrices: device copy and pinned staging
+    std::vector<FD1> fd_cache;   // recent 1-D decompositions (a geometry seen before costs no eigen-solve)
+    size_t fd_cache_next = 0;
     // reductions / mailboxes
     int *d_rect = nullptr;
     int *h_rect = nullptr;       // pinned

@@ -115,12 +115,10 @@ static bool tridiag_ql(int n, std::vector<double> &d, std::vector<double> &e, st
     return true;
 }
 
-struct FD1 { int n; std::vector<double> lam, q, ee; };   // q[k*n + i]: component i of eigenvector k; ee: diagonal of E
-
 static bool fd_decompose(const MGDim &g, FD1 &o)
 {
     const int n = g.n;
-    o.n = n;
+    o.n = n; o.cw_last = g.cw_last; o.d_last = g.d_last;
     o.ee.assign(n, 1.0);
     std::vector<double> d(n, -2.0), e(n, 0.0);
     for (int i = 0; i + 1 < n; ++i) e[i] = 1.0;
@@ -132,6 +130,21 @@ static bool fd_decompose(const MGDim &g, FD1 &o)
     if (!tridiag_ql(n, d, e, o.q)) return false;
     o.lam = d;
     return true;
+}
+
+// 1-D decompositions are kept in a small per-instance cache: alternating between a few ROI sizes (or a
+// square ROI, whose two directions are the same operator) then costs no eigen-solve.
+static const FD1 *fd_cached(Instance *I, const MGDim &g)
+{
+    for (const FD1 &f : I->fd_cache)
+        if (f.n == g.n && f.cw_last == g.cw_last && f.d_last == g.d_last) return &f;
+    FD1 f;
+    if (!fd_decompose(g, f)) return nullptr;
+    constexpr size_t CAP = 16;
+    if (I->fd_cache.size() < CAP) { I->fd_cache.reserve(CAP); I->fd_cache.push_back(std::move(f)); return &I->fd_cache.back(); }
+    const size_t slot = I->fd_cache_next++ % CAP;
+    I->fd_cache[slot] = std::move(f);
+    return &I->fd_cache[slot];
 }
 
 // Chooses the bottom level solved directly and uploads its matrices.  I->fd_level = -1 when nothing fits.
@@ -147,8 +160,11 @@ static int build_fd(Instance *I)
         const int nx = L.g.x.n, ny = L.g.y.n, nxp = round_up(nx, 4), nyp = round_up(ny, 4);
         if (nx > 128 || ny > 128) continue;
         if ((planes + fd_lds_floats(nxp, nyp)) * (long)sizeof(float) > (long)MG_BOTTOM_LDS_BYTES) continue;
-        FD1 fx, fy;
-        if (!fd_decompose(L.g.x, fx) || !fd_decompose(L.g.y, fy)) return SC_OK;   // keep the V-cycle bottom
+        const FD1 *pfx = fd_cached(I, L.g.x), *pfy = fd_cached(I, L.g.y);
+        if (pfx && !(pfx->n == nx && pfx->cw_last == L.g.x.cw_last && pfx->d_last == L.g.x.d_last))
+            pfx = fd_cached(I, L.g.x);          // inserting y evicted x from a full cache: x goes into the next slot
+        if (!pfx || !pfy) return SC_OK;                                           // keep the V-cycle bottom
+        const FD1 &fx = *pfx, &fy = *pfy;
         const long nf = fd_mat_floats(nxp, nyp);
         int rc;
         if ((rc = ensure_pinned(I, I->h_fd, sizeof(float) * (size_t)nf))) return rc;
