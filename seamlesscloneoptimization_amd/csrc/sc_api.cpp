@@ -201,10 +201,16 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
                           I->stream);
         if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[5], I->stream));
         I->info.sweep_launches = 0;
+        I->spec_post.body_org = body_org; I->spec_post.bstep = bstep;
+        I->spec_post.ev_solved = (pass == passes - 1) ? I->ev[6] : nullptr;
+        I->spec_post.armed = true; I->spec_post.done = false;
         solve_rc = solve(I);
+        I->spec_post.armed = false;
         if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
-        if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[6], I->stream));
-        launch_postprocess(result(I), body_org, bstep, I->stream);
+        if (!I->spec_post.done) {          // otherwise the solver already enqueued it behind its last cycle
+            if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[6], I->stream));
+            launch_postprocess(result(I), body_org, bstep, I->stream);
+        }
         SC_HIP(I, hipGetLastError());
     }
     SC_HIP(I, hipEventRecord(I->ev[7], I->stream));

@@ -46,6 +46,10 @@ struct Instance {
     DevBuf d_U0, d_U1, d_F;
     Field U0, U1, F;      // current views into the buffers above
     bool result_in_U1 = false;
+    // Speculative epilogue: the multigrid driver enqueues the post-process right behind the cycle whose
+    // convergence check it is about to wait for, so the host round trip of the check overlaps useful work.
+    // If the check then fails the solve simply continues and the post-process runs again at the end.
+    struct { uint8_t *body_org = nullptr; int bstep = 0; hipEvent_t ev_solved = nullptr; bool armed = false, done = false; } spec_post;
     bool bench_tag = false;   // sc_hip_field_time_sweeps: launch the second-symbol instantiations
     // multigrid hierarchy (level 0 aliases U0/U1/F)
     std::vector<DevBuf> mg_bufs;

@@ -400,6 +400,11 @@ int mg_solve(Instance *I)
             if (nb <= 16384) {
                 if ((rc = ensure_pinned(I, I->h_partial, sizeof(float) * (size_t)nb))) return rc;
                 SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)nb, hipMemcpyDeviceToHost, I->stream));
+                if (I->spec_post.armed && o.tol <= 0.f) {      // see Instance::spec_post
+                    if (I->spec_post.ev_solved) SC_HIP(I, hipEventRecord(I->spec_post.ev_solved, I->stream));
+                    launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream);
+                    I->spec_post.done = true;
+                }
                 SC_HIP(I, hipStreamSynchronize(I->stream));
                 const float *hp = (const float *)I->h_partial.p;
                 for (int i = 0; i < nb; ++i) m = hp[i] > m ? hp[i] : m;
@@ -419,6 +424,7 @@ int mg_solve(Instance *I)
                 if (rel <= (double)o.tol) { ok = true; break; }
             }
             if (m <= utol) { ok = true; break; }
+            I->spec_post.done = false;     // not converged: the field moves on, the output is written again later
         }
         I->info.sweeps = cyc;
         I->info.converged = ok ? 1 : 0;

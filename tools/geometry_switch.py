@@ -1,0 +1,19 @@
+"""Cost of changing the ROI geometry between calls (level tables, arena growth, direct-solver matrices)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from seamlesscloneoptimization_amd import capi
+from oracle import oracle_np as o
+inst = capi.Instance(0)
+cases = {k: o.synth_inputs(*k, margin=64) for k in [(298, 192), (260, 200), (1024, 1024), (1000, 900)]}
+def call(k):
+    dst, patch, mask, cx, cy = cases[k]
+    body = dst.copy()
+    t = time.perf_counter(); inst.run(patch, body, mask, cx, cy); return (time.perf_counter() - t) * 1e3
+for k in cases: call(k); call(k)
+for a, b in [((298, 192), (260, 200)), ((1024, 1024), (1000, 900))]:
+    same = min(call(a) for _ in range(10))
+    alt = []
+    for _ in range(10):
+        alt.append(call(b)); alt.append(call(a))
+    print(a, "same geometry %.3f ms/call; alternating with %s: %.3f ms/call (median)" % (same, b, float(np.median(alt))))
