@@ -49,8 +49,8 @@ __device__ __forceinline__ double wave_sum_d(double v)
 // rect = {x_min, x_max, y_min, y_max}, host-seeded with {mw-1, 0, mh-1, 0} (:1006).
 // Each lane scans 16-byte chunks (uint4 loads from the 16-B aligned address at or below the
 // row start; bytes outside [1, mw-2] are masked off) of BB_ROWS rows, so a 2050^2 mask is read
-// by ~200 workgroups with 8 independent 16-B loads in flight per lane.
-constexpr int BB_ROWS = 8;
+// by ~400 workgroups with 4 independent 16-B loads in flight per lane.
+constexpr int BB_ROWS = 4;
 
 __device__ __forceinline__ unsigned nonzero_bytes(unsigned w)
 {
@@ -64,16 +64,28 @@ __global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ m
     const int chunk = blockIdx.x * 64 + lane;
     const int yb = (blockIdx.y * 4 + wave) * BB_ROWS;
     int minx = INT_MAX, maxx = -1, miny = INT_MAX, maxy = -1;
+    // all BB_ROWS loads are issued before the first one is used: row and chunk indices are clamped to a
+    // chunk that is valid to read (chunk 0 of row 1) and the result of a clamped load is masked off, instead
+    // of skipping the load with a branch (which serialises the loads behind one another's latency)
+    uint4 v[BB_ROWS];
+    int xbs[BB_ROWS];
+    bool ok[BB_ROWS];
 #pragma unroll
     for (int r = 0; r < BB_ROWS; ++r) {
         const int y = yb + r;
-        if (y < 1 || y >= mh - 1) continue;
-        const uint8_t *row = mask + (size_t)y * mstep;
+        const bool yin = (y >= 1) && (y < mh - 1);
+        const uint8_t *row = mask + (size_t)(yin ? y : min(1, mh - 1)) * mstep;
         const int a0 = (int)((uintptr_t)row & 15);
         const int xb = chunk * 16 - a0;               // x of byte 0 of this chunk
-        if (xb >= mw - 1 || xb + 15 < 1) continue;
-        const uint4 v = *reinterpret_cast<const uint4 *>(row + xb);
-        const unsigned w[4] = { v.x, v.y, v.z, v.w };
+        ok[r] = yin && (xb < mw - 1) && (xb + 15 >= 1);
+        xbs[r] = xb;
+        v[r] = *reinterpret_cast<const uint4 *>(row + (ok[r] ? xb : -a0));
+    }
+#pragma unroll
+    for (int r = 0; r < BB_ROWS; ++r) {
+        if (!ok[r]) continue;
+        const int y = yb + r, xb = xbs[r];
+        const unsigned w[4] = { v[r].x, v[r].y, v[r].z, v[r].w };
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             unsigned m = nonzero_bytes(w[k]);
@@ -101,8 +113,15 @@ __global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ m
             miny = min(miny, red[w][2]); maxy = max(maxy, red[w][3]);
         }
         if (maxx >= 0) {
-            atomicMin(&rect[0], minx); atomicMax(&rect[1], maxx);
-            atomicMin(&rect[2], miny); atomicMax(&rect[3], maxy);
+            // Hundreds of workgroups updating the same four words cost ~12 ns per atomic, more than the scan
+            // itself.  Look first: a plain (possibly stale) read of a min word is never below its true value
+            // and of a max word never above it, so "my value would not improve what I see" safely skips the
+            // atomic; for an all-255 mask only the workgroups on the mask's border still issue one.
+            const volatile int *seen = rect;
+            if (minx < seen[0]) atomicMin(&rect[0], minx);
+            if (maxx > seen[1]) atomicMax(&rect[1], maxx);
+            if (miny < seen[2]) atomicMin(&rect[2], miny);
+            if (maxy > seen[3]) atomicMax(&rect[3], maxy);
         }
     }
 }
@@ -392,10 +411,11 @@ __global__ __launch_bounds__(256) void k_jacobi_roll(Field Uin, Field Uout, Fiel
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = Uin.W, H = Uin.H, P = Uin.pitch;
-    // 1-D launch; vertically adjacent workgroups (they share two rows) are given to the same XCD
+    // 1-D launch; each XCD gets a contiguous band of rows (vertical neighbours share two rows -> same L2),
+    // walked row-major so that consecutive workgroups stream whole image rows (DRAM pages) when the field is HBM resident
     const int nbx = (W + 255) / 256, nby = (H + 4 * S - 1) / (4 * S);
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int by = tile % nby, bx = (tile / nby) % nbx, c = tile / (nbx * nby);    // column strips: by runs fastest
+    const int bx = tile % nbx, by = (tile / nbx) % nby, c = tile / (nbx * nby);
     const int x = bx * 256 + 4 * lane;
     const int ya = (by * 4 + wv) * S;
     if (x >= P || ya >= H) return;
