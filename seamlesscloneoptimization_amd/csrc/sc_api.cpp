@@ -157,8 +157,8 @@ static int validate_images(Instance *I, const void *face, int fc, int fr, int fs
     return SC_OK;
 }
 
-// bbox kernel + read-back; fills geo.  mask is a device pointer.
-static int device_bbox(Instance *I, const uint8_t *d_mask, int mc, int mr, int ms, int cx, int cy, Geo &g)
+// bbox kernel + read-back of the rectangle into h_rect[4..7] (enqueue only).  mask is a device pointer.
+static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int ms)
 {
     I->h_rect[0] = mc - 1; I->h_rect[1] = 0; I->h_rect[2] = mr - 1; I->h_rect[3] = 0; // seamlessClone_imp.cpp:1006
     SC_HIP(I, hipMemcpyAsync(I->d_rect, I->h_rect, 4 * sizeof(int), hipMemcpyHostToDevice, I->stream));
@@ -166,13 +166,53 @@ static int device_bbox(Instance *I, const uint8_t *d_mask, int mc, int mr, int m
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipMemcpyAsync(I->h_rect + 4, I->d_rect, 4 * sizeof(int), hipMemcpyDeviceToHost, I->stream));
     SC_HIP(I, hipEventRecord(I->ev[2], I->stream));
-    SC_HIP(I, hipStreamSynchronize(I->stream));
-    const int x0 = I->h_rect[4], x1 = I->h_rect[5], y0 = I->h_rect[6], y1 = I->h_rect[7];
+    return SC_OK;
+}
+
+static int geo_from_rect(Instance *I, const int r[4], int cx, int cy, Geo &g)
+{
+    const int x0 = r[0], x1 = r[1], y0 = r[2], y1 = r[3];
     if (!((x1 - x0) > 0 && (y1 - y0) > 0)) { I->err = "mask has no usable non-zero region"; return SC_ERR_EMPTY_MASK; }
     g.x0 = x0; g.y0 = y0; g.W = x1 - x0 + 1; g.H = y1 - y0 + 1;
     g.ltx = cx - (g.W >> 1); // seamlessClone_imp.cpp:1066
     g.lty = cy - (g.H >> 1);
     return SC_OK;
+}
+
+// synchronous form: waits for the device's rectangle (the reference does the same, seamlessClone_imp.cpp:1012)
+static int device_bbox(Instance *I, const uint8_t *d_mask, int mc, int mr, int ms, int cx, int cy, Geo &g)
+{
+    int rc = bbox_enqueue(I, d_mask, mc, mr, ms);
+    if (rc) return rc;
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    return geo_from_rect(I, I->h_rect + 4, cx, cy, g);
+}
+
+// Predicted bounding box for a clone launched before the device's answer is back: the previous rectangle when the
+// mask has the size of the previous call's (a sequence of clones with one mask), else the whole interior (every
+// mask that touches its four inner borders, all-255 masks in particular).  After a wrong guess speculation pauses
+// for a few calls, so a stream of unpredictable masks pays at most one wasted clone in nine.
+static bool predict_rect(Instance *I, int mc, int mr, int r[4])
+{
+    static const int off = [] { const char *e = getenv("SC_NO_SPECULATE"); return e ? atoi(e) : 0; }();
+    if (off || mc < 3 || mr < 3) return false;
+    if (I->spec_cooldown > 0) { --I->spec_cooldown; return false; }
+    if (I->last_mc == mc && I->last_mr == mr) { memcpy(r, I->last_rect, sizeof(int) * 4); return true; }
+    r[0] = 1; r[1] = mc - 2; r[2] = 1; r[3] = mr - 2;
+    return true;
+}
+
+static void remember_rect(Instance *I, int mc, int mr, const int r[4])
+{
+    I->last_mc = mc; I->last_mr = mr;
+    memcpy(I->last_rect, r, sizeof(int) * 4);
+}
+
+static RectGuard make_guard(Instance *I, const int r[4])
+{
+    RectGuard g;
+    g.d_rect = I->d_rect; g.x0 = r[0]; g.x1 = r[1]; g.y0 = r[2]; g.y1 = r[3];
+    return g;
 }
 
 static int check_roi(Instance *I, const Geo &g, int bc, int br)
@@ -209,7 +249,7 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
         if (!I->spec_post.done) {          // otherwise the solver already enqueued it behind its last cycle
             if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[6], I->stream));
-            launch_postprocess(result(I), body_org, bstep, I->stream);
+            launch_postprocess(result(I), body_org, bstep, I->stream, I->guard);
         }
         SC_HIP(I, hipGetLastError());
     }
@@ -438,36 +478,74 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     SC_HIP(I, hipEventRecord(I->ev[0], I->stream));
     if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
     SC_HIP(I, hipEventRecord(I->ev[1], I->stream));
-    Geo g;
-    if ((rc = device_bbox(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, cx, cy, g))) return rc;
+    // One attempt on a given geometry: ROI of face/body to the device (the reference uploads both images
+    // whole), clone, result into pinned staging, wait.
+    int dfs = 0;
+    auto attempt = [&](const Geo &g) -> int {
+        int r;
+        dfs = round_up(3 * g.W, 256);
+        if ((r = ensure(I, I->d_face, (size_t)dfs * g.H))) return r;
+        if ((r = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return r;
+        if ((r = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return r;
+        if ((r = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return r;
+        SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
+        const int passes = I->opts.reference_warmup ? 2 : 1;
+        r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p, dfs,
+                         (uint8_t *)I->d_body_roi.p, dfs, g, passes);
+        if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
+        // interior back towards the caller's image: one linear D2H of the compact ROI buffer into pinned staging
+        // (a 2-D copy would be one DMA per row); the row-wise memcpy follows once the geometry is confirmed
+        if (g.H > 2 && g.W > 2) {
+            int prc = ensure_pinned(I, I->h_out, (size_t)dfs * g.H);
+            if (prc) return prc;
+            SC_HIP(I, hipMemcpyAsync(I->h_out.p, I->d_body_roi.p, (size_t)dfs * (g.H - 1) + 3 * (size_t)g.W,
+                                     hipMemcpyDeviceToHost, I->stream));
+        }
+        SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+        // the result has to land in caller memory, so the call completes before returning whatever
+        // bSync says (the reference is effectively synchronous too: its D2H + host splice, imp.cpp:471)
+        SC_HIP(I, hipStreamSynchronize(I->stream));
+        return r;
+    };
+    Geo g{};
+    bool done = false;
+    int guess[4];
+    I->guard = RectGuard();
+    if (predict_rect(I, mc, mr, guess)) {
+        Geo gp{};
+        if (geo_from_rect(I, guess, cx, cy, gp) == SC_OK && check_roi(I, gp, bc, br) == SC_OK) {
+            // launch on the predicted box; the bbox kernel's answer is checked when the clone has finished
+            if ((rc = bbox_enqueue(I, (const uint8_t *)I->d_mask.p, mc, mr, dms))) return rc;
+            I->guard = make_guard(I, guess);
+            rc = attempt(gp);
+            I->guard = RectGuard();
+            if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+            if (memcmp(guess, I->h_rect + 4, sizeof(guess)) == 0) {
+                g = gp;
+            } else {                                  // wrong guess: nothing was written; repeat on the true box
+                I->spec_cooldown = 8;
+                if ((rc = geo_from_rect(I, I->h_rect + 4, cx, cy, g))) return rc;
+                fill_info_geo(I, g);
+                if ((rc = check_roi(I, g, bc, br))) return rc;
+                rc = attempt(g);
+                if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+            }
+            done = true;
+        }
+        I->err.clear();                               // a guess that did not fit the destination is not an error
+    }
+    if (!done) {                                      // no usable prediction: wait for the device's box first
+        if ((rc = device_bbox(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, cx, cy, g))) return rc;
+        fill_info_geo(I, g);
+        if ((rc = check_roi(I, g, bc, br))) return rc;
+        rc = attempt(g);
+        if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+    }
     fill_info_geo(I, g);
-    if ((rc = check_roi(I, g, bc, br))) return rc;
-    // --- only the ROI of face and body travels (the reference uploads both images whole)
-    const int dfs = round_up(3 * g.W, 256);
-    if ((rc = ensure(I, I->d_face, (size_t)dfs * g.H))) return rc;
-    if ((rc = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return rc;
-    if ((rc = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return rc;
-    if ((rc = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return rc;
-    SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
-    const int passes = I->opts.reference_warmup ? 2 : 1;
-    rc = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p, dfs,
-                      (uint8_t *)I->d_body_roi.p, dfs, g, passes);
-    if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
-    // --- interior back into the caller's image.  One linear D2H of the compact ROI buffer into
-    //     pinned staging (a 2-D copy would be one DMA per row), then a row-wise memcpy.
+    remember_rect(I, mc, mr, I->h_rect + 4);
     const size_t ob = 3 * (size_t)(g.W - 2);
     const int orows = g.H - 2;
     uint8_t *dst_org = body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1);
-    if (orows > 0 && ob > 0) {
-        int prc = ensure_pinned(I, I->h_out, (size_t)dfs * g.H);
-        if (prc) return prc;
-        SC_HIP(I, hipMemcpyAsync(I->h_out.p, I->d_body_roi.p, (size_t)dfs * (g.H - 1) + 3 * (size_t)g.W,
-                                 hipMemcpyDeviceToHost, I->stream));
-    }
-    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
-    // the result has to land in caller memory, so the call completes before returning whatever
-    // bSync says (the reference is effectively synchronous too: its D2H + host splice, imp.cpp:471)
-    SC_HIP(I, hipStreamSynchronize(I->stream));
     if (orows > 0 && ob > 0) copy_rows(dst_org, (size_t)bs, (const uint8_t *)I->h_out.p + dfs + 3, (size_t)dfs, ob, orows);
     (void)bSync;
     finish_timing(I, true);
@@ -485,20 +563,55 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     if (rc) return rc;
     SC_HIP(I, hipEventRecord(I->ev[0], I->stream));
     SC_HIP(I, hipEventRecord(I->ev[1], I->stream));
-    Geo g;
-    if ((rc = device_bbox(I, d_mask, mc, mr, ms, cx, cy, g))) return rc;
-    fill_info_geo(I, g);
-    if ((rc = check_roi(I, g, bc, br))) return rc;
-    SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
     const int passes = I->opts.reference_warmup ? 2 : 1;
-    rc = device_clone(I, d_mask, ms, mr, d_face + (size_t)g.y0 * fs + 3 * g.x0, fs,
-                      d_body + (size_t)g.lty * bs + 3 * g.ltx, bs, g, passes);
-    if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
-    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
-    if (bSync) {
-        SC_HIP(I, hipStreamSynchronize(I->stream));
-        finish_timing(I, false);
+    auto attempt = [&](const Geo &g) -> int {
+        SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
+        int r = device_clone(I, d_mask, ms, mr, d_face + (size_t)g.y0 * fs + 3 * g.x0, fs,
+                             d_body + (size_t)g.lty * bs + 3 * g.ltx, bs, g, passes);
+        if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
+        SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+        return r;
+    };
+    Geo g{};
+    bool done = false;
+    int guess[4];
+    I->guard = RectGuard();
+    // a predicted box needs the final wait to be checked against the device's answer: synchronous calls only
+    if (bSync && predict_rect(I, mc, mr, guess)) {
+        Geo gp{};
+        if (geo_from_rect(I, guess, cx, cy, gp) == SC_OK && check_roi(I, gp, bc, br) == SC_OK) {
+            if ((rc = bbox_enqueue(I, d_mask, mc, mr, ms))) return rc;
+            I->guard = make_guard(I, guess);
+            rc = attempt(gp);
+            I->guard = RectGuard();
+            if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+            SC_HIP(I, hipStreamSynchronize(I->stream));
+            if (memcmp(guess, I->h_rect + 4, sizeof(guess)) == 0) {
+                g = gp;
+            } else {                                  // wrong guess: the destination was not touched
+                I->spec_cooldown = 8;
+                if ((rc = geo_from_rect(I, I->h_rect + 4, cx, cy, g))) return rc;
+                fill_info_geo(I, g);
+                if ((rc = check_roi(I, g, bc, br))) return rc;
+                rc = attempt(g);
+                if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+                SC_HIP(I, hipStreamSynchronize(I->stream));
+            }
+            done = true;
+        }
+        I->err.clear();
     }
+    if (!done) {
+        if ((rc = device_bbox(I, d_mask, mc, mr, ms, cx, cy, g))) return rc;
+        fill_info_geo(I, g);
+        if ((rc = check_roi(I, g, bc, br))) return rc;
+        rc = attempt(g);
+        if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+        if (bSync) SC_HIP(I, hipStreamSynchronize(I->stream));
+    }
+    fill_info_geo(I, g);
+    remember_rect(I, mc, mr, I->h_rect + 4);
+    if (bSync) finish_timing(I, false);
     return rc;
 }
 

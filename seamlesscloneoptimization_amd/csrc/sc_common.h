@@ -37,7 +37,9 @@ void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, ui
 // body_org: pointer to the pixel that corresponds to ROI (0,0); face_org likewise (patch + offset)
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s);
-void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s);
+// bounding box the host assumed when it launched a clone before the device's answer was back (d_rect == nullptr: none)
+struct RectGuard { const int *d_rect = nullptr; int x0 = 0, x1 = 0, y0 = 0, y1 = 0; };
+void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard());
 
 void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag = false);
 void launch_rb_half(Field U, Field F, int color, float omega, hipStream_t s, bool tag = false);

@@ -50,6 +50,12 @@ struct Instance {
     // convergence check it is about to wait for, so the host round trip of the check overlaps useful work.
     // If the check then fails the solve simply continues and the post-process runs again at the end.
     struct { uint8_t *body_org = nullptr; int bstep = 0; hipEvent_t ev_solved = nullptr; bool armed = false, done = false; } spec_post;
+    // Speculative geometry: a clone may be launched on a predicted bounding box (the previous one for the same
+    // mask size, else the whole mask interior) while the bbox kernel's answer is still in flight; `guard` makes
+    // the post-process a no-op on a wrong guess and the host then repeats the clone (sc_api.cpp).
+    RectGuard guard;
+    int last_mc = -1, last_mr = -1, last_rect[4] = { 0, 0, 0, 0 };
+    int spec_cooldown = 0;
     bool bench_tag = false;   // sc_hip_field_time_sweeps: launch the second-symbol instantiations
     // multigrid hierarchy (level 0 aliases U0/U1/F)
     std::vector<DevBuf> mg_bufs;

@@ -313,8 +313,15 @@ void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_o
 // fused post-process: clamp to [0,255], truncate toward zero, interleave, splice into the
 // destination at (lty+y, ltx+x) for the interior only (seamlessClone_imp.cpp:2091-2096 and
 // the host splice loop :470-483).
-__global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restrict__ body, int bstep)
+// guard: when the host launched this clone on a PREDICTED bounding box (RectGuard, sc_common.h) the output is only
+// written if the bounding box the device found is the predicted one; otherwise the destination stays untouched
+// and the host repeats the clone with the true geometry.
+__global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restrict__ body, int bstep, RectGuard guard)
 {
+    if (guard.d_rect) {
+        const int *__restrict__ r = guard.d_rect;
+        if (r[0] != guard.x0 || r[1] != guard.x1 || r[2] != guard.y0 || r[3] != guard.y1) return;
+    }
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < 1 || x > U.W - 2 || y < 1 || y > U.H - 2) return;
@@ -329,10 +336,10 @@ __global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restric
     }
 }
 
-void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s)
+void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard)
 {
     dim3 grid((U.W + 63) / 64, (U.H + 3) / 4);
-    hipLaunchKernelGGL(k_postprocess, grid, dim3(256), 0, s, U, body_org, bstep);
+    hipLaunchKernelGGL(k_postprocess, grid, dim3(256), 0, s, U, body_org, bstep, guard);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -402,7 +402,7 @@ int mg_solve(Instance *I)
                 SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)nb, hipMemcpyDeviceToHost, I->stream));
                 if (I->spec_post.armed && o.tol <= 0.f) {      // see Instance::spec_post
                     if (I->spec_post.ev_solved) SC_HIP(I, hipEventRecord(I->spec_post.ev_solved, I->stream));
-                    launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream);
+                    launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
                     I->spec_post.done = true;
                 }
                 SC_HIP(I, hipStreamSynchronize(I->stream));
