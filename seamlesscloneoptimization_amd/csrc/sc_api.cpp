@@ -7,7 +7,9 @@
 //   iterative solve -> fused post-process into the body ROI -> D2H of the interior straight
 //   into the caller's image (replaces the reference's D2H + host splice loop, :470-483).
 #include "sc_instance.h"
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -64,28 +66,30 @@ static bool is_pinned(const void *p)
     return attr.type == hipMemoryTypeHost;
 }
 
-// Row-wise host copy between a caller image and the pinned staging.  Large images are split
-// over a few short-lived threads: a single core moves ~14 GB/s, which would make the packing
-// (not PCIe, not the GPU) the longest part of a 2048^2 call.
-static void copy_rows(uint8_t *dst, size_t dpitch, const uint8_t *src, size_t spitch, size_t row_bytes, int rows)
+// Row-wise host copy between a caller image and the pinned staging.  A single core moves ~14 GB/s, which
+// would make the packing (not PCIe, not the GPU) the longest part of a 2048^2 call, so copies above 1 MB are
+// shared between the calling thread and the instance's parked helpers (sc_hostcopy.h) in ~256 KB pieces.
+static void copy_rows(Instance *I, uint8_t *dst, size_t dpitch, const uint8_t *src, size_t spitch, size_t row_bytes, int rows)
 {
     const size_t total = row_bytes * (size_t)rows;
-    int nthr = total >= (size_t)(4u << 20) ? 4 : 1;
-    const unsigned hw = std::thread::hardware_concurrency();
-    if (hw && (unsigned)nthr > hw) nthr = (int)hw;
-    auto work = [=](int t) {
-        const int y0 = (int)((long)rows * t / nthr), y1 = (int)((long)rows * (t + 1) / nthr);
+    auto span = [=](int y0, int y1) {
         if (dpitch == row_bytes && spitch == row_bytes) {
             memcpy(dst + (size_t)y0 * row_bytes, src + (size_t)y0 * row_bytes, row_bytes * (size_t)(y1 - y0));
             return;
         }
         for (int y = y0; y < y1; ++y) memcpy(dst + (size_t)y * dpitch, src + (size_t)y * spitch, row_bytes);
     };
-    if (nthr == 1) { work(0); return; }
-    std::thread th[3];
-    for (int t = 1; t < nthr; ++t) th[t - 1] = std::thread(work, t);
-    work(0);
-    for (int t = 1; t < nthr; ++t) th[t - 1].join();
+    if (total < ((size_t)1 << 20)) { span(0, rows); return; }
+    if (!I->copier) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        static const int want = [] { const char *e = getenv("SC_COPY_THREADS"); return e ? atoi(e) : 8; }();
+        int n = want < 1 ? 1 : want;
+        if (hw && (unsigned)n > hw) n = (int)hw;
+        I->copier.reset(new RowCopier(n - 1));
+    }
+    const int rows_per = (int)std::max<size_t>(1, ((size_t)256 << 10) / std::max<size_t>(row_bytes, 1));
+    const int parts = (rows + rows_per - 1) / rows_per;
+    I->copier->parallel(parts, [&](int i) { span(i * rows_per, std::min(rows, (i + 1) * rows_per)); });
 }
 
 // rows x row_bytes from caller memory (pitch hpitch) to device memory (pitch dpitch).
@@ -106,8 +110,14 @@ static int upload_rows(Instance *I, DevBuf &stage, void *d, size_t dpitch, const
     int rc = ensure_pinned(I, stage, dpitch * (size_t)rows);
     if (rc) return rc;
     uint8_t *s = (uint8_t *)stage.p;
-    copy_rows(s, dpitch, h, hpitch, row_bytes, rows);
-    SC_HIP(I, hipMemcpyAsync(d, s, dpitch * (size_t)(rows - 1) + row_bytes, hipMemcpyHostToDevice, I->stream));
+    // ~4 MB pieces: the DMA of piece k runs while piece k+1 is being packed
+    const int rows_per = (int)std::max<size_t>(1, ((size_t)4 << 20) / dpitch);
+    for (int y0 = 0; y0 < rows; y0 += rows_per) {
+        const int n = std::min(rows_per, rows - y0);
+        copy_rows(I, s + (size_t)y0 * dpitch, dpitch, h + (size_t)y0 * hpitch, hpitch, row_bytes, n);
+        SC_HIP(I, hipMemcpyAsync((uint8_t *)d + (size_t)y0 * dpitch, s + (size_t)y0 * dpitch, dpitch * (size_t)(n - 1) + row_bytes,
+                                 hipMemcpyHostToDevice, I->stream));
+    }
     return SC_OK;
 }
 
@@ -318,6 +328,7 @@ void *my_seamlessclone_api_imp_create_instance(int gpu_id)
     ok = ok && mg_bottom_prepare() == hipSuccess;   // opt in to >64 KiB dynamic LDS for the bottom kernel
     for (int i = 0; ok && i < 8; ++i) ok = hipEventCreate(&I->ev[i]) == hipSuccess;
     ok = ok && hipEventCreate(&I->ev_k0) == hipSuccess && hipEventCreate(&I->ev_k1) == hipSuccess;
+    for (int i = 0; ok && i < 8; ++i) ok = hipEventCreate(&I->ev_chunk[i]) == hipSuccess;
     if (!ok) {
         fprintf(stderr, "seamlessclone_hip: instance creation failed on GPU %d: %s\n", gpu_id,
                 hipGetErrorString(hipGetLastError()));
@@ -349,6 +360,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->h_red) (void)hipHostFree(I->h_red);
     for (DevBuf *b : { &I->h_face, &I->h_body, &I->h_mask, &I->h_out }) if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < 8; ++i) if (I->ev[i]) (void)hipEventDestroy(I->ev[i]);
+    for (int i = 0; i < 8; ++i) if (I->ev_chunk[i]) (void)hipEventDestroy(I->ev_chunk[i]);
     if (I->ev_k0) (void)hipEventDestroy(I->ev_k0);
     if (I->ev_k1) (void)hipEventDestroy(I->ev_k1);
     if (I->stream) (void)hipStreamDestroy(I->stream);
@@ -478,12 +490,13 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     SC_HIP(I, hipEventRecord(I->ev[0], I->stream));
     if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
     SC_HIP(I, hipEventRecord(I->ev[1], I->stream));
-    // One attempt on a given geometry: ROI of face/body to the device (the reference uploads both images
-    // whole), clone, result into pinned staging, wait.
-    int dfs = 0;
-    auto attempt = [&](const Geo &g) -> int {
+    // One attempt on a given geometry: ROI of face/body to the device (the reference uploads both images whole),
+    // clone, [check the predicted box], result back into the caller's image.  SC_GUESS_WRONG = the device found a
+    // different box than `guess`; nothing has been written anywhere the caller can see.
+    constexpr int SC_GUESS_WRONG = 1;
+    auto attempt = [&](const Geo &g, const int *guess) -> int {
         int r;
-        dfs = round_up(3 * g.W, 256);
+        const int dfs = round_up(3 * g.W, 256);
         if ((r = ensure(I, I->d_face, (size_t)dfs * g.H))) return r;
         if ((r = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return r;
         if ((r = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return r;
@@ -493,17 +506,39 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p, dfs,
                          (uint8_t *)I->d_body_roi.p, dfs, g, passes);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
-        // interior back towards the caller's image: one linear D2H of the compact ROI buffer into pinned staging
-        // (a 2-D copy would be one DMA per row); the row-wise memcpy follows once the geometry is confirmed
-        if (g.H > 2 && g.W > 2) {
-            int prc = ensure_pinned(I, I->h_out, (size_t)dfs * g.H);
-            if (prc) return prc;
-            SC_HIP(I, hipMemcpyAsync(I->h_out.p, I->d_body_roi.p, (size_t)dfs * (g.H - 1) + 3 * (size_t)g.W,
-                                     hipMemcpyDeviceToHost, I->stream));
+        if (guess) {      // the rectangle's read-back (recorded as ev[2]) finished long ago: this wait is free
+            SC_HIP(I, hipEventSynchronize(I->ev[2]));
+            if (memcmp(guess, I->h_rect + 4, 4 * sizeof(int)) != 0) return SC_GUESS_WRONG;
         }
-        SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
-        // the result has to land in caller memory, so the call completes before returning whatever
-        // bSync says (the reference is effectively synchronous too: its D2H + host splice, imp.cpp:471)
+        // Interior back into the caller's image: linear D2H pieces of the compact ROI buffer into pinned staging
+        // (a 2-D copy would be one DMA per row), each spliced into the image row by row while the next one is
+        // still crossing PCIe.  The call completes before returning whatever bSync says: the result has to be in
+        // caller memory (the reference is effectively synchronous too: its D2H + host splice, imp.cpp:471).
+        const int orows = g.H - 2;
+        const size_t ob = 3 * (size_t)(g.W - 2);
+        if (orows > 0 && g.W > 2) {
+            if ((r = ensure_pinned(I, I->h_out, (size_t)dfs * g.H))) return r;
+            uint8_t *dst_org = body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1);
+            const uint8_t *src = (const uint8_t *)I->d_body_roi.p + dfs;          // ROI row 1
+            uint8_t *stage = (uint8_t *)I->h_out.p + dfs;
+            int pieces = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)dfs * orows) >> 22));
+            const int rows_per = (orows + pieces - 1) / pieces;
+            pieces = (orows + rows_per - 1) / rows_per;
+            for (int k = 0; k < pieces; ++k) {
+                const int y0 = k * rows_per, n = std::min(rows_per, orows - y0);
+                SC_HIP(I, hipMemcpyAsync(stage + (size_t)y0 * dfs, src + (size_t)y0 * dfs, (size_t)dfs * (n - 1) + 3 + ob,
+                                         hipMemcpyDeviceToHost, I->stream));
+                SC_HIP(I, hipEventRecord(I->ev_chunk[k], I->stream));
+            }
+            SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+            for (int k = 0; k < pieces; ++k) {
+                const int y0 = k * rows_per, n = std::min(rows_per, orows - y0);
+                SC_HIP(I, hipEventSynchronize(I->ev_chunk[k]));
+                copy_rows(I, dst_org + (size_t)y0 * bs, (size_t)bs, stage + (size_t)y0 * dfs + 3, (size_t)dfs, ob, n);
+            }
+        } else {
+            SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+        }
         SC_HIP(I, hipStreamSynchronize(I->stream));
         return r;
     };
@@ -514,22 +549,21 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     if (predict_rect(I, mc, mr, guess)) {
         Geo gp{};
         if (geo_from_rect(I, guess, cx, cy, gp) == SC_OK && check_roi(I, gp, bc, br) == SC_OK) {
-            // launch on the predicted box; the bbox kernel's answer is checked when the clone has finished
+            // launch on the predicted box; the bbox kernel's answer is checked before anything reaches the caller
             if ((rc = bbox_enqueue(I, (const uint8_t *)I->d_mask.p, mc, mr, dms))) return rc;
             I->guard = make_guard(I, guess);
-            rc = attempt(gp);
+            rc = attempt(gp, guess);
             I->guard = RectGuard();
-            if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
-            if (memcmp(guess, I->h_rect + 4, sizeof(guess)) == 0) {
-                g = gp;
-            } else {                                  // wrong guess: nothing was written; repeat on the true box
+            if (rc == SC_GUESS_WRONG) {               // repeat on the true box, pause speculation for a while
                 I->spec_cooldown = 8;
                 if ((rc = geo_from_rect(I, I->h_rect + 4, cx, cy, g))) return rc;
                 fill_info_geo(I, g);
                 if ((rc = check_roi(I, g, bc, br))) return rc;
-                rc = attempt(g);
-                if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+                rc = attempt(g, nullptr);
+            } else {
+                g = gp;
             }
+            if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
             done = true;
         }
         I->err.clear();                               // a guess that did not fit the destination is not an error
@@ -538,15 +572,11 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         if ((rc = device_bbox(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, cx, cy, g))) return rc;
         fill_info_geo(I, g);
         if ((rc = check_roi(I, g, bc, br))) return rc;
-        rc = attempt(g);
+        rc = attempt(g, nullptr);
         if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
     }
     fill_info_geo(I, g);
     remember_rect(I, mc, mr, I->h_rect + 4);
-    const size_t ob = 3 * (size_t)(g.W - 2);
-    const int orows = g.H - 2;
-    uint8_t *dst_org = body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1);
-    if (orows > 0 && ob > 0) copy_rows(dst_org, (size_t)bs, (const uint8_t *)I->h_out.p + dfs + 3, (size_t)dfs, ob, orows);
     (void)bSync;
     finish_timing(I, true);
     return rc;

@@ -4,6 +4,8 @@
 // (bounding box, residual norm) and hipEvents for per-stage timing.
 #pragma once
 #include "sc_common.h"
+#include "sc_hostcopy.h"
+#include <memory>
 #include <cmath>
 
 namespace sc {
@@ -39,6 +41,8 @@ struct Instance {
     // page-locked host staging (grow-only): pageable caller images are packed here row by row so
     // each image crosses PCIe as ONE DMA instead of one slow pageable 2-D copy
     DevBuf h_face, h_body, h_mask, h_out;
+    std::unique_ptr<RowCopier> copier;   // helper threads for the packing / splicing copies (created on first use)
+    hipEvent_t ev_chunk[8]{};            // D2H chunk completions (host path): splice chunk k while k+1 is in flight
     // ROI mask after 3x erode
     DevBuf d_M;
     int mpitch = 0;
