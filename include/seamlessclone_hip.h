@@ -198,6 +198,11 @@ SC_API int   sc_hip_pool_run(void *pool, sc_batch_job *jobs, int n, int device_r
  * MULTIGRID run (values are discarded; bench.py roofline) */
 SC_API int sc_hip_time_cycle0(void *instance, int launches, float *ms_per_launch);
 
+/* host-only self test (needs no GPU): the parked-thread row copier of the host path and the tridiagonal
+ * eigen-solver behind the direct bottom solve (residual of T V = V L for level operators with an irregular
+ * last interval).  Returns 0, or the number of the check that failed. */
+SC_API int sc_hip_selftest_host(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <thread>
+#include <vector>
 
 using namespace sc;
 
@@ -643,6 +644,35 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     remember_rect(I, mc, mr, I->h_rect + 4);
     if (bSync) finish_timing(I, false);
     return rc;
+}
+
+int sc_hip_selftest_host(void)
+{
+    // 1: row copier -- strided copy of an awkward shape through the parked helpers, twice (reuse of the pool)
+    {
+        RowCopier rc(5);
+        const int rows = 1237, rb = 3001, sp = 3100, dp = 3072;
+        std::vector<uint8_t> src((size_t)rows * sp), dst((size_t)rows * dp, 0);
+        for (size_t i = 0; i < src.size(); ++i) src[i] = (uint8_t)(i * 2654435761u >> 24);
+        for (int rep = 0; rep < 2; ++rep) {
+            std::fill(dst.begin(), dst.end(), 0);
+            const int per = 17, parts = (rows + per - 1) / per;
+            rc.parallel(parts, [&](int i) {
+                for (int y = i * per; y < std::min(rows, (i + 1) * per); ++y) memcpy(&dst[(size_t)y * dp], &src[(size_t)y * sp], rb);
+            });
+            for (int y = 0; y < rows; ++y) {
+                if (memcmp(&dst[(size_t)y * dp], &src[(size_t)y * sp], rb) != 0) return 1;
+                for (int x = rb; x < dp; ++x) if (dst[(size_t)y * dp + x]) return 1;
+            }
+        }
+        int hits = 0;
+        rc.parallel(1, [&](int) { ++hits; });              // single part runs inline
+        rc.parallel(0, [&](int) { ++hits; });
+        if (hits != 1) return 1;
+    }
+    // 2: eigen-decomposition of the 1-D level operators
+    if (!(sc::fd_selftest_error() < 1e-11)) return 2;
+    return 0;
 }
 
 // ---------------------------------------------------------------- stage-level hooks

@@ -97,6 +97,7 @@ int hip_fail(Instance *I, hipError_t e, const char *what);
 
 int ensure(Instance *I, DevBuf &b, size_t bytes);
 int ensure_pinned(Instance *I, DevBuf &b, size_t bytes);
+double fd_selftest_error();   // sc_multigrid.cpp
 int setup_fields(Instance *I, int W, int H, int C);
 
 // solver drivers (sc_solver.cpp) -- operate on I->U0/U1/F, leave the answer in result(I)

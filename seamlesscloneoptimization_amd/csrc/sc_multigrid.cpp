@@ -147,6 +147,40 @@ static const FD1 *fd_cached(Instance *I, const MGDim &g)
     return &I->fd_cache[slot];
 }
 
+// host-only check of the decomposition (sc_hip_selftest_host): max |T v_k - l_k v_k| and max |V^-1 V - I| over a few
+// level operators, regular and with an irregular last interval
+double fd_selftest_error()
+{
+    double worst = 0.0;
+    const int ns[] = { 1, 2, 3, 7, 31, 63, 74, 128 };
+    const double alphas[] = { 1.0, 0.5, 0.75, 1.5, 0.96875 };
+    for (int n : ns)
+        for (double a : alphas) {
+            MGDim g = make_dim(n, a, 0);
+            FD1 f;
+            if (!fd_decompose(g, f)) return 1e30;
+            auto T = [&](int i, int j) -> double {          // the level operator itself
+                if (i == j) return i == n - 1 ? -(double)g.d_last : -2.0;
+                if (j == i + 1) return 1.0;
+                if (j == i - 1) return i == n - 1 ? (double)g.cw_last : 1.0;
+                return 0.0;
+            };
+            for (int k = 0; k < n; ++k) {
+                for (int i = 0; i < n; ++i) {
+                    double tv = 0.0;
+                    for (int j = std::max(0, i - 1); j <= std::min(n - 1, i + 1); ++j) tv += T(i, j) * f.q[(size_t)k * n + j] / f.ee[j];
+                    worst = std::max(worst, std::fabs(tv - f.lam[k] * f.q[(size_t)k * n + i] / f.ee[i]));
+                }
+                for (int m = 0; m < n; ++m) {                // rows of V^-1 = Q^T E against columns of V = E^-1 Q
+                    double dot = 0.0;
+                    for (int i = 0; i < n; ++i) dot += f.q[(size_t)k * n + i] * f.ee[i] * f.q[(size_t)m * n + i] / f.ee[i];
+                    worst = std::max(worst, std::fabs(dot - (k == m ? 1.0 : 0.0)));
+                }
+            }
+        }
+    return worst;
+}
+
 // Chooses the bottom level solved directly and uploads its matrices.  I->fd_level = -1 when nothing fits.
 static int build_fd(Instance *I)
 {

@@ -29,6 +29,13 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert o.method == capi.SC_METHOD_MULTIGRID and o.mg_pre == 2 and o.update_tol == pytest.approx(0.25)
 
 
+def test_host_selftest_row_copier_and_eigen_solver():
+    """Host-only pieces of the library that need no GPU: the parked-thread row copier of the host path and the
+    tridiagonal eigen-solver behind the direct bottom solve (T V = V L to 1e-11 for irregular level operators)."""
+    from seamlesscloneoptimization_amd import capi
+    assert capi.load().sc_hip_selftest_host() == 0
+
+
 def test_library_is_gfx950_only():
     from seamlesscloneoptimization_amd import capi
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",

@@ -120,8 +120,28 @@ def test_multigrid_spec_converges_for_awkward_sizes():
         g = F[1:-1, 1:-1].astype(np.float64)[:, :, None].copy()
         g[:, 0, 0] -= B[1:-1, 0]; g[0, :, 0] -= B[0, 1:-1]; g[:, -1, 0] -= B[1:-1, -1]; g[-1, :, 0] -= B[-1, 1:-1]
         uex = o.solve_dst(g)[:, :, 0]
-        U = mg_np.solve(B, F, cycles=5)
+        U = mg_np.solve(B, F, cycles=5)                      # with the level the library solves directly (sparse LU here)
         assert np.abs(U[1:-1, 1:-1] - uex).max() < 5e-3, (W, H)
+        U = mg_np.solve(B, F, cycles=5, direct=None)         # plain V-cycle down to the coarsest level
+        assert np.abs(U[1:-1, 1:-1] - uex).max() < 5e-3, (W, H)
+
+
+def test_direct_level_choice_and_exact_level_solve():
+    """The level the bottom kernel solves directly: first bottom level whose matrices fit the LDS budget
+    (mirrors sc_multigrid.cpp); the exact level solve leaves no residual for irregular last intervals either."""
+    from oracle import mg_np
+    expect = {(2048, 2048): (5, 5), (298, 192): (2, 2), (1000, 700): (3, 5), (300, 9): (1, None), (64, 64): (1, 1)}
+    for (W, H), (b, d) in expect.items():
+        lv = mg_np.build_levels(W, H)
+        assert (mg_np.bottom_start(lv), mg_np.direct_level(lv)) == (b, d), (W, H)
+    lv = mg_np.build_levels(298, 192)
+    dx, dy = lv[2]
+    assert dx.alpha != 1.0 or dy.alpha != 1.0                # an irregular last interval is in play
+    rng = np.random.default_rng(0)
+    F = np.zeros((dy.n + 2, dx.n + 2), np.float32)
+    F[1:-1, 1:-1] = rng.normal(0, 1, (dy.n, dx.n))
+    U = mg_np.solve_exact(F, dx, dy)
+    assert np.abs(mg_np.residual_field(U, F, dx, dy)).max() < 5e-5
 
 
 def test_edge_cases():
