@@ -145,11 +145,27 @@ int setup_fields(Instance *I, int W, int H, int C)
     I->U1 = make_field(I->d_U1.p, W, H, C);
     I->F = make_field(I->d_F.p, W, H, C);
     I->result_in_U1 = false;
+    I->f_half = false;        // whoever fills F next says what it holds
     if (!same) I->mg.clear(); // the multigrid hierarchy is rebuilt only when the ROI shape changes
     return SC_OK;
 }
 
 } // namespace sc
+
+// A multigrid clone leaves its right-hand side as float16 inside F's buffer; the diagnostic hooks below read
+// float.  Expand through the field that does not hold the result and copy back (not on any hot path).
+static int float_rhs(Instance *I)
+{
+    if (!I->f_half) return SC_OK;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    Field scratch = I->result_in_U1 ? I->U0 : I->U1;
+    const size_t n = I->F.plane * (size_t)I->F.C;
+    launch_half_to_float(I->F.p, scratch.p, n, I->stream);
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipMemcpyAsync(I->F.p, scratch.p, n * sizeof(float), hipMemcpyDeviceToDevice, I->stream));
+    I->f_half = false;
+    return SC_OK;
+}
 
 static Instance *get(void *p)
 {
@@ -248,8 +264,9 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
     int solve_rc = SC_OK;
     for (int pass = 0; pass < passes; ++pass) {
         I->result_in_U1 = false;
+        I->f_half = mg_reads_half_rhs(I);
         launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
-                          I->stream);
+                          I->stream, I->f_half);
         if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[5], I->stream));
         I->info.sweep_launches = 0;
         I->spec_post.body_org = body_org; I->spec_post.bstep = bstep;
@@ -771,6 +788,7 @@ int sc_hip_field_load(void *p, int W, int H, int C, const float *U, const float 
 int sc_hip_field_sweep(void *p, int method, int sweeps, float omega, int spl)
 {
     Instance *I = get(p);
+    if (I && I->f_half) { int frc = float_rhs(I); if (frc) return frc; }
     if (!I || !I->F.p) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));
     I->info.sweep_launches = 0;
@@ -783,6 +801,7 @@ int sc_hip_field_sweep(void *p, int method, int sweeps, float omega, int spl)
 int sc_hip_field_residual(void *p, double out[2])
 {
     Instance *I = get(p);
+    if (I && I->f_half) { int frc = float_rhs(I); if (frc) return frc; }
     if (!I || !I->F.p || !out) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));
     return eval_residual(I, out);
@@ -791,6 +810,7 @@ int sc_hip_field_residual(void *p, double out[2])
 int sc_hip_field_solve(void *p)
 {
     Instance *I = get(p);
+    if (I && I->f_half) { int frc = float_rhs(I); if (frc) return frc; }
     if (!I || !I->F.p) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));
     I->info.sweep_launches = 0;
@@ -823,6 +843,7 @@ int sc_hip_field_store(void *p, float *U_out, size_t capacity_floats)
 int sc_hip_field_time_sweeps(void *p, int method, int launches, int spl, float omega, float *ms_per_launch)
 {
     Instance *I = get(p);
+    if (I && I->f_half) { int frc = float_rhs(I); if (frc) return frc; }
     if (!I || !I->F.p || !ms_per_launch || launches < 1) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));
     int d = fused_depth(method, spl);
@@ -854,7 +875,7 @@ int sc_hip_time_cycle0(void *p, int launches, float *ms_per_launch)
     SC_HIP(I, hipSetDevice(I->gpu));
     auto once = [&]() {
         launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, 4, true,
-                      (float *)I->mg_partial.p, I->stream, true);
+                      (float *)I->mg_partial.p, I->stream, true, I->f_half);
         I->result_in_U1 = !I->result_in_U1;
     };
     once();

@@ -18,6 +18,7 @@
 // HX = 12 columns (3 float4 lanes) and HY = 2T+2 rows on every side.  HY is even so that coarse
 // rows (even fine rows) pair up inside each lane's R-row band.
 #include "sc_common.h"
+#include <hip/hip_fp16.h>
 #include "sc_wave.h"
 #include "sc_mg_device.h"
 
@@ -42,14 +43,37 @@ __device__ __forceinline__ void c0_load(const float *__restrict__ p, int P, int 
     }
 }
 
+// The level-0 right-hand side of a clone is an integer in [-1020, 1020] (sums of four differences of 8-bit values,
+// blended with a 0/1 mask), which float16 holds exactly; the pre-process can store it as such (sc_kernels.hip) and
+// the cycle kernel then reads 2 bytes per unknown instead of 4.  Same element pitch / plane size as the float field.
+template <int R>
+__device__ __forceinline__ void c0_load_half(const __half *__restrict__ p, int P, int H, int x, int y0, float4 (&v)[R])
+{
+    const int xc = min(max(x, 0), P - 4);
+    uint2 raw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int yc = min(max(y0 + r, 0), H - 1);
+        raw[r] = *reinterpret_cast<const uint2 *>(p + (size_t)yc * P + xc);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const __half2 a = *reinterpret_cast<const __half2 *>(&raw[r].x), b = *reinterpret_cast<const __half2 *>(&raw[r].y);
+        const float2 fa = __half22float2(a), fb = __half22float2(b);
+        v[r] = make_float4(fa.x, fa.y, fb.x, fb.y);
+    }
+}
+
 // GEN    = coarse multigrid level: general stencil coefficients at the last column / row (MGDim)
 //          and the interpolation-tail weights in the restriction of the last coarse column / row.
 // ZEROIN = the incoming correction is identically zero and is not read (first visit of a level).
-template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG: second symbol for isolated timing
+template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG bit 0: second symbol for isolated timing; bit 1: F is float16
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
                                                     float *__restrict__ partial)
 {
     constexpr int HY = 2 * T + 2, RH = NW * R;
+    constexpr bool HF = (TAG & 2) != 0;
+    static_assert(!(HF && GEN), "float16 right-hand sides exist on level 0 only");
     static_assert(2 * T + 2 <= C0_HX, "column halo too small");
     static_assert(R % 2 == 0, "bands must hold whole coarse-row pairs");
     __shared__ float4 edge[2][NW][2][64];
@@ -84,7 +108,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             ecc[j] = er[2];
         }
     }
-    if (!PRO) c0_load<R>(F.at(c), P, H, x, y0, f);   // with PRO the RHS is fetched after the prolongation
+    if (!PRO) {   // with PRO the RHS is fetched after the prolongation
+        if (HF) c0_load_half<R>(reinterpret_cast<const __half *>(F.p) + (size_t)c * F.plane, P, H, x, y0, f);
+        else c0_load<R>(F.at(c), P, H, x, y0, f);
+    }
     const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
     const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
 
@@ -146,7 +173,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
                 if (x3ok) { u[r].w = u[r].w + cr[3]; m = fmaxf(m, fabsf(cr[3])); }
             }
         }
-        c0_load<R>(F.at(c), P, H, x, y0, f);   // after the prolongation (VGPR pressure), in flight during the reduction
+        // after the prolongation (VGPR pressure), in flight during the reduction
+        if (HF) c0_load_half<R>(reinterpret_cast<const __half *>(F.p) + (size_t)c * F.plane, P, H, x, y0, f);
+        else c0_load<R>(F.at(c), P, H, x, y0, f);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         __shared__ float red[NW];
@@ -324,25 +353,30 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
     return blocks;
 }
 
-// sweeps = T red-black GS sweeps; prolong: add P*E first and write per-block max|P*E| to `partial`.
-// Returns the number of partial maxima written (0 without prolong), or -1 for an unsupported depth.
+// sweeps = T red-black GS sweeps; prolong: add P*E first and write per-block max|P*E| to `partial`; f_half: F holds
+// float16 values (same element layout).  Returns the number of partial maxima written (0 without prolong), or -1
+// for an unsupported depth.
 int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                  float *partial, hipStream_t s, bool tag)
+                  float *partial, hipStream_t s, bool tag, bool f_half)
 {
-    if (tag && prolong && sweeps == 4) return launch_c0<4, true, 1>(Uin, Uout, F, Fc, E, g, partial, s);
+#define SC_C0(T_, PRO_) (f_half ? (tag ? launch_c0<T_, PRO_, 3>(Uin, Uout, F, Fc, E, g, partial, s)      \
+                                       : launch_c0<T_, PRO_, 2>(Uin, Uout, F, Fc, E, g, partial, s))      \
+                                : (tag ? launch_c0<T_, PRO_, 1>(Uin, Uout, F, Fc, E, g, partial, s)      \
+                                       : launch_c0<T_, PRO_, 0>(Uin, Uout, F, Fc, E, g, partial, s)))
     if (prolong) {
         switch (sweeps) {
-        case 2: return launch_c0<2, true>(Uin, Uout, F, Fc, E, g, partial, s);
-        case 3: return launch_c0<3, true>(Uin, Uout, F, Fc, E, g, partial, s);
-        case 4: return launch_c0<4, true>(Uin, Uout, F, Fc, E, g, partial, s);
+        case 2: return SC_C0(2, true);
+        case 3: return SC_C0(3, true);
+        case 4: return SC_C0(4, true);
         default: return -1;
         }
     }
     switch (sweeps) {
-    case 1: launch_c0<1, false>(Uin, Uout, F, Fc, E, g, partial, s); return 0;
-    case 2: launch_c0<2, false>(Uin, Uout, F, Fc, E, g, partial, s); return 0;
+    case 1: SC_C0(1, false); return 0;
+    case 2: SC_C0(2, false); return 0;
     default: return -1;
     }
+#undef SC_C0
 }
 
 int cycle0_blocks(int W, int H, int C, int sweeps)

@@ -50,6 +50,7 @@ struct Instance {
     DevBuf d_U0, d_U1, d_F;
     Field U0, U1, F;      // current views into the buffers above
     bool result_in_U1 = false;
+    bool f_half = false;      // F currently holds float16 values (written by the pre-process for the fused multigrid path)
     // Speculative epilogue: the multigrid driver enqueues the post-process right behind the cycle whose
     // convergence check it is about to wait for, so the host round trip of the check overlaps useful work.
     // If the check then fails the solve simply continues and the post-process runs again at the end.
@@ -102,6 +103,7 @@ int setup_fields(Instance *I, int W, int H, int C);
 
 // solver drivers (sc_solver.cpp) -- operate on I->U0/U1/F, leave the answer in result(I)
 int solve(Instance *I);
+bool mg_reads_half_rhs(const Instance *I);   // sc_multigrid.cpp: would the solve configured in I->opts read a float16 F?
 int run_sweeps(Instance *I, int method, int sweeps, float omega, int sweeps_per_launch);
 int fused_depth(int method, int sweeps_per_launch); // 0 = plain kernels
 int eval_residual(Instance *I, double out[2]);

@@ -11,8 +11,10 @@
 // Compiled with -ffp-contract=off: every float expression below is evaluated exactly as
 // written so the oracle can check the sweeps bit for bit.
 #include "sc_common.h"
+#include <hip/hip_fp16.h>
 #include "sc_wave.h"
 #include <limits.h>
+#include <algorithm>
 #include <stdlib.h>
 
 namespace sc {
@@ -247,6 +249,9 @@ __device__ __forceinline__ void pp_stage(const uint8_t *__restrict__ img, int st
     }
 }
 
+// HF: the right-hand side is stored as float16 (exact: it is an integer in [-1020, 1020]) at the same element
+// pitch / plane size inside F's buffer; the fused multigrid path reads it that way (sc_cycle0.hip).
+template <bool HF>
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ body, int bstep,
                                                     const uint8_t *__restrict__ face, int fstep,
                                                     const uint8_t *__restrict__ M, int mpitch,
@@ -298,16 +303,32 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
                 lap = (gx - gxl) + (gy - gyu);
             }
             U0.at(c)[o] = bc;      // U1 needs no initialisation: every sweep kernel writes its whole
-            F.at(c)[o] = lap;      // output plane, ring included, before anything reads it
+                                   // output plane, ring included, before anything reads it
+            if (HF) (reinterpret_cast<__half *>(F.p) + (size_t)c * F.plane)[o] = __float2half(lap);
+            else F.at(c)[o] = lap;
         }
     }
 }
 
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
-                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s)
+                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half)
 {
     dim3 grid((U0.W + PP_TW - 1) / PP_TW, (U0.H + PP_TH - 1) / PP_TH);
-    hipLaunchKernelGGL(k_preprocess, grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    if (f_half) hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    else hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+}
+
+// float16 right-hand side (left by a multigrid clone) -> float, into another buffer; used only when a
+// diagnostic hook wants to read F after such a clone
+__global__ __launch_bounds__(256) void k_half_to_float(const __half *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = __half2float(src[i]);
+}
+
+void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_half_to_float, dim3(blocks), dim3(256), 0, s, (const __half *)src_half, dst, n);
 }
 
 // fused post-process: clamp to [0,255], truncate toward zero, interleave, splice into the

@@ -386,6 +386,22 @@ static int vcycle(Instance *I, size_t l, int pre, int post)
     return SC_OK;
 }
 
+// The fused level-0 cycle kernel is the only reader of the right-hand side that understands float16; every other
+// path (sweep solvers, unfused cycle, residual-based stop rule, stage hooks) needs the float field.
+static bool fused_level0(const sc_solver_opts &o)
+{
+    const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
+    return o.sweeps_per_launch != 1 && pre >= 1 && pre <= 2 && post >= 1 && pre + post <= 4;
+}
+
+bool mg_reads_half_rhs(const Instance *I)
+{
+    static const int off = [] { const char *e = getenv("SC_NO_HALF_RHS"); return e ? atoi(e) : 0; }();
+    const sc_solver_opts &o = I->opts;
+    // at least two levels: min(W, H) - 2 > 3 (build_levels)
+    return !off && o.method == SC_METHOD_MULTIGRID && o.tol <= 0.f && fused_level0(o) && std::min(I->F.W, I->F.H) - 2 > 3;
+}
+
 int mg_solve(Instance *I)
 {
     const sc_solver_opts &o = I->opts;
@@ -406,18 +422,18 @@ int mg_solve(Instance *I)
     // Fused level-0 form: one launch per cycle does [prolongation +] post-smoothing of this cycle,
     // pre-smoothing of the next, residual and restriction (sc_cycle0.hip).  The first launch has no
     // correction to add; after the last one the field has simply had `pre` extra sweeps.
-    const bool fused0 = o.sweeps_per_launch != 1 && I->mg.size() >= 2 && pre >= 1 && pre <= 2 && post >= 1 &&
-                        pre + post <= 4;
+    const bool fused0 = fused_level0(o) && I->mg.size() >= 2;
+    if (I->f_half && !(fused0 && o.tol <= 0.f)) { I->err = "internal: float16 right-hand side on a path that needs float"; return SC_ERR_BAD_ARG; }
     if (fused0) {
         Field none{};
         launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
-                      I->stream);
+                      I->stream, false, I->f_half);
         I->result_in_U1 = !I->result_in_U1;
         I->info.sweep_launches += 1;
         while (cyc < budget) {
             if ((rc = vcycle(I, 1, pre, post))) return rc;
             const int nb = launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
-                                         I->mg[0].g, post + pre, true, (float *)I->mg_partial.p, I->stream);
+                                         I->mg[0].g, post + pre, true, (float *)I->mg_partial.p, I->stream, false, I->f_half);
             if (nb <= 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
             I->result_in_U1 = !I->result_in_U1;
             I->info.sweep_launches += 1;

@@ -9,6 +9,7 @@ inst = capi.Instance(0)
 dst, patch, mask, cx, cy = o.synth_inputs(roi, roi, margin=64)
 body = dst.copy(); inst.run(patch, body, mask, cx, cy)
 print("cycle0", inst.time_cycle0(6))
+inst.build_rhs(patch, dst, mask, cx, cy)      # float fields for the sweep kernels (the clone left a float16 right-hand side)
 print("rb4", inst.field_time_sweeps(1, 24, 4, 1.0))
 print("jac8", inst.field_time_sweeps(0, 48, 8, 1.0))
 print("jac1", inst.field_time_sweeps(0, 6, 1, 1.0))
