@@ -146,6 +146,7 @@ int setup_fields(Instance *I, int W, int H, int C)
     I->F = make_field(I->d_F.p, W, H, C);
     I->result_in_U1 = false;
     I->f_half = false;        // whoever fills F next says what it holds
+    I->u_half = false;
     if (!same) I->mg.clear(); // the multigrid hierarchy is rebuilt only when the ROI shape changes
     return SC_OK;
 }
@@ -265,8 +266,10 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
     for (int pass = 0; pass < passes; ++pass) {
         I->result_in_U1 = false;
         I->f_half = mg_reads_half_rhs(I);
+        static const int no_hu = [] { const char *e = getenv("SC_NO_HALF_U"); return e ? atoi(e) : 0; }();
+        I->u_half = I->f_half && !no_hu;
         launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
-                          I->stream, I->f_half);
+                          I->stream, I->f_half, I->u_half);
         if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[5], I->stream));
         I->info.sweep_launches = 0;
         I->spec_post.body_org = body_org; I->spec_post.bstep = bstep;

@@ -36,7 +36,7 @@ void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rec
 void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, uint8_t *M, int mpitch, hipStream_t s);
 // body_org: pointer to the pixel that corresponds to ROI (0,0); face_org likewise (patch + offset)
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
-                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false);
+                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false);
 // bounding box the host assumed when it launched a clone before the device's answer was back (d_rect == nullptr: none)
 struct RectGuard { const int *d_rect = nullptr; int x0 = 0, x1 = 0, y0 = 0, y1 = 0; };
 void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard());
@@ -60,7 +60,7 @@ void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_
 // whole level-0 part of a V-cycle in one launch (sc_cycle0.hip): [prolong E] + `sweeps` RBGS sweeps +
 // residual + restriction into Fc.  Returns #partials written, 0 without prolong, -1 if unsupported.
 int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                   float *partial, hipStream_t s, bool tag = false, bool f_half = false);
+                   float *partial, hipStream_t s, bool tag = false, bool f_half = false, bool u_half = false);
 int  cycle0_blocks(int W, int H, int C, int sweeps);
 // coarse level: zero-guess pre-smoothing + residual + restriction fused (Uout = smoothed correction, Fc = next RHS)
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s);

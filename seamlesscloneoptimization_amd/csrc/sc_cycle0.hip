@@ -67,12 +67,12 @@ __device__ __forceinline__ void c0_load_half(const __half *__restrict__ p, int P
 // GEN    = coarse multigrid level: general stencil coefficients at the last column / row (MGDim)
 //          and the interpolation-tail weights in the restriction of the last coarse column / row.
 // ZEROIN = the incoming correction is identically zero and is not read (first visit of a level).
-template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG bit 0: second symbol for isolated timing; bit 1: F is float16
+template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG bit 0: second symbol for isolated timing; bit 1: F is float16; bit 2: Uin is float16
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
                                                     float *__restrict__ partial)
 {
     constexpr int HY = 2 * T + 2, RH = NW * R;
-    constexpr bool HF = (TAG & 2) != 0;
+    constexpr bool HF = (TAG & 2) != 0, HU = (TAG & 4) != 0;   // HU: the first launch of a clone reads the 8-bit destination values the pre-process stored as float16
     static_assert(!(HF && GEN), "float16 right-hand sides exist on level 0 only");
     static_assert(2 * T + 2 <= C0_HX, "column halo too small");
     static_assert(R % 2 == 0, "bands must hold whole coarse-row pairs");
@@ -91,6 +91,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     if (ZEROIN) {
 #pragma unroll
         for (int r = 0; r < R; ++r) u[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (HU) {
+        c0_load_half<R>(reinterpret_cast<const __half *>(Uin.p) + (size_t)c * Uin.plane, P, H, x, y0, u);
     } else {
         c0_load<R>(Uin.at(c), P, H, x, y0, u);
     }
@@ -353,12 +355,20 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
     return blocks;
 }
 
-// sweeps = T red-black GS sweeps; prolong: add P*E first and write per-block max|P*E| to `partial`; f_half: F holds
-// float16 values (same element layout).  Returns the number of partial maxima written (0 without prolong), or -1
+// sweeps = T red-black GS sweeps; prolong: add P*E first and write per-block max|P*E| to `partial`; f_half / u_half: F /
+// Uin hold float16 values (same element layout).  Returns the number of partial maxima written (0 without prolong), or -1
 // for an unsupported depth.
 int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                  float *partial, hipStream_t s, bool tag, bool f_half)
+                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half)
 {
+    if (u_half) {      // first launch of a clone on the float16 fields the pre-process wrote
+        if (prolong || !f_half) return -1;
+        switch (sweeps) {
+        case 1: launch_c0<1, false, 6>(Uin, Uout, F, Fc, E, g, partial, s); return 0;
+        case 2: launch_c0<2, false, 6>(Uin, Uout, F, Fc, E, g, partial, s); return 0;
+        default: return -1;
+        }
+    }
 #define SC_C0(T_, PRO_) (f_half ? (tag ? launch_c0<T_, PRO_, 3>(Uin, Uout, F, Fc, E, g, partial, s)      \
                                        : launch_c0<T_, PRO_, 2>(Uin, Uout, F, Fc, E, g, partial, s))      \
                                 : (tag ? launch_c0<T_, PRO_, 1>(Uin, Uout, F, Fc, E, g, partial, s)      \

@@ -51,6 +51,7 @@ struct Instance {
     Field U0, U1, F;      // current views into the buffers above
     bool result_in_U1 = false;
     bool f_half = false;      // F currently holds float16 values (written by the pre-process for the fused multigrid path)
+    bool u_half = false;      // ... and so does the initial field U0 until the first cycle has consumed it
     // Speculative epilogue: the multigrid driver enqueues the post-process right behind the cycle whose
     // convergence check it is about to wait for, so the host round trip of the check overlaps useful work.
     // If the check then fails the solve simply continues and the post-process runs again at the end.

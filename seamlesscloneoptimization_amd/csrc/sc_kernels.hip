@@ -249,9 +249,10 @@ __device__ __forceinline__ void pp_stage(const uint8_t *__restrict__ img, int st
     }
 }
 
-// HF: the right-hand side is stored as float16 (exact: it is an integer in [-1020, 1020]) at the same element
-// pitch / plane size inside F's buffer; the fused multigrid path reads it that way (sc_cycle0.hip).
-template <bool HF>
+// HF: the right-hand side (an integer in [-1020, 1020]) and the initial field (8-bit values) are stored as float16,
+// exactly, at the same element pitch / plane size inside their buffers; the fused multigrid path reads them that
+// way (sc_cycle0.hip: every launch reads F, the first one U0).
+template <bool HF, bool HU>
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ body, int bstep,
                                                     const uint8_t *__restrict__ face, int fstep,
                                                     const uint8_t *__restrict__ M, int mpitch,
@@ -302,8 +303,11 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
                 const float gyu = (1.0f - mu) * (bc - bup) + mu * (pc - pup);
                 lap = (gx - gxl) + (gy - gyu);
             }
-            U0.at(c)[o] = bc;      // U1 needs no initialisation: every sweep kernel writes its whole
-                                   // output plane, ring included, before anything reads it
+            // U1 needs no initialisation: every sweep kernel writes its whole output plane, ring included,
+            // before anything reads it
+            // 8-bit values and small integers: exact in float16
+            if (HU) (reinterpret_cast<__half *>(U0.p) + (size_t)c * U0.plane)[o] = __float2half(bc);
+            else U0.at(c)[o] = bc;
             if (HF) (reinterpret_cast<__half *>(F.p) + (size_t)c * F.plane)[o] = __float2half(lap);
             else F.at(c)[o] = lap;
         }
@@ -311,11 +315,12 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
 }
 
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
-                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half)
+                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half, bool u_half)
 {
     dim3 grid((U0.W + PP_TW - 1) / PP_TW, (U0.H + PP_TH - 1) / PP_TH);
-    if (f_half) hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
-    else hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    if (f_half && u_half) hipLaunchKernelGGL((k_preprocess<true, true>), grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    else if (f_half) hipLaunchKernelGGL((k_preprocess<true, false>), grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    else hipLaunchKernelGGL((k_preprocess<false, false>), grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
 }
 
 // float16 right-hand side (left by a multigrid clone) -> float, into another buffer; used only when a

@@ -426,9 +426,11 @@ int mg_solve(Instance *I)
     if (I->f_half && !(fused0 && o.tol <= 0.f)) { I->err = "internal: float16 right-hand side on a path that needs float"; return SC_ERR_BAD_ARG; }
     if (fused0) {
         Field none{};
-        launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
-                      I->stream, false, I->f_half);
+        // on the float16 path the pre-process stored the initial field as float16 as well (first launch only)
+        if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
+                          I->stream, false, I->f_half, I->u_half) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
         I->result_in_U1 = !I->result_in_U1;
+        I->u_half = false;             // consumed: both U buffers hold float from here on
         I->info.sweep_launches += 1;
         while (cyc < budget) {
             if ((rc = vcycle(I, 1, pre, post))) return rc;
