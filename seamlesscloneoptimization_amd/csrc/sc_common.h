@@ -60,7 +60,8 @@ void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_
 // whole level-0 part of a V-cycle in one launch (sc_cycle0.hip): [prolong E] + `sweeps` RBGS sweeps +
 // residual + restriction into Fc.  Returns #partials written, 0 without prolong, -1 if unsupported.
 int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                   float *partial, hipStream_t s, bool tag = false, bool f_half = false, bool u_half = false);
+                   float *partial, hipStream_t s, bool tag = false, bool f_half = false, bool u_half = false,
+                   bool final_cycle = false);
 int  cycle0_blocks(int W, int H, int C, int sweeps);
 // coarse level: zero-guess pre-smoothing + residual + restriction fused (Uout = smoothed correction, Fc = next RHS)
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s);

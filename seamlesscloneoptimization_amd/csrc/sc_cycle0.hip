@@ -67,11 +67,12 @@ __device__ __forceinline__ void c0_load_half(const __half *__restrict__ p, int P
 // GEN    = coarse multigrid level: general stencil coefficients at the last column / row (MGDim)
 //          and the interpolation-tail weights in the restriction of the last coarse column / row.
 // ZEROIN = the incoming correction is identically zero and is not read (first visit of a level).
-template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG bit 0: second symbol for isolated timing; bit 1: F is float16; bit 2: Uin is float16
+template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG bit 0: second symbol for isolated timing; bit 1: F is float16; bit 2: Uin is float16; bit 3: last cycle (no residual / restriction)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
                                                     float *__restrict__ partial)
 {
     constexpr int HY = 2 * T + 2, RH = NW * R;
+    constexpr bool FINAL = (TAG & 8) != 0;      // prolongation + post-smoothing only: the cycle the stop rule is expected to accept
     constexpr bool HF = (TAG & 2) != 0, HU = (TAG & 4) != 0;   // HU: the first launch of a clone reads the 8-bit destination values the pre-process stored as float16
     static_assert(!(HF && GEN), "float16 right-hand sides exist on level 0 only");
     static_assert(2 * T + 2 <= C0_HX, "column halo too small");
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 
     // ------------------------------------------------------------------ residual + restriction
 #undef SC_C0_GS
-    {
+    if (!FINAL) {
         constexpr int buf = (2 * T) & 1;       // the edges written after the last half-step
         const float4 up = (wv > 0) ? edge[buf][wv - 1][1][lane] : zero;
         const float4 dn = (wv < NW - 1) ? edge[buf][wv + 1][0][lane] : zero;
@@ -359,8 +360,16 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
 // Uin hold float16 values (same element layout).  Returns the number of partial maxima written (0 without prolong), or -1
 // for an unsupported depth.
 int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half)
+                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle)
 {
+    if (final_cycle) {   // prolongation + `sweeps` post-smoothing sweeps, nothing restricted
+        if (!prolong || u_half) return -1;
+        switch (sweeps) {
+        case 1: return f_half ? launch_c0<1, true, 10>(Uin, Uout, F, Fc, E, g, partial, s) : launch_c0<1, true, 8>(Uin, Uout, F, Fc, E, g, partial, s);
+        case 2: return f_half ? launch_c0<2, true, 10>(Uin, Uout, F, Fc, E, g, partial, s) : launch_c0<2, true, 8>(Uin, Uout, F, Fc, E, g, partial, s);
+        default: return -1;
+        }
+    }
     if (u_half) {      // first launch of a clone on the float16 fields the pre-process wrote
         if (prolong || !f_half) return -1;
         switch (sweeps) {

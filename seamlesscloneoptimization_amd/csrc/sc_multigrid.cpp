@@ -421,7 +421,11 @@ int mg_solve(Instance *I)
     bool ok = false;
     // Fused level-0 form: one launch per cycle does [prolongation +] post-smoothing of this cycle,
     // pre-smoothing of the next, residual and restriction (sc_cycle0.hip).  The first launch has no
-    // correction to add; after the last one the field has simply had `pre` extra sweeps.
+    // correction to add.  A cycle whose result the stop rule is about to judge is launched in its
+    // "final" form instead (prolongation + post-smoothing only): when the rule accepts it -- the normal
+    // case for the third cycle -- nothing was computed for a cycle that never runs, and the field is
+    // exactly the textbook V-cycle's; when it does not, one pre-smoothing + residual + restriction launch
+    // (the form of the very first launch) catches up and the cycles continue.
     const bool fused0 = fused_level0(o) && I->mg.size() >= 2;
     if (I->f_half && !(fused0 && o.tol <= 0.f)) { I->err = "internal: float16 right-hand side on a path that needs float"; return SC_ERR_BAD_ARG; }
     if (fused0) {
@@ -434,17 +438,19 @@ int mg_solve(Instance *I)
         I->info.sweep_launches += 1;
         while (cyc < budget) {
             if ((rc = vcycle(I, 1, pre, post))) return rc;
+            // The first two corrections of a solve are never below the stop threshold unless the
+            // initial guess was already the answer, and every check costs a host round trip
+            // (~25 us), so checking starts with the third cycle.
+            const bool judged = !(cyc + 1 < 3 && cyc + 1 < budget && o.tol <= 0.f);
             const int nb = launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
-                                         I->mg[0].g, post + pre, true, (float *)I->mg_partial.p, I->stream, false, I->f_half);
+                                         I->mg[0].g, judged ? post : post + pre, true, (float *)I->mg_partial.p, I->stream,
+                                         false, I->f_half, false, judged);
             if (nb <= 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
             I->result_in_U1 = !I->result_in_U1;
             I->info.sweep_launches += 1;
             ++cyc;
             SC_HIP(I, hipGetLastError());
-            // The first two corrections of a solve are never below the stop threshold unless the
-            // initial guess was already the answer, and every check costs a host round trip
-            // (~35 us of idle GPU), so checking starts with the third cycle.
-            if (cyc < 3 && cyc < budget && o.tol <= 0.f) continue;
+            if (!judged) continue;
             // max |correction| = max over the per-workgroup maxima.  A few thousand of them are folded here
             // on the host (the read-back is needed anyway and a reduction launch costs ~5 us of GPU time);
             // large grids reduce on the device first.
@@ -477,6 +483,12 @@ int mg_solve(Instance *I)
             }
             if (m <= utol) { ok = true; break; }
             I->spec_post.done = false;     // not converged: the field moves on, the output is written again later
+            if (cyc < budget) {            // catch up: pre-smoothing + residual + restriction for the next cycle
+                if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false,
+                                  nullptr, I->stream, false, I->f_half, false) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
+                I->result_in_U1 = !I->result_in_U1;
+                I->info.sweep_launches += 1;
+            }
         }
         I->info.sweeps = cyc;
         I->info.converged = ok ? 1 : 0;
