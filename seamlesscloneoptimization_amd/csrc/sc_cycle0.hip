@@ -1,17 +1,23 @@
 // sc_cycle0.hip -- the whole level-0 part of a multigrid V-cycle in ONE launch (gfx950).
 //
-// k_cycle0<T, NW, R, PRO> reads U and the RHS once and, with the field held in registers
-// (same register-blocked layout as sc_sweep_tb.hip), performs
+// k_cycle0<T, NW, R, PRO, GEN, ZEROIN, TAG> reads U and the RHS once and, with the field held in
+// registers (same register-blocked layout as sc_sweep_tb.hip), performs
 //     [PRO]  U += P*E  (bilinear prolongation of the coarse correction) and the per-block
 //            max|P*E| used by the stop rule,
 //     T      red-black Gauss-Seidel sweeps (post-smoothing of this cycle and pre-smoothing of the
-//            next one back to back: T = post + pre; the first launch of a solve has T = pre),
-//     then   the residual (double arithmetic) and its full-weighting restriction to the coarse RHS,
+//            next one back to back: T = post + pre; the first launch of a solve has T = pre; the
+//            cycle the stop rule judges has T = post and stops here: TAG bit 3),
+//     then   the residual (float32 in difference form on level 0, see below) and its full-weighting
+//            restriction to the coarse RHS,
 // and writes U and the coarse RHS once.  Against the three-kernel form (smoother, residual +
-// restriction, prolongation + smoother: ~39 B of HBM traffic per unknown and cycle) this moves
-// ~17 B.  Level 0 only: exact 5-point stencil, regular spacing (alpha = 1), where the restriction
-// is the plain 1/4-1/2-1/4 tensor stencil up to a normalisation factor at the last coarse
-// row/column (MGDim::inv_last).
+// restriction, prolongation + smoother: ~39 B of fabric traffic per unknown and cycle) this moves
+// ~12 B.  Level 0 (GEN = false): exact 5-point stencil, regular spacing, the restriction is the plain
+// 1/4-1/2-1/4 tensor stencil up to a normalisation factor at the last coarse row/column
+// (MGDim::inv_last); the RHS and, for the first launch, the incoming field may be float16 where the
+// pre-process stored them so (TAG bits 1, 2).  GEN = true: the same kernel on a coarse level, general
+// coefficients at the last column / row, starting from a zero correction (ZEROIN).
+//
+// Workgroups are numbered so that neighbouring tiles share an XCD and its L2 (xcd_tile, sc_wave.h).
 //
 // Halo: values at depth d from the region edge are exact for d half-steps; the residual needs one
 // more ring and the restriction a second one, so the exact output tile is the region minus
