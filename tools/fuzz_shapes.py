@@ -1,0 +1,45 @@
+"""Long-running shape fuzz (not part of the test suite): random ROI shapes incl. tiny, thin and level-boundary sizes,
+random rectangular / elliptic / speckled masks, every result against the numpy oracle.  python tools/fuzz_shapes.py [n] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from seamlesscloneoptimization_amd import capi, compare
+from oracle import oracle_np as o
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+inst = capi.Instance(0)
+worst = (0, None); fails = 0; empties = 0
+for case in range(n):
+    kind = case % 5
+    if kind == 0: W, H = int(rng.integers(3, 24)), int(rng.integers(3, 24))
+    elif kind == 1: W, H = int(rng.integers(200, 1400)), int(rng.integers(3, 24))
+    elif kind == 2: W, H = int(rng.integers(3, 24)), int(rng.integers(200, 900))
+    elif kind == 3: W, H = int(rng.choice([63, 64, 65, 66, 127, 128, 129, 130, 255, 256, 257, 258])), int(rng.choice([63, 64, 65, 66, 127, 128, 129, 130, 150]))
+    else: W, H = int(rng.integers(24, 700)), int(rng.integers(24, 500))
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=case, seed_patch=1000 + case, margin=16)
+    mk = int(rng.integers(0, 4))
+    if mk == 1 and W > 10 and H > 10:
+        mask = np.zeros_like(mask); mask[int(rng.integers(1, 4)):H - int(rng.integers(0, 3)), int(rng.integers(1, 4)):W - int(rng.integers(0, 3))] = 255
+    elif mk == 2 and W > 10 and H > 10:
+        yy, xx = np.mgrid[0:H + 2, 0:W + 2]
+        mask = np.where(((yy - H / 2) / (H / 2 - 1)) ** 2 + ((xx - W / 2) / (W / 2 - 1)) ** 2 <= 1.0, 255, 0).astype(np.uint8)
+    elif mk == 3:
+        mask = mask.copy(); mask[rng.integers(0, H + 2, 6), rng.integers(0, W + 2, 6)] = rng.integers(0, 255, 6)
+    body = dst.copy()
+    try:
+        want = o.seamless_clone(dst, patch, mask, cx, cy)
+    except Exception as e:           # the oracle rejects what the reference asserts on (empty / degenerate box)
+        try:
+            inst.run(patch, body, mask, cx, cy); print("case", case, W, H, "oracle rejected, GPU accepted:", e); fails += 1
+        except capi.SeamlessCloneError:
+            empties += 1
+        continue
+    try:
+        inst.run(patch, body, mask, cx, cy)
+    except capi.SeamlessCloneError as e:
+        print("case", case, W, H, mk, "GPU error", e); fails += 1; continue
+    s = compare.image_diff_stats(want, body)
+    if s["max"] > 1: print("case", case, W, H, mk, "FAIL", compare.format_stats(s), flush=True); fails += 1
+    if s["percent"] > worst[0]: worst = (s["percent"], (case, W, H, mk))
+print("cases", n, "fails", fails, "rejected by both", empties, "worst percent", worst, flush=True)
