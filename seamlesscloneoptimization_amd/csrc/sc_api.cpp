@@ -186,10 +186,20 @@ static int validate_images(Instance *I, const void *face, int fc, int fr, int fs
 }
 
 // bbox kernel + read-back of the rectangle into h_rect[4..7] (enqueue only).  mask is a device pointer.
-static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int ms)
+// With `predicted` the same launch also erodes that ROI (the whole mask stage in one kernel: the erode of a predicted box
+// does not depend on the box being computed); device_clone then skips its own erode launch.
+static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int ms, const Geo *predicted = nullptr)
 {
     I->h_rect[0] = mc - 1; I->h_rect[1] = 0; I->h_rect[2] = mr - 1; I->h_rect[3] = 0; // seamlessClone_imp.cpp:1006
     SC_HIP(I, hipMemcpyAsync(I->d_rect, I->h_rect, 4 * sizeof(int), hipMemcpyHostToDevice, I->stream));
+    I->erode_done = false;
+    if (predicted) {
+        I->mpitch = round_up(predicted->W, 64);
+        int rc = ensure(I, I->d_M, (size_t)I->mpitch * predicted->H);
+        if (rc) return rc;
+        launch_mask_stage(d_mask, mc, mr, ms, I->d_rect, *predicted, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+        I->erode_done = true;
+    } else
     launch_mask_bbox(d_mask, mc, mr, ms, I->d_rect, I->stream);
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipMemcpyAsync(I->h_rect + 4, I->d_rect, 4 * sizeof(int), hipMemcpyDeviceToHost, I->stream));
@@ -260,7 +270,8 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
     I->mpitch = round_up(g.W, 64);
     if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
     if ((rc = setup_fields(I, g.W, g.H, 3))) return rc;
-    launch_mask_erode3(d_mask, ms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    if (!I->erode_done) launch_mask_erode3(d_mask, ms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    I->erode_done = false;
     SC_HIP(I, hipEventRecord(I->ev[4], I->stream));
     int solve_rc = SC_OK;
     for (int pass = 0; pass < passes; ++pass) {
@@ -571,7 +582,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         Geo gp{};
         if (geo_from_rect(I, guess, cx, cy, gp) == SC_OK && check_roi(I, gp, bc, br) == SC_OK) {
             // launch on the predicted box; the bbox kernel's answer is checked before anything reaches the caller
-            if ((rc = bbox_enqueue(I, (const uint8_t *)I->d_mask.p, mc, mr, dms))) return rc;
+            if ((rc = bbox_enqueue(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, &gp))) return rc;
             I->guard = make_guard(I, guess);
             rc = attempt(gp, guess);
             I->guard = RectGuard();
@@ -631,7 +642,7 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     if (bSync && predict_rect(I, mc, mr, guess)) {
         Geo gp{};
         if (geo_from_rect(I, guess, cx, cy, gp) == SC_OK && check_roi(I, gp, bc, br) == SC_OK) {
-            if ((rc = bbox_enqueue(I, d_mask, mc, mr, ms))) return rc;
+            if ((rc = bbox_enqueue(I, d_mask, mc, mr, ms, &gp))) return rc;
             I->guard = make_guard(I, guess);
             rc = attempt(gp);
             I->guard = RectGuard();

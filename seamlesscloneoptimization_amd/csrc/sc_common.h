@@ -34,6 +34,8 @@ struct Img8 {
 // ---------------------------------------------------------------- kernel launchers (sc_kernels.hip)
 void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s);
 void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, uint8_t *M, int mpitch, hipStream_t s);
+// bounding box of the whole mask + erode of the (predicted) ROI g in one launch
+void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, Geo g, uint8_t *M, int mpitch, hipStream_t s);
 // body_org: pointer to the pixel that corresponds to ROI (0,0); face_org likewise (patch + offset)
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false);

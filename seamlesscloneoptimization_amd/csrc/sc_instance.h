@@ -62,6 +62,7 @@ struct Instance {
     RectGuard guard;
     int last_mc = -1, last_mr = -1, last_rect[4] = { 0, 0, 0, 0 };
     int spec_cooldown = 0;
+    bool erode_done = false;   // the fused mask-stage launch already eroded the ROI device_clone is about to process
     bool bench_tag = false;   // sc_hip_field_time_sweeps: launch the second-symbol instantiations
     // multigrid hierarchy (level 0 aliases U0/U1/F)
     std::vector<DevBuf> mg_bufs;

@@ -59,12 +59,12 @@ __device__ __forceinline__ unsigned nonzero_bytes(unsigned w)
     return (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u; // bit 7 of every non-zero byte
 }
 
-__global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
-                                                   int *__restrict__ rect)
+__device__ __forceinline__ void mask_bbox_block(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
+                                                int *__restrict__ rect, int bx, int by)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = blockIdx.x * 64 + lane;
-    const int yb = (blockIdx.y * 4 + wave) * BB_ROWS;
+    const int chunk = bx * 64 + lane;
+    const int yb = (by * 4 + wave) * BB_ROWS;
     int minx = INT_MAX, maxx = -1, miny = INT_MAX, maxy = -1;
     // all BB_ROWS loads are issued before the first one is used: row and chunk indices are clamped to a
     // chunk that is valid to read (chunk 0 of row 1) and the result of a clamped load is masked off, instead
@@ -128,6 +128,12 @@ __global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ m
     }
 }
 
+__global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
+                                                   int *__restrict__ rect)
+{
+    mask_bbox_block(mask, mw, mh, mstep, rect, blockIdx.x, blockIdx.y);
+}
+
 void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s)
 {
     const int chunks = (mw + 15 + 15) / 16;   // +15: a row may start up to 15 bytes into its first chunk
@@ -154,14 +160,14 @@ __device__ __forceinline__ unsigned is255_flags(unsigned w)   // 0x80 in every b
     return ~((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t)) & 0x80808080u;
 }
 
-__global__ __launch_bounds__(256) void k_mask_erode3(const uint8_t *__restrict__ mask, int mstep, size_t mask_bytes,
-                                                     Geo g, uint8_t *__restrict__ M, int mpitch)
+__device__ __forceinline__ void mask_erode3_block(const uint8_t *__restrict__ mask, int mstep, size_t mask_bytes,
+                                                  const Geo &g, uint8_t *__restrict__ M, int mpitch, int bx, int by)
 {
     // aligned dwords that overlap the mask buffer [mask, mask + mask_bytes): nothing outside is touched
     const uintptr_t lo = (uintptr_t)mask & ~(uintptr_t)3, hi = ((uintptr_t)mask + mask_bytes - 1) & ~(uintptr_t)3;
-    const int xw = blockIdx.x * 64 + (threadIdx.x & 63);       // word column
+    const int xw = bx * 64 + (threadIdx.x & 63);       // word column
     const int x = 4 * xw;
-    const int ys = (blockIdx.y * 4 + (threadIdx.x >> 6)) * ER_STRIP;
+    const int ys = (by * 4 + (threadIdx.x >> 6)) * ER_STRIP;
     if (x >= g.W || ys >= g.H) return;
     // per-pixel ring-in-x mask for the four bytes of this word
     unsigned xring = 0;
@@ -203,12 +209,40 @@ __global__ __launch_bounds__(256) void k_mask_erode3(const uint8_t *__restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void k_mask_erode3(const uint8_t *__restrict__ mask, int mstep, size_t mask_bytes,
+                                                     Geo g, uint8_t *__restrict__ M, int mpitch)
+{
+    mask_erode3_block(mask, mstep, mask_bytes, g, M, mpitch, blockIdx.x, blockIdx.y);
+}
+
 void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, uint8_t *M, int mpitch, hipStream_t s)
 {
     dim3 grid(((g.W + 3) / 4 + 63) / 64, (g.H + 4 * ER_STRIP - 1) / (4 * ER_STRIP));
     // last row may be shorter than the step: count only what the caller guarantees
     const size_t bytes = (size_t)mstep * (mask_rows - 1) + (size_t)(g.x0 + g.W + 1);
     hipLaunchKernelGGL(k_mask_erode3, grid, dim3(256), 0, s, mask, mstep, bytes, g, M, mpitch);
+}
+
+// Whole mask stage in one launch, for a clone launched on a PREDICTED bounding box (sc_api.cpp): the erode of the
+// predicted ROI does not wait for the bounding box the same launch computes.  1-D grid; a workgroup does its share
+// of the scan (if it has one) and then its erode strip (if it has one) -- the two are independent.
+__global__ __launch_bounds__(256) void k_mask_stage(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
+                                                    int *__restrict__ rect, int bb_nx, int bb_n, size_t mask_bytes, Geo g,
+                                                    uint8_t *__restrict__ M, int mpitch, int er_nx, int er_n)
+{
+    const int b = blockIdx.x;
+    if (b < bb_n) mask_bbox_block(mask, mw, mh, mstep, rect, b % bb_nx, b / bb_nx);     // block-uniform branch (it has a barrier)
+    if (b < er_n) mask_erode3_block(mask, mstep, mask_bytes, g, M, mpitch, b % er_nx, b / er_nx);
+}
+
+void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, Geo g, uint8_t *M, int mpitch, hipStream_t s)
+{
+    const int chunks = (mw + 15 + 15) / 16;
+    const int bb_nx = (chunks + 63) / 64, bb_n = bb_nx * ((mh + 4 * BB_ROWS - 1) / (4 * BB_ROWS));
+    const int er_nx = ((g.W + 3) / 4 + 63) / 64, er_n = er_nx * ((g.H + 4 * ER_STRIP - 1) / (4 * ER_STRIP));
+    const size_t bytes = (size_t)mstep * (mh - 1) + (size_t)(g.x0 + g.W + 1);
+    hipLaunchKernelGGL(k_mask_stage, dim3(std::max(bb_n, er_n)), dim3(256), 0, s, mask, mw, mh, mstep, d_rect, bb_nx, bb_n, bytes, g,
+                       M, mpitch, er_nx, er_n);
 }
 
 // ------------------------------------------------------------------------------------------
