@@ -225,7 +225,7 @@ def main():
     c0_bytes = (4 * 12.0 + 8.0 + 1.0 + 9.0) * unknowns
     if args.method == "mg":
         roofline = roof("k_cycle0<4,8,8,PRO> (prolongation + 4 red-black sweeps + residual + restriction, one launch)",
-                        "k_cycle0<4, 8, 8, true, false, false, 3>", c0_bytes, ms_c0,
+                        "k_cycle0<4, 8, 8, true, false, false, 19>", c0_bytes, ms_c0,
                         "dominant kernel of the timed clone (whole level-0 part of a V-cycle); algorithmic bytes = sum of the "
                         "SURVEY 8d figures of the fused operations = 66 B/unknown/channel, so >1.0 is 'effective' bandwidth; "
                         + cache_note)

@@ -182,7 +182,14 @@ def solve_exact(F, dx: Dim, dy: Dim):
     return U
 
 
-def vcycle(levels, l, U, F, pre=2, post=2, direct=None):
+def composes_level1(levels) -> bool:
+    """The fused GPU path runs level 1 with 4 pre-smoothing sweeps and no post-smoothing when it is a launched level with a
+    level 2 below it: the level-0 launch then interpolates from "level-1 correction + interpolated level-2 correction"
+    directly and level 1 needs no prolongation launch (sc_multigrid.cpp: mg_composes_level1)."""
+    return len(levels) >= 3 and bottom_start(levels) >= 2
+
+
+def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post_level=0):
     dx, dy = levels[l]
     if direct is not None and l == direct:
         return solve_exact(F, dx, dy)
@@ -190,21 +197,27 @@ def vcycle(levels, l, U, F, pre=2, post=2, direct=None):
         rho = 0.5 * (np.cos(np.pi / (dx.n + 1.0)) + np.cos(np.pi / (dy.n + 1.0)))
         om = 2.0 / (1.0 + np.sqrt(max(0.0, 1.0 - rho * rho)))
         return rb_gen(U, F, dx, dy, max(8, min(64, 2 * max(dx.n, dy.n))), float(F32(om)))
-    U = rb_gen(U, F, dx, dy, pre)
+    # a level without post-smoothing does all its sweeps before the restriction
+    U = rb_gen(U, F, dx, dy, pre + post if (l > 0 and l == no_post_level) else pre)
     Fc = restrict(residual_field(U, F, dx, dy), dx, dy)
-    E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post, direct)
+    E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post, direct, no_post_level)
     U = U.copy()
     U += prolong(E, dx, dy)
+    if l > 0 and l == no_post_level:
+        return U
     return rb_gen(U, F, dx, dy, post)
 
 
-def solve(U0, F, cycles=6, direct="auto"):
+def solve(U0, F, cycles=6, direct="auto", fused=True):
     """Multigrid solve of one plane: U0 carries the Dirichlet ring (level 0 is regular).
-    direct: "auto" = the level the library solves directly, None = V-cycle down to the coarsest level."""
+    direct: "auto" = the level the library solves directly, None = V-cycle down to the coarsest level.
+    fused: the library's default (fused) schedule, in which level 1 has no post-smoothing where composes_level1();
+    False = the textbook V(2,2) of the unfused path (sweeps_per_launch = 1)."""
     H, W = U0.shape
     levels = build_levels(W, H)
     d = direct_level(levels) if direct == "auto" else direct
+    npl = 1 if (fused and composes_level1(levels)) else 0
     U = U0.astype(F32).copy()
     for _ in range(cycles):
-        U = vcycle(levels, 0, U, F, direct=d)
+        U = vcycle(levels, 0, U, F, direct=d, no_post_level=npl)
     return U

@@ -887,9 +887,14 @@ int sc_hip_time_cycle0(void *p, int launches, float *ms_per_launch)
     if (!I || !ms_per_launch || launches < 1) return SC_ERR_BAD_ARG;
     if (!I->F.p || I->mg.size() < 2 || !I->mg_partial.p) { I->err = "time_cycle0: run a multigrid clone first"; return SC_ERR_BAD_ARG; }
     SC_HIP(I, hipSetDevice(I->gpu));
+    const bool comp = mg_composes_level1(I);          // time the form the clone itself runs
     auto once = [&]() {
-        launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, 4, true,
-                      (float *)I->mg_partial.p, I->stream, true, I->f_half);
+        if (comp)
+            launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, 4,
+                                   (float *)I->mg_partial.p, I->stream, true, I->f_half, false, I->mg[2].U, I->mg[1].g);
+        else
+            launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, 4, true,
+                          (float *)I->mg_partial.p, I->stream, true, I->f_half);
         I->result_in_U1 = !I->result_in_U1;
     };
     once();

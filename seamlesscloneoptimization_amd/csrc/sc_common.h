@@ -65,6 +65,10 @@ int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGe
                    float *partial, hipStream_t s, bool tag = false, bool f_half = false, bool u_half = false,
                    bool final_cycle = false);
 int  cycle0_blocks(int W, int H, int C, int sweeps);
+// the same launch with its prolongation source composed on the fly from level 1 (before post-smoothing) and level 2
+// (sc_cycle0.hip, ComposeArgs); -1: combination not instantiated
+int  launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
+                            hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1);
 // coarse level: zero-guess pre-smoothing + residual + restriction fused (Uout = smoothed correction, Fc = next RHS)
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s);
 

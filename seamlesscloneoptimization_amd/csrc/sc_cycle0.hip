@@ -70,14 +70,26 @@ __device__ __forceinline__ void c0_load_half(const __half *__restrict__ p, int P
     }
 }
 
+// TAG bit 4 (level 0 only): level 1 runs without post-smoothing and without its own prolongation launch.  Its finished
+// correction E1 = U1 + P21 E2 (U1: level-1 correction after pre-smoothing, E2: finished level-2 correction) is formed on
+// the fly where this kernel interpolates from it: two extra level-2 values per level-2 row and a few adds per lane.
+// Leaving out the level-1 post-smoothing changes the contraction per cycle by a few percent (oracle/mg_np.py carries
+// the same schedule); leaving out its launch is worth ~10 % of the clone throughput.
+struct ComposeArgs {
+    Field E2;          // finished level-2 correction (ring and pads zero)
+    MGGeom g1;         // level-1 geometry: its transfer to level 2
+};
+
 // GEN    = coarse multigrid level: general stencil coefficients at the last column / row (MGDim)
 //          and the interpolation-tail weights in the restriction of the last coarse column / row.
 // ZEROIN = the incoming correction is identically zero and is not read (first visit of a level).
 template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG bit 0: second symbol for isolated timing; bit 1: F is float16; bit 2: Uin is float16; bit 3: last cycle (no residual / restriction)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
-                                                    float *__restrict__ partial)
+                                                    float *__restrict__ partial, ComposeArgs comp)
 {
     constexpr int HY = 2 * T + 2, RH = NW * R;
+    constexpr bool COMP = (TAG & 16) != 0;      // E is U1; the interpolated level-2 correction is added on the fly (ComposeArgs)
+    static_assert(!COMP || (PRO && !GEN && R % 2 == 0), "composition of two prolongations exists on level 0 only");
     constexpr bool FINAL = (TAG & 8) != 0;      // prolongation + post-smoothing only: the cycle the stop rule is expected to accept
     constexpr bool HF = (TAG & 2) != 0, HU = (TAG & 4) != 0;   // HU: the first launch of a clone reads the 8-bit destination values the pre-process stored as float16
     static_assert(!(HF && GEN), "float16 right-hand sides exist on level 0 only");
@@ -103,18 +115,33 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     } else {
         c0_load<R>(Uin.at(c), P, H, x, y0, u);
     }
-    // coarse rows of the prolongation (fast path), requested together with U; lanes / rows outside
-    // the regular part of the coarse grid read a clamped address and take the general path below
-    float2 eab[PRO ? R / 2 + 1 : 1];
-    float ecc[PRO ? R / 2 + 1 : 1];
+    // Coarse values the lane interpolates from, requested together with U: level-1 rows y0/2 - 1 .. y0/2 + R/2 at columns
+    // x/2 .. x/2 + 2 (the extra row above feeds the ghost row, see the prolongation), and for the composed form the
+    // level-2 rows under them at columns x/4, x/4 + 1.  Indices are clamped; what a clamped index reads is a ring or pad
+    // value (zero) or is never used.
+    constexpr int NE = R / 2 + 2, NQ = R / 4 + 3;
+    float2 eab[PRO ? NE : 1];
+    float ecc[PRO ? NE : 1];
+    float2 e2r[COMP ? NQ : 1];
+    float e2l[COMP ? NQ : 1];          // level-2 column x/4 - 1: source of the ghost value when x/4 itself is the ghost column
     if (PRO) {
         const float *__restrict__ e = E.at(c);
-        const int cx = min(max(x >> 1, 0), E.pitch - 4), J = y0 >> 1;
+        const int cx = min(max(x >> 1, 0), E.pitch - 4), J = (y0 >> 1) - 1;
 #pragma unroll
-        for (int j = 0; j <= R / 2; ++j) {
+        for (int j = 0; j < NE; ++j) {
             const float *er = e + (size_t)min(max(J + j, 0), E.H - 1) * E.pitch + cx;
             eab[j] = *reinterpret_cast<const float2 *>(er);
             ecc[j] = er[2];
+        }
+    }
+    if (COMP) {
+        const float *__restrict__ e2 = comp.E2.at(c);
+        const int qx = min(max(x >> 2, 0), comp.E2.pitch - 2), Q = ((y0 >> 1) - 1) >> 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float *er = e2 + (size_t)min(max(Q + q, 0), comp.E2.H - 1) * comp.E2.pitch + qx;
+            e2r[q] = make_float2(er[0], er[1]);
+            e2l[q] = er[qx > 0 ? -1 : 0];
         }
     }
     if (!PRO) {   // with PRO the RHS is fetched after the prolongation
@@ -125,25 +152,65 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
 
     // ------------------------------------------------------------------ prolongation
+    // Bilinear interpolation from coarse columns x/2, x/2+1, x/2+2 and rows y0/2 .. y0/2+R/2.  The last interval of a level
+    // is irregular (MGDim): the one or two fine points beyond the last coarse point nc interpolate between E[nc] and the
+    // boundary value 0 with weights tw1 / tw2.  Both equal the REGULAR formula applied to a ghost value
+    //     E[nc + 1] := (2 tw1 - 1) E[nc]
+    // (tw2 = 2 tw1 - 1: the two tail points lie on one straight line to the boundary), so one code path serves every lane:
+    // the ghost column / row is patched in where the lane's window contains index nc + 1.  The same holds one level up for
+    // the composed form (level-2 ghosts with level 1's tail weights).
     if (PRO) {
-        const float *__restrict__ e = E.at(c);
-        const int Pc = E.pitch;
         float m = 0.f;
-        const bool fast = x >= 0 && x + 4 <= 2 * g.x.nc && y0 >= 0 && y0 + R <= 2 * g.y.nc;
-        if (fast) {
-            float4 row[R / 2 + 1];
+        if (x >= 0 && x <= W - 2 && y0 + R - 1 >= 1 && y0 <= H - 2) {       // the lane owns at least one interior point
+            const int ncx = g.x.nc, ncy = g.y.nc;
+            const float gx = 2.0f * g.x.tw1 - 1.0f, gy = 2.0f * g.y.tw1 - 1.0f;
+            const int c0 = x >> 1, Jb = (y0 >> 1) - 1;                      // first coarse column / first loaded coarse row
+            float p0[COMP ? NE : 1], p1[COMP ? NE : 1], p2[COMP ? NE : 1];   // P21 E2 at the lane's level-1 columns, per level-1 row
+            if (COMP) {
+                const int n2x = comp.g1.x.nc, n2y = comp.g1.y.nc, q0 = x >> 2, Qb = Jb >> 1;
+                const float g1x = 2.0f * comp.g1.x.tw1 - 1.0f, g1y = 2.0f * comp.g1.y.tw1 - 1.0f;
+                float h0[NQ], h1[NQ], h2[NQ];
 #pragma unroll
-            for (int j = 0; j <= R / 2; ++j) {
-                const float2 ab = eab[j];
-                const float cc = ecc[j];
-                row[j] = make_float4(ab.x, 0.5f * ab.x + 0.5f * ab.y, ab.y, 0.5f * ab.y + 0.5f * cc);
+                for (int q = 0; q < NQ; ++q) {
+                    float a2 = (q0 <= n2x) ? e2r[q].x : 0.f, b2 = (q0 + 1 <= n2x) ? e2r[q].y : 0.f;
+                    if (q0 == n2x) b2 = g1x * a2;                           // ghost column of level 2
+                    if (q0 == n2x + 1) a2 = g1x * e2l[q];
+                    h0[q] = a2; h1[q] = 0.5f * a2 + 0.5f * b2; h2[q] = b2;
+                }
+#pragma unroll
+                for (int q = 1; q < NQ; ++q)
+                    if (Qb + q == n2y + 1) { h0[q] = g1y * h0[q - 1]; h1[q] = g1y * h1[q - 1]; h2[q] = g1y * h2[q - 1]; }   // ghost row
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int Jr = Jb + j, q = (Jr >> 1) - Qb;              // level-1 row and the level-2 row at / above it
+                    if (Jr & 1) { p0[j] = 0.5f * h0[q] + 0.5f * h0[q + 1]; p1[j] = 0.5f * h1[q] + 0.5f * h1[q + 1]; p2[j] = 0.5f * h2[q] + 0.5f * h2[q + 1]; }
+                    else { p0[j] = h0[q]; p1[j] = h1[q]; p2[j] = h2[q]; }
+                }
+            }
+            float4 row[NE];      // coarse row j of the window, interpolated in x to the lane's four fine columns
+            float3 prev = make_float3(0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int Jr = Jb + j;
+                float ea = eab[j].x, eb = eab[j].y, ec = ecc[j];
+                if (COMP) {      // level-1 correction = pre-smoothed U1 + interpolated level-2 correction, zero outside level 1
+                    const bool rin = (Jr >= 1) && (Jr <= ncy);
+                    ea = (rin && c0 >= 1 && c0 <= ncx) ? ea + p0[j] : 0.f;
+                    eb = (rin && c0 + 1 <= ncx) ? eb + p1[j] : 0.f;
+                    ec = (rin && c0 + 2 <= ncx) ? ec + p2[j] : 0.f;
+                }
+                if (c0 == ncx) eb = gx * ea;                                // ghost column of this level
+                if (c0 + 1 == ncx) ec = gx * eb;
+                if (Jr == ncy + 1) { ea = gy * prev.x; eb = gy * prev.y; ec = gy * prev.z; }   // ghost row
+                prev = make_float3(ea, eb, ec);
+                row[j] = make_float4(ea, 0.5f * ea + 0.5f * eb, eb, 0.5f * eb + 0.5f * ec);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int y = y0 + r;
-                float4 cr = row[r / 2];
+                float4 cr = row[r / 2 + 1];
                 if (r & 1) {
-                    const float4 nx = row[r / 2 + 1];
+                    const float4 nx = row[r / 2 + 2];
                     cr = make_float4(0.5f * cr.x + 0.5f * nx.x, 0.5f * cr.y + 0.5f * nx.y, 0.5f * cr.z + 0.5f * nx.z,
                                      0.5f * cr.w + 0.5f * nx.w);
                 }
@@ -152,34 +219,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
                 if (x1ok) { u[r].y = u[r].y + cr.y; m = fmaxf(m, fabsf(cr.y)); }
                 if (x2ok) { u[r].z = u[r].z + cr.z; m = fmaxf(m, fabsf(cr.z)); }
                 if (x3ok) { u[r].w = u[r].w + cr.w; m = fmaxf(m, fabsf(cr.w)); }
-            }
-        } else {
-            int I0[4], I1[4];
-            float wa[4], wb[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int xi = min(max(x + k, 1), g.x.n);
-                interp_1d(g.x, xi, I0[k], I1[k], wa[k], wb[k]);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int y = y0 + r;
-                if (y < 1 || y > H - 2) continue;
-                int J0, J1;
-                float wy0, wy1;
-                interp_1d(g.y, y, J0, J1, wy0, wy1);
-                const float *e0 = e + (size_t)J0 * Pc, *e1 = e + (size_t)J1 * Pc;
-                float cr[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float top = wa[k] * e0[I0[k]] + wb[k] * e0[I1[k]];
-                    const float bot = wa[k] * e1[I0[k]] + wb[k] * e1[I1[k]];
-                    cr[k] = wy0 * top + wy1 * bot;
-                }
-                if (x0ok) { u[r].x = u[r].x + cr[0]; m = fmaxf(m, fabsf(cr[0])); }
-                if (x1ok) { u[r].y = u[r].y + cr[1]; m = fmaxf(m, fabsf(cr[1])); }
-                if (x2ok) { u[r].z = u[r].z + cr[2]; m = fmaxf(m, fabsf(cr[2])); }
-                if (x3ok) { u[r].w = u[r].w + cr[3]; m = fmaxf(m, fabsf(cr[3])); }
             }
         }
         // after the prolongation (VGPR pressure), in flight during the reduction
@@ -353,13 +392,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 constexpr int C0_NW = 8, C0_R = 8;
 
 template <int T, bool PRO, int TAG = 0>
-static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s)
+static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s,
+                     const ComposeArgs &comp = ComposeArgs())
 {
     constexpr int RH = C0_NW * C0_R, HY = 2 * T + 2;
     const int blocks = ((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
     hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false, TAG>), dim3(blocks), dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E,
-                       g, partial);
+                       g, partial, comp);
     return blocks;
+}
+
+// Level-0 launch whose prolongation source is composed on the fly: U1 = level-1 correction after its pre-smoothing (level 1
+// has no post-smoothing and no prolongation launch of its own), E2 = finished level-2 correction, g1 = level-1 geometry.
+// sweeps = post + pre (4) or, final_cycle, post (2).  Returns the number of partial maxima, -1 if not instantiated.
+int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
+                           hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1)
+{
+    ComposeArgs ca;
+    ca.E2 = E2; ca.g1 = g1;
+    if (final_cycle) {
+        if (sweeps != 2) return -1;
+        return f_half ? launch_c0<2, true, 26>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<2, true, 24>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
+    }
+    if (sweeps != 4) return -1;
+    if (tag) return f_half ? launch_c0<4, true, 19>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 17>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
+    return f_half ? launch_c0<4, true, 18>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 16>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
 }
 
 // sweeps = T red-black GS sweeps; prolong: add P*E first and write per-block max|P*E| to `partial`; f_half / u_half: F /
@@ -419,15 +476,22 @@ static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_
     Field none{};
     const int blocks = ((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * F.C;
     hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true>), dim3(blocks), dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
-                       Uout, F, Fc, none, g, (float *)nullptr);
+                       Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs());
 }
 
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s)
 {
-    if (sweeps != 1 && sweeps != 2) return false;
-    const int R = tb_gen_rows(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
+    if (sweeps < 1 || sweeps > 4) return false;
+    int R = tb_gen_rows(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
     if (sweeps == 1) { R == 8 ? launch_cn<1, 8>(Uout, F, Fc, g, s) : R == 6 ? launch_cn<1, 6>(Uout, F, Fc, g, s) : launch_cn<1, 4>(Uout, F, Fc, g, s); }
-    else             { R == 8 ? launch_cn<2, 8>(Uout, F, Fc, g, s) : R == 6 ? launch_cn<2, 6>(Uout, F, Fc, g, s) : launch_cn<2, 4>(Uout, F, Fc, g, s); }
+    else if (sweeps == 2) { R == 8 ? launch_cn<2, 8>(Uout, F, Fc, g, s) : R == 6 ? launch_cn<2, 6>(Uout, F, Fc, g, s) : launch_cn<2, 4>(Uout, F, Fc, g, s); }
+    else {
+        // deeper pre-smoothing (a level that gets no post-smoothing: 3 or 4 sweeps): 8-row bands would spill, 6-row bands
+        // keep 28 of 48 rows at depth 4
+        if (R == 8) R = 6;
+        if (sweeps == 3) { R == 6 ? launch_cn<3, 6>(Uout, F, Fc, g, s) : launch_cn<3, 4>(Uout, F, Fc, g, s); }
+        else             { R == 6 ? launch_cn<4, 6>(Uout, F, Fc, g, s) : launch_cn<4, 4>(Uout, F, Fc, g, s); }
+    }
     return true;
 }
 

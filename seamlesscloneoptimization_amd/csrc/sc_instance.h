@@ -105,7 +105,8 @@ int setup_fields(Instance *I, int W, int H, int C);
 
 // solver drivers (sc_solver.cpp) -- operate on I->U0/U1/F, leave the answer in result(I)
 int solve(Instance *I);
-bool mg_reads_half_rhs(const Instance *I);   // sc_multigrid.cpp: would the solve configured in I->opts read a float16 F?
+bool mg_reads_half_rhs(const Instance *I);
+bool mg_composes_level1(const Instance *I);   // sc_multigrid.cpp   // sc_multigrid.cpp: would the solve configured in I->opts read a float16 F?
 int run_sweeps(Instance *I, int method, int sweeps, float omega, int sweeps_per_launch);
 int fused_depth(int method, int sweeps_per_launch); // 0 = plain kernels
 int eval_residual(Instance *I, double out[2]);

@@ -329,7 +329,9 @@ static int smooth_gen(Instance *I, size_t l, int n, int mode, Field E)
     return SC_OK;
 }
 
-static int vcycle(Instance *I, size_t l, int pre, int post)
+// no_post_level: that level gets no post-smoothing and no prolongation launch of its own -- its caller interpolates from
+// "its correction + the interpolated correction of the level below" directly (sc_cycle0.hip, ComposeArgs); 0 = none.
+static int vcycle(Instance *I, size_t l, int pre, int post, size_t no_post_level = 0)
 {
     MGLevel &L = I->mg[l];
     int rc;
@@ -345,21 +347,28 @@ static int vcycle(Instance *I, size_t l, int pre, int post)
         return SC_OK;
     }
     MGLevel &Lc = I->mg[l + 1];
+    // a level without post-smoothing does all its sweeps before the restriction
+    int pre_here = pre;
+    if (l > 0 && l == no_post_level) {
+        static const int extra = [] { const char *e = getenv("SC_COMPOSE_PRE"); return e ? atoi(e) : 4; }();
+        pre_here = std::max(pre, std::min(extra, pre + post));
+    }
     // ---- pre-smoothing (levels >= 1 start from a zero correction), residual + restriction
     bool restricted = false;
     if (l == 0) {
-        if ((rc = run_sweeps(I, SC_METHOD_RBGS, pre, 1.0f, I->opts.sweeps_per_launch))) return rc;
-    } else if (pre > 0 && I->opts.sweeps_per_launch != 1 &&
-               launch_cycle_coarse(L.T, L.F, Lc.F, L.g, pre, I->stream)) {
+        if ((rc = run_sweeps(I, SC_METHOD_RBGS, pre_here, 1.0f, I->opts.sweeps_per_launch))) return rc;
+    } else if (pre_here > 0 && I->opts.sweeps_per_launch != 1 &&
+               launch_cycle_coarse(L.T, L.F, Lc.F, L.g, pre_here, I->stream)) {
         std::swap(L.U, L.T);      // one launch did all three
         restricted = true;
-    } else if (pre > 0) {
-        if ((rc = smooth_gen(I, l, pre, TBM_ZEROIN, Field{}))) return rc;
+    } else if (pre_here > 0) {
+        if ((rc = smooth_gen(I, l, pre_here, TBM_ZEROIN, Field{}))) return rc;
     } else {
         launch_fill_zero(L.U, I->stream);
     }
     if (!restricted) launch_residual_restrict(l == 0 ? result(I) : L.U, L.F, Lc.F, L.g, I->stream);
-    if ((rc = vcycle(I, l + 1, pre, post))) return rc;
+    if ((rc = vcycle(I, l + 1, pre, post, no_post_level))) return rc;
+    if (l > 0 && l == no_post_level) return SC_OK;
     // ---- prolongation fused into the first post-smoothing launch
     if (l == 0) {
         const int T = std::min(2, post);
@@ -392,6 +401,18 @@ static bool fused_level0(const sc_solver_opts &o)
 {
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
     return o.sweeps_per_launch != 1 && pre >= 1 && pre <= 2 && post >= 1 && pre + post <= 4;
+}
+
+// Fused solve on the current hierarchy: does level 1 run pre-smoothing only, with the level-0 launch composing its
+// prolongation source from levels 1 and 2 (sc_cycle0.hip, ComposeArgs)?  Needs a launched level 1 with a level 2 below
+// it and the standard 2 + 2 cycle.  The contraction per cycle is within a few percent of the full V(2,2)
+// (oracle/mg_np.py runs the same schedule); one launch per cycle less is worth ~10 % of the clone throughput.
+bool mg_composes_level1(const Instance *I)
+{
+    static const int off = [] { const char *e = getenv("SC_NO_COMPOSE_L1"); return e ? atoi(e) : 0; }();
+    const sc_solver_opts &o = I->opts;
+    const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
+    return !off && I->mg.size() >= 3 && I->mg_bottom >= 2 && pre == 2 && post == 2;
 }
 
 bool mg_reads_half_rhs(const Instance *I)
@@ -437,14 +458,19 @@ int mg_solve(Instance *I)
         I->u_half = false;             // consumed: both U buffers hold float from here on
         I->info.sweep_launches += 1;
         while (cyc < budget) {
-            if ((rc = vcycle(I, 1, pre, post))) return rc;
+            const bool comp1 = mg_composes_level1(I);
+            if ((rc = vcycle(I, 1, pre, post, comp1 ? 1 : 0))) return rc;
             // The first two corrections of a solve are never below the stop threshold unless the
             // initial guess was already the answer, and every check costs a host round trip
             // (~25 us), so checking starts with the third cycle.
             const bool judged = !(cyc + 1 < 3 && cyc + 1 < budget && o.tol <= 0.f);
-            const int nb = launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
-                                         I->mg[0].g, judged ? post : post + pre, true, (float *)I->mg_partial.p, I->stream,
-                                         false, I->f_half, false, judged);
+            const int nb = comp1
+                ? launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
+                                         judged ? post : post + pre, (float *)I->mg_partial.p, I->stream, false, I->f_half, judged,
+                                         I->mg[2].U, I->mg[1].g)
+                : launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
+                                I->mg[0].g, judged ? post : post + pre, true, (float *)I->mg_partial.p, I->stream,
+                                false, I->f_half, false, judged);
             if (nb <= 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
             I->result_in_U1 = !I->result_in_U1;
             I->info.sweep_launches += 1;
