@@ -72,13 +72,16 @@ typedef struct sc_solver_opts {
     int   reference_warmup;  /* 1: clone twice in place, as the reference's run() does
                                 (warm-up + 1, seamlessClone_imp.cu:303-318)                */
     int   mg_pre, mg_post;   /* multigrid smoothing sweeps per level (0 = default 2/2)      */
-    float update_tol;        /* MULTIGRID stop rule: finish once the largest coarse-grid
-                                correction applied to the ROI in a V-cycle is <= update_tol grey
-                                levels.  The error left is ~18x smaller (contraction 0.055 per
-                                cycle).  Default 0.25: 3-4 cycles, error ~0.01 grey levels, i.e.
-                                max |delta| 1 on <0.2 % of channels vs the exact solution -- the
-                                level of the reference's own float32 deviation from OpenCV (0.16 %
-                                at 2400x1552, PDF p3).  0.02 costs one more cycle (<0.02 %).
+    float update_tol;        /* MULTIGRID stop rule, in grey levels.  The error a V-cycle leaves is
+                                ~rho/(1-rho) times the largest coarse-grid correction it applied to
+                                the ROI (rho = contraction per cycle, 0.05-0.1).  From the third cycle
+                                on the driver measures rho from two successive corrections and stops
+                                once that predicted error is <= 0.1 x update_tol; with only one
+                                correction known (max_sweeps = 1) it stops once the correction itself
+                                is <= update_tol.  Default 0.25 (error <= 0.025): normally 3 cycles,
+                                max |delta| 1 on 0.004-0.1 % of channels vs the exact solution -- below
+                                the reference's own float32 deviation from OpenCV (0.16 % at 2400x1552,
+                                PDF p3).  0.02 costs one or two more cycles.
                                 The float32 residual norm stalls earlier and is only reported. */
     int   reserved[5];
 } sc_solver_opts;

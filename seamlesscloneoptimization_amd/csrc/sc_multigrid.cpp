@@ -431,7 +431,7 @@ int mg_solve(Instance *I)
     {
         const int nb = std::max(std::max(prolong_blocks(I->F.W - 2, I->F.H - 2, I->F.C), tb_blocks_level0(I->F.W, I->F.H, I->F.C, 1)),
                                 cycle0_blocks(I->F.W, I->F.H, I->F.C, 1));
-        if ((rc = ensure(I, I->mg_partial, sizeof(float) * (size_t)nb))) return rc;
+        if ((rc = ensure(I, I->mg_partial, 2 * sizeof(float) * (size_t)nb))) return rc;   // two cycles' worth (see the stop rule)
     }
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
     const float utol = o.update_tol > 0.f ? o.update_tol : 0.25f;
@@ -457,6 +457,7 @@ int mg_solve(Instance *I)
         I->result_in_U1 = !I->result_in_U1;
         I->u_half = false;             // consumed: both U buffers hold float from here on
         I->info.sweep_launches += 1;
+        int nb_last = 0;                   // workgroups (= partial maxima) of the previous cycle's level-0 launch
         while (cyc < budget) {
             const bool comp1 = mg_composes_level1(I);
             if ((rc = vcycle(I, 1, pre, post, comp1 ? 1 : 0))) return rc;
@@ -464,26 +465,34 @@ int mg_solve(Instance *I)
             // initial guess was already the answer, and every check costs a host round trip
             // (~25 us), so checking starts with the third cycle.
             const bool judged = !(cyc + 1 < 3 && cyc + 1 < budget && o.tol <= 0.f);
+            const int nb_cap = cycle0_blocks(I->F.W, I->F.H, I->F.C, 1);
+            float *const part_now = (float *)I->mg_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;    // this cycle's maxima
+            const float *const part_prev = (const float *)I->mg_partial.p + (size_t)(cyc & 1) * nb_cap;   // the previous cycle's
             const int nb = comp1
                 ? launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
-                                         judged ? post : post + pre, (float *)I->mg_partial.p, I->stream, false, I->f_half, judged,
+                                         judged ? post : post + pre, part_now, I->stream, false, I->f_half, judged,
                                          I->mg[2].U, I->mg[1].g)
                 : launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
-                                I->mg[0].g, judged ? post : post + pre, true, (float *)I->mg_partial.p, I->stream,
+                                I->mg[0].g, judged ? post : post + pre, true, part_now, I->stream,
                                 false, I->f_half, false, judged);
             if (nb <= 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
             I->result_in_U1 = !I->result_in_U1;
             I->info.sweep_launches += 1;
             ++cyc;
             SC_HIP(I, hipGetLastError());
+            const int nb_prev = nb_last;
+            nb_last = nb;
             if (!judged) continue;
             // max |correction| = max over the per-workgroup maxima.  A few thousand of them are folded here
             // on the host (the read-back is needed anyway and a reduction launch costs ~5 us of GPU time);
             // large grids reduce on the device first.
-            float m = 0.f;
+            float m = 0.f, m_prev = -1.f;          // m_prev < 0: unknown
             if (nb <= 16384) {
-                if ((rc = ensure_pinned(I, I->h_partial, sizeof(float) * (size_t)nb))) return rc;
-                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)nb, hipMemcpyDeviceToHost, I->stream));
+                const bool have_prev = nb_prev > 0 && nb_prev <= 16384;   // the launch of the previous cycle wrote the other half
+                if ((rc = ensure_pinned(I, I->h_partial, sizeof(float) * (size_t)(nb + nb_prev)))) return rc;
+                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, part_now, sizeof(float) * (size_t)nb, hipMemcpyDeviceToHost, I->stream));
+                if (have_prev)
+                    SC_HIP(I, hipMemcpyAsync((float *)I->h_partial.p + nb, part_prev, sizeof(float) * (size_t)nb_prev, hipMemcpyDeviceToHost, I->stream));
                 if (I->spec_post.armed && o.tol <= 0.f) {      // see Instance::spec_post
                     if (I->spec_post.ev_solved) SC_HIP(I, hipEventRecord(I->spec_post.ev_solved, I->stream));
                     launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
@@ -492,8 +501,12 @@ int mg_solve(Instance *I)
                 SC_HIP(I, hipStreamSynchronize(I->stream));
                 const float *hp = (const float *)I->h_partial.p;
                 for (int i = 0; i < nb; ++i) m = hp[i] > m ? hp[i] : m;
+                if (have_prev) {
+                    m_prev = 0.f;
+                    for (int i = nb; i < nb + nb_prev; ++i) m_prev = hp[i] > m_prev ? hp[i] : m_prev;
+                }
             } else {
-                launch_max_final((const float *)I->mg_partial.p, nb, I->d_maxcorr, I->stream);
+                launch_max_final(part_now, nb, I->d_maxcorr, I->stream);
                 SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
                 SC_HIP(I, hipStreamSynchronize(I->stream));
                 unsigned bits = *I->h_maxcorr;
@@ -507,7 +520,16 @@ int mg_solve(Instance *I)
                 I->info.rel_residual = rel;
                 if (rel <= (double)o.tol) { ok = true; break; }
             }
-            if (m <= utol) { ok = true; break; }
+            // Stop rule.  The error left after a cycle is about rho / (1 - rho) times the correction it applied, rho being the
+            // contraction per cycle (measured: the prediction matches the next correction to ~10 %).  With two successive
+            // corrections known the bound is applied to that prediction: error <= 0.1 x update_tol (0.025 grey levels at the
+            // default 0.25, i.e. the error the plain threshold "correction <= update_tol" leaves at rho = 0.09).  A solve that
+            // contracts faster stops on a larger last correction, a slower one on a smaller.  Without a previous correction
+            // (max_sweeps = 1) the plain threshold decides.
+            if (m_prev > 0.f) {
+                const float rho = std::min(0.5f, std::max(0.02f, m / m_prev));
+                if (m * rho / (1.0f - rho) <= 0.1f * utol) { ok = true; break; }
+            } else if (m <= utol) { ok = true; break; }
             I->spec_post.done = false;     // not converged: the field moves on, the output is written again later
             if (cyc < budget) {            // catch up: pre-smoothing + residual + restriction for the next cycle
                 if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false,
