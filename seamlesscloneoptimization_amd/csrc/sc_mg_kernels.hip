@@ -380,17 +380,19 @@ __device__ __forceinline__ void fd_product(const float *LT, int pL, const float 
     const int tc = cols >> 2, ntiles = (rows >> 1) * tc;
     for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
         const int r0 = (t / tc) << 1, c0 = (t % tc) << 2;
-        float a00 = 0.f, a01 = 0.f, a02 = 0.f, a03 = 0.f, a10 = 0.f, a11 = 0.f, a12 = 0.f, a13 = 0.f;
+        // packed FMAs (v_pk_fma_f32: two lanes of a float2 per instruction): 4 instead of 8 per k
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 p00 = { 0.f, 0.f }, p02 = { 0.f, 0.f }, p10 = { 0.f, 0.f }, p12 = { 0.f, 0.f };
         const float *lp = LT + r0, *rp = R + c0;
 #pragma unroll 4
         for (int k = 0; k < K; ++k) {
             const float2 l = *reinterpret_cast<const float2 *>(lp + k * pL);
             const float4 r = *reinterpret_cast<const float4 *>(rp + k * pR);
-            a00 = __builtin_fmaf(l.x, r.x, a00); a01 = __builtin_fmaf(l.x, r.y, a01);
-            a02 = __builtin_fmaf(l.x, r.z, a02); a03 = __builtin_fmaf(l.x, r.w, a03);
-            a10 = __builtin_fmaf(l.y, r.x, a10); a11 = __builtin_fmaf(l.y, r.y, a11);
-            a12 = __builtin_fmaf(l.y, r.z, a12); a13 = __builtin_fmaf(l.y, r.w, a13);
+            const f2 r01 = { r.x, r.y }, r23 = { r.z, r.w }, lx = { l.x, l.x }, ly = { l.y, l.y };
+            p00 = __builtin_elementwise_fma(lx, r01, p00); p02 = __builtin_elementwise_fma(lx, r23, p02);
+            p10 = __builtin_elementwise_fma(ly, r01, p10); p12 = __builtin_elementwise_fma(ly, r23, p12);
         }
+        float a00 = p00.x, a01 = p00.y, a02 = p02.x, a03 = p02.y, a10 = p10.x, a11 = p10.y, a12 = p12.x, a13 = p12.y;
         if (SCALE) {
             const float4 s0 = *reinterpret_cast<const float4 *>(scale + r0 * cols + c0);
             const float4 s1 = *reinterpret_cast<const float4 *>(scale + (r0 + 1) * cols + c0);
@@ -412,21 +414,34 @@ __device__ __forceinline__ void fd_product(const float *LT, int pL, const float 
 
 // Solves level `v` (RHS plane lds + v.offF, result into lds + v.offU) exactly.  mats: the five matrices
 // already staged in LDS at fd; P0, P1: two nxp x nyp scratch planes behind them.
-__device__ __forceinline__ void fd_solve(float *lds, const MGBottomLevel &v, const float *fd, int nxp, int nyp)
+// GLOBAL (the solved level is the bottom's first): the right-hand side comes straight from its HBM plane `fg` (pitch gp) and
+// the solution goes straight to `ug` -- the level has no LDS planes at all and the caller has already put F^T into P0.
+template <bool GLOBAL>
+__device__ __forceinline__ void fd_solve(float *lds, const MGBottomLevel &v, const float *fd, int nxp, int nyp,
+                                         float *__restrict__ ug, int gp)
 {
     const int nx = v.g.x.n, ny = v.g.y.n;
     const float *Mx1 = fd, *My1T = Mx1 + nxp * nxp, *My2T = My1T + nyp * nyp, *Mx2 = My2T + nyp * nyp, *Dinv = Mx2 + nxp * nxp;
     float *P0 = const_cast<float *>(Dinv) + nyp * nxp, *P1 = P0 + nxp * nyp;
-    const float *f = lds + v.offF;
-    for (int i = threadIdx.x; i < nxp * nyp; i += blockDim.x) {          // P0 = F^T, zero padded
-        const int x = i / nyp, y = i - x * nyp;
-        P0[i] = (x < nx && y < ny) ? f[(y + 1) * v.pitch + x + 1] : 0.f;
+    if (!GLOBAL) {
+        const float *f = lds + v.offF;
+        for (int i = threadIdx.x; i < nxp * nyp; i += blockDim.x) {          // P0 = F^T, zero padded
+            const int x = i / nyp, y = i - x * nyp;
+            P0[i] = (x < nx && y < ny) ? f[(y + 1) * v.pitch + x + 1] : 0.f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     fd_product<false, false>(P0, nyp, Mx1, nxp, nxp, nyp, nxp, P1, nxp, nullptr);      // G1 = F Vx^-T          [y][i]
     fd_product<false, true>(My1T, nyp, P1, nxp, nyp, nyp, nxp, P0, nxp, Dinv);         // G2 = (Vy^-1 G1) / (ly + lx)
     fd_product<true, false>(My2T, nyp, P0, nxp, nyp, nyp, nxp, P1, nyp, nullptr);      // G3^T = (Vy G2)^T      [i][y]
     fd_product<false, false>(P1, nyp, Mx2, nxp, nxp, nyp, nxp, P0, nxp, nullptr);      // U = G3 Vx^T           [y][x]
+    if (GLOBAL) {
+        for (int i = threadIdx.x; i < nxp * ny; i += blockDim.x) {          // rows of nxp: consecutive lanes, consecutive addresses
+            const int y = i / nxp, x = i - y * nxp;
+            if (x < nx) ug[(size_t)(y + 1) * gp + x + 1] = P0[i];
+        }
+        return;
+    }
     float *u = lds + v.offU;
     for (int i = threadIdx.x; i < nx * ny; i += blockDim.x) {
         const int y = i / nx, x = i - y * nx;
@@ -443,6 +458,25 @@ __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
     const int L = a.nlevels;
     if (threadIdx.x < MG_BOTTOM_MAX_LEVELS) lv[threadIdx.x] = a.lv[threadIdx.x];
     const bool fd = a.fd_level >= 0;
+    if (fd && a.fd_level == 0) {
+        // The usual case: the bottom's first level is the one solved directly.  No level planes in LDS, nothing to zero:
+        // matrices and the transposed, zero-padded right-hand side are fetched together, the solution goes straight to HBM.
+        const int nxp = a.fd_nxp, nyp = a.fd_nyp;
+        const int n4 = (int)(fd_mat_floats(nxp, nyp) >> 2);
+        const float4 *__restrict__ src = reinterpret_cast<const float4 *>(a.fd_mats);
+        float4 *dst = reinterpret_cast<float4 *>(lds + a.fd_off);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+        const MGBottomLevel &v = a.lv[0];
+        const float *__restrict__ fg = a.Ftop.at(c);
+        float *P0 = lds + a.fd_off + fd_mat_floats(nxp, nyp);
+        for (int i = threadIdx.x; i < nxp * nyp; i += blockDim.x) {       // y fastest: P0 = F^T; reads stride the plane's rows (L2 resident)
+            const int x = i / nyp, y = i - x * nyp;
+            P0[i] = (x < v.g.x.n && y < v.g.y.n) ? fg[(size_t)(y + 1) * a.Ftop.pitch + x + 1] : 0.f;
+        }
+        __syncthreads();
+        fd_solve<true>(lds, v, lds + a.fd_off, nxp, nyp, a.Utop.at(c), a.Utop.pitch);
+        return;
+    }
     const int nzero = fd ? a.fd_off : a.lds_floats;
     for (int i = threadIdx.x; i < nzero; i += blockDim.x) lds[i] = 0.f;   // zero corrections, rings, pads
     if (fd) {   // stage the direct solver's matrices (16-byte loads; the region is 16-byte aligned and a multiple of 4 floats)
@@ -469,7 +503,7 @@ __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
         // V-cycle levels [0, fd_level) with all waves, level fd_level solved exactly, nothing below it
         const int lf = a.fd_level;
         bt_subcycle<false>(lds, lv, lf + 1, a.pre, 0, lf);
-        fd_solve(lds, lv[lf], lds + a.fd_off, a.fd_nxp, a.fd_nyp);
+        fd_solve<false>(lds, lv[lf], lds + a.fd_off, a.fd_nxp, a.fd_nyp, nullptr, 0);
         bt_ascent<false>(lds, lv, lf + 1, a.post, 0, lf);
     } else {
     int ls = L;
