@@ -189,7 +189,12 @@ def composes_level1(levels) -> bool:
     return len(levels) >= 3 and bottom_start(levels) >= 2
 
 
-def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post_level=0):
+def no_post_levels(levels):
+    """Levels of the fused GPU schedule that run pre-smoothing only (sc_multigrid.cpp): level 1, where composes_level1()."""
+    return (1,) if composes_level1(levels) else ()
+
+
+def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post=()):
     dx, dy = levels[l]
     if direct is not None and l == direct:
         return solve_exact(F, dx, dy)
@@ -198,12 +203,12 @@ def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post_level=0):
         om = 2.0 / (1.0 + np.sqrt(max(0.0, 1.0 - rho * rho)))
         return rb_gen(U, F, dx, dy, max(8, min(64, 2 * max(dx.n, dy.n))), float(F32(om)))
     # a level without post-smoothing does all its sweeps before the restriction
-    U = rb_gen(U, F, dx, dy, pre + post if (l > 0 and l == no_post_level) else pre)
+    U = rb_gen(U, F, dx, dy, pre + post if (l > 0 and l in no_post) else pre)
     Fc = restrict(residual_field(U, F, dx, dy), dx, dy)
-    E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post, direct, no_post_level)
+    E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post, direct, no_post)
     U = U.copy()
     U += prolong(E, dx, dy)
-    if l > 0 and l == no_post_level:
+    if l > 0 and l in no_post:
         return U
     return rb_gen(U, F, dx, dy, post)
 
@@ -216,8 +221,8 @@ def solve(U0, F, cycles=6, direct="auto", fused=True):
     H, W = U0.shape
     levels = build_levels(W, H)
     d = direct_level(levels) if direct == "auto" else direct
-    npl = 1 if (fused and composes_level1(levels)) else 0
+    npl = no_post_levels(levels) if fused else ()
     U = U0.astype(F32).copy()
     for _ in range(cycles):
-        U = vcycle(levels, 0, U, F, direct=d, no_post_level=npl)
+        U = vcycle(levels, 0, U, F, direct=d, no_post=npl)
     return U

@@ -54,6 +54,7 @@ int  tb_hard_max_depth(int method);
 long tb_big_side();
 int  tb_gen_rows(int W, int H, int C, int hx, int hy);   // band height (rows per lane) of a coarse-level launch
 struct MGGeom;
+struct ComposeArgs;
 constexpr int TBM_PLAIN = 0, TBM_PROLONG = 1, TBM_ZEROIN = 4;   // mode of launch_rb_tb_gen
 bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s);
 int  launch_rb_tb_prolong0(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, Field E, float *partial, hipStream_t s);
@@ -90,6 +91,9 @@ struct MGDim {
     float inv_last;   // 1 / (row sum of the transposed interpolation at coarse point nc)
 };
 struct MGGeom { MGDim x, y; };
+// Composed prolongation source (sc_mg_device.h): the level interpolated from ran without post-smoothing and without a
+// prolongation launch of its own; E2 = finished correction of the level below it, g1 = its geometry (transfer to that level).
+struct ComposeArgs { Field E2; MGGeom g1; };
 
 void launch_rb_half_gen(Field U, Field F, int color, float omega, MGGeom g, hipStream_t s);
 void launch_residual_restrict(Field U, Field F, Field Fc, MGGeom g, hipStream_t s); // Fc = 4 * normalised P^T (F - A U)

@@ -75,10 +75,9 @@ __device__ __forceinline__ void c0_load_half(const __half *__restrict__ p, int P
 // the fly where this kernel interpolates from it: two extra level-2 values per level-2 row and a few adds per lane.
 // Leaving out the level-1 post-smoothing changes the contraction per cycle by a few percent (oracle/mg_np.py carries
 // the same schedule); leaving out its launch is worth ~10 % of the clone throughput.
-struct ComposeArgs {
-    Field E2;          // finished level-2 correction (ring and pads zero)
-    MGGeom g1;         // level-1 geometry: its transfer to level 2
-};
+// (ComposeArgs: sc_common.h.  The prolongation below is the level-0 specialisation of sc_mg_device.h's prolong_apply -- no
+// LEFT column, level 0 has at most one tail point; kept inline here because the shared form costs this kernel 11 VGPRs and
+// ~100 SGPR spill moves: 48.7 instead of 45.6 us per launch.)
 
 // GEN    = coarse multigrid level: general stencil coefficients at the last column / row (MGDim)
 //          and the interpolation-tail weights in the restriction of the last coarse column / row.

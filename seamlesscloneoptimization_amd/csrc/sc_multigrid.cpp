@@ -329,10 +329,13 @@ static int smooth_gen(Instance *I, size_t l, int n, int mode, Field E)
     return SC_OK;
 }
 
-// no_post_level: that level gets no post-smoothing and no prolongation launch of its own -- its caller interpolates from
-// "its correction + the interpolated correction of the level below" directly (sc_cycle0.hip, ComposeArgs); 0 = none.
-static int vcycle(Instance *I, size_t l, int pre, int post, size_t no_post_level = 0)
+// no_post: bit l set = level l gets no post-smoothing and no prolongation launch of its own -- the level above interpolates
+// from "its correction + the interpolated correction of the level below" directly (sc_mg_device.h, ComposeArgs).  Used for
+// level 1 (composed by the level-0 launch); doing the same for level 3 inside level 2's post launch was measured neutral
+// (481 vs 494 us for a single 2048^2 clone, no change in throughput) and is not kept.
+static int vcycle(Instance *I, size_t l, int pre, int post, unsigned no_post = 0)
 {
+    const bool skip_post = l > 0 && l < 32 && ((no_post >> l) & 1u);
     MGLevel &L = I->mg[l];
     int rc;
     if (l > 0 && l == I->mg_bottom) return run_bottom(I, l, pre, post);
@@ -349,7 +352,7 @@ static int vcycle(Instance *I, size_t l, int pre, int post, size_t no_post_level
     MGLevel &Lc = I->mg[l + 1];
     // a level without post-smoothing does all its sweeps before the restriction
     int pre_here = pre;
-    if (l > 0 && l == no_post_level) {
+    if (skip_post) {
         static const int extra = [] { const char *e = getenv("SC_COMPOSE_PRE"); return e ? atoi(e) : 4; }();
         pre_here = std::max(pre, std::min(extra, pre + post));
     }
@@ -367,8 +370,8 @@ static int vcycle(Instance *I, size_t l, int pre, int post, size_t no_post_level
         launch_fill_zero(L.U, I->stream);
     }
     if (!restricted) launch_residual_restrict(l == 0 ? result(I) : L.U, L.F, Lc.F, L.g, I->stream);
-    if ((rc = vcycle(I, l + 1, pre, post, no_post_level))) return rc;
-    if (l > 0 && l == no_post_level) return SC_OK;
+    if ((rc = vcycle(I, l + 1, pre, post, no_post))) return rc;
+    if (skip_post) return SC_OK;
     // ---- prolongation fused into the first post-smoothing launch
     if (l == 0) {
         const int T = std::min(2, post);
@@ -429,8 +432,8 @@ int mg_solve(Instance *I)
     int rc = build_levels(I);
     if (rc) return rc;
     {
-        const int nb = std::max(std::max(prolong_blocks(I->F.W - 2, I->F.H - 2, I->F.C), tb_blocks_level0(I->F.W, I->F.H, I->F.C, 1)),
-                                cycle0_blocks(I->F.W, I->F.H, I->F.C, 1));
+        const int nb = std::max(std::max(prolong_blocks(I->F.W - 2, I->F.H - 2, I->F.C), tb_blocks_level0(I->F.W, I->F.H, I->F.C, 2)),
+                                cycle0_blocks(I->F.W, I->F.H, I->F.C, 4));      // the deepest forms have the most workgroups
         if ((rc = ensure(I, I->mg_partial, 2 * sizeof(float) * (size_t)nb))) return rc;   // two cycles' worth (see the stop rule)
     }
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
@@ -460,14 +463,13 @@ int mg_solve(Instance *I)
         int nb_last = 0;                   // workgroups (= partial maxima) of the previous cycle's level-0 launch
         while (cyc < budget) {
             const bool comp1 = mg_composes_level1(I);
-            if ((rc = vcycle(I, 1, pre, post, comp1 ? 1 : 0))) return rc;
+            if ((rc = vcycle(I, 1, pre, post, comp1 ? (1u << 1) : 0u))) return rc;
             // The first two corrections of a solve are never below the stop threshold unless the
             // initial guess was already the answer, and every check costs a host round trip
             // (~25 us), so checking starts with the third cycle.
             const bool judged = !(cyc + 1 < 3 && cyc + 1 < budget && o.tol <= 0.f);
-            const int nb_cap = cycle0_blocks(I->F.W, I->F.H, I->F.C, 1);
-            float *const part_now = (float *)I->mg_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;    // this cycle's maxima
-            const float *const part_prev = (const float *)I->mg_partial.p + (size_t)(cyc & 1) * nb_cap;   // the previous cycle's
+            const int nb_cap = cycle0_blocks(I->F.W, I->F.H, I->F.C, 4);   // deepest form = largest halo = most workgroups
+            float *const part_now = (float *)I->mg_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;    // this cycle's maxima; the previous cycle's sit in the other half
             const int nb = comp1
                 ? launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
                                          judged ? post : post + pre, part_now, I->stream, false, I->f_half, judged,
@@ -489,21 +491,22 @@ int mg_solve(Instance *I)
             float m = 0.f, m_prev = -1.f;          // m_prev < 0: unknown
             if (nb <= 16384) {
                 const bool have_prev = nb_prev > 0 && nb_prev <= 16384;   // the launch of the previous cycle wrote the other half
-                if ((rc = ensure_pinned(I, I->h_partial, sizeof(float) * (size_t)(nb + nb_prev)))) return rc;
-                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, part_now, sizeof(float) * (size_t)nb, hipMemcpyDeviceToHost, I->stream));
-                if (have_prev)
-                    SC_HIP(I, hipMemcpyAsync((float *)I->h_partial.p + nb, part_prev, sizeof(float) * (size_t)nb_prev, hipMemcpyDeviceToHost, I->stream));
+                // both halves in ONE copy (a second small D2H costs ~5 us on the critical path)
+                if ((rc = ensure_pinned(I, I->h_partial, 2 * sizeof(float) * (size_t)nb_cap))) return rc;
+                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap : ((cyc & 1) * nb_cap + nb)),
+                                         hipMemcpyDeviceToHost, I->stream));
                 if (I->spec_post.armed && o.tol <= 0.f) {      // see Instance::spec_post
                     if (I->spec_post.ev_solved) SC_HIP(I, hipEventRecord(I->spec_post.ev_solved, I->stream));
                     launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
                     I->spec_post.done = true;
                 }
                 SC_HIP(I, hipStreamSynchronize(I->stream));
-                const float *hp = (const float *)I->h_partial.p;
+                const float *hp = (const float *)I->h_partial.p + (size_t)(cyc & 1) * nb_cap;            // this cycle's half (cyc is already incremented)
+                const float *hq = (const float *)I->h_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;      // the previous cycle's
                 for (int i = 0; i < nb; ++i) m = hp[i] > m ? hp[i] : m;
                 if (have_prev) {
                     m_prev = 0.f;
-                    for (int i = nb; i < nb + nb_prev; ++i) m_prev = hp[i] > m_prev ? hp[i] : m_prev;
+                    for (int i = 0; i < nb_prev; ++i) m_prev = hq[i] > m_prev ? hq[i] : m_prev;
                 }
             } else {
                 launch_max_final(part_now, nb, I->d_maxcorr, I->stream);

@@ -45,10 +45,11 @@ __device__ __forceinline__ void tb_load(const float *__restrict__ p, int P, int 
 // TB_ZEROIN treats Uin as all-zero without reading it (first smoothing of a coarse correction).
 constexpr int TB_PROLONG = 1, TB_MAXC = 2, TB_ZEROIN = 4;
 constexpr int TB_TAG = 8;   // no effect on the code: a second symbol for the isolated roofline launches (see k_jacobi)
+constexpr int TB_COMP = 16; // with TB_PROLONG: composed prolongation source (ComposeArgs); not instantiated for this kernel (measured neutral)
 
 template <int T, int NW, int R, bool SOR, bool GEN, int FLAGS, int HXQ = 1>
 __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field F, float omega, MGGeom g, Field E,
-                                                   float *__restrict__ partial)
+                                                   float *__restrict__ partial, ComposeArgs comp)
 {
     constexpr int HY = 2 * T, RH = NW * R, HX = 4 * HXQ;   // HXQ halo lanes per side: 4 columns each
     static_assert(2 * T <= HX, "column halo too small for this depth");
@@ -71,84 +72,16 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
         tb_load<R>(Uin.at(c), P, H, x, y0, u);
     }
     tb_load<R>(F.at(c), P, H, x, y0, f);
-    // coarse rows of the prolongation's fast path, requested together with U and F
-    constexpr bool PROL = (FLAGS & TB_PROLONG) != 0 && (R % 2 == 0);
-    float2 eab[PROL ? R / 2 + 1 : 1];
-    float ecc[PROL ? R / 2 + 1 : 1];
-    if (PROL) {
-        const float *__restrict__ e = E.at(c);
-        const int cx = min(max(x >> 1, 0), E.pitch - 4), J = y0 >> 1;
-#pragma unroll
-        for (int j = 0; j <= R / 2; ++j) {
-            const float *er = e + (size_t)min(max(J + j, 0), E.H - 1) * E.pitch + cx;
-            eab[j] = *reinterpret_cast<const float2 *>(er);
-            ecc[j] = er[2];
-        }
-    }
+    // coarse values the lane interpolates from (sc_mg_device.h), requested together with U and F
+    constexpr bool PROL = (FLAGS & TB_PROLONG) != 0, COMP = PROL && (FLAGS & TB_COMP) != 0;
+    static_assert(!PROL || R % 2 == 0, "the prolongation pairs fine rows");
+    ProlongWindow<R, COMP, GEN> pw;        // a coarse level can have two tail points: LEFT = GEN
+    if (PROL) prolong_load(pw, E, comp, c, x, y0);
     const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
     const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
     if (FLAGS & TB_PROLONG) {
-        // u += P*E: bilinear interpolation of the coarse correction (MGDim tail weights at the end)
-        const float *__restrict__ e = E.at(c);
-        const int Pc = E.pitch;
-        float m = 0.f;
-        // Fast path (everything away from the irregular last interval): x is a multiple of 4 and
-        // y0 is even, so the lane's 4 x R fine points interpolate from 3 coarse columns x/2..x/2+2
-        // and R/2+1 coarse rows -- (R/2+1) x (float2 + float) loads instead of 16 per fine row.
-        const bool fast = (R % 2 == 0) && ((y0 & 1) == 0) && x >= 0 && x + 4 <= 2 * g.x.nc && y0 >= 0 &&
-                          y0 + R <= 2 * g.y.nc;
-        if (fast) {
-            float4 row[R / 2 + 1];
-#pragma unroll
-            for (int j = 0; j <= R / 2; ++j) {
-                const float2 ab = eab[PROL ? j : 0];
-                const float cc = ecc[PROL ? j : 0];
-                row[j] = make_float4(ab.x, 0.5f * ab.x + 0.5f * ab.y, ab.y, 0.5f * ab.y + 0.5f * cc);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int y = y0 + r;
-                float4 cr = row[r / 2];
-                if (r & 1) {
-                    const float4 nx = row[r / 2 + 1];
-                    cr = make_float4(0.5f * cr.x + 0.5f * nx.x, 0.5f * cr.y + 0.5f * nx.y, 0.5f * cr.z + 0.5f * nx.z,
-                                     0.5f * cr.w + 0.5f * nx.w);
-                }
-                if (y < 1 || y > H - 2) continue;
-                if (x0ok) { u[r].x = u[r].x + cr.x; m = fmaxf(m, fabsf(cr.x)); }
-                if (x1ok) { u[r].y = u[r].y + cr.y; m = fmaxf(m, fabsf(cr.y)); }
-                if (x2ok) { u[r].z = u[r].z + cr.z; m = fmaxf(m, fabsf(cr.z)); }
-                if (x3ok) { u[r].w = u[r].w + cr.w; m = fmaxf(m, fabsf(cr.w)); }
-            }
-        } else {
-            int I0[4], I1[4];
-            float wa[4], wb[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int xi = min(max(x + k, 1), g.x.n);
-                interp_1d(g.x, xi, I0[k], I1[k], wa[k], wb[k]);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int y = y0 + r;
-                if (y < 1 || y > H - 2) continue;
-                int J0, J1;
-                float wy0, wy1;
-                interp_1d(g.y, y, J0, J1, wy0, wy1);
-                const float *e0 = e + (size_t)J0 * Pc, *e1 = e + (size_t)J1 * Pc;
-                float cr[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float top = wa[k] * e0[I0[k]] + wb[k] * e0[I1[k]];
-                    const float bot = wa[k] * e1[I0[k]] + wb[k] * e1[I1[k]];
-                    cr[k] = wy0 * top + wy1 * bot;
-                }
-                if (x0ok) { u[r].x = u[r].x + cr[0]; m = fmaxf(m, fabsf(cr[0])); }
-                if (x1ok) { u[r].y = u[r].y + cr[1]; m = fmaxf(m, fabsf(cr[1])); }
-                if (x2ok) { u[r].z = u[r].z + cr[2]; m = fmaxf(m, fabsf(cr[2])); }
-                if (x3ok) { u[r].w = u[r].w + cr[3]; m = fmaxf(m, fabsf(cr[3])); }
-            }
-        }
+        // u += P*E (one branch-free path for every lane, sc_mg_device.h)
+        float m = prolong_apply(pw, g, comp, x, y0, W, H, u);
         if (FLAGS & TB_MAXC) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -304,12 +237,13 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
 constexpr int TB_NW = 8, TB_R = 8;
 
 template <int T, int NW, bool SOR, bool GEN, int FLAGS, int R = TB_R>
-static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom &g, Field E, float *partial, hipStream_t s)
+static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom &g, Field E, float *partial, hipStream_t s,
+                       const ComposeArgs &comp = ComposeArgs())
 {
     constexpr int HXQ = 2 * T <= 4 ? 1 : 2, HX = 4 * HXQ;
     constexpr int RH = NW * R, HY = 2 * T;
     const int blocks = ((Uin.W + (256 - 2 * HX) - 1) / (256 - 2 * HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
-    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS, HXQ>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
+    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS, HXQ>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial, comp);
     return blocks;
 }
 
