@@ -186,6 +186,16 @@ static int validate_images(Instance *I, const void *face, int fc, int fr, int fs
 }
 
 // bbox kernel + read-back of the rectangle into h_rect[4..7] (enqueue only).  mask is a device pointer.
+// Stage mark k of the run's timeline (finish_timing).  An empty stage reuses the previous mark instead of recording an
+// event: every hipEventRecord is a few microseconds of host time in front of the next launch.
+static int tmark(Instance *I, int k, bool empty_stage = false)
+{
+    if (empty_stage && k > 0) { I->tm[k] = I->tm[k - 1]; return SC_OK; }
+    I->tm[k] = I->ev[k];
+    SC_HIP(I, hipEventRecord(I->ev[k], I->stream));
+    return SC_OK;
+}
+
 // With `predicted` the same launch also erodes that ROI (the whole mask stage in one kernel: the erode of a predicted box
 // does not depend on the box being computed); device_clone then skips its own erode launch.
 static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int ms, const Geo *predicted = nullptr)
@@ -203,8 +213,7 @@ static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int 
     launch_mask_bbox(d_mask, mc, mr, ms, I->d_rect, I->stream);
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipMemcpyAsync(I->h_rect + 4, I->d_rect, 4 * sizeof(int), hipMemcpyDeviceToHost, I->stream));
-    SC_HIP(I, hipEventRecord(I->ev[2], I->stream));
-    return SC_OK;
+    return tmark(I, 2);
 }
 
 static int geo_from_rect(Instance *I, const int r[4], int cx, int cy, Geo &g)
@@ -270,9 +279,10 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
     I->mpitch = round_up(g.W, 64);
     if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
     if ((rc = setup_fields(I, g.W, g.H, 3))) return rc;
-    if (!I->erode_done) launch_mask_erode3(d_mask, ms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    const bool eroded = I->erode_done;
+    if (!eroded) launch_mask_erode3(d_mask, ms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
     I->erode_done = false;
-    SC_HIP(I, hipEventRecord(I->ev[4], I->stream));
+    if ((rc = tmark(I, 4, eroded))) return rc;
     int solve_rc = SC_OK;
     for (int pass = 0; pass < passes; ++pass) {
         I->result_in_U1 = false;
@@ -281,21 +291,22 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         I->u_half = I->f_half && !no_hu;
         launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
                           I->stream, I->f_half, I->u_half);
-        if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[5], I->stream));
+        if (pass == passes - 1 && (rc = tmark(I, 5))) return rc;
         I->info.sweep_launches = 0;
         I->spec_post.body_org = body_org; I->spec_post.bstep = bstep;
         I->spec_post.ev_solved = (pass == passes - 1) ? I->ev[6] : nullptr;
+        I->tm[6] = I->ev[6];
         I->spec_post.armed = true; I->spec_post.done = false;
         solve_rc = solve(I);
         I->spec_post.armed = false;
         if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
         if (!I->spec_post.done) {          // otherwise the solver already enqueued it behind its last cycle
-            if (pass == passes - 1) SC_HIP(I, hipEventRecord(I->ev[6], I->stream));
+            if (pass == passes - 1 && (rc = tmark(I, 6))) return rc;
             launch_postprocess(result(I), body_org, bstep, I->stream, I->guard);
         }
         SC_HIP(I, hipGetLastError());
     }
-    SC_HIP(I, hipEventRecord(I->ev[7], I->stream));
+    if ((rc = tmark(I, 7))) return rc;
     return solve_rc;
 }
 
@@ -496,12 +507,12 @@ static void finish_timing(Instance *I, bool staged)
 {
     // ev: 0 start | 1 mask on device | 2 bbox done | 3 ROI images on device | 4 erode done |
     //     5 pre-process done | 6 solve done | 7 post-process done ; ev_k1 = D2H done
-    I->info.ms_h2d = staged ? ev_ms(I->ev[0], I->ev[1]) + ev_ms(I->ev[2], I->ev[3]) : 0.f;
-    I->info.ms_mask = ev_ms(I->ev[1], I->ev[2]) + ev_ms(I->ev[3], I->ev[4]);
-    I->info.ms_pre = ev_ms(I->ev[4], I->ev[5]);
-    I->info.ms_solve = ev_ms(I->ev[5], I->ev[6]);
-    I->info.ms_post = ev_ms(I->ev[6], I->ev[7]);
-    I->info.ms_d2h = staged ? ev_ms(I->ev[7], I->ev_k1) : 0.f;
+    I->info.ms_h2d = staged ? ev_ms(I->tm[0], I->tm[1]) + ev_ms(I->tm[2], I->tm[3]) : 0.f;
+    I->info.ms_mask = ev_ms(I->tm[1], I->tm[2]) + ev_ms(I->tm[3], I->tm[4]);
+    I->info.ms_pre = ev_ms(I->tm[4], I->tm[5]);
+    I->info.ms_solve = ev_ms(I->tm[5], I->tm[6]);
+    I->info.ms_post = ev_ms(I->tm[6], I->tm[7]);
+    I->info.ms_d2h = staged ? ev_ms(I->tm[7], I->ev_k1) : 0.f;
     I->info.ms_device_total = I->info.ms_mask + I->info.ms_pre + I->info.ms_solve + I->info.ms_post;
 }
 
@@ -519,9 +530,9 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     // --- mask to the device, bounding box
     const int dms = round_up(mc, 256);
     if ((rc = ensure(I, I->d_mask, (size_t)dms * mr))) return rc;
-    SC_HIP(I, hipEventRecord(I->ev[0], I->stream));
+    if ((rc = tmark(I, 0))) return rc;
     if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
-    SC_HIP(I, hipEventRecord(I->ev[1], I->stream));
+    if ((rc = tmark(I, 1))) return rc;
     // One attempt on a given geometry: ROI of face/body to the device (the reference uploads both images whole),
     // clone, [check the predicted box], result back into the caller's image.  SC_GUESS_WRONG = the device found a
     // different box than `guess`; nothing has been written anywhere the caller can see.
@@ -533,7 +544,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         if ((r = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return r;
         if ((r = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return r;
         if ((r = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return r;
-        SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
+        if ((r = tmark(I, 3))) return r;
         const int passes = I->opts.reference_warmup ? 2 : 1;
         r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p, dfs,
                          (uint8_t *)I->d_body_roi.p, dfs, g, passes);
@@ -623,12 +634,13 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     SC_HIP(I, hipSetDevice(I->gpu));
     int rc = validate_images(I, d_face, fc, fr, fs, d_body, bc, br, bs, d_mask, mc, mr, ms);
     if (rc) return rc;
-    SC_HIP(I, hipEventRecord(I->ev[0], I->stream));
-    SC_HIP(I, hipEventRecord(I->ev[1], I->stream));
+    if ((rc = tmark(I, 0))) return rc;
+    if ((rc = tmark(I, 1, true))) return rc;       // nothing to upload: images are device resident
     const int passes = I->opts.reference_warmup ? 2 : 1;
     auto attempt = [&](const Geo &g) -> int {
-        SC_HIP(I, hipEventRecord(I->ev[3], I->stream));
-        int r = device_clone(I, d_mask, ms, mr, d_face + (size_t)g.y0 * fs + 3 * g.x0, fs,
+        int r = tmark(I, 3, true);
+        if (r) return r;
+        r = device_clone(I, d_mask, ms, mr, d_face + (size_t)g.y0 * fs + 3 * g.x0, fs,
                              d_body + (size_t)g.lty * bs + 3 * g.ltx, bs, g, passes);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
         SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
