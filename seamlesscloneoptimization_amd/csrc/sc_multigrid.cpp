@@ -493,13 +493,14 @@ int mg_solve(Instance *I)
                 const bool have_prev = nb_prev > 0 && nb_prev <= 16384;   // the launch of the previous cycle wrote the other half
                 // both halves in ONE copy (a second small D2H costs ~5 us on the critical path)
                 if ((rc = ensure_pinned(I, I->h_partial, 2 * sizeof(float) * (size_t)nb_cap))) return rc;
-                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap : ((cyc & 1) * nb_cap + nb)),
-                                         hipMemcpyDeviceToHost, I->stream));
-                if (I->spec_post.armed && o.tol <= 0.f) {      // see Instance::spec_post
-                    if (I->spec_post.ev_solved) SC_HIP(I, hipEventRecord(I->spec_post.ev_solved, I->stream));
+                // the post-process goes in FIRST (see Instance::spec_post): enqueued while the cycle launch is still running it
+                // starts without a gap, and the read-back of the maxima follows it
+                if (I->spec_post.armed && o.tol <= 0.f) {
                     launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
                     I->spec_post.done = true;
                 }
+                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap : ((cyc & 1) * nb_cap + nb)),
+                                         hipMemcpyDeviceToHost, I->stream));
                 SC_HIP(I, hipStreamSynchronize(I->stream));
                 const float *hp = (const float *)I->h_partial.p + (size_t)(cyc & 1) * nb_cap;            // this cycle's half (cyc is already incremented)
                 const float *hq = (const float *)I->h_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;      // the previous cycle's
