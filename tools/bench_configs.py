@@ -59,7 +59,7 @@ def c2(inst):
     """single 512x512 ROI, 3-channel float, 1000 Jacobi sweeps."""
     load_clone_fields(inst, 512)
     unknowns = 510 * 510 * 3
-    for spl, name in [(1, "k_jacobi, 1 sweep/launch"), (4, "k_jacobi_tb<4>, 4 sweeps/launch"), (0, "k_jacobi_tb<8>, 8 sweeps/launch (default)")]:
+    for spl, name in [(1, "k_jacobi_roll<4>, 1 sweep/launch"), (4, "k_jacobi_tb<4>, 4 sweeps/launch"), (0, "k_jacobi_tb<8>, 8 sweeps/launch (default)")]:
         depth = {1: 1, 4: 4, 0: 8}[spl]
         inst.field_sweep(capi.SC_METHOD_JACOBI, 8, 1.0, spl)
         ms = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, 1000 // depth, spl, 1.0) * (1000 // depth)
@@ -88,7 +88,7 @@ def c4(inst):
     """single 4096x4096 ROI, 3-channel, sweep kernels: HBM-bound (604 MB working set)."""
     load_clone_fields(inst, 4096)
     unknowns = 4094 * 4094 * 3
-    for method, mname, spl, depth, name in [(capi.SC_METHOD_JACOBI, "jacobi", 1, 1, "k_jacobi"), (capi.SC_METHOD_JACOBI, "jacobi", -1, 1, "k_jacobi_tb<1>"),
+    for method, mname, spl, depth, name in [(capi.SC_METHOD_JACOBI, "jacobi", 1, 1, "k_jacobi_roll<4>"), (capi.SC_METHOD_JACOBI, "jacobi", -1, 1, "k_jacobi_tb<1>"),
                                             (capi.SC_METHOD_JACOBI, "jacobi", 4, 4, "k_jacobi_tb<4>"), (capi.SC_METHOD_JACOBI, "jacobi", 0, 8, "k_jacobi_tb<8>"),
                                             (capi.SC_METHOD_RBGS, "rbgs", -1, 1, "k_rb_tb<1>"),
                                             (capi.SC_METHOD_RBGS, "rbgs", 0, 2, "k_rb_tb<2>")]:
