@@ -403,7 +403,7 @@ static int vcycle(Instance *I, size_t l, int pre, int post, unsigned no_post = 0
 static bool fused_level0(const sc_solver_opts &o)
 {
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
-    return o.sweeps_per_launch != 1 && pre >= 1 && pre <= 2 && post >= 1 && pre + post <= 4;
+    return o.sweeps_per_launch != 1 && pre >= 1 && pre <= 2 && post >= 1 && post <= 2;   // the forms sc_cycle0.hip instantiates
 }
 
 // Fused solve on the current hierarchy: does level 1 run pre-smoothing only, with the level-0 launch composing its

@@ -388,6 +388,26 @@ def test_wrong_bounding_box_guess_is_repeated_not_written(oracles):
     inst.destroy()
 
 
+def test_other_smoothing_counts_and_the_unfused_path(hip, oracles):
+    """mg_pre / mg_post other than the default 2 + 2, through the fused launches where they exist and the plain kernels
+    otherwise (sweeps_per_launch = 1 forces the latter): same answer within one grey level."""
+    from seamlesscloneoptimization_amd import compare
+    o, _ = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(298, 192, margin=32)
+    want = o.seamless_clone(dst, patch, mask, cx, cy)
+    try:
+        for pre, post in [(1, 1), (2, 1), (1, 2), (3, 3), (1, 3), (3, 1)]:
+            for spl in (0, 1):
+                hip.set_solver(mg_pre=pre, mg_post=post, sweeps_per_launch=spl)
+                body = dst.copy()
+                assert hip.run(patch, body, mask, cx, cy) == 0, (pre, post, spl)
+                s = compare.image_diff_stats(want, body)
+                assert s["max"] <= 1 and s["percent"] < 1.0, (pre, post, spl, compare.format_stats(s))
+    finally:
+        d = hip.default_opts()
+        hip.set_solver(mg_pre=d.mg_pre, mg_post=d.mg_post, sweeps_per_launch=d.sweeps_per_launch)
+
+
 @pytest.mark.parametrize("kind", ["noise", "black_white", "constant"])
 def test_extreme_inputs_stay_within_one(hip, oracles, kind):
     """Inputs that stress the stop rule and the clamp: full-range noise (largest possible right-hand side),
