@@ -403,9 +403,16 @@ def test_other_smoothing_counts_and_the_unfused_path(hip, oracles):
                 assert hip.run(patch, body, mask, cx, cy) == 0, (pre, post, spl)
                 s = compare.image_diff_stats(want, body)
                 assert s["max"] <= 1 and s["percent"] < 1.0, (pre, post, spl, compare.format_stats(s))
+        # residual-based stop rule on top of the multigrid cycles (every cycle judged, float right-hand side)
+        hip.set_solver(mg_pre=2, mg_post=2, sweeps_per_launch=0, tol=3e-5)
+        body = dst.copy()
+        assert hip.run(patch, body, mask, cx, cy) == 0
+        i = hip.info()
+        assert i.converged == 1 and 0.0 < i.rel_residual < 1e-3 and i.sweeps <= 6      # stops on whichever rule is met first
+        assert compare.image_diff_stats(want, body)["max"] <= 1
     finally:
         d = hip.default_opts()
-        hip.set_solver(mg_pre=d.mg_pre, mg_post=d.mg_post, sweeps_per_launch=d.sweeps_per_launch)
+        hip.set_solver(mg_pre=d.mg_pre, mg_post=d.mg_post, sweeps_per_launch=d.sweeps_per_launch, tol=d.tol)
 
 
 @pytest.mark.parametrize("kind", ["noise", "black_white", "constant"])
