@@ -36,6 +36,30 @@ def test_host_selftest_row_copier_and_eigen_solver():
     assert capi.load().sc_hip_selftest_host() == 0
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The Python binding's structures against the C header as a C compiler lays it out: size and the offset of
+    every field of sc_solver_opts, sc_run_info and sc_batch_job (a silent mismatch would corrupt options / results)."""
+    import ctypes as C
+    import subprocess
+    from seamlesscloneoptimization_amd import capi
+    structs = {"sc_solver_opts": capi.SolverOpts, "sc_run_info": capi.RunInfo, "sc_batch_job": capi.BatchJob}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "seamlessclone_hip.h"\nint main(void) {\n' + "\n".join(lines) +
+                   "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(out[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_library_is_gfx950_only():
     from seamlesscloneoptimization_amd import capi
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
