@@ -253,21 +253,22 @@ void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, int *d_re
 // (:1937,:1940,:1944,:1947) only feed gdX/gdY at the last column/row, which no interior
 // divergence reads, so they vanish here.
 // ------------------------------------------------------------------------------------------
-// Tile = 64 x 16 pixels per 256-thread block.  The interleaved u8 rows of both images (tile +
-// 1-px halo, 198 bytes per row) are staged in LDS with aligned dword loads -- the ROI origin has
-// arbitrary byte alignment -- and every pixel then reads its 5-point neighbourhood as LDS bytes;
-// the three float fields are written with lane-contiguous (coalesced) stores.
-constexpr int PP_TW = 64, PP_TH = 16;
-constexpr int PP_ROWB = 3 * (PP_TW + 2) + 6;            // bytes kept per staged row (+ alignment slack)
-constexpr int PP_ROWD = (PP_ROWB + 3) / 4;              // dwords per staged row
+// Tile = 128 x 8 pixels per 256-thread block (lane = 4 consecutive pixels of one row).  The interleaved u8 rows of both
+// images (tile + 1-px halo) are staged in LDS with aligned dword loads -- the ROI origin has arbitrary byte alignment
+// -- together with each row's byte offset of the first pixel.  The staged rows are read back
+// as aligned dwords (6 per image for the centre row, 5 for the rows above / below) and re-aligned with v_alignbyte --
+// the shift is the same for every lane of a row -- instead of one ds_read_u8 per byte (28 LDS reads per 4 pixels
+// instead of 120); bytes become floats with v_cvt_f32_ubyteN.  The eroded mask is 0 / 255, so the blend
+// (1 - m) a + m b is a select (bit-identical: m is exactly 0 or 1).  The fields are written as one 8- or 16-byte store
+// per lane, channel and field.
+constexpr int P4_TW = 128, P4_TH = 8;
+constexpr int P4_ROWD = (3 * (P4_TW + 2) + 6 + 3) / 4 + 1;    // dwords per staged row (+1: the re-alignment reads one ahead)
 
-__device__ __forceinline__ void pp_stage(const uint8_t *__restrict__ img, int step, int W, int H, int tx0, int ty0,
-                                         unsigned (*sm)[PP_ROWD], int *org)
+__device__ __forceinline__ void p4_stage(const uint8_t *__restrict__ img, int step, int W, int H, int tx0, int ty0,
+                                         unsigned (*sm)[P4_ROWD], int *org)
 {
-    // row ry of the tile holds image row ty0-1+ry; its LDS byte 0 is the 4-B aligned address at or
-    // below pixel (tx0-1).  Only dwords that contain a byte of a pixel inside [0,W) are loaded.
-    for (int i = threadIdx.x; i < (PP_TH + 2) * PP_ROWD; i += 256) {
-        const int ry = i / PP_ROWD, k = i - ry * PP_ROWD;
+    for (int i = threadIdx.x; i < (P4_TH + 2) * P4_ROWD; i += 256) {
+        const int ry = i / P4_ROWD, k = i - ry * P4_ROWD;
         const int y = ty0 - 1 + ry;
         unsigned v = 0;
         int a = 0;
@@ -283,78 +284,104 @@ __device__ __forceinline__ void pp_stage(const uint8_t *__restrict__ img, int st
     }
 }
 
-// HF: the right-hand side (an integer in [-1020, 1020]) and the initial field (8-bit values) are stored as float16,
-// exactly, at the same element pitch / plane size inside their buffers; the fused multigrid path reads them that
-// way (sc_cycle0.hip: every launch reads F, the first one U0).
+// bytes of pixels x-1 .. x+4 (N = 5 words) or x-1 .. x+3 and a bit (N = 4 words) of a staged row, as re-aligned words
+template <int N>
+__device__ __forceinline__ void p4_window(const unsigned *row, int word0, int shift, unsigned (&w)[N])
+{
+    unsigned d[N + 1];
+#pragma unroll
+    for (int k = 0; k <= N; ++k) d[k] = row[word0 + k];
+#pragma unroll
+    for (int k = 0; k < N; ++k) w[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], shift);
+}
+
+#define P4_BYTE(w, b) ((float)(((w)[(b) >> 2] >> (8 * ((b) & 3))) & 0xffu))     // -> v_cvt_f32_ubyteN
+
+// HF / HU: the right-hand side (an integer in [-1020, 1020]) / the initial field (8-bit values) are stored as float16,
+// exactly, at the same element pitch / plane size inside their buffers; the fused multigrid path reads them that way
+// (sc_cycle0.hip: every launch reads F, the first one U0).
 template <bool HF, bool HU>
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ body, int bstep,
-                                                    const uint8_t *__restrict__ face, int fstep,
-                                                    const uint8_t *__restrict__ M, int mpitch,
-                                                    Field U0, Field U1, Field F)
+                                                     const uint8_t *__restrict__ face, int fstep,
+                                                     const uint8_t *__restrict__ M, int mpitch,
+                                                     Field U0, Field U1, Field F)
 {
-    __shared__ unsigned sb[PP_TH + 2][PP_ROWD], sp[PP_TH + 2][PP_ROWD];
-    __shared__ int ob[PP_TH + 2], op[PP_TH + 2];
+    __shared__ unsigned sb[P4_TH + 2][P4_ROWD], sp[P4_TH + 2][P4_ROWD];
+    __shared__ int ob[P4_TH + 2], op[P4_TH + 2];
     const int W = U0.W, H = U0.H;
-    const int tx0 = blockIdx.x * PP_TW, ty0 = blockIdx.y * PP_TH;
-    pp_stage(body, bstep, W, H, tx0, ty0, sb, ob);
-    pp_stage(face, fstep, W, H, tx0, ty0, sp, op);
+    const int tx0 = blockIdx.x * P4_TW, ty0 = blockIdx.y * P4_TH;
+    p4_stage(body, bstep, W, H, tx0, ty0, sb, ob);
+    p4_stage(face, fstep, W, H, tx0, ty0, sp, op);
     __syncthreads();
-    const int lx = threadIdx.x & 63, x = tx0 + lx;
-    if (x >= W) return;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = tx0 + 4 * lx, y = ty0 + ly;
+    if (x >= W || y >= H) return;
+    const int ry = ly + 1;
+    // windows: staged column 0 is pixel tx0-1, so pixel x-1 sits at byte org + 12 lx of the row
+    unsigned bc[5], bu[4], bd[4], pc[5], pu[4], pd[4];
+    p4_window<5>(sb[ry], (ob[ry] >> 2) + 3 * lx, ob[ry] & 3, bc);
+    p4_window<4>(sb[ry - 1], (ob[ry - 1] >> 2) + 3 * lx, ob[ry - 1] & 3, bu);
+    p4_window<4>(sb[ry + 1], (ob[ry + 1] >> 2) + 3 * lx, ob[ry + 1] & 3, bd);
+    p4_window<5>(sp[ry], (op[ry] >> 2) + 3 * lx, op[ry] & 3, pc);
+    p4_window<4>(sp[ry - 1], (op[ry - 1] >> 2) + 3 * lx, op[ry - 1] & 3, pu);
+    p4_window<4>(sp[ry + 1], (op[ry + 1] >> 2) + 3 * lx, op[ry + 1] & 3, pd);
+    // eroded mask: pixels x .. x+3 of rows y and y-1 (aligned words: x % 4 == 0) and pixel x-1 of row y
+    const bool yin = (y >= 1) && (y <= H - 2);
+    unsigned mw = 0, muw = 0, mlb = 0;
+    if (yin) {
+        mw = *reinterpret_cast<const unsigned *>(M + (size_t)y * mpitch + x);
+        muw = *reinterpret_cast<const unsigned *>(M + (size_t)(y - 1) * mpitch + x);
+        mlb = x > 0 ? M[(size_t)y * mpitch + x - 1] : 0u;
+    }
+    const size_t o = (size_t)y * U0.pitch + x;
 #pragma unroll
-    for (int k = 0; k < PP_TH / 4; ++k) {
-        const int ly = (threadIdx.x >> 6) + 4 * k, y = ty0 + ly;
-        if (y >= H) break;
-        const int ry = ly + 1;                                  // tile row of y
-        // byte offsets of pixel x in rows y-1, y, y+1 of both staged tiles
-        const uint8_t *bu = reinterpret_cast<const uint8_t *>(sb[ry - 1]) + ob[ry - 1] + 3 * (lx + 1);
-        const uint8_t *b0 = reinterpret_cast<const uint8_t *>(sb[ry]) + ob[ry] + 3 * (lx + 1);
-        const uint8_t *bd = reinterpret_cast<const uint8_t *>(sb[ry + 1]) + ob[ry + 1] + 3 * (lx + 1);
-        const uint8_t *pu = reinterpret_cast<const uint8_t *>(sp[ry - 1]) + op[ry - 1] + 3 * (lx + 1);
-        const uint8_t *p0 = reinterpret_cast<const uint8_t *>(sp[ry]) + op[ry] + 3 * (lx + 1);
-        const uint8_t *pd = reinterpret_cast<const uint8_t *>(sp[ry + 1]) + op[ry + 1] + 3 * (lx + 1);
-        const bool interior = (x >= 1) && (x <= W - 2) && (y >= 1) && (y <= H - 2);
-        float m = 0.f, ml = 0.f, mu = 0.f;
-        if (interior) {
-            const uint8_t *mp = M + (size_t)y * mpitch + x;
-            m = (float)mp[0] * (1.0f / 255.0f);
-            ml = (float)mp[-1] * (1.0f / 255.0f);
-            mu = (float)mp[-mpitch] * (1.0f / 255.0f);
-        }
-        const size_t o = (size_t)y * U0.pitch + x;
+    for (int c = 0; c < 3; ++c) {
+        float uv[4], lv[4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float bc = (float)b0[c];
+        for (int j = 0; j < 4; ++j) {              // pixel x + j = window pixel j + 1
+            const int b = 3 * (j + 1) + c;
+            const float bcc = P4_BYTE(bc, b);
+            uv[j] = (x + j < W) ? bcc : 0.f;
             float lap = 0.0f;
-            if (interior) {
-                const float bl = (float)b0[c - 3], br = (float)b0[c + 3];
-                const float bup = (float)bu[c], bdn = (float)bd[c];
-                const float pc = (float)p0[c], pl = (float)p0[c - 3], pr = (float)p0[c + 3];
-                const float pup = (float)pu[c], pdn = (float)pd[c];
-                const float gx = (1.0f - m) * (br - bc) + m * (pr - pc);
-                const float gxl = (1.0f - ml) * (bc - bl) + ml * (pc - pl);
-                const float gy = (1.0f - m) * (bdn - bc) + m * (pdn - pc);
-                const float gyu = (1.0f - mu) * (bc - bup) + mu * (pc - pup);
+            if (yin && x + j >= 1 && x + j <= W - 2) {
+                const float bl = P4_BYTE(bc, b - 3), br = P4_BYTE(bc, b + 3), bup = P4_BYTE(bu, b), bdn = P4_BYTE(bd, b);
+                const float pcc = P4_BYTE(pc, b), pl = P4_BYTE(pc, b - 3), pr = P4_BYTE(pc, b + 3), pup = P4_BYTE(pu, b), pdn = P4_BYTE(pd, b);
+                const bool m = ((mw >> (8 * j)) & 0xffu) != 0u;
+                const bool ml = (j == 0 ? mlb : ((mw >> (8 * (j - 1))) & 0xffu)) != 0u;
+                const bool mu = ((muw >> (8 * j)) & 0xffu) != 0u;
+                const float gx = m ? (pr - pcc) : (br - bcc);
+                const float gxl = ml ? (pcc - pl) : (bcc - bl);
+                const float gy = m ? (pdn - pcc) : (bdn - bcc);
+                const float gyu = mu ? (pcc - pup) : (bcc - bup);
                 lap = (gx - gxl) + (gy - gyu);
             }
-            // U1 needs no initialisation: every sweep kernel writes its whole output plane, ring included,
-            // before anything reads it
-            // 8-bit values and small integers: exact in float16
-            if (HU) (reinterpret_cast<__half *>(U0.p) + (size_t)c * U0.plane)[o] = __float2half(bc);
-            else U0.at(c)[o] = bc;
-            if (HF) (reinterpret_cast<__half *>(F.p) + (size_t)c * F.plane)[o] = __float2half(lap);
-            else F.at(c)[o] = lap;
+            lv[j] = lap;
+        }
+        if (HU) {
+            const __half2 a = __floats2half2_rn(uv[0], uv[1]), b2 = __floats2half2_rn(uv[2], uv[3]);
+            uint2 pk; pk.x = *reinterpret_cast<const unsigned *>(&a); pk.y = *reinterpret_cast<const unsigned *>(&b2);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(U0.p) + (size_t)c * U0.plane + o) = pk;
+        } else {
+            *reinterpret_cast<float4 *>(U0.at(c) + o) = make_float4(uv[0], uv[1], uv[2], uv[3]);
+        }
+        if (HF) {
+            const __half2 a = __floats2half2_rn(lv[0], lv[1]), b2 = __floats2half2_rn(lv[2], lv[3]);
+            uint2 pk; pk.x = *reinterpret_cast<const unsigned *>(&a); pk.y = *reinterpret_cast<const unsigned *>(&b2);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(F.p) + (size_t)c * F.plane + o) = pk;
+        } else {
+            *reinterpret_cast<float4 *>(F.at(c) + o) = make_float4(lv[0], lv[1], lv[2], lv[3]);
         }
     }
 }
+#undef P4_BYTE
 
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half, bool u_half)
 {
-    dim3 grid((U0.W + PP_TW - 1) / PP_TW, (U0.H + PP_TH - 1) / PP_TH);
-    if (f_half && u_half) hipLaunchKernelGGL((k_preprocess<true, true>), grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
-    else if (f_half) hipLaunchKernelGGL((k_preprocess<true, false>), grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
-    else hipLaunchKernelGGL((k_preprocess<false, false>), grid, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    dim3 g4((U0.W + P4_TW - 1) / P4_TW, (U0.H + P4_TH - 1) / P4_TH);
+    if (f_half && u_half) hipLaunchKernelGGL((k_preprocess<true, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    else if (f_half) hipLaunchKernelGGL((k_preprocess<true, false>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    else hipLaunchKernelGGL((k_preprocess<false, false>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
 }
 
 // float16 right-hand side (left by a multigrid clone) -> float, into another buffer; used only when a
