@@ -45,11 +45,10 @@ __device__ __forceinline__ void tb_load(const float *__restrict__ p, int P, int 
 // TB_ZEROIN treats Uin as all-zero without reading it (first smoothing of a coarse correction).
 constexpr int TB_PROLONG = 1, TB_MAXC = 2, TB_ZEROIN = 4;
 constexpr int TB_TAG = 8;   // no effect on the code: a second symbol for the isolated roofline launches (see k_jacobi)
-constexpr int TB_COMP = 16; // with TB_PROLONG: composed prolongation source (ComposeArgs); not instantiated for this kernel (measured neutral)
 
 template <int T, int NW, int R, bool SOR, bool GEN, int FLAGS, int HXQ = 1>
 __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field F, float omega, MGGeom g, Field E,
-                                                   float *__restrict__ partial, ComposeArgs comp)
+                                                   float *__restrict__ partial)
 {
     constexpr int HY = 2 * T, RH = NW * R, HX = 4 * HXQ;   // HXQ halo lanes per side: 4 columns each
     static_assert(2 * T <= HX, "column halo too small for this depth");
@@ -73,9 +72,10 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
     }
     tb_load<R>(F.at(c), P, H, x, y0, f);
     // coarse values the lane interpolates from (sc_mg_device.h), requested together with U and F
-    constexpr bool PROL = (FLAGS & TB_PROLONG) != 0, COMP = PROL && (FLAGS & TB_COMP) != 0;
+    constexpr bool PROL = (FLAGS & TB_PROLONG) != 0;
     static_assert(!PROL || R % 2 == 0, "the prolongation pairs fine rows");
-    ProlongWindow<R, COMP, GEN> pw;        // a coarse level can have two tail points: LEFT = GEN
+    ProlongWindow<R, false, GEN> pw;       // a coarse level can have two tail points: LEFT = GEN; never composed here
+    const ComposeArgs comp{};              // (composing level 3 into level 2's launch was measured neutral, sc_multigrid.cpp)
     if (PROL) prolong_load(pw, E, comp, c, x, y0);
     const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
     const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
@@ -237,13 +237,12 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
 constexpr int TB_NW = 8, TB_R = 8;
 
 template <int T, int NW, bool SOR, bool GEN, int FLAGS, int R = TB_R>
-static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom &g, Field E, float *partial, hipStream_t s,
-                       const ComposeArgs &comp = ComposeArgs())
+static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom &g, Field E, float *partial, hipStream_t s)
 {
     constexpr int HXQ = 2 * T <= 4 ? 1 : 2, HX = 4 * HXQ;
     constexpr int RH = NW * R, HY = 2 * T;
     const int blocks = ((Uin.W + (256 - 2 * HX) - 1) / (256 - 2 * HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
-    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS, HXQ>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial, comp);
+    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS, HXQ>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
     return blocks;
 }
 
