@@ -106,8 +106,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--roi", type=int, default=2048)
-    ap.add_argument("--batch", type=int, default=4, help="independent images per GPU per step")
-    ap.add_argument("--streams", type=int, default=4, help="concurrent library instances (HIP streams) per GPU")
+    ap.add_argument("--batch", type=int, default=8, help="independent images per GPU per step")
+    ap.add_argument("--streams", type=int, default=8, help="concurrent library instances (HIP streams) per GPU")
     ap.add_argument("--method", default="mg", choices=sorted(METHODS))
     ap.add_argument("--sweeps-per-launch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
