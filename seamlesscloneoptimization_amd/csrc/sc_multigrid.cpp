@@ -37,7 +37,9 @@ static Field level_field(void *p, int W, int H, int C)
 {
     Field f;
     f.p = (float *)p; f.W = W; f.H = H; f.C = C;
-    f.pitch = round_up(W, 64);
+    // at least two pad columns behind the ring: the level-0 kernel reads three coarse columns starting at an even column <= nc
+    // (k_cycle0's prolongation), and must find them where it expects them, not shifted by an address clamp
+    f.pitch = round_up(W + 2, 64);
     f.plane = (size_t)f.pitch * H;
     return f;
 }

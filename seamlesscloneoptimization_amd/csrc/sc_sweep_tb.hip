@@ -96,6 +96,10 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
             }
         }
     }
+    if constexpr (!GEN) {      // regular stencil: keep q = -f/4 (exact), the update is then one fused multiply-add
+#pragma unroll
+        for (int r = 0; r < R; ++r) f[r] = make_float4(-0.25f * f[r].x, -0.25f * f[r].y, -0.25f * f[r].z, -0.25f * f[r].w);
+    }
     // general coefficients (compile away when !GEN)
     const float cw0 = (GEN && x + 0 == g.x.n) ? g.x.cw_last : 1.0f, dx0 = (GEN && x + 0 == g.x.n) ? g.x.d_last : 2.0f;
     const float cw1 = (GEN && x + 1 == g.x.n) ? g.x.cw_last : 1.0f, dx1 = (GEN && x + 1 == g.x.n) ? g.x.d_last : 2.0f;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
     const float rdB2 = GEN ? 1.0f / (dx2 + g.y.d_last) : 0.25f, rdB3 = GEN ? 1.0f / (dx3 + g.y.d_last) : 0.25f;
 #define SC_TB_GS(L, R_, A, B, FF, CW, K)                                                          \
     (GEN ? ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - (FF)) * (ylast ? rdB##K : rdA##K)        \
-         : 0.25f * ((((L) + (R_)) + ((A) + (B))) - (FF)))
+         : __builtin_fmaf((((L) + (R_)) + ((A) + (B))), 0.25f, (FF)))     /* regular stencil: FF is -f/4, one rounding as in 0.25 (S - f) */
     edge[0][wv][0][lane] = u[0];
     edge[0][wv][1][lane] = u[R - 1];
     __syncthreads();
@@ -188,6 +192,10 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
     float4 u[R], f[R];
     tb_load<R>(Uin.at(c), P, H, x, y0, u);
     tb_load<R>(F.at(c), P, H, x, y0, f);
+    // The update 0.25 (S - f) is one fused multiply-add on q = -f/4: S/4 and q are exact (powers of two), so the fma's
+    // single rounding is that of 0.25 (S - f), bit for bit the subtract-then-scale form.
+#pragma unroll
+    for (int r = 0; r < R; ++r) f[r] = make_float4(-0.25f * f[r].x, -0.25f * f[r].y, -0.25f * f[r].z, -0.25f * f[r].w);
     const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
     const bool x2ok = (x + 2 >= 1) && (x + 2 <= W - 2), x3ok = (x + 3 >= 1) && (x + 3 <= W - 2);
     edge[0][wv][0][lane] = u[0];
@@ -207,10 +215,10 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
             const float4 b = (r == R - 1) ? dn : u[r + 1];
             float l = wave_from_left(cur.w), rr = wave_from_right(cur.x);
             float4 nw = cur;
-            const float n0 = 0.25f * (((l + cur.y) + (prev.x + b.x)) - f[r].x);
-            const float n1 = 0.25f * (((cur.x + cur.z) + (prev.y + b.y)) - f[r].y);
-            const float n2 = 0.25f * (((cur.y + cur.w) + (prev.z + b.z)) - f[r].z);
-            const float n3 = 0.25f * (((cur.z + rr) + (prev.w + b.w)) - f[r].w);
+            const float n0 = __builtin_fmaf((l + cur.y) + (prev.x + b.x), 0.25f, f[r].x);      // f holds -f/4, see above
+            const float n1 = __builtin_fmaf((cur.x + cur.z) + (prev.y + b.y), 0.25f, f[r].y);
+            const float n2 = __builtin_fmaf((cur.y + cur.w) + (prev.z + b.z), 0.25f, f[r].z);
+            const float n3 = __builtin_fmaf((cur.z + rr) + (prev.w + b.w), 0.25f, f[r].w);
             nw.x = (yok & x0ok) ? n0 : nw.x;
             nw.y = (yok & x1ok) ? n1 : nw.y;
             nw.z = (yok & x2ok) ? n2 : nw.z;

@@ -124,7 +124,7 @@ def test_sor_to_tolerance_and_auto_omega(hip, oracles):
     hip.set_solver(**{k: getattr(hip.default_opts(), k) for k in ("method", "tol", "max_sweeps", "check_every", "omega")})
 
 
-@pytest.mark.parametrize("W,H", [(77, 53), (130, 41), (64, 64), (298, 192), (300, 9), (400, 12), (517, 400), (260, 203), (1030, 1000)])
+@pytest.mark.parametrize("W,H", [(77, 53), (130, 41), (64, 64), (298, 192), (300, 9), (400, 12), (517, 400), (260, 203), (1030, 1000), (126, 90), (255, 141), (254, 127), (510, 254)])
 def test_multigrid_cycles_follow_the_spec(hip, W, H):
     """k V-cycles on the GPU track the numpy restatement of the same cycle (oracle/mg_np.py), including the
     level the bottom kernel solves directly (spec: sparse LU; GPU: fast diagonalisation in LDS) and thin ROIs
