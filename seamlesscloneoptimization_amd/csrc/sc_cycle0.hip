@@ -19,6 +19,12 @@
 //
 // Workgroups are numbered so that neighbouring tiles share an XCD and its L2 (xcd_tile, sc_wave.h).
 //
+// On level 0 a wave that lies strictly inside the domain (a wave-uniform test, three waves in four of
+// a large ROI) takes forms of the prolongation, the half-steps and the residual without masks, ghost
+// values or validity selects; they produce the same values, operation for operation, as the checked
+// forms.  Weights that are powers of two are applied inside fused multiply-adds (exact products: the
+// single rounding is the one the separate multiply-and-add forms perform).
+//
 // Halo: values at depth d from the region edge are exact for d half-steps; the residual needs one
 // more ring and the restriction a second one, so the exact output tile is the region minus
 // HX = 12 columns (3 float4 lanes) and HY = 2T+2 rows on every side.  HY is even so that coarse
