@@ -94,7 +94,8 @@ typedef struct sc_run_info {
     double rel_residual;            /* last evaluated ||r||/||lap|| (NaN if never evaluated) */
     float  ms_h2d, ms_mask, ms_pre, ms_solve, ms_post, ms_d2h; /* hipEvent times on the instance stream; the multigrid
                                    driver enqueues the post-process directly behind its last cycle, without a mark between
-                                   them: ms_post is then 0 and ms_solve includes it */
+                                   them: ms_post is then 0 and ms_solve includes it.  sc_hip_run_device with
+                                   bSync = false records no marks (each is an event in the stream) and reports 0 */
     float  ms_device_total;         /* mask + pre + solve + post                            */
     int    sweep_launches;          /* launches of the dominant sweep kernel in the last run */
     float  last_update;             /* MULTIGRID: max |coarse-grid correction| of the last checked cycle (grey levels) */

@@ -190,6 +190,7 @@ static int validate_images(Instance *I, const void *face, int fc, int fr, int fs
 // event: every hipEventRecord is a few microseconds of host time in front of the next launch.
 static int tmark(Instance *I, int k, bool empty_stage = false)
 {
+    if (!I->stage_marks) { I->tm[k] = nullptr; return SC_OK; }    // asynchronous device call: nobody reads the timeline
     if (empty_stage && k > 0) { I->tm[k] = I->tm[k - 1]; return SC_OK; }
     I->tm[k] = I->ev[k];
     SC_HIP(I, hipEventRecord(I->ev[k], I->stream));
@@ -532,6 +533,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     // --- mask to the device, bounding box
     const int dms = round_up(mc, 256);
     if ((rc = ensure(I, I->d_mask, (size_t)dms * mr))) return rc;
+    I->stage_marks = true;         // a host-image call is synchronous whatever bSync says: its timeline is always read
     if ((rc = tmark(I, 0))) return rc;
     if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
     if ((rc = tmark(I, 1))) return rc;
@@ -636,6 +638,8 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     SC_HIP(I, hipSetDevice(I->gpu));
     int rc = validate_images(I, d_face, fc, fr, fs, d_body, bc, br, bs, d_mask, mc, mr, ms);
     if (rc) return rc;
+    I->stage_marks = bSync;        // the stage timeline (sc_run_info::ms_*) is filled for synchronous calls only, like the
+                                   // reference's bSync timing: each mark is an event in the stream and a ~5 us bubble behind it
     if ((rc = tmark(I, 0))) return rc;
     if ((rc = tmark(I, 1, true))) return rc;       // nothing to upload: images are device resident
     const int passes = I->opts.reference_warmup ? 2 : 1;
@@ -688,6 +692,7 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     fill_info_geo(I, g);
     remember_rect(I, mc, mr, I->h_rect + 4);
     if (bSync) finish_timing(I, false);
+    else I->info.ms_h2d = I->info.ms_mask = I->info.ms_pre = I->info.ms_solve = I->info.ms_post = I->info.ms_d2h = I->info.ms_device_total = 0.f;
     return rc;
 }
 

@@ -84,6 +84,7 @@ struct Instance {
     unsigned *d_maxcorr = nullptr;
     unsigned *h_maxcorr = nullptr; // pinned
     hipEvent_t ev[8]{};
+    bool stage_marks = true;   // record the stage marks (synchronous calls); tmark() in sc_api.cpp
     hipEvent_t tm[8]{};   // stage marks of the current run: ev[k], or the previous mark where a stage is empty (no record call)
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     size_t arena_bytes = 0;
