@@ -4,12 +4,14 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch: `--batch` (default 4) independent
+A "step" is one pass of the hot path over one batch: `--batch` (default 32) independent
 NORMAL_CLONEs of a 2048x2048 ROI per GPU (mask stage + fused pre-process + Poisson solve to +-1
-grey-level parity + fused post-process), each through the C ABI with its three images already
-resident in HBM (sc_hip_run_device), issued by the library's native pool (sc_hip_pool_run: `--streams`,
-default 4, instances = HIP streams, one C++ worker thread each) so one clone's latency-bound phases
-overlap another's bandwidth-bound ones.  Every rank
+grey-level parity + fused post-process), through the C ABI with their images already resident in HBM,
+issued by the library's native pool (sc_hip_pool_run: `--streams`, default 4, instances = HIP streams,
+one C++ worker thread each) so one clone's latency-bound phases overlap another's bandwidth-bound
+ones.  Each worker takes `--group` (default 8) clones at a time and solves them as ONE field of 3n
+channels (sc_hip_run_device_batch: same-size ROIs share one set of solver launches); `--group 1` is
+one clone per set of launches (sc_hip_run_device).  Every rank
 owns its own synthetic images (weak scaling: independent images, no data-path collective);
 value = total ROI Mpix / max-over-ranks wall time.  Each destination is restored from a pristine
 device copy before every clone (inside the timed region) so no clone starts from an
@@ -106,8 +108,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--roi", type=int, default=2048)
-    ap.add_argument("--batch", type=int, default=8, help="independent images per GPU per step")
-    ap.add_argument("--streams", type=int, default=8, help="concurrent library instances (HIP streams) per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="independent images per GPU per step")
+    ap.add_argument("--streams", type=int, default=4, help="concurrent library instances (HIP streams) per GPU")
+    ap.add_argument("--group", type=int, default=8, help="clones of one ROI size a worker solves as ONE field of 3n channels (sc_hip_run_device_batch)")
     ap.add_argument("--method", default="mg", choices=sorted(METHODS))
     ap.add_argument("--sweeps-per-launch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
@@ -131,7 +134,9 @@ def main():
         opts.update(sweeps_per_launch=args.sweeps_per_launch)
     streams = max(1, min(args.streams, args.batch))
     # % ndev only matters when rehearsing N ranks on a 1-GPU box
-    pool = capi.Pool(comm.local_rank % ndev, streams, **opts)      # native C++ workers, one per HIP stream
+    group = max(1, min(args.group, args.batch))
+    streams = max(1, min(streams, (args.batch + group - 1) // group))
+    pool = capi.Pool(comm.local_rank % ndev, streams, group=group, **opts)      # native C++ workers, one per HIP stream
     inst = pool.instances[0]
 
     W = H = args.roi
@@ -244,9 +249,10 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.batch} independent {W}x{H}-ROI NORMAL_CLONEs per GPU per step on {streams} HIP "
-                               f"streams, 3-channel u8 images resident in HBM, solver={args.method}, "
+                               f"streams, {group} clones per set of solver launches, 3-channel u8 images resident in HBM, solver={args.method}, "
                                f"parity +-1 grey level vs the float64 oracle",
                    "roi": [W, H], "dst": list(dst.shape[:2]), "batch_per_gpu": args.batch, "streams_per_gpu": streams,
+                   "clones_per_launch_group": group,
                    "parallelism": f"{args.gpus} GPU(s) x {args.batch} independent images, no collective",
                    "cycles_or_sweeps": int(info.sweeps)},
         "single_clone_stages_ms": {"mask": round(info.ms_mask, 4), "pre": round(info.ms_pre, 4), "solve": round(info.ms_solve, 4),

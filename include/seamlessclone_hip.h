@@ -193,12 +193,22 @@ typedef struct sc_batch_job {
                                       this device image (body_step * body_rows bytes) before the clone */
     int rc;                        /* out: SC_OK or SC_ERR_* of this job */
 } sc_batch_job;
+/* n device-resident clones on ONE instance.  When their ROIs have the same size (W x H; masks, positions and
+ * images are free) they are solved as one field of 3n channels: every solver launch is n times larger and there is one
+ * set of launches for the group, which is what fills a 256-CU GPU with small and medium ROIs.  Results are the ones the
+ * clones get one by one (channels never interact), except that the stop rule sees the group's largest correction, so
+ * every member gets the cycle count of the slowest.  Other groups run one after the other.  jobs[i].rc receives each
+ * clone's code; the call is asynchronous like sc_hip_run_device(..., false): sync the instance before reading bodies. */
+SC_API int   sc_hip_run_device_batch(void *instance, sc_batch_job *jobs, int n);
 SC_API void *sc_hip_pool_create(int gpu_id, int streams);
 SC_API void  sc_hip_pool_destroy(void *pool);
 SC_API int   sc_hip_pool_size(void *pool);
 SC_API void *sc_hip_pool_instance(void *pool, int k);          /* instance k, e.g. for sc_hip_get_info */
 SC_API int   sc_hip_pool_set_solver(void *pool, const sc_solver_opts *opts);
 SC_API int   sc_hip_pool_run(void *pool, sc_batch_job *jobs, int n, int device_resident);
+/* device-resident batches: every worker takes `group` consecutive jobs at a time and runs them through
+ * sc_hip_run_device_batch (default 1 = one clone per set of launches) */
+SC_API int   sc_hip_pool_set_group(void *pool, int group);
 
 /* isolated timing of the fused level-0 multigrid cycle kernel on the state left by the last
  * MULTIGRID run (values are discarded; bench.py roofline) */

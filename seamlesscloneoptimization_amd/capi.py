@@ -157,6 +157,10 @@ def load():
     L.sc_hip_pool_set_solver.restype = C.c_int
     L.sc_hip_pool_run.argtypes = [C.c_void_p, C.POINTER(BatchJob), C.c_int, C.c_int]
     L.sc_hip_pool_run.restype = C.c_int
+    L.sc_hip_pool_set_group.argtypes = [C.c_void_p, C.c_int]
+    L.sc_hip_pool_set_group.restype = C.c_int
+    L.sc_hip_run_device_batch.argtypes = [C.c_void_p, C.POINTER(BatchJob), C.c_int]
+    L.sc_hip_run_device_batch.restype = C.c_int
     L.sc_hip_time_cycle0.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.sc_hip_time_cycle0.restype = C.c_int
     L.sc_hip_selftest_host.argtypes = []
@@ -354,7 +358,7 @@ class Pool:
     """The library's native batch driver (csrc/sc_pool.cpp): K instances = K HIP streams on one GPU,
     one C++ worker thread each, jobs pulled from a shared counter."""
 
-    def __init__(self, gpu_id: int = 0, streams: int = 4, **solver):
+    def __init__(self, gpu_id: int = 0, streams: int = 4, group: int = 1, **solver):
         self.L = load()
         self.h = self.L.sc_hip_pool_create(int(gpu_id), int(streams))
         if not self.h:
@@ -362,6 +366,9 @@ class Pool:
         self.gpu_id = gpu_id
         self.instances = [_Borrowed(self.L, self.L.sc_hip_pool_instance(self.h, k), gpu_id)
                           for k in range(self.L.sc_hip_pool_size(self.h))]
+        if group != 1 and self.L.sc_hip_pool_set_group(self.h, int(group)) != SC_OK:
+            raise SeamlessCloneError(SC_ERR_BAD_ARG, f"bad group size {group}")
+        self.group = group
         if solver:
             o = self.instances[0].get_solver()
             for k, v in solver.items():

@@ -696,6 +696,110 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     return rc;
 }
 
+// ---- n device-resident clones through ONE set of launches ------------------------------------------------------
+// The solver treats the channels of a field as independent planes, so n clones whose ROIs have the same size are one
+// field of 3n channels: every multigrid launch is n times larger (the coarse levels stop being launch-latency bound,
+// the level-1 grid fills whole rounds of workgroup slots) and there are 27 solver launches for the group instead of
+// 27 n.  Masks, positions and images are per clone (bounding box, erode, pre- and post-process are launched per clone
+// on channel views); the stop rule sees the largest correction of the group.  Groups with different ROI sizes, a
+// failing member or the reference's warm-up option run one after the other through sc_hip_run_device.
+static Field channel_view(const Field &f, int c0, bool half)
+{
+    Field v = f;
+    v.C = 3;
+    v.p = half ? reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(f.p) + (size_t)c0 * f.plane) : f.p + (size_t)c0 * f.plane;
+    return v;
+}
+
+int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
+{
+    Instance *I = get(p);
+    if (!I || !jobs || n <= 0) return SC_ERR_BAD_ARG;
+    I->err.clear();
+    SC_HIP(I, hipSetDevice(I->gpu));
+    auto one_by_one = [&]() -> int {
+        int worst = SC_OK;
+        for (int i = 0; i < n; ++i) {
+            sc_batch_job &j = jobs[i];
+            j.rc = sc_hip_run_device(p, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows, j.body_step,
+                                     j.mask, j.mask_cols, j.mask_rows, j.mask_step, j.centerX, j.centerY, false);
+            if (j.rc != SC_OK && worst == SC_OK) worst = j.rc;
+        }
+        return worst;
+    };
+    for (int i = 0; i < n; ++i) {
+        const sc_batch_job &j = jobs[i];
+        if (j.body_restore) SC_HIP(I, hipMemcpyAsync(j.body, j.body_restore, (size_t)j.body_step * j.body_rows, hipMemcpyDeviceToDevice, I->stream));
+    }
+    if (n == 1 || I->opts.reference_warmup) return one_by_one();
+    for (int i = 0; i < n; ++i) {
+        const sc_batch_job &j = jobs[i];
+        if (validate_images(I, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows, j.body_step,
+                            j.mask, j.mask_cols, j.mask_rows, j.mask_step) != SC_OK) { I->err.clear(); return one_by_one(); }
+    }
+    I->stage_marks = false;
+    // --- bounding boxes of all masks, one read-back
+    int rc;
+    if ((rc = ensure(I, I->d_rects, (size_t)n * 4 * sizeof(int)))) return rc;
+    if ((rc = ensure_pinned(I, I->h_rects, (size_t)n * 8 * sizeof(int)))) return rc;
+    int *h_in = (int *)I->h_rects.p, *h_out = h_in + 4 * n, *d_r = (int *)I->d_rects.p;
+    for (int i = 0; i < n; ++i) {
+        h_in[4 * i + 0] = jobs[i].mask_cols - 1; h_in[4 * i + 1] = 0; h_in[4 * i + 2] = jobs[i].mask_rows - 1; h_in[4 * i + 3] = 0;
+    }
+    SC_HIP(I, hipMemcpyAsync(d_r, h_in, (size_t)n * 4 * sizeof(int), hipMemcpyHostToDevice, I->stream));
+    for (int i = 0; i < n; ++i) launch_mask_bbox(jobs[i].mask, jobs[i].mask_cols, jobs[i].mask_rows, jobs[i].mask_step, d_r + 4 * i, I->stream);
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, I->stream));
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    std::vector<Geo> geo(n);
+    bool same = true;
+    for (int i = 0; i < n && same; ++i) {
+        if (geo_from_rect(I, h_out + 4 * i, jobs[i].centerX, jobs[i].centerY, geo[i]) != SC_OK ||
+            check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) != SC_OK)
+            same = false;
+        else if (geo[i].W != geo[0].W || geo[i].H != geo[0].H)
+            same = false;
+    }
+    if (!same) { I->err.clear(); return one_by_one(); }
+    const Geo &g0 = geo[0];
+    // --- eroded masks, fields of 3n channels, right-hand sides
+    I->mpitch = round_up(g0.W, 64);
+    const size_t mplane = (size_t)I->mpitch * g0.H;
+    if ((rc = ensure(I, I->d_M, mplane * n))) return rc;
+    if ((rc = setup_fields(I, g0.W, g0.H, 3 * n))) return rc;
+    for (int i = 0; i < n; ++i)
+        launch_mask_erode3(jobs[i].mask, jobs[i].mask_step, jobs[i].mask_rows, geo[i], (uint8_t *)I->d_M.p + mplane * i, I->mpitch, I->stream);
+    I->erode_done = false;
+    I->result_in_U1 = false;
+    I->f_half = mg_reads_half_rhs(I);
+    static const int no_hu = [] { const char *e = getenv("SC_NO_HALF_U"); return e ? atoi(e) : 0; }();
+    I->u_half = I->f_half && !no_hu;
+    for (int i = 0; i < n; ++i) {
+        const sc_batch_job &j = jobs[i];
+        launch_preprocess(j.body + (size_t)geo[i].lty * j.body_step + 3 * geo[i].ltx, j.body_step,
+                          j.face + (size_t)geo[i].y0 * j.face_step + 3 * geo[i].x0, j.face_step,
+                          (const uint8_t *)I->d_M.p + mplane * i, I->mpitch, channel_view(I->U0, 3 * i, I->u_half),
+                          channel_view(I->U1, 3 * i, false), channel_view(I->F, 3 * i, I->f_half), I->stream, I->f_half, I->u_half);
+    }
+    SC_HIP(I, hipGetLastError());
+    // --- one solve for the group, results spliced per clone
+    I->info.sweep_launches = 0;
+    I->spec_post.armed = false; I->spec_post.done = false;
+    I->guard = RectGuard();
+    const int solve_rc = solve(I);
+    if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
+    for (int i = 0; i < n; ++i) {
+        sc_batch_job &j = jobs[i];
+        launch_postprocess(channel_view(result(I), 3 * i, false), j.body + (size_t)geo[i].lty * j.body_step + 3 * geo[i].ltx, j.body_step, I->stream);
+        j.rc = solve_rc;
+    }
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    fill_info_geo(I, g0);
+    I->info.ms_h2d = I->info.ms_mask = I->info.ms_pre = I->info.ms_solve = I->info.ms_post = I->info.ms_d2h = I->info.ms_device_total = 0.f;
+    return solve_rc;
+}
+
 int sc_hip_selftest_host(void)
 {
     // 1: row copier -- strided copy of an awkward shape through the parked helpers, twice (reuse of the pool)

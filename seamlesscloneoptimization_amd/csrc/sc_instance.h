@@ -76,6 +76,7 @@ struct Instance {
     std::vector<FD1> fd_cache;   // recent 1-D decompositions (a geometry seen before costs no eigen-solve)
     size_t fd_cache_next = 0;
     // reductions / mailboxes
+    DevBuf d_rects, h_rects;     // bounding boxes of a group of clones (sc_hip_run_device_batch): device, pinned
     int *d_rect = nullptr;
     int *h_rect = nullptr;       // pinned
     double *d_partials = nullptr;

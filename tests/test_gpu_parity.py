@@ -557,6 +557,78 @@ def test_native_pool_matches_sequential(oracles):
     pool.close()
 
 
+def test_grouped_clones_share_one_set_of_launches(oracles):
+    """sc_hip_run_device_batch / pool groups: clones whose ROIs have one size are solved as one field of 3n channels
+    (different masks, positions and images); every member is within one grey level of the oracle and equal to the
+    clone run alone whenever both took the same number of cycles.  A group of mixed sizes and a group with a failing
+    member fall back to one clone after the other."""
+    from seamlesscloneoptimization_amd import capi
+    o, _ = oracles
+    W, H = 333, 207
+    items = []
+    for k in range(5):
+        dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=70 + k, seed_patch=80 + k, margin=48)
+        if k == 1:                                           # elliptic mask touching the same bounding box
+            yy, xx = np.mgrid[0:H + 2, 0:W + 2]
+            mask = np.where(((yy - (H + 1) / 2) / (H / 2)) ** 2 + ((xx - (W + 1) / 2) / (W / 2)) ** 2 <= 1.0, 255, 0).astype(np.uint8)
+        if k == 2:                                           # same size, holes in the mask
+            mask = mask.copy(); mask[40:60, 100:180] = 0
+        items.append((dst, patch, mask, cx + 3 * k - 6, cy + 2 * k - 4))
+    seq = capi.Instance(0)
+    alone, cycles = [], []
+    for dst, patch, mask, cx, cy in items:
+        b = dst.copy(); seq.run(patch, b, mask, cx, cy); alone.append(b); cycles.append(seq.info().sweeps)
+    pool = capi.Pool(0, 2, group=3)
+    inst = pool.instances[0]
+
+    def device_jobs(its):
+        jobs = pool.make_jobs(len(its)); keep = []
+        for j, (dst, patch, mask, cx, cy) in zip(jobs, its):
+            f, b0, b, m = inst.to_device(patch), inst.to_device(dst), inst.to_device(np.zeros_like(dst)), inst.to_device(mask)
+            keep.append((f, b0, b, m, dst.shape))
+            j.face, j.face_cols, j.face_rows, j.face_step = f, patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+            j.body, j.body_cols, j.body_rows, j.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+            j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
+            j.centerX, j.centerY, j.body_restore = cx, cy, b0
+        return jobs, keep
+
+    jobs, keep = device_jobs(items)
+    for _ in range(2):                                       # twice: the bodies are restored from b0 every time
+        pool.run(jobs, device_resident=True)
+        group_cycles = max(i.info().sweeps for i in pool.instances)
+        for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
+            got = inst.from_device(b, shape)
+            want = o.seamless_clone(it[0], it[1], it[2], it[3], it[4])
+            assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1, k
+            if cycles[k] == group_cycles:
+                assert np.array_equal(got, alone[k]), k
+    # the C entry point itself, on one instance: all five in one group
+    rc = inst.L.sc_hip_run_device_batch(inst.h, jobs, len(jobs))
+    inst.sync()
+    assert rc == 0 and all(j.rc == 0 for j in jobs)
+    assert inst.info().W == W and inst.info().H == H
+    for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
+        want = o.seamless_clone(it[0], it[1], it[2], it[3], it[4])
+        assert np.abs(inst.from_device(b, shape).astype(np.int16) - want.astype(np.int16)).max() <= 1, k
+    # mixed sizes -> one after the other, same answers as alone
+    other = o.synth_inputs(120, 90, seed_dst=5, seed_patch=6, margin=32)
+    b_other = other[0].copy(); seq.run(other[1], b_other, other[2], other[3], other[4])
+    jobs2, keep2 = device_jobs([items[0], other, items[3]])
+    pool.run(jobs2, device_resident=True)
+    for (f, b0, b, m, shape), w in zip(keep2, (alone[0], b_other, alone[3])):
+        assert np.array_equal(inst.from_device(b, shape), w)
+    # a member whose ROI leaves its image fails alone
+    jobs[1].centerX = 1
+    with pytest.raises(capi.SeamlessCloneError) as e:
+        pool.run(jobs, device_resident=True)
+    assert e.value.code == capi.SC_ERR_ROI_OOB and jobs[1].rc == capi.SC_ERR_ROI_OOB and jobs[0].rc == 0 and jobs[4].rc == 0
+    for kp in (keep, keep2):
+        for f, b0, b, m, _ in kp:
+            for p in (f, b0, b, m):
+                inst.free(p)
+    pool.close(); seq.destroy()
+
+
 def test_error_codes(hip, oracles):
     from seamlesscloneoptimization_amd import capi
     o, _ = oracles

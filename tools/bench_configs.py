@@ -126,6 +126,33 @@ def c5(inst):
             for key in ("f", "b0", "b", "m"): pool.instances[0].free(j[key])
         pool.close()
 
+def c5g(inst):
+    """the same 64 clones through the native pool, `group` clones per set of solver launches (sc_hip_run_device_batch)."""
+    from seamlesscloneoptimization_amd import capi
+    hosts = [synth(1024, 100 + k) for k in range(8)]
+    for streams, group in ((8, 1), (8, 4), (8, 8), (4, 16)):
+        pool = capi.Pool(0, streams, group=group)
+        owner = pool.instances[0]
+        cj = pool.make_jobs(64); keep = []
+        for k in range(64):
+            dst, patch, mask, cx, cy = hosts[k % 8]
+            f, b0, b, m = owner.to_device(patch), owner.to_device(dst), owner.to_device(dst), owner.to_device(mask)
+            keep.append((f, b0, b, m))
+            c = cj[k]
+            c.face, c.face_cols, c.face_rows, c.face_step = f, patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+            c.body, c.body_cols, c.body_rows, c.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+            c.mask, c.mask_cols, c.mask_rows, c.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
+            c.centerX, c.centerY, c.body_restore = cx, cy, b0
+        pool.run(cj, device_resident=True)
+        t0 = time.perf_counter()
+        pool.run(cj, device_resident=True)
+        dt = time.perf_counter() - t0
+        emit({"config": "c5 64 independent 1024x1024 clones on ONE GPU, native pool", "streams": streams, "clones_per_launch_group": group,
+              "ms_total": round(dt * 1e3, 3), "ms_per_clone": round(dt / 64 * 1e3, 4), "Mpix/s": round(64 * 1024 * 1024 / dt / 1e6, 1)})
+        for kp in keep:
+            for ptr in kp: owner.free(ptr)
+        pool.close()
+
 def c3s(inst):
     """flagship 2048^2 clone with 1..4 concurrent streams (independent images)."""
     from seamlesscloneoptimization_amd.batch import StreamPool
@@ -155,5 +182,5 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]
     inst = capi.Instance(0)
     for w in which:
-        {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5, "c3s": c3s, "host": host}[w](inst)
+        {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5, "c5g": c5g, "c3s": c3s, "host": host}[w](inst)
     inst.destroy()
