@@ -740,21 +740,31 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     I->stage_marks = false;
     // --- bounding boxes of all masks, one read-back
     int rc;
-    if ((rc = ensure(I, I->d_rects, (size_t)n * 4 * sizeof(int)))) return rc;
-    if ((rc = ensure_pinned(I, I->h_rects, (size_t)n * 8 * sizeof(int)))) return rc;
-    int *h_in = (int *)I->h_rects.p, *h_out = h_in + 4 * n, *d_r = (int *)I->d_rects.p;
+    // one rectangle per 128-byte line: the scans of different masks must not share a line for their atomics (eight
+    // rectangles in one line: 162 us for the group's scan instead of 20)
+    constexpr int RS = 32;
+    if ((rc = ensure(I, I->d_rects, (size_t)n * RS * sizeof(int)))) return rc;
+    if ((rc = ensure_pinned(I, I->h_rects, (size_t)n * 2 * RS * sizeof(int)))) return rc;
+    int *h_in = (int *)I->h_rects.p, *h_out = h_in + RS * n, *d_r = (int *)I->d_rects.p;
+    memset(h_in, 0, (size_t)n * RS * sizeof(int));
     for (int i = 0; i < n; ++i) {
-        h_in[4 * i + 0] = jobs[i].mask_cols - 1; h_in[4 * i + 1] = 0; h_in[4 * i + 2] = jobs[i].mask_rows - 1; h_in[4 * i + 3] = 0;
+        h_in[RS * i + 0] = jobs[i].mask_cols - 1; h_in[RS * i + 1] = 0; h_in[RS * i + 2] = jobs[i].mask_rows - 1; h_in[RS * i + 3] = 0;
     }
-    SC_HIP(I, hipMemcpyAsync(d_r, h_in, (size_t)n * 4 * sizeof(int), hipMemcpyHostToDevice, I->stream));
-    for (int i = 0; i < n; ++i) launch_mask_bbox(jobs[i].mask, jobs[i].mask_cols, jobs[i].mask_rows, jobs[i].mask_step, d_r + 4 * i, I->stream);
+    SC_HIP(I, hipMemcpyAsync(d_r, h_in, (size_t)n * RS * sizeof(int), hipMemcpyHostToDevice, I->stream));
+    std::vector<MaskJob> mj(n);
+    for (int i = 0; i < n; ++i) {
+        mj[i] = MaskJob{};
+        mj[i].mask = jobs[i].mask; mj[i].mw = jobs[i].mask_cols; mj[i].mh = jobs[i].mask_rows; mj[i].mstep = jobs[i].mask_step;
+        mj[i].rect = d_r + RS * i;
+    }
+    launch_mask_bbox_group(mj.data(), n, I->stream);
     SC_HIP(I, hipGetLastError());
-    SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToHost, I->stream));
+    SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * RS * sizeof(int), hipMemcpyDeviceToHost, I->stream));
     SC_HIP(I, hipStreamSynchronize(I->stream));
     std::vector<Geo> geo(n);
     bool same = true;
     for (int i = 0; i < n && same; ++i) {
-        if (geo_from_rect(I, h_out + 4 * i, jobs[i].centerX, jobs[i].centerY, geo[i]) != SC_OK ||
+        if (geo_from_rect(I, h_out + RS * i, jobs[i].centerX, jobs[i].centerY, geo[i]) != SC_OK ||
             check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) != SC_OK)
             same = false;
         else if (geo[i].W != geo[0].W || geo[i].H != geo[0].H)
@@ -767,8 +777,8 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     const size_t mplane = (size_t)I->mpitch * g0.H;
     if ((rc = ensure(I, I->d_M, mplane * n))) return rc;
     if ((rc = setup_fields(I, g0.W, g0.H, 3 * n))) return rc;
-    for (int i = 0; i < n; ++i)
-        launch_mask_erode3(jobs[i].mask, jobs[i].mask_step, jobs[i].mask_rows, geo[i], (uint8_t *)I->d_M.p + mplane * i, I->mpitch, I->stream);
+    for (int i = 0; i < n; ++i) { mj[i].g = geo[i]; mj[i].M = (uint8_t *)I->d_M.p + mplane * i; mj[i].mpitch = I->mpitch; }
+    launch_mask_erode3_group(mj.data(), n, I->stream);
     I->erode_done = false;
     I->result_in_U1 = false;
     I->f_half = mg_reads_half_rhs(I);
@@ -784,14 +794,21 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     SC_HIP(I, hipGetLastError());
     // --- one solve for the group, results spliced per clone
     I->info.sweep_launches = 0;
-    I->spec_post.armed = false; I->spec_post.done = false;
     I->guard = RectGuard();
+    I->spec_post.group.clear();
+    for (int i = 0; i < n; ++i)
+        I->spec_post.group.push_back({ jobs[i].body + (size_t)geo[i].lty * jobs[i].body_step + 3 * geo[i].ltx, jobs[i].body_step });
+    I->spec_post.ev_solved = nullptr;
+    I->spec_post.armed = true; I->spec_post.done = false;     // the solver enqueues the splices behind the cycle it expects to accept
     const int solve_rc = solve(I);
+    I->spec_post.armed = false;
+    const bool spliced = I->spec_post.done;
+    const std::vector<Instance::SpecTarget> targets = I->spec_post.group;
+    I->spec_post.group.clear();
     if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
     for (int i = 0; i < n; ++i) {
-        sc_batch_job &j = jobs[i];
-        launch_postprocess(channel_view(result(I), 3 * i, false), j.body + (size_t)geo[i].lty * j.body_step + 3 * geo[i].ltx, j.body_step, I->stream);
-        j.rc = solve_rc;
+        if (!spliced) launch_postprocess(channel_view(result(I), 3 * i, false), targets[i].body_org, targets[i].bstep, I->stream);
+        jobs[i].rc = solve_rc;
     }
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));

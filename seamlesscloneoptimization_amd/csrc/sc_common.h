@@ -31,9 +31,22 @@ struct Img8 {
     const uint8_t *p; int cols, rows, step;
 };
 
+// mask stage of one member of a group of clones (launch_mask_*_group): the scan uses mask/mw/mh/mstep/rect, the erode
+// additionally g/M/mpitch (mask_bytes is filled in by the launcher)
+struct MaskJob {
+    const uint8_t *mask; int mw, mh, mstep;
+    int *rect;
+    size_t mask_bytes;
+    Geo g;
+    uint8_t *M; int mpitch;
+};
+struct MaskJobs { enum { MAX = 16 }; MaskJob j[MAX]; };     // by value in the kernel arguments
+
 // ---------------------------------------------------------------- kernel launchers (sc_kernels.hip)
 void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s);
 void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, uint8_t *M, int mpitch, hipStream_t s);
+void launch_mask_bbox_group(const MaskJob *jobs, int n, hipStream_t s);
+void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s);
 // bounding box of the whole mask + erode of the (predicted) ROI g in one launch
 void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, Geo g, uint8_t *M, int mpitch, hipStream_t s);
 // body_org: pointer to the pixel that corresponds to ROI (0,0); face_org likewise (patch + offset)
@@ -53,6 +66,7 @@ int  tb_max_depth(int method);
 int  tb_hard_max_depth(int method);
 long tb_big_side();
 int  tb_gen_rows(int W, int H, int C, int hx, int hy);   // band height (rows per lane) of a coarse-level launch
+int  tb_gen_rows_deep(int W, int H, int C, int hx, int hy);   // the same for launches of depth 3 or 4: 4 or 6
 struct MGGeom;
 struct ComposeArgs;
 constexpr int TBM_PLAIN = 0, TBM_PROLONG = 1, TBM_ZEROIN = 4;   // mode of launch_rb_tb_gen

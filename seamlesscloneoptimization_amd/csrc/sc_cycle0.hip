@@ -606,13 +606,12 @@ static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s)
 {
     if (sweeps < 1 || sweeps > 4) return false;
-    int R = tb_gen_rows(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
+    const int R = sweeps >= 3 ? tb_gen_rows_deep(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2) : tb_gen_rows(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
     if (sweeps == 1) { R == 8 ? launch_cn<1, 8>(Uout, F, Fc, g, s) : R == 6 ? launch_cn<1, 6>(Uout, F, Fc, g, s) : launch_cn<1, 4>(Uout, F, Fc, g, s); }
     else if (sweeps == 2) { R == 8 ? launch_cn<2, 8>(Uout, F, Fc, g, s) : R == 6 ? launch_cn<2, 6>(Uout, F, Fc, g, s) : launch_cn<2, 4>(Uout, F, Fc, g, s); }
     else {
-        // deeper pre-smoothing (a level that gets no post-smoothing: 3 or 4 sweeps): 8-row bands spill with the general
-        // coefficients (23 us against 20.6 us for level 1 of a 2048^2 ROI), 6-row bands keep 28 of 48 rows at depth 4
-        if (R == 8) R = 6;
+        // deeper pre-smoothing (a level that gets no post-smoothing: 3 or 4 sweeps): 4- or 6-row bands (tb_gen_rows_deep);
+        // 8-row bands spill with the general coefficients (23 us against 20.6 us for level 1 of a 2048^2 ROI)
         if (sweeps == 3) { R == 6 ? launch_cn<3, 6>(Uout, F, Fc, g, s) : launch_cn<3, 4>(Uout, F, Fc, g, s); }
         else             { R == 6 ? launch_cn<4, 6>(Uout, F, Fc, g, s) : launch_cn<4, 4>(Uout, F, Fc, g, s); }
     }

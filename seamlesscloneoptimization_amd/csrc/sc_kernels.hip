@@ -245,6 +245,56 @@ void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, int *d_re
                        M, mpitch, er_nx, er_n);
 }
 
+// The mask stage of a GROUP of clones (sc_hip_run_device_batch): both kernels are latency bound (a few hundred
+// workgroups each), so the group's scans, and after the read-back its erodes, go out as one launch each; blockIdx.z
+// picks the clone, whose parameters travel in the kernel arguments.
+__global__ __launch_bounds__(256) void k_mask_bbox_group(MaskJobs t)
+{
+    const MaskJob &j = t.j[blockIdx.z];
+    const int chunks = (j.mw + 15 + 15) / 16;
+    if ((int)blockIdx.x >= (chunks + 63) / 64 || (int)blockIdx.y >= (j.mh + 4 * BB_ROWS - 1) / (4 * BB_ROWS)) return;   // block-uniform
+    mask_bbox_block(j.mask, j.mw, j.mh, j.mstep, j.rect, blockIdx.x, blockIdx.y);
+}
+
+__global__ __launch_bounds__(256) void k_mask_erode3_group(MaskJobs t)
+{
+    const MaskJob &j = t.j[blockIdx.z];
+    if ((int)blockIdx.x >= ((j.g.W + 3) / 4 + 63) / 64 || (int)blockIdx.y >= (j.g.H + 4 * ER_STRIP - 1) / (4 * ER_STRIP)) return;
+    mask_erode3_block(j.mask, j.mstep, j.mask_bytes, j.g, j.M, j.mpitch, blockIdx.x, blockIdx.y);
+}
+
+void launch_mask_bbox_group(const MaskJob *jobs, int n, hipStream_t s)
+{
+    for (int i0 = 0; i0 < n; i0 += MaskJobs::MAX) {
+        MaskJobs t{};
+        const int cnt = std::min(n - i0, (int)MaskJobs::MAX);
+        int gx = 1, gy = 1;
+        for (int i = 0; i < cnt; ++i) {
+            t.j[i] = jobs[i0 + i];
+            gx = std::max(gx, ((t.j[i].mw + 15 + 15) / 16 + 63) / 64);
+            gy = std::max(gy, (t.j[i].mh + 4 * BB_ROWS - 1) / (4 * BB_ROWS));
+        }
+        hipLaunchKernelGGL(k_mask_bbox_group, dim3(gx, gy, cnt), dim3(256), 0, s, t);
+    }
+}
+
+void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s)
+{
+    for (int i0 = 0; i0 < n; i0 += MaskJobs::MAX) {
+        MaskJobs t{};
+        const int cnt = std::min(n - i0, (int)MaskJobs::MAX);
+        int gx = 1, gy = 1;
+        for (int i = 0; i < cnt; ++i) {
+            t.j[i] = jobs[i0 + i];
+            // last row may be shorter than the step: count only what the caller guarantees
+            t.j[i].mask_bytes = (size_t)t.j[i].mstep * (t.j[i].mh - 1) + (size_t)(t.j[i].g.x0 + t.j[i].g.W + 1);
+            gx = std::max(gx, ((t.j[i].g.W + 3) / 4 + 63) / 64);
+            gy = std::max(gy, (t.j[i].g.H + 4 * ER_STRIP - 1) / (4 * ER_STRIP));
+        }
+        hipLaunchKernelGGL(k_mask_erode3_group, dim3(gx, gy, cnt), dim3(256), 0, s, t);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fused pre-process: ROI crop + u8->f32 + forward-difference gradients of dst ROI and patch +
 // mask blend + backward-difference divergence  (seamlessClone_imp.cpp:1920-2018 in one pass,

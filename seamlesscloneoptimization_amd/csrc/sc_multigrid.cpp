@@ -498,7 +498,15 @@ int mg_solve(Instance *I)
                 // the post-process goes in FIRST (see Instance::spec_post): enqueued while the cycle launch is still running it
                 // starts without a gap, and the read-back of the maxima follows it
                 if (I->spec_post.armed && o.tol <= 0.f) {
-                    launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
+                    if (I->spec_post.group.empty()) {
+                        launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
+                    } else {
+                        const Field U = result(I);
+                        for (size_t k = 0; k < I->spec_post.group.size(); ++k) {
+                            Field v = U; v.C = 3; v.p = U.p + 3 * k * U.plane;
+                            launch_postprocess(v, I->spec_post.group[k].body_org, I->spec_post.group[k].bstep, I->stream, I->guard);
+                        }
+                    }
                     I->spec_post.done = true;
                 }
                 SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap : ((cyc & 1) * nb_cap + nb)),

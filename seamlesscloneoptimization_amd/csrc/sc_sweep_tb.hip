@@ -319,6 +319,19 @@ int tb_gen_rows(int W, int H, int C, int hx, int hy)
     return 4;
 }
 
+// The same choice for launches of depth 3 or 4 (a level that does all its smoothing before the restriction): their halo
+// is 2T + 2 = 8 or 10 rows, so 4-row bands keep only 16 or 12 of 32 rows and are worth it only while they make the grid
+// fit one round; beyond that 6-row bands (28 of 48 at depth 4) are the efficient form -- 8-row bands spill with the
+// general coefficients.  Measured on level 1 of a group of eight 2048^2 clones: 141 us with 4 rows, 103 us with 6.
+int tb_gen_rows_deep(int W, int H, int C, int hx, int hy)
+{
+    const int R = tb_gen_rows(W, H, C, hx, hy);
+    if (R != 4) return 6;
+    const int nbx = (W + (256 - 2 * hx) - 1) / (256 - 2 * hx), rows = 8 * 4 - 2 * hy;
+    static const int forced = [] { const char *e = getenv("SC_GEN_R"); return e ? atoi(e) : 0; }();
+    return (forced == 4 || nbx * ((H + rows - 1) / rows) * C <= 512) ? 4 : 6;
+}
+
 // coarse multigrid levels: Gauss-Seidel only (omega = 1).  mode: 0 plain, TB_ZEROIN, TB_PROLONG (with E).
 bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s)
 {

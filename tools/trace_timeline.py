@@ -4,7 +4,7 @@ import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a clone starts at k_mask_bbox
-starts = [i for i, r in enumerate(rows) if "k_mask_bbox" in r["Kernel_Name"] or "k_mask_stage" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "k_mask_bbox" in r["Kernel_Name"] or "k_mask_stage" in r["Kernel_Name"]]   # k_mask_bbox_group too
 a = starts[-1]
 b = len(rows)
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0
