@@ -311,7 +311,7 @@ void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s)
 // instead of 120); bytes become floats with v_cvt_f32_ubyteN.  The eroded mask is 0 / 255, so the blend
 // (1 - m) a + m b is a select (bit-identical: m is exactly 0 or 1).  The fields are written as one 8- or 16-byte store
 // per lane, channel and field.
-constexpr int P4_TW = 128, P4_TH = 8;
+constexpr int P4_TW = 128, P4_RPT = 2, P4_TH = 8 * P4_RPT;     // tile: 32 lanes x 4 pixels wide, 8 thread rows x P4_RPT rows high
 constexpr int P4_ROWD = (3 * (P4_TW + 2) + 6 + 3) / 4 + 1;    // dwords per staged row (+1: the re-alignment reads one ahead)
 
 __device__ __forceinline__ void p4_stage(const uint8_t *__restrict__ img, int step, int W, int H, int tx0, int ty0,
@@ -363,9 +363,14 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
     p4_stage(body, bstep, W, H, tx0, ty0, sb, ob);
     p4_stage(face, fstep, W, H, tx0, ty0, sp, op);
     __syncthreads();
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x = tx0 + 4 * lx, y = ty0 + ly;
-    if (x >= W || y >= H) return;
+    const int lx = threadIdx.x & 31;
+    const int x = tx0 + 4 * lx;
+    if (x >= W) return;
+#pragma unroll 1
+    for (int rr = 0; rr < P4_RPT; ++rr) {
+    const int ly = (threadIdx.x >> 5) + 8 * rr;
+    const int y = ty0 + ly;
+    if (y >= H) break;
     const int ry = ly + 1;
     // windows: staged column 0 is pixel tx0-1, so pixel x-1 sits at byte org + 12 lx of the row
     unsigned bc[5], bu[4], bd[4], pc[5], pu[4], pd[4];
@@ -421,6 +426,7 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
         } else {
             *reinterpret_cast<float4 *>(F.at(c) + o) = make_float4(lv[0], lv[1], lv[2], lv[3]);
         }
+    }
     }
 }
 #undef P4_BYTE
