@@ -218,7 +218,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     const int xw = bx * (256 - 2 * C0_HX) - C0_HX;             // column of lane 0
     // (Level 0 only.  The same split on the coarse levels -- regular stencil for waves clear of the last column / row --
     // was measured and changes nothing there: 20.6 vs 20.8 us on level 1 of a 2048^2 ROI; those launches are bounded by the
-    // latency of one workgroup, not by instruction count.)
+    // latency of one workgroup, not by instruction count; the many-round launches of a group of clones do not gain either:
+    // 104.6 vs 103 us on level 1 of eight 2048^2 clones, level 2 and a single 8192^2 clone get slower.)
     bool inner = !GEN && (xw >= 4) && (xw + 255 <= W - 2) && (y0 >= 1) && (y0 + R - 1 <= H - 2);
     if (PRO) {
         const int Jb = (y0 >> 1) - 1;
