@@ -172,6 +172,13 @@ def main():
     out = inst.from_device(jobs[0]["b"], dst.shape)
     if not all(i.info().converged for i in pool.instances) or np.array_equal(out, dst):
         sys.exit("bench.py: the clone did not converge / did not modify the destination")
+    # the last image of the batch once more, alone: what the pool (groups, several streams) wrote must be the clone's result
+    jl = jobs[-1]
+    pooled_last = inst.from_device(jl["b"], jl["host"][0].shape)
+    clone(inst, jl, sync=True)
+    alone_last = inst.from_device(jl["b"], jl["host"][0].shape)
+    if int(np.abs(pooled_last.astype(np.int16) - alone_last.astype(np.int16)).max()) > 1:
+        sys.exit("bench.py: a pooled clone differs from the same clone run alone by more than one grey level")
     # one synchronous clone alone on the GPU for the per-stage hipEvent breakdown (the first call re-sizes the instance
     # from a group's 3n channels to 3; the second is the steady state)
     clone(inst, jobs[0], sync=True)
