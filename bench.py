@@ -165,6 +165,7 @@ def main():
         for i in pool.instances:
             i.sync()
 
+    step()                                   # set-up, not a warm-up step: sizes every instance's device arena for this ROI (hipMalloc)
     for _ in range(args.warmup):
         step()
     elapsed = timed_region(comm, sync_all, lambda: [step() for _ in range(args.steps)])
