@@ -278,6 +278,14 @@ class Instance:
                                       d_mask, mshape[1], mshape[0], mshape[1], int(cx), int(cy), bool(sync))
         return self._check(rc, allow=(SC_ERR_NOT_CONVERGED,) if allow_not_converged else ())
 
+    def run_device_batch(self, jobs, sync=True):
+        """jobs: a BatchJob array (Pool.make_jobs) of device-resident clones.  Members whose ROIs have one size are solved
+        as one field of 3n channels through one set of launches (sc_hip_run_device_batch); per-member codes in jobs[i].rc."""
+        rc = self.L.sc_hip_run_device_batch(self.h, jobs, len(jobs))
+        if sync:
+            self.sync()
+        return self._check(rc, allow=(SC_ERR_NOT_CONVERGED,))
+
     # ---- stage hooks
     def mask_stage(self, mask, cx, cy):
         m = _img(mask)

@@ -603,13 +603,18 @@ def test_grouped_clones_share_one_set_of_launches(oracles):
             if cycles[k] == group_cycles:
                 assert np.array_equal(got, alone[k]), k
     # the C entry point itself, on one instance: all five in one group
-    rc = inst.L.sc_hip_run_device_batch(inst.h, jobs, len(jobs))
-    inst.sync()
-    assert rc == 0 and all(j.rc == 0 for j in jobs)
+    assert inst.run_device_batch(jobs) == 0 and all(j.rc == 0 for j in jobs)
     assert inst.info().W == W and inst.info().H == H
     for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
         want = o.seamless_clone(it[0], it[1], it[2], it[3], it[4])
         assert np.abs(inst.from_device(b, shape).astype(np.int16) - want.astype(np.int16)).max() <= 1, k
+    # more members than one group launch of the mask stage carries (16): eighteen small clones in one call
+    small = [o.synth_inputs(37, 29, seed_dst=300 + k, seed_patch=400 + k, margin=12) for k in range(18)]
+    jobs3, keep3 = device_jobs(small)
+    assert inst.run_device_batch(jobs3) == 0 and all(j.rc == 0 for j in jobs3)
+    for (f, b0, b, m, shape), it in zip(keep3, small):
+        want = o.seamless_clone(*it)
+        assert np.abs(inst.from_device(b, shape).astype(np.int16) - want.astype(np.int16)).max() <= 1
     # mixed sizes -> one after the other, same answers as alone
     other = o.synth_inputs(120, 90, seed_dst=5, seed_patch=6, margin=32)
     b_other = other[0].copy(); seq.run(other[1], b_other, other[2], other[3], other[4])
@@ -622,7 +627,7 @@ def test_grouped_clones_share_one_set_of_launches(oracles):
     with pytest.raises(capi.SeamlessCloneError) as e:
         pool.run(jobs, device_resident=True)
     assert e.value.code == capi.SC_ERR_ROI_OOB and jobs[1].rc == capi.SC_ERR_ROI_OOB and jobs[0].rc == 0 and jobs[4].rc == 0
-    for kp in (keep, keep2):
+    for kp in (keep, keep2, keep3):
         for f, b0, b, m, _ in kp:
             for p in (f, b0, b, m):
                 inst.free(p)
