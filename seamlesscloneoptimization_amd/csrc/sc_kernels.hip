@@ -465,23 +465,46 @@ __global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restric
         const int *__restrict__ r = guard.d_rect;
         if (r[0] != guard.x0 || r[1] != guard.x1 || r[2] != guard.y0 || r[3] != guard.y1) return;
     }
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    // four pixels per lane: one 16-byte load per channel, twelve output bytes; a lane whose twelve bytes are all interior
+    // pixels and start on a 4-byte boundary (the same for every lane of a row) writes three words, the others bytes
+    const int x = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < 1 || x > U.W - 2 || y < 1 || y > U.H - 2) return;
+    if (x > U.W - 2 || y < 1 || y > U.H - 2) return;
     uint8_t *b = body + (size_t)y * bstep + 3 * x;
     const size_t o = (size_t)y * U.pitch + x;
+    float4 v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = *reinterpret_cast<const float4 *>(U.at(c) + o);      // x < pitch, pitch % 4 == 0
+    unsigned char px[12];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float d = U.at(c)[o];
-        d = d > 255.0f ? 255.0f : d;
-        d = d < 0.0f ? 0.0f : d;
-        b[c] = (uint8_t)d;
+        const float e[4] = { v[c].x, v[c].y, v[c].z, v[c].w };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float d = e[k];
+            d = d > 255.0f ? 255.0f : d;
+            d = d < 0.0f ? 0.0f : d;
+            px[3 * k + c] = (unsigned char)d;
+        }
+    }
+    if (x >= 1 && x + 3 <= U.W - 2 && ((uintptr_t)b & 3) == 0) {
+        unsigned w[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
+        unsigned *d32 = reinterpret_cast<unsigned *>(b);
+        d32[0] = w[0]; d32[1] = w[1]; d32[2] = w[2];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (x + k < 1 || x + k > U.W - 2) continue;
+            b[3 * k + 0] = px[3 * k + 0]; b[3 * k + 1] = px[3 * k + 1]; b[3 * k + 2] = px[3 * k + 2];
+        }
     }
 }
 
 void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard)
 {
-    dim3 grid((U.W + 63) / 64, (U.H + 3) / 4);
+    dim3 grid(((U.W + 3) / 4 + 63) / 64, (U.H + 3) / 4);
     hipLaunchKernelGGL(k_postprocess, grid, dim3(256), 0, s, U, body_org, bstep, guard);
 }
 
