@@ -312,25 +312,40 @@ void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s)
 // (1 - m) a + m b is a select (bit-identical: m is exactly 0 or 1).  The fields are written as one 8- or 16-byte store
 // per lane, channel and field.
 constexpr int P4_TW = 128, P4_RPT = 2, P4_TH = 8 * P4_RPT;     // tile: 32 lanes x 4 pixels wide, 8 thread rows x P4_RPT rows high
-constexpr int P4_ROWD = (3 * (P4_TW + 2) + 6 + 3) / 4 + 1;    // dwords per staged row (+1: the re-alignment reads one ahead)
+constexpr int P4_ROWQ = (3 * (P4_TW + 2) + 15 + 4 + 15) / 16;   // 16-byte pieces per staged row: the row may start up to 15 bytes into its first piece, the re-alignment reads one word ahead
+constexpr int P4_ROWD = 4 * P4_ROWQ;                            // the same in dwords
 
+// Rows ty0-1 .. ty0+P4_TH of an interleaved 8-bit image, columns tx0-1 .. tx0+P4_TW, staged as 16-byte pieces starting at
+// the 16-byte boundary at or below the first byte (org[ry] = offset of that byte in its row of LDS).  A piece that lies
+// inside the ROI row is one 16-byte load; the pieces at the row's ends are fetched word by word under the same bounds
+// test as before (nothing is read further than 3 bytes outside the ROI's row).
 __device__ __forceinline__ void p4_stage(const uint8_t *__restrict__ img, int step, int W, int H, int tx0, int ty0,
                                          unsigned (*sm)[P4_ROWD], int *org)
 {
-    for (int i = threadIdx.x; i < (P4_TH + 2) * P4_ROWD; i += 256) {
-        const int ry = i / P4_ROWD, k = i - ry * P4_ROWD;
+    for (int i = threadIdx.x; i < (P4_TH + 2) * P4_ROWQ; i += 256) {
+        const int ry = i / P4_ROWQ, q = i - ry * P4_ROWQ;
         const int y = ty0 - 1 + ry;
-        unsigned v = 0;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
         int a = 0;
         if (y >= 0 && y < H) {
             const uint8_t *row = img + (size_t)y * step;
             const uint8_t *first = row + 3 * (tx0 - 1);
-            a = (int)((uintptr_t)first & 3);
-            const uint8_t *p = first - a + 4 * k;               // aligned dword k of this row
-            if (p + 3 >= row && p < row + 3 * W) v = *reinterpret_cast<const unsigned *>(p);
+            a = (int)((uintptr_t)first & 15);
+            const uint8_t *p = first - a + 16 * q;              // aligned piece q of this row
+            if (p >= row && p + 16 <= row + 3 * W) {
+                v = *reinterpret_cast<const uint4 *>(p);
+            } else {
+                unsigned w[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint8_t *pk = p + 4 * k;
+                    if (pk + 3 >= row && pk < row + 3 * W) w[k] = *reinterpret_cast<const unsigned *>(pk);
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
         }
-        if (k == 0) org[ry] = a;
-        sm[ry][k] = v;
+        if (q == 0) org[ry] = a;
+        *reinterpret_cast<uint4 *>(&sm[ry][4 * q]) = v;
     }
 }
 
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
                                                      const uint8_t *__restrict__ M, int mpitch,
                                                      Field U0, Field U1, Field F)
 {
-    __shared__ unsigned sb[P4_TH + 2][P4_ROWD], sp[P4_TH + 2][P4_ROWD];
+    __shared__ __attribute__((aligned(16))) unsigned sb[P4_TH + 2][P4_ROWD], sp[P4_TH + 2][P4_ROWD];
     __shared__ int ob[P4_TH + 2], op[P4_TH + 2];
     const int W = U0.W, H = U0.H;
     const int tx0 = blockIdx.x * P4_TW, ty0 = blockIdx.y * P4_TH;
