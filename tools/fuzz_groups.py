@@ -1,6 +1,6 @@
 """Shape fuzz of the grouped path (not part of the test suite): random groups of same-size clones (tiny, thin, level-boundary
 and ordinary ROI sizes; rectangular / elliptic / speckled masks; different positions), every member against the numpy oracle.
-python tools/fuzz_groups.py [groups] [seed]"""
+python tools/fuzz_groups.py [groups] [seed] [big]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +9,7 @@ from oracle import oracle_np as o
 
 ngroups = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"       # every third group with an ROI of 900..2300 x 700..2100
 pool = capi.Pool(0, 1, group=64)
 inst = pool.instances[0]
 fails = 0; members = 0; worst = 0.0
@@ -19,7 +20,8 @@ for gi in range(ngroups):
     elif kind == 2: W, H = int(rng.integers(3, 24)), int(rng.integers(200, 600))
     elif kind == 3: W, H = int(rng.choice([63, 64, 65, 126, 127, 128, 129, 254, 255, 256, 257])), int(rng.choice([63, 64, 65, 66, 127, 128, 129, 130]))
     else: W, H = int(rng.integers(24, 600)), int(rng.integers(24, 400))
-    n = int(rng.integers(2, 10))
+    if big and gi % 3 == 0: W, H = int(rng.integers(900, 2300)), int(rng.integers(700, 2100))   # interior-wave paths, many rounds
+    n = int(rng.integers(2, 6 if (big and gi % 3 == 0) else 10))
     items = []
     for k in range(n):
         dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=1000 * gi + k, seed_patch=1000 * gi + 500 + k, margin=24)
