@@ -634,6 +634,39 @@ def test_grouped_clones_share_one_set_of_launches(oracles):
     pool.close(); seq.destroy()
 
 
+def test_grouped_clones_large_roi(oracles):
+    """A group of three 1100x900 clones: fields of nine channels, many rounds of workgroups, interior-wave paths; each
+    member equals the clone run alone (same cycle count) and is within one grey level of the C oracle."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    W, H = 1100, 900
+    items = [o.synth_inputs(W, H, seed_dst=910 + k, seed_patch=920 + k, margin=40) for k in range(3)]
+    inst = capi.Instance(0)
+    alone, cycles = [], []
+    for dst, patch, mask, cx, cy in items:
+        b = dst.copy(); inst.run(patch, b, mask, cx, cy); alone.append(b); cycles.append(inst.info().sweeps)
+    jobs = capi.Pool.make_jobs(3); keep = []
+    for j, (dst, patch, mask, cx, cy) in zip(jobs, items):
+        f, b0, b, m = inst.to_device(patch), inst.to_device(dst), inst.to_device(dst), inst.to_device(mask)
+        keep.append((f, b0, b, m, dst.shape))
+        j.face, j.face_cols, j.face_rows, j.face_step = f, patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+        j.body, j.body_cols, j.body_rows, j.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+        j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
+        j.centerX, j.centerY, j.body_restore = cx, cy, b0
+    assert inst.run_device_batch(jobs) == 0
+    group_cycles = inst.info().sweeps
+    assert group_cycles == max(cycles)
+    for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
+        got = inst.from_device(b, shape)
+        want = oc.seamless_clone(it[0], it[1], it[2], it[3], it[4], nthreads=min(16, oc.max_threads()), exact_den=True)
+        assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1, k
+        if cycles[k] == group_cycles:
+            assert np.array_equal(got, alone[k]), k
+        for p in (f, b0, b, m):
+            inst.free(p)
+    inst.destroy()
+
+
 def test_error_codes(hip, oracles):
     from seamlesscloneoptimization_amd import capi
     o, _ = oracles
