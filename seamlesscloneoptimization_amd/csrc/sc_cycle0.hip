@@ -363,7 +363,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
 #define SC_C0_F(K) c0_comp(f[HF ? 0 : r], K)
 #define SC_C0_GS(G, L, R_, A, B, CW, K)                                                           \
-    ((G) ? ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - SC_C0_F(K)) * (ylast ? rdB##K : rdA##K)  \
+    ((G) ? ((__builtin_fmaf((CW), (L), (R_)) + __builtin_fmaf(cn, (A), (B))) - SC_C0_F(K)) * (ylast ? rdB##K : rdA##K)  \
      : HF ? c0_gs_q<K>((((L) + (R_)) + ((A) + (B))), quarter, fh[HF ? r : 0])                    \
           : __builtin_fmaf((((L) + (R_)) + ((A) + (B))), 0.25f, SC_C0_F(K)))
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);

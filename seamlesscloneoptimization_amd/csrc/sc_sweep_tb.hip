@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field 
     const float rdB0 = GEN ? 1.0f / (dx0 + g.y.d_last) : 0.25f, rdB1 = GEN ? 1.0f / (dx1 + g.y.d_last) : 0.25f;
     const float rdB2 = GEN ? 1.0f / (dx2 + g.y.d_last) : 0.25f, rdB3 = GEN ? 1.0f / (dx3 + g.y.d_last) : 0.25f;
 #define SC_TB_GS(L, R_, A, B, FF, CW, K)                                                          \
-    (GEN ? ((((CW) * (L) + (R_)) + (cn * (A) + (B))) - (FF)) * (ylast ? rdB##K : rdA##K)        \
+    (GEN ? ((__builtin_fmaf((CW), (L), (R_)) + __builtin_fmaf(cn, (A), (B))) - (FF)) * (ylast ? rdB##K : rdA##K)        \
          : __builtin_fmaf((((L) + (R_)) + ((A) + (B))), 0.25f, (FF)))     /* regular stencil: FF is -f/4, one rounding as in 0.25 (S - f) */
     edge[0][wv][0][lane] = u[0];
     edge[0][wv][1][lane] = u[R - 1];
