@@ -700,17 +700,9 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
 // The solver treats the channels of a field as independent planes, so n clones whose ROIs have the same size are one
 // field of 3n channels: every multigrid launch is n times larger (the coarse levels stop being launch-latency bound,
 // the level-1 grid fills whole rounds of workgroup slots) and there are 27 solver launches for the group instead of
-// 27 n.  Masks, positions and images are per clone (bounding box, erode, pre- and post-process are launched per clone
-// on channel views); the stop rule sees the largest correction of the group.  Groups with different ROI sizes, a
+// 27 n.  Masks, positions and images are per clone (bounding box, erode, pre- and post-process each go out as one launch
+// for the group, blockIdx.z = member); the stop rule sees the largest correction of the group.  Groups with different ROI sizes, a
 // failing member or the reference's warm-up option run one after the other through sc_hip_run_device.
-static Field channel_view(const Field &f, int c0, bool half)
-{
-    Field v = f;
-    v.C = 3;
-    v.p = half ? reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(f.p) + (size_t)c0 * f.plane) : f.p + (size_t)c0 * f.plane;
-    return v;
-}
-
 int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
 {
     Instance *I = get(p);
@@ -784,32 +776,28 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     I->f_half = mg_reads_half_rhs(I);
     static const int no_hu = [] { const char *e = getenv("SC_NO_HALF_U"); return e ? atoi(e) : 0; }();
     I->u_half = I->f_half && !no_hu;
+    std::vector<ImageJob> ij(n);
     for (int i = 0; i < n; ++i) {
         const sc_batch_job &j = jobs[i];
-        launch_preprocess(j.body + (size_t)geo[i].lty * j.body_step + 3 * geo[i].ltx, j.body_step,
-                          j.face + (size_t)geo[i].y0 * j.face_step + 3 * geo[i].x0, j.face_step,
-                          (const uint8_t *)I->d_M.p + mplane * i, I->mpitch, channel_view(I->U0, 3 * i, I->u_half),
-                          channel_view(I->U1, 3 * i, false), channel_view(I->F, 3 * i, I->f_half), I->stream, I->f_half, I->u_half);
+        ij[i].face_org = j.face + (size_t)geo[i].y0 * j.face_step + 3 * geo[i].x0; ij[i].fstep = j.face_step;
+        ij[i].body_org = j.body + (size_t)geo[i].lty * j.body_step + 3 * geo[i].ltx; ij[i].bstep = j.body_step;
+        ij[i].M = (const uint8_t *)I->d_M.p + mplane * i;
     }
+    launch_preprocess_group(ij.data(), n, I->mpitch, I->U0, I->F, I->stream, I->f_half, I->u_half);
     SC_HIP(I, hipGetLastError());
     // --- one solve for the group, results spliced per clone
     I->info.sweep_launches = 0;
     I->guard = RectGuard();
-    I->spec_post.group.clear();
-    for (int i = 0; i < n; ++i)
-        I->spec_post.group.push_back({ jobs[i].body + (size_t)geo[i].lty * jobs[i].body_step + 3 * geo[i].ltx, jobs[i].body_step });
+    I->spec_post.group = ij;
     I->spec_post.ev_solved = nullptr;
     I->spec_post.armed = true; I->spec_post.done = false;     // the solver enqueues the splices behind the cycle it expects to accept
     const int solve_rc = solve(I);
     I->spec_post.armed = false;
     const bool spliced = I->spec_post.done;
-    const std::vector<Instance::SpecTarget> targets = I->spec_post.group;
     I->spec_post.group.clear();
     if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
-    for (int i = 0; i < n; ++i) {
-        if (!spliced) launch_postprocess(channel_view(result(I), 3 * i, false), targets[i].body_org, targets[i].bstep, I->stream);
-        jobs[i].rc = solve_rc;
-    }
+    if (!spliced) launch_postprocess_group(result(I), ij.data(), n, I->stream);
+    for (int i = 0; i < n; ++i) jobs[i].rc = solve_rc;
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
     fill_info_geo(I, g0);

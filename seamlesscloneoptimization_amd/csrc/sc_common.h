@@ -41,6 +41,10 @@ struct MaskJob {
     uint8_t *M; int mpitch;
 };
 struct MaskJobs { enum { MAX = 16 }; MaskJob j[MAX]; };     // by value in the kernel arguments
+// pre- / post-process of the members of a group: ROI origins in the images and the member's eroded mask; member i owns
+// channels 3i..3i+2 of the fields (blockIdx.z = i)
+struct ImageJob { const uint8_t *face_org; int fstep; uint8_t *body_org; int bstep; const uint8_t *M; };
+struct ImageJobs { enum { MAX = 16 }; ImageJob j[MAX]; };
 
 // ---------------------------------------------------------------- kernel launchers (sc_kernels.hip)
 void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s);
@@ -55,6 +59,9 @@ void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_o
 // bounding box the host assumed when it launched a clone before the device's answer was back (d_rect == nullptr: none)
 struct RectGuard { const int *d_rect = nullptr; int x0 = 0, x1 = 0, y0 = 0, y1 = 0; };
 void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard());
+// the same for a group (fields of 3n channels), one launch per 16 members
+void launch_preprocess_group(const ImageJob *jobs, int n, int mpitch, Field U0, Field F, hipStream_t s, bool f_half, bool u_half);
+void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s);
 void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_t s);
 
 void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag = false);

@@ -55,9 +55,8 @@ struct Instance {
     // Speculative epilogue: the multigrid driver enqueues the post-process right behind the cycle whose
     // convergence check it is about to wait for, so the host round trip of the check overlaps useful work.
     // If the check then fails the solve simply continues and the post-process runs again at the end.
-    struct SpecTarget { uint8_t *body_org; int bstep; };
     struct { uint8_t *body_org = nullptr; int bstep = 0; hipEvent_t ev_solved = nullptr; bool armed = false, done = false;
-             std::vector<SpecTarget> group; } spec_post;   // group: one destination per member (channels 3i..3i+2) of a group of clones
+             std::vector<ImageJob> group; } spec_post;     // group: one destination per member (channels 3i..3i+2) of a group of clones
     // Speculative geometry: a clone may be launched on a predicted bounding box (the previous one for the same
     // mask size, else the whole mask interior) while the bbox kernel's answer is still in flight; `guard` makes
     // the post-process a no-op on a wrong guess and the host then repeats the clone (sc_api.cpp).

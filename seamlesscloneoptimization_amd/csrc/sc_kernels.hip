@@ -366,10 +366,10 @@ __device__ __forceinline__ void p4_window(const unsigned *row, int word0, int sh
 // exactly, at the same element pitch / plane size inside their buffers; the fused multigrid path reads them that way
 // (sc_cycle0.hip: every launch reads F, the first one U0).
 template <bool HF, bool HU>
-__global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ body, int bstep,
-                                                     const uint8_t *__restrict__ face, int fstep,
-                                                     const uint8_t *__restrict__ M, int mpitch,
-                                                     Field U0, Field U1, Field F)
+__device__ __forceinline__ void preprocess_block(const uint8_t *__restrict__ body, int bstep,
+                                                 const uint8_t *__restrict__ face, int fstep,
+                                                 const uint8_t *__restrict__ M, int mpitch,
+                                                 const Field &U0, const Field &F, int c0)
 {
     __shared__ __attribute__((aligned(16))) unsigned sb[P4_TH + 2][P4_ROWD], sp[P4_TH + 2][P4_ROWD];
     __shared__ int ob[P4_TH + 2], op[P4_TH + 2];
@@ -430,21 +430,54 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
         if (HU) {
             const __half2 a = __floats2half2_rn(uv[0], uv[1]), b2 = __floats2half2_rn(uv[2], uv[3]);
             uint2 pk; pk.x = *reinterpret_cast<const unsigned *>(&a); pk.y = *reinterpret_cast<const unsigned *>(&b2);
-            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(U0.p) + (size_t)c * U0.plane + o) = pk;
+            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(U0.p) + (size_t)(c0 + c) * U0.plane + o) = pk;
         } else {
-            *reinterpret_cast<float4 *>(U0.at(c) + o) = make_float4(uv[0], uv[1], uv[2], uv[3]);
+            *reinterpret_cast<float4 *>(U0.at(c0 + c) + o) = make_float4(uv[0], uv[1], uv[2], uv[3]);
         }
         if (HF) {
             const __half2 a = __floats2half2_rn(lv[0], lv[1]), b2 = __floats2half2_rn(lv[2], lv[3]);
             uint2 pk; pk.x = *reinterpret_cast<const unsigned *>(&a); pk.y = *reinterpret_cast<const unsigned *>(&b2);
-            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(F.p) + (size_t)c * F.plane + o) = pk;
+            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(F.p) + (size_t)(c0 + c) * F.plane + o) = pk;
         } else {
-            *reinterpret_cast<float4 *>(F.at(c) + o) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+            *reinterpret_cast<float4 *>(F.at(c0 + c) + o) = make_float4(lv[0], lv[1], lv[2], lv[3]);
         }
     }
     }
 }
 #undef P4_BYTE
+
+template <bool HF, bool HU>
+__global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ body, int bstep,
+                                                     const uint8_t *__restrict__ face, int fstep,
+                                                     const uint8_t *__restrict__ M, int mpitch,
+                                                     Field U0, Field U1, Field F)
+{
+    preprocess_block<HF, HU>(body, bstep, face, fstep, M, mpitch, U0, F, 0);
+}
+
+// a group of clones in one launch: blockIdx.z = member, which owns channels 3z..3z+2 of the group's fields
+template <bool HF, bool HU>
+__global__ __launch_bounds__(256) void k_preprocess_group(ImageJobs t, int mpitch, Field U0, Field F)
+{
+    const ImageJob &j = t.j[blockIdx.z];
+    preprocess_block<HF, HU>(j.body_org, j.bstep, j.face_org, j.fstep, j.M, mpitch, U0, F, 3 * blockIdx.z);
+}
+
+void launch_preprocess_group(const ImageJob *jobs, int n, int mpitch, Field U0, Field F, hipStream_t s, bool f_half, bool u_half)
+{
+    for (int i0 = 0; i0 < n; i0 += ImageJobs::MAX) {
+        ImageJobs t{};
+        const int cnt = std::min(n - i0, (int)ImageJobs::MAX);
+        for (int i = 0; i < cnt; ++i) t.j[i] = jobs[i0 + i];
+        Field u = U0, f = F;      // this launch's first member owns channel 3 i0
+        u.p = u_half ? reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(U0.p) + (size_t)3 * i0 * U0.plane) : U0.p + (size_t)3 * i0 * U0.plane;
+        f.p = f_half ? reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(F.p) + (size_t)3 * i0 * F.plane) : F.p + (size_t)3 * i0 * F.plane;
+        dim3 g4((U0.W + P4_TW - 1) / P4_TW, (U0.H + P4_TH - 1) / P4_TH, cnt);
+        if (f_half && u_half) hipLaunchKernelGGL((k_preprocess_group<true, true>), g4, dim3(256), 0, s, t, mpitch, u, f);
+        else if (f_half) hipLaunchKernelGGL((k_preprocess_group<true, false>), g4, dim3(256), 0, s, t, mpitch, u, f);
+        else hipLaunchKernelGGL((k_preprocess_group<false, false>), g4, dim3(256), 0, s, t, mpitch, u, f);
+    }
+}
 
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half, bool u_half)
@@ -474,12 +507,8 @@ void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_
 // guard: when the host launched this clone on a PREDICTED bounding box (RectGuard, sc_common.h) the output is only
 // written if the bounding box the device found is the predicted one; otherwise the destination stays untouched
 // and the host repeats the clone with the true geometry.
-__global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restrict__ body, int bstep, RectGuard guard)
+__device__ __forceinline__ void postprocess_block(const Field &U, uint8_t *__restrict__ body, int bstep, int c0)
 {
-    if (guard.d_rect) {
-        const int *__restrict__ r = guard.d_rect;
-        if (r[0] != guard.x0 || r[1] != guard.x1 || r[2] != guard.y0 || r[3] != guard.y1) return;
-    }
     // four pixels per lane: one 16-byte load per channel, twelve output bytes; a lane whose twelve bytes are all interior
     // pixels and start on a 4-byte boundary (the same for every lane of a row) writes three words, the others bytes
     const int x = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
@@ -489,7 +518,7 @@ __global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restric
     const size_t o = (size_t)y * U.pitch + x;
     float4 v[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) v[c] = *reinterpret_cast<const float4 *>(U.at(c) + o);      // x < pitch, pitch % 4 == 0
+    for (int c = 0; c < 3; ++c) v[c] = *reinterpret_cast<const float4 *>(U.at(c0 + c) + o);      // x < pitch, pitch % 4 == 0
     unsigned char px[12];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -514,6 +543,34 @@ __global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restric
             if (x + k < 1 || x + k > U.W - 2) continue;
             b[3 * k + 0] = px[3 * k + 0]; b[3 * k + 1] = px[3 * k + 1]; b[3 * k + 2] = px[3 * k + 2];
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restrict__ body, int bstep, RectGuard guard)
+{
+    if (guard.d_rect) {
+        const int *__restrict__ r = guard.d_rect;
+        if (r[0] != guard.x0 || r[1] != guard.x1 || r[2] != guard.y0 || r[3] != guard.y1) return;
+    }
+    postprocess_block(U, body, bstep, 0);
+}
+
+__global__ __launch_bounds__(256) void k_postprocess_group(Field U, ImageJobs t)
+{
+    const ImageJob &j = t.j[blockIdx.z];
+    postprocess_block(U, j.body_org, j.bstep, 3 * blockIdx.z);
+}
+
+void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s)
+{
+    for (int i0 = 0; i0 < n; i0 += ImageJobs::MAX) {
+        ImageJobs t{};
+        const int cnt = std::min(n - i0, (int)ImageJobs::MAX);
+        for (int i = 0; i < cnt; ++i) t.j[i] = jobs[i0 + i];
+        Field u = U;
+        u.p = U.p + (size_t)3 * i0 * U.plane;
+        dim3 grid(((U.W + 3) / 4 + 63) / 64, (U.H + 3) / 4, cnt);
+        hipLaunchKernelGGL(k_postprocess_group, grid, dim3(256), 0, s, u, t);
     }
 }
 

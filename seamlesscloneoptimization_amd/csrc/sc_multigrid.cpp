@@ -501,11 +501,7 @@ int mg_solve(Instance *I)
                     if (I->spec_post.group.empty()) {
                         launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
                     } else {
-                        const Field U = result(I);
-                        for (size_t k = 0; k < I->spec_post.group.size(); ++k) {
-                            Field v = U; v.C = 3; v.p = U.p + 3 * k * U.plane;
-                            launch_postprocess(v, I->spec_post.group[k].body_org, I->spec_post.group[k].bstep, I->stream, I->guard);
-                        }
+                        launch_postprocess_group(result(I), I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream);
                     }
                     I->spec_post.done = true;
                 }
