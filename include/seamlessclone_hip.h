@@ -197,7 +197,9 @@ typedef struct sc_batch_job {
  * images are free) they are solved as one field of 3n channels: every solver launch is n times larger and there is one
  * set of launches for the group, which is what fills a 256-CU GPU with small and medium ROIs.  Results are the ones the
  * clones get one by one (channels never interact), except that the stop rule sees the group's largest correction, so
- * every member gets the cycle count of the slowest.  Other groups run one after the other.  jobs[i].rc receives each
+ * every member gets the cycle count of the slowest.  The group is launched on predicted bounding boxes (the masks'
+ * interiors); a member whose box turns out different is left untouched by the group and repeated alone.  Other groups
+ * (different ROI sizes, a failing member) run one after the other.  jobs[i].rc receives each
  * clone's code; the call is asynchronous like sc_hip_run_device(..., false): sync the instance before reading bodies. */
 SC_API int   sc_hip_run_device_batch(void *instance, sc_batch_job *jobs, int n);
 SC_API void *sc_hip_pool_create(int gpu_id, int streams);

@@ -398,6 +398,8 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
     if (I->h_fd.p) (void)hipHostFree(I->h_fd.p);
     if (I->d_rect) (void)hipFree(I->d_rect);
+    if (I->d_rects.p) (void)hipFree(I->d_rects.p);
+    if (I->h_rects.p) (void)hipHostFree(I->h_rects.p);
     if (I->d_partials) (void)hipFree(I->d_partials);
     if (I->d_red) (void)hipFree(I->d_red);
     if (I->d_maxcorr) (void)hipFree(I->d_maxcorr);
@@ -409,6 +411,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     for (int i = 0; i < 8; ++i) if (I->ev_chunk[i]) (void)hipEventDestroy(I->ev_chunk[i]);
     if (I->ev_k0) (void)hipEventDestroy(I->ev_k0);
     if (I->ev_k1) (void)hipEventDestroy(I->ev_k1);
+    if (I->ev_rects) (void)hipEventDestroy(I->ev_rects);
     if (I->stream) (void)hipStreamDestroy(I->stream);
     I->magic = 0;
     delete I;
@@ -752,17 +755,38 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     launch_mask_bbox_group(mj.data(), n, I->stream);
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * RS * sizeof(int), hipMemcpyDeviceToHost, I->stream));
-    SC_HIP(I, hipStreamSynchronize(I->stream));
+    if (!I->ev_rects) SC_HIP(I, hipEventCreateWithFlags(&I->ev_rects, hipEventDisableTiming));
+    SC_HIP(I, hipEventRecord(I->ev_rects, I->stream));
+    // Like a single clone (predict_rect), the group is launched on PREDICTED bounding boxes -- the interior of every mask,
+    // which is what a mask that touches its four inner borders gives -- while the scans' answers are in flight: no host
+    // wait in front of the erodes.  Every member's splice carries its guess and writes nothing unless the device found
+    // that box; the host compares when the answers are in (they are by the time the solver has waited for its stop rule)
+    // and repeats the members that were guessed wrong, one by one on their true boxes.
     std::vector<Geo> geo(n);
-    bool same = true;
-    for (int i = 0; i < n && same; ++i) {
-        if (geo_from_rect(I, h_out + RS * i, jobs[i].centerX, jobs[i].centerY, geo[i]) != SC_OK ||
-            check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) != SC_OK)
-            same = false;
-        else if (geo[i].W != geo[0].W || geo[i].H != geo[0].H)
-            same = false;
+    std::vector<int> guess(4 * (size_t)n);
+    static const int no_spec = [] { const char *e = getenv("SC_NO_SPECULATE"); return e ? atoi(e) : 0; }();
+    bool speculative = !no_spec && I->group_spec_cooldown == 0;
+    if (I->group_spec_cooldown > 0) --I->group_spec_cooldown;
+    for (int i = 0; i < n && speculative; ++i) {
+        int *r = &guess[4 * i];
+        r[0] = 1; r[1] = jobs[i].mask_cols - 2; r[2] = 1; r[3] = jobs[i].mask_rows - 2;
+        if (jobs[i].mask_cols < 3 || jobs[i].mask_rows < 3 || geo_from_rect(I, r, jobs[i].centerX, jobs[i].centerY, geo[i]) != SC_OK ||
+            check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) != SC_OK || geo[i].W != geo[0].W || geo[i].H != geo[0].H)
+            speculative = false;
     }
-    if (!same) { I->err.clear(); return one_by_one(); }
+    I->err.clear();
+    if (!speculative) {
+        SC_HIP(I, hipStreamSynchronize(I->stream));
+        bool same = true;
+        for (int i = 0; i < n && same; ++i) {
+            if (geo_from_rect(I, h_out + RS * i, jobs[i].centerX, jobs[i].centerY, geo[i]) != SC_OK ||
+                check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) != SC_OK)
+                same = false;
+            else if (geo[i].W != geo[0].W || geo[i].H != geo[0].H)
+                same = false;
+        }
+        if (!same) { I->err.clear(); return one_by_one(); }
+    }
     const Geo &g0 = geo[0];
     // --- eroded masks, fields of 3n channels, right-hand sides
     I->mpitch = round_up(g0.W, 64);
@@ -782,6 +806,8 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
         ij[i].face_org = j.face + (size_t)geo[i].y0 * j.face_step + 3 * geo[i].x0; ij[i].fstep = j.face_step;
         ij[i].body_org = j.body + (size_t)geo[i].lty * j.body_step + 3 * geo[i].ltx; ij[i].bstep = j.body_step;
         ij[i].M = (const uint8_t *)I->d_M.p + mplane * i;
+        ij[i].d_rect = speculative ? d_r + RS * i : nullptr;
+        ij[i].rx0 = guess[4 * i]; ij[i].rx1 = guess[4 * i + 1]; ij[i].ry0 = guess[4 * i + 2]; ij[i].ry1 = guess[4 * i + 3];
     }
     launch_preprocess_group(ij.data(), n, I->mpitch, I->U0, I->F, I->stream, I->f_half, I->u_half);
     SC_HIP(I, hipGetLastError());
@@ -802,7 +828,25 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
     fill_info_geo(I, g0);
     I->info.ms_h2d = I->info.ms_mask = I->info.ms_pre = I->info.ms_solve = I->info.ms_post = I->info.ms_d2h = I->info.ms_device_total = 0.f;
-    return solve_rc;
+    int worst = solve_rc;
+    if (speculative) {
+        SC_HIP(I, hipEventSynchronize(I->ev_rects));       // long since passed when the solver has waited for its stop rule
+        std::vector<int> wrong;
+        for (int i = 0; i < n; ++i)
+            if (memcmp(&guess[4 * i], h_out + RS * i, 4 * sizeof(int)) != 0) wrong.push_back(i);
+        if (!wrong.empty()) {
+            I->group_spec_cooldown = 8;
+            const sc_run_info keep = I->info;
+            for (int i : wrong) {                              // its destination was not touched: repeat it alone on its true box
+                sc_batch_job &j = jobs[i];
+                j.rc = sc_hip_run_device(p, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows, j.body_step,
+                                         j.mask, j.mask_cols, j.mask_rows, j.mask_step, j.centerX, j.centerY, false);
+                if (j.rc != SC_OK && (worst == SC_OK || worst == SC_ERR_NOT_CONVERGED)) worst = j.rc;
+            }
+            if ((int)wrong.size() < n) I->info = keep;
+        }
+    }
+    return worst;
 }
 
 int sc_hip_selftest_host(void)

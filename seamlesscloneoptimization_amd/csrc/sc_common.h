@@ -43,7 +43,8 @@ struct MaskJob {
 struct MaskJobs { enum { MAX = 16 }; MaskJob j[MAX]; };     // by value in the kernel arguments
 // pre- / post-process of the members of a group: ROI origins in the images and the member's eroded mask; member i owns
 // channels 3i..3i+2 of the fields (blockIdx.z = i)
-struct ImageJob { const uint8_t *face_org; int fstep; uint8_t *body_org; int bstep; const uint8_t *M; };
+struct ImageJob { const uint8_t *face_org; int fstep; uint8_t *body_org; int bstep; const uint8_t *M;
+                  const int *d_rect; int rx0, rx1, ry0, ry1; };   // d_rect != nullptr: the member ran on a PREDICTED bounding box and is spliced only if the device found exactly that box (RectGuard semantics)
 struct ImageJobs { enum { MAX = 16 }; ImageJob j[MAX]; };
 
 // ---------------------------------------------------------------- kernel launchers (sc_kernels.hip)

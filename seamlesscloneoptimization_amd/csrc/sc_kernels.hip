@@ -558,6 +558,7 @@ __global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restric
 __global__ __launch_bounds__(256) void k_postprocess_group(Field U, ImageJobs t)
 {
     const ImageJob &j = t.j[blockIdx.z];
+    if (j.d_rect && (j.d_rect[0] != j.rx0 || j.d_rect[1] != j.rx1 || j.d_rect[2] != j.ry0 || j.d_rect[3] != j.ry1)) return;
     postprocess_block(U, j.body_org, j.bstep, 3 * blockIdx.z);
 }
 

@@ -608,6 +608,15 @@ def test_grouped_clones_share_one_set_of_launches(oracles):
     for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
         want = o.seamless_clone(it[0], it[1], it[2], it[3], it[4])
         assert np.abs(inst.from_device(b, shape).astype(np.int16) - want.astype(np.int16)).max() <= 1, k
+    # a member whose bounding box is not its mask's interior: the group is launched on predicted boxes, that member is
+    # guessed wrong, left untouched by the group's splice and repeated alone on its true box
+    odd = list(items[3]); m_odd = odd[2].copy(); m_odd[:6, :] = 0; m_odd[:, -9:] = 0; odd[2] = m_odd
+    mixed = [items[0], tuple(odd), items[4]]
+    jobs4, keep4 = device_jobs(mixed)
+    assert inst.run_device_batch(jobs4) == 0 and all(j.rc == 0 for j in jobs4)
+    for (f, b0, b, m, shape), it in zip(keep4, mixed):
+        want = o.seamless_clone(*it)
+        assert np.abs(inst.from_device(b, shape).astype(np.int16) - want.astype(np.int16)).max() <= 1
     # more members than one group launch of the mask stage carries (16): eighteen small clones in one call
     small = [o.synth_inputs(37, 29, seed_dst=300 + k, seed_patch=400 + k, margin=12) for k in range(18)]
     jobs3, keep3 = device_jobs(small)
@@ -627,7 +636,7 @@ def test_grouped_clones_share_one_set_of_launches(oracles):
     with pytest.raises(capi.SeamlessCloneError) as e:
         pool.run(jobs, device_resident=True)
     assert e.value.code == capi.SC_ERR_ROI_OOB and jobs[1].rc == capi.SC_ERR_ROI_OOB and jobs[0].rc == 0 and jobs[4].rc == 0
-    for kp in (keep, keep2, keep3):
+    for kp in (keep, keep2, keep3, keep4):
         for f, b0, b, m, _ in kp:
             for p in (f, b0, b, m):
                 inst.free(p)
