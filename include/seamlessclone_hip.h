@@ -83,8 +83,33 @@ typedef struct sc_solver_opts {
                                 the reference's own float32 deviation from OpenCV (0.16 % at 2400x1552,
                                 PDF p3).  0.02 costs one or two more cycles.
                                 The float32 residual norm stalls earlier and is only reported. */
-    int   reserved[5];
+    int   flags;             /* SC_FLAG_* bits below; 0 = the default paths                  */
+    int   jacobi_tile_rows;  /* single-sweep Jacobi launches (sweeps_per_launch = 1): 0 = rows rolling through
+                                registers (k_jacobi_roll, default); 16, 32 or 64 = the LDS-staged 256 x rows tile
+                                with a 1-pixel halo (k_jacobi<rows>).  Bit-identical fields.              */
+    int   reserved[3];
 } sc_solver_opts;
+
+/* ---- sc_solver_opts.flags: non-default variants of the same path, selectable per instance so one process (one
+ *      test run) can drive every variant.  Unless noted a variant gives the default path's result bit for bit. */
+#define SC_FLAG_NO_SPECULATE   (1 << 0)  /* wait for the device's bounding box before launching the clone (the
+                                            reference's order, seamlessClone_imp.cpp:1012) instead of launching on
+                                            a predicted box                                                      */
+#define SC_FLAG_FLOAT_RHS      (1 << 1)  /* multigrid: keep the right-hand side as float32 (default: float16,
+                                            exact -- it is an integer in [-1020, 1020])                         */
+#define SC_FLAG_FLOAT_U0       (1 << 2)  /* multigrid: initial field as float32 (default: float16, exact -- 8-bit
+                                            values)                                                             */
+#define SC_FLAG_NO_COMPOSE_L1  (1 << 3)  /* multigrid: level 1 gets its own post-smoothing launch (textbook V(2,2));
+                                            default: the level-0 launch composes its prolongation source from
+                                            levels 1 and 2.  Same fixed point, slightly different iterates      */
+#define SC_FLAG_VCYCLE_BOTTOM  (1 << 4)  /* multigrid: cycle down to the coarsest level inside the bottom kernel
+                                            instead of solving its first level directly (fast diagonalisation).
+                                            Same fixed point, slightly different iterates                       */
+#define SC_FLAG_EXACT_TABLES   (1 << 5)  /* MULTIGRID / sweep solvers: return the exact solution of the 5-point
+                                            system.  Default: the answer OpenCV and the reference compute, whose
+                                            eigenvalue tables are stored and combined in float32
+                                            (seamlessClone_imp.cpp:596-599, :1651-1653) -- see DESIGN.md sec. 5,
+                                            "float-table correction"                                            */
 
 /* ---- statistics of the last run */
 typedef struct sc_run_info {
@@ -151,6 +176,10 @@ SC_API int   sc_hip_memcpy_h2d(void *instance, void *dptr, const void *hptr, siz
 SC_API int   sc_hip_memcpy_d2h(void *instance, void *hptr, const void *dptr, size_t bytes);
 SC_API int   sc_hip_memcpy_d2d_async(void *instance, void *dst, const void *src, size_t bytes); /* on the instance stream */
 SC_API int   sc_hip_device_count(void);
+/* page-locked host memory for callers that want their images DMA-able in place (run() copies a page-locked image
+ * whose row step equals the library's device pitch without staging; every other host image is packed first) */
+SC_API void *sc_hip_host_alloc(void *instance, size_t bytes);
+SC_API void  sc_hip_host_free(void *instance, void *hptr);
 
 /* ---- stage-level hooks (parity tests drive each kernel through these) ------------------- */
 
@@ -174,6 +203,15 @@ SC_API int sc_hip_field_residual(void *instance, double out[2] /* sum r^2, sum l
 SC_API int sc_hip_field_solve(void *instance);                      /* run the configured solver on the loaded field */
 SC_API int sc_hip_field_shape(void *instance, int whc[3]);   /* W, H, C of the fields currently on the device */
 SC_API int sc_hip_field_store(void *instance, float *U_out, size_t capacity_floats);
+
+/* post-process alone (seamlessClone_imp.cpp:2078-2103 and the host splice :470-483) on the field currently on the
+ * device (sc_hip_field_load, or what a solve left): clamp to [0,255], truncate, interleave the interior of the
+ * 3-channel field into the host image `body` with the ROI origin at (ltx, lty). */
+SC_API int sc_hip_field_finish(void *instance, uint8_t *body, int body_cols, int body_rows, int body_step, int ltx, int lty);
+/* float-table correction alone on the field currently on the device: the result becomes
+ * result + correction, i.e. the exact solution of the 5-point system turns into what the reference's float32
+ * eigenvalue tables give (seamlessClone_imp.cpp:596-599, :1651-1653). */
+SC_API int sc_hip_field_lowmode(void *instance);
 
 /* microbenchmark hook used by bench.py: runs `launches` launches of the sweep kernel
  * (method, sweeps_per_launch) on the loaded field and returns the mean launch time measured

@@ -1,0 +1,58 @@
+"""numpy restatement of the float-table correction (seamlesscloneoptimization_amd/csrc/sc_lowmode.hip).
+
+TEST INFRASTRUCTURE ONLY (see oracle/oracle_np.py).  No reference counterpart as code: the reference
+(seamlessClone_imp.cpp:1814-1896) divides the 2-D DST-I of the right-hand side by den = filter_X[i] + filter_Y[j] - 4
+with float tables (:596-599, PI = the float literal of seamlessClone_imp.h:17) and float addition (:1651-1653).
+Relative to the exact solution u of the 5-point system that is
+
+    u_ref - u = S^-1[ S(u) * (den_exact / den_float - 1) ],      S = 2-D DST-I,
+
+restricted here to the first K modes per direction, exactly as the HIP kernels do (K = lowmode_count(n)).
+`full_correction` keeps every mode (what K -> n converges to) and is what the tests use to bound the truncation.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+PI_F = float(np.float32(3.14159265358979323846))     # seamlessClone_imp.h:17
+
+
+def lowmode_count(n: int) -> int:
+    k = (n + 63) // 64
+    k = (max(k, 8) + 7) & ~7
+    return min(k, n, 256)
+
+
+def float_table(n: int, count: int | None = None) -> np.ndarray:
+    """filter_X / filter_Y of the reference (IMP.cpp:596-599): double cos, float storage."""
+    i = np.arange(n if count is None else count, dtype=np.float64)
+    return (2.0 * np.cos(PI_F / (n + 1.0) * (i + 1.0))).astype(np.float32)
+
+
+def ratio(w: int, h: int, Kx: int, Ky: int) -> np.ndarray:
+    """den_exact / den_float - 1 for the first Ky x Kx modes (float64)."""
+    fx, fy = float_table(w, Kx), float_table(h, Ky)
+    den_f = ((fx[None, :] + fy[:, None]).astype(np.float32) - np.float32(4.0)).astype(np.float64)
+    sa = np.sin(0.5 * np.pi * (np.arange(Kx) + 1.0) / (w + 1.0))
+    sb = np.sin(0.5 * np.pi * (np.arange(Ky) + 1.0) / (h + 1.0))
+    den_e = -4.0 * (sa[None, :] ** 2 + sb[:, None] ** 2)
+    return den_e / den_f - 1.0
+
+
+def correction(u: np.ndarray, Kx: int | None = None, Ky: int | None = None) -> np.ndarray:
+    """u: interior field (h x w, float).  Returns the K-mode correction (float64, h x w)."""
+    h, w = u.shape
+    Kx = lowmode_count(w) if Kx is None else Kx
+    Ky = lowmode_count(h) if Ky is None else Ky
+    Sx = np.sin(np.pi * np.outer(np.arange(1, w + 1), np.arange(1, Kx + 1)) / (w + 1.0))   # w x Kx
+    Sy = np.sin(np.pi * np.outer(np.arange(1, h + 1), np.arange(1, Ky + 1)) / (h + 1.0))   # h x Ky
+    uh = Sy.T @ u.astype(np.float64) @ Sx * (4.0 / ((w + 1.0) * (h + 1.0)))
+    return Sy @ (uh * ratio(w, h, Kx, Ky)) @ Sx.T
+
+
+def full_correction(u: np.ndarray) -> np.ndarray:
+    """All modes: S^-1[S(u) (den_e/den_f - 1)] through scipy's DST-I."""
+    import scipy.fft as sfft
+    h, w = u.shape
+    t = sfft.dstn(u.astype(np.float64), type=1)
+    return sfft.idstn(t * ratio(w, h, w, h), type=1)

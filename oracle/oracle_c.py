@@ -139,6 +139,15 @@ def residual(U, lap):
     return float(out[0]), float(out[1])
 
 
+def finish(dst, U, geo):
+    """clamp -> truncate -> splice the interior of the planar field U (3,H,W) into dst IN PLACE (sco_finish)."""
+    assert dst.dtype == np.uint8 and dst.flags.c_contiguous and dst.flags.writeable
+    U = np.ascontiguousarray(U, np.float32)
+    geo = np.ascontiguousarray(geo, np.int32)
+    lib().sco_finish(_u8(dst), dst.strides[0], _f32(U), geo.ctypes.data_as(i32p))
+    return dst
+
+
 def seamless_clone(dst, patch, mask, cx, cy, nthreads=1, exact_den=False):
     """Returns a new blended image (input dst is not modified)."""
     out = np.array(dst, np.uint8, copy=True, order="C")

@@ -146,17 +146,29 @@ def build_rhs(dst: np.ndarray, patch: np.ndarray, geo: dict, dtype=F32):
 # --------------------------------------------------------------------------------------
 # A.4  direct solve (float64 DST-I)
 # --------------------------------------------------------------------------------------
-def solve_dst(g: np.ndarray) -> np.ndarray:
+PI_F = float(np.float32(3.14159265358979323846))     # the reference's `#define PI ...f` (seamlessClone_imp.h:17)
+
+
+def solve_dst(g: np.ndarray, float_tables: bool = False) -> np.ndarray:
     """u = DST1^-1( DST1(g) / (2cos(pi(i+1)/(w+1)) + 2cos(pi(j+1)/(h+1)) - 4) ), per channel.
 
-    seamlessClone_imp.cpp:1825-1832 (divide), :596-599 (filter_X/Y tables)."""
+    seamlessClone_imp.cpp:1825-1832 (divide), :596-599 (filter_X/Y tables).
+    float_tables=False: the exact linear system (denominator in float64).
+    float_tables=True : the reference's own denominator -- tables computed in double from the float literal PI
+    but STORED as float (:596-599) and summed in float (:1651-1653); the transforms stay float64.  The two answers
+    differ by up to 3 grey levels at 2048^2 and 7 at 4096^2 (low modes only)."""
     if _sfft is None:  # pragma: no cover
         raise RuntimeError("scipy required for solve_dst")
     g64 = g.astype(np.float64)
     h, w = g64.shape[:2]
-    fx = 2.0 * np.cos(np.pi * (np.arange(w) + 1.0) / (w + 1.0))
-    fy = 2.0 * np.cos(np.pi * (np.arange(h) + 1.0) / (h + 1.0))
-    den = (fx[None, :] + fy[:, None] - 4.0)
+    if float_tables:
+        fx = (2.0 * np.cos(PI_F / (w + 1.0) * (np.arange(w) + 1.0))).astype(F32)
+        fy = (2.0 * np.cos(PI_F / (h + 1.0) * (np.arange(h) + 1.0))).astype(F32)
+        den = ((fx[None, :] + fy[:, None]).astype(F32) - F32(4.0)).astype(np.float64)
+    else:
+        fx = 2.0 * np.cos(np.pi * (np.arange(w) + 1.0) / (w + 1.0))
+        fy = 2.0 * np.cos(np.pi * (np.arange(h) + 1.0) / (h + 1.0))
+        den = (fx[None, :] + fy[:, None] - 4.0)
     out = np.empty_like(g64)
     for c in range(g64.shape[2]):
         t = _sfft.dstn(g64[:, :, c], type=1)
@@ -237,12 +249,13 @@ def splice(dst: np.ndarray, u8: np.ndarray, geo: dict) -> np.ndarray:
     return out
 
 
-def seamless_clone(dst, patch, mask, cx, cy, return_all=False):
+def seamless_clone(dst, patch, mask, cx, cy, return_all=False, float_tables=False):
     """Full NORMAL_CLONE path with the float64 direct solve.  dst HxWx3 u8 BGR (any channel
-    order works, channels are independent), patch hxwx3 u8, mask hxw u8."""
+    order works, channels are independent), patch hxwx3 u8, mask hxw u8.  float_tables: see solve_dst
+    (True = the reference's arithmetic, which the HIP library reproduces by default)."""
     geo = mask_stage(mask, cx, cy)
     B, lap, g = build_rhs(dst, patch, geo, dtype=np.float64)
-    u = solve_dst(g)
+    u = solve_dst(g, float_tables)
     out = splice(dst, clamp_truncate(u), geo)
     if return_all:
         return out, dict(geo=geo, B=B, lap=lap, g=g, u=u)

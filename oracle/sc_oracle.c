@@ -303,8 +303,12 @@ SCO_API void sco_solve_dst2(const float *g, int w, int h, int C, float *u, int n
     fft_plan *pw = plan_create(2 * w + 2), *ph = plan_create(2 * h + 2);
     float *fx = (float *)malloc(sizeof(float) * w), *fy = (float *)malloc(sizeof(float) * h);
     double *dx = (double *)malloc(sizeof(double) * w), *dy = (double *)malloc(sizeof(double) * h);
-    for (int i = 0; i < w; ++i) { dx[i] = 2.0 * cos(M_PI * (i + 1.0) / (w + 1.0)); fx[i] = (float)dx[i]; }
-    for (int j = 0; j < h; ++j) { dy[j] = 2.0 * cos(M_PI * (j + 1.0) / (h + 1.0)); fy[j] = (float)dy[j]; }
+    /* float tables exactly as the reference builds them (IMP.cpp:596-599): double cos of PI/(n+1.0)*(x+1.0) with PI the
+     * FLOAT literal 3.14159265358979323846f of seamlessClone_imp.h:17, stored as float.  The exact-denominator
+     * variant (not the reference's: the exact linear system) uses the true pi in double. */
+    const double PIf = (double)3.14159265358979323846f;
+    for (int i = 0; i < w; ++i) { dx[i] = 2.0 * cos(M_PI * (i + 1.0) / (w + 1.0)); fx[i] = (float)(2.0 * cos(PIf / (w + 1.0) * (i + 1.0))); }
+    for (int j = 0; j < h; ++j) { dy[j] = 2.0 * cos(M_PI * (j + 1.0) / (h + 1.0)); fy[j] = (float)(2.0 * cos(PIf / (h + 1.0) * (j + 1.0))); }
     const size_t pl = (size_t)w * h;
     float *a = (float *)malloc(sizeof(float) * pl), *b = (float *)malloc(sizeof(float) * pl);
     const float scale = (float)(4.0 / ((double)(w + 1) * (double)(h + 1)));

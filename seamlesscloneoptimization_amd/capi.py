@@ -30,6 +30,13 @@ SC_METHOD_RBGS = 1
 SC_METHOD_SOR = 2
 SC_METHOD_MULTIGRID = 3
 
+SC_FLAG_NO_SPECULATE = 1 << 0
+SC_FLAG_FLOAT_RHS = 1 << 1
+SC_FLAG_FLOAT_U0 = 1 << 2
+SC_FLAG_NO_COMPOSE_L1 = 1 << 3
+SC_FLAG_VCYCLE_BOTTOM = 1 << 4
+SC_FLAG_EXACT_TABLES = 1 << 5
+
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",
     SC_ERR_ROI_OOB: "SC_ERR_ROI_OOB", SC_ERR_HIP: "SC_ERR_HIP", SC_ERR_NOT_CONVERGED: "SC_ERR_NOT_CONVERGED",
@@ -39,7 +46,7 @@ ERR_NAMES = {
 class SolverOpts(C.Structure):
     _fields_ = [("method", C.c_int), ("max_sweeps", C.c_int), ("tol", C.c_float), ("check_every", C.c_int),
                 ("omega", C.c_float), ("sweeps_per_launch", C.c_int), ("reference_warmup", C.c_int),
-                ("mg_pre", C.c_int), ("mg_post", C.c_int), ("update_tol", C.c_float), ("reserved", C.c_int * 5)]
+                ("mg_pre", C.c_int), ("mg_post", C.c_int), ("update_tol", C.c_float), ("flags", C.c_int), ("jacobi_tile_rows", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class RunInfo(C.Structure):
@@ -119,6 +126,10 @@ def load():
     L.sc_hip_malloc.restype = C.c_void_p
     L.sc_hip_free.argtypes = [C.c_void_p, C.c_void_p]
     L.sc_hip_free.restype = None
+    L.sc_hip_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    L.sc_hip_host_alloc.restype = C.c_void_p
+    L.sc_hip_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.sc_hip_host_free.restype = None
     L.sc_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.sc_hip_memcpy_h2d.restype = C.c_int
     L.sc_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -143,6 +154,10 @@ def load():
     L.sc_hip_field_shape.restype = C.c_int
     L.sc_hip_field_store.argtypes = [C.c_void_p, f32p, C.c_size_t]
     L.sc_hip_field_store.restype = C.c_int
+    L.sc_hip_field_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.sc_hip_field_finish.restype = C.c_int
+    L.sc_hip_field_lowmode.argtypes = [C.c_void_p]
+    L.sc_hip_field_lowmode.restype = C.c_int
     L.sc_hip_field_time_sweeps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)]
     L.sc_hip_field_time_sweeps.restype = C.c_int
     L.sc_hip_pool_create.argtypes = [C.c_int, C.c_int]
@@ -256,6 +271,19 @@ class Instance:
     def free(self, p):
         self.L.sc_hip_free(self.h, p)
 
+    def pinned_array(self, shape, dtype=np.uint8):
+        """numpy array over page-locked host memory (hipHostMalloc).  Returns (array, handle); release the memory with
+        free_pinned(handle) after the last use of the array."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.L.sc_hip_host_alloc(self.h, n)
+        if not p:
+            raise SeamlessCloneError(SC_ERR_HIP, f"hipHostMalloc({n}) failed")
+        buf = (C.c_uint8 * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape), p
+
+    def free_pinned(self, handle):
+        self.L.sc_hip_host_free(self.h, handle)
+
     def to_device(self, a: np.ndarray):
         a = np.ascontiguousarray(a)
         p = self.malloc(a.nbytes)
@@ -335,6 +363,15 @@ class Instance:
         out = np.zeros(self.field_shape(), np.float32)
         self._check(self.L.sc_hip_field_store(self.h, out.ctypes.data_as(f32p), out.size))
         return out
+
+    def field_finish(self, body, ltx, lty):
+        """Post-process alone: the field on the device -> clamp, truncate, interleave into `body` (in place)."""
+        b = _img(body)
+        self._check(self.L.sc_hip_field_finish(self.h, *b, int(ltx), int(lty)))
+
+    def field_lowmode(self):
+        """Float-table correction alone on the field on the device (result += correction)."""
+        self._check(self.L.sc_hip_field_lowmode(self.h))
 
     def field_time_sweeps(self, method, launches, sweeps_per_launch=1, omega=1.0) -> float:
         ms = C.c_float(0)

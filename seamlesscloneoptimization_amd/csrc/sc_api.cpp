@@ -83,8 +83,7 @@ static void copy_rows(Instance *I, uint8_t *dst, size_t dpitch, const uint8_t *s
     if (total < ((size_t)1 << 20)) { span(0, rows); return; }
     if (!I->copier) {
         const unsigned hw = std::thread::hardware_concurrency();
-        static const int want = [] { const char *e = getenv("SC_COPY_THREADS"); return e ? atoi(e) : 8; }();
-        int n = want < 1 ? 1 : want;
+        int n = 8;                         // measured: packing saturates near 8 threads
         if (hw && (unsigned)n > hw) n = (int)hw;
         I->copier.reset(new RowCopier(n - 1));
     }
@@ -94,18 +93,19 @@ static void copy_rows(Instance *I, uint8_t *dst, size_t dpitch, const uint8_t *s
 }
 
 // rows x row_bytes from caller memory (pitch hpitch) to device memory (pitch dpitch).
-// hipMemcpy2DAsync issues one DMA per row (~6 us each, measured with rocprofv3: 384 copies per
-// 298x192 clone), so pageable sources are packed into the pinned staging AT THE DEVICE PITCH and
-// cross PCIe as a single linear copy; only caller-pinned strided images use the 2-D form.
+// The library issues NO 2-D copies.  hipMemcpy2DAsync becomes one DMA per row (~6 us each, measured with
+// rocprofv3: 384 copies per 298x192 clone), and under rocprofv3's copy interception the row DMAs of the SECOND of two
+// back-to-back 2-D copies were released out of stream order (they landed after the kernels
+// that read them had started, the last ones after teardown had freed the arena -> GPU memory-access fault).  So
+// every strided host image -- pageable or caller-pinned -- is packed into the instance's pinned staging AT THE
+// DEVICE PITCH and crosses PCIe as linear copies; only a caller-pinned image that already has the device pitch is
+// copied in place.  The caller must not reuse `stage` before the stream has passed these copies.
 static int upload_rows(Instance *I, DevBuf &stage, void *d, size_t dpitch, const uint8_t *h, size_t hpitch,
                        size_t row_bytes, int rows)
 {
     if (rows <= 0 || row_bytes == 0) return SC_OK;
-    if (is_pinned(h)) {
-        if (hpitch == dpitch)
-            SC_HIP(I, hipMemcpyAsync(d, h, dpitch * (size_t)(rows - 1) + row_bytes, hipMemcpyHostToDevice, I->stream));
-        else
-            SC_HIP(I, hipMemcpy2DAsync(d, dpitch, h, hpitch, row_bytes, rows, hipMemcpyHostToDevice, I->stream));
+    if (hpitch == dpitch && is_pinned(h)) {
+        SC_HIP(I, hipMemcpyAsync(d, h, dpitch * (size_t)(rows - 1) + row_bytes, hipMemcpyHostToDevice, I->stream));
         return SC_OK;
     }
     int rc = ensure_pinned(I, stage, dpitch * (size_t)rows);
@@ -119,6 +119,21 @@ static int upload_rows(Instance *I, DevBuf &stage, void *d, size_t dpitch, const
         SC_HIP(I, hipMemcpyAsync((uint8_t *)d + (size_t)y0 * dpitch, s + (size_t)y0 * dpitch, dpitch * (size_t)(n - 1) + row_bytes,
                                  hipMemcpyHostToDevice, I->stream));
     }
+    return SC_OK;
+}
+
+// rows x row_bytes from device memory (pitch dpitch) into caller memory (pitch hpitch): ONE linear device-to-host copy
+// into the pinned staging, a wait, then the rows are spliced on the host (no 2-D copy, see upload_rows).  Synchronous.
+static int download_rows(Instance *I, DevBuf &stage, uint8_t *h, size_t hpitch, const void *d, size_t dpitch,
+                         size_t row_bytes, int rows)
+{
+    if (rows <= 0 || row_bytes == 0) return SC_OK;
+    const size_t total = dpitch * (size_t)(rows - 1) + row_bytes;
+    int rc = ensure_pinned(I, stage, total);
+    if (rc) return rc;
+    SC_HIP(I, hipMemcpyAsync(stage.p, d, total, hipMemcpyDeviceToHost, I->stream));
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    copy_rows(I, h, hpitch, (const uint8_t *)stage.p, dpitch, row_bytes, rows);
     return SC_OK;
 }
 
@@ -242,8 +257,7 @@ static int device_bbox(Instance *I, const uint8_t *d_mask, int mc, int mr, int m
 // for a few calls, so a stream of unpredictable masks pays at most one wasted clone in nine.
 static bool predict_rect(Instance *I, int mc, int mr, int r[4])
 {
-    static const int off = [] { const char *e = getenv("SC_NO_SPECULATE"); return e ? atoi(e) : 0; }();
-    if (off || mc < 3 || mr < 3) return false;
+    if ((I->opts.flags & SC_FLAG_NO_SPECULATE) || mc < 3 || mr < 3) return false;
     if (I->spec_cooldown > 0) { --I->spec_cooldown; return false; }
     if (I->last_mc == mc && I->last_mr == mr) { memcpy(r, I->last_rect, sizeof(int) * 4); return true; }
     r[0] = 1; r[1] = mc - 2; r[2] = 1; r[3] = mr - 2;
@@ -288,8 +302,7 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
     for (int pass = 0; pass < passes; ++pass) {
         I->result_in_U1 = false;
         I->f_half = mg_reads_half_rhs(I);
-        static const int no_hu = [] { const char *e = getenv("SC_NO_HALF_U"); return e ? atoi(e) : 0; }();
-        I->u_half = I->f_half && !no_hu;
+        I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
         launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
                           I->stream, I->f_half, I->u_half);
         if (pass == passes - 1 && (rc = tmark(I, 5))) return rc;
@@ -302,7 +315,9 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
         if (!I->spec_post.done) {          // otherwise the solver already enqueued it behind its last cycle
             if (pass == passes - 1 && (rc = tmark(I, 6))) return rc;
-            launch_postprocess(result(I), body_org, bstep, I->stream, I->guard);
+            Field outf;
+            if ((rc = output_field(I, outf))) return rc;
+            launch_postprocess(outf, body_org, bstep, I->stream, I->guard);
         } else if (pass == passes - 1) {
             I->tm[6] = nullptr;            // no mark between the last cycle and the post-process (an event there costs a
         }                                  // ~5 us bubble): ms_post is reported as 0 and ms_solve includes it
@@ -395,6 +410,8 @@ void my_seamlessclone_api_imp_destroy(void *p)
     for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
     if (I->mg_partial.p) (void)hipFree(I->mg_partial.p);
     if (I->h_partial.p) (void)hipHostFree(I->h_partial.p);
+    for (DevBuf *b : { &I->lm.Sx, &I->lm.Sy, &I->lm.R, &I->lm.P, &I->lm.E }) if (b->p) (void)hipFree(b->p);
+    if (I->lm.hR.p) (void)hipHostFree(I->lm.hR.p);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
     if (I->h_fd.p) (void)hipHostFree(I->h_fd.p);
     if (I->d_rect) (void)hipFree(I->d_rect);
@@ -433,6 +450,11 @@ int sc_hip_set_solver(void *p, const sc_solver_opts *o)
         I->err = "bad solver options";
         return SC_ERR_BAD_ARG;
     }
+    if (o->jacobi_tile_rows != 0 && o->jacobi_tile_rows != 16 && o->jacobi_tile_rows != 32 && o->jacobi_tile_rows != 64) {
+        I->err = "jacobi_tile_rows must be 0, 16, 32 or 64";
+        return SC_ERR_BAD_ARG;
+    }
+    if (o->flags != I->opts.flags) I->mg.clear();   // the hierarchy (direct bottom solve or not) depends on the flags
     I->opts = *o;
     return SC_OK;
 }
@@ -478,6 +500,25 @@ void sc_hip_free(void *p, void *d)
     (void)hipSetDevice(I->gpu);
     (void)hipStreamSynchronize(I->stream);
     (void)hipFree(d);
+}
+
+void *sc_hip_host_alloc(void *p, size_t bytes)
+{
+    Instance *I = get(p);
+    if (!I || bytes == 0) return nullptr;
+    (void)hipSetDevice(I->gpu);
+    void *h = nullptr;
+    if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return h;
+}
+
+void sc_hip_host_free(void *p, void *h)
+{
+    Instance *I = get(p);
+    if (!I || !h) return;
+    (void)hipSetDevice(I->gpu);
+    (void)hipStreamSynchronize(I->stream);
+    (void)hipHostFree(h);
 }
 
 int sc_hip_memcpy_h2d(void *p, void *d, const void *h, size_t bytes)
@@ -764,8 +805,7 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     // and repeats the members that were guessed wrong, one by one on their true boxes.
     std::vector<Geo> geo(n);
     std::vector<int> guess(4 * (size_t)n);
-    static const int no_spec = [] { const char *e = getenv("SC_NO_SPECULATE"); return e ? atoi(e) : 0; }();
-    bool speculative = !no_spec && I->group_spec_cooldown == 0;
+    bool speculative = !(I->opts.flags & SC_FLAG_NO_SPECULATE) && I->group_spec_cooldown == 0;
     if (I->group_spec_cooldown > 0) --I->group_spec_cooldown;
     for (int i = 0; i < n && speculative; ++i) {
         int *r = &guess[4 * i];
@@ -798,8 +838,7 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     I->erode_done = false;
     I->result_in_U1 = false;
     I->f_half = mg_reads_half_rhs(I);
-    static const int no_hu = [] { const char *e = getenv("SC_NO_HALF_U"); return e ? atoi(e) : 0; }();
-    I->u_half = I->f_half && !no_hu;
+    I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
     std::vector<ImageJob> ij(n);
     for (int i = 0; i < n; ++i) {
         const sc_batch_job &j = jobs[i];
@@ -822,7 +861,11 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     const bool spliced = I->spec_post.done;
     I->spec_post.group.clear();
     if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
-    if (!spliced) launch_postprocess_group(result(I), ij.data(), n, I->stream);
+    if (!spliced) {
+        Field outf;
+        if ((rc = output_field(I, outf))) return rc;
+        launch_postprocess_group(outf, ij.data(), n, I->stream);
+    }
     for (int i = 0; i < n; ++i) jobs[i].rc = solve_rc;
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
@@ -891,7 +934,7 @@ int sc_hip_mask_stage(void *p, const uint8_t *mask, int mc, int mr, int ms, int 
     int rc;
     const int dms = round_up(mc, 256);
     if ((rc = ensure(I, I->d_mask, (size_t)dms * mr))) return rc;
-    SC_HIP(I, hipMemcpy2DAsync(I->d_mask.p, dms, mask, ms, mc, mr, hipMemcpyHostToDevice, I->stream));
+    if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
     Geo g;
     if ((rc = device_bbox(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, cx, cy, g))) return rc;
     fill_info_geo(I, g);
@@ -902,19 +945,18 @@ int sc_hip_mask_stage(void *p, const uint8_t *mask, int mc, int mr, int ms, int 
     SC_HIP(I, hipGetLastError());
     if (M_out) {
         if (M_capacity < (size_t)g.W * g.H) return SC_ERR_BAD_SIZE;
-        SC_HIP(I, hipMemcpy2DAsync(M_out, g.W, I->d_M.p, I->mpitch, g.W, g.H, hipMemcpyDeviceToHost, I->stream));
+        if ((rc = download_rows(I, I->h_out, M_out, g.W, I->d_M.p, I->mpitch, g.W, g.H))) return rc;
     }
     SC_HIP(I, hipStreamSynchronize(I->stream));
     return SC_OK;
 }
 
+// planar float field -> dense [C][H][W] host array.  The planes of a field are contiguous (plane = pitch * H), so the
+// whole field is C * H rows at one pitch.
 static int download_field(Instance *I, const Field &f, float *out)
 {
-    for (int c = 0; c < f.C; ++c)
-        SC_HIP(I, hipMemcpy2DAsync(out + (size_t)c * f.W * f.H, (size_t)f.W * sizeof(float), f.at(c),
-                                   (size_t)f.pitch * sizeof(float), (size_t)f.W * sizeof(float), f.H,
-                                   hipMemcpyDeviceToHost, I->stream));
-    return SC_OK;
+    return download_rows(I, I->h_out, (uint8_t *)out, (size_t)f.W * sizeof(float), f.p, (size_t)f.pitch * sizeof(float),
+                         (size_t)f.W * sizeof(float), f.C * f.H);
 }
 
 int sc_hip_build_rhs(void *p, const uint8_t *face, int fc, int fr, int fs, const uint8_t *body, int bc, int br, int bs,
@@ -934,10 +976,8 @@ int sc_hip_build_rhs(void *p, const uint8_t *face, int fc, int fr, int fs, const
     const int dfs = round_up(3 * g.W, 256);
     if ((rc = ensure(I, I->d_face, (size_t)dfs * g.H))) return rc;
     if ((rc = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return rc;
-    SC_HIP(I, hipMemcpy2DAsync(I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H,
-                               hipMemcpyHostToDevice, I->stream));
-    SC_HIP(I, hipMemcpy2DAsync(I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H,
-                               hipMemcpyHostToDevice, I->stream));
+    if ((rc = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return rc;
+    if ((rc = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return rc;
     if ((rc = setup_fields(I, g.W, g.H, 3))) return rc;
     launch_preprocess((const uint8_t *)I->d_body_roi.p, dfs, (const uint8_t *)I->d_face.p, dfs,
                       (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F, I->stream);
@@ -962,11 +1002,10 @@ int sc_hip_field_load(void *p, int W, int H, int C, const float *U, const float 
     SC_HIP(I, hipMemsetAsync(I->d_U1.p, 0, I->U1.bytes(), I->stream));
     SC_HIP(I, hipMemsetAsync(I->d_F.p, 0, I->F.bytes(), I->stream));
     const size_t wb = (size_t)W * sizeof(float), pb = (size_t)I->U0.pitch * sizeof(float);
-    for (int c = 0; c < C; ++c) {
-        SC_HIP(I, hipMemcpy2DAsync(I->U0.at(c), pb, U + (size_t)c * W * H, wb, wb, H, hipMemcpyHostToDevice, I->stream));
-        SC_HIP(I, hipMemcpy2DAsync(I->U1.at(c), pb, U + (size_t)c * W * H, wb, wb, H, hipMemcpyHostToDevice, I->stream));
-        SC_HIP(I, hipMemcpy2DAsync(I->F.at(c), pb, lap + (size_t)c * W * H, wb, wb, H, hipMemcpyHostToDevice, I->stream));
-    }
+    // a field's planes are contiguous: C * H rows at one pitch, one packed upload each (separate staging buffers)
+    if ((rc = upload_rows(I, I->h_face, I->U0.p, pb, (const uint8_t *)U, wb, wb, C * H))) return rc;
+    if ((rc = upload_rows(I, I->h_body, I->F.p, pb, (const uint8_t *)lap, wb, wb, C * H))) return rc;
+    SC_HIP(I, hipMemcpyAsync(I->U1.p, I->U0.p, pb * (size_t)(C * H - 1) + wb, hipMemcpyDeviceToDevice, I->stream));
     SC_HIP(I, hipStreamSynchronize(I->stream));
     return SC_OK;
 }
@@ -1022,6 +1061,43 @@ int sc_hip_field_store(void *p, float *U_out, size_t capacity_floats)
     SC_HIP(I, hipSetDevice(I->gpu));
     int rc = download_field(I, result(I), U_out);
     if (rc) return rc;
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    return SC_OK;
+}
+
+int sc_hip_field_finish(void *p, uint8_t *body, int bc, int br, int bs, int ltx, int lty)
+{
+    Instance *I = get(p);
+    if (!I || !I->F.p || !body) return SC_ERR_BAD_ARG;
+    I->err.clear();
+    SC_HIP(I, hipSetDevice(I->gpu));
+    const Field &U = result(I);
+    if (U.C != 3) { I->err = "field_finish: needs a 3-channel field"; return SC_ERR_BAD_SIZE; }
+    if (bc <= 0 || br <= 0 || bs < 3 * bc) return SC_ERR_BAD_SIZE;
+    Geo g{ 0, 0, U.W, U.H, ltx, lty };
+    int rc;
+    if ((rc = check_roi(I, g, bc, br))) return rc;
+    const int dfs = round_up(3 * g.W, 256);
+    if ((rc = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return rc;
+    uint8_t *roi = body + (size_t)lty * bs + 3 * ltx;
+    if ((rc = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, roi, bs, 3 * (size_t)g.W, g.H))) return rc;
+    launch_postprocess(U, (uint8_t *)I->d_body_roi.p, dfs, I->stream);
+    SC_HIP(I, hipGetLastError());
+    return download_rows(I, I->h_out, roi, bs, I->d_body_roi.p, dfs, 3 * (size_t)g.W, g.H);
+}
+
+int sc_hip_field_lowmode(void *p)
+{
+    Instance *I = get(p);
+    if (I && I->f_half) { int frc = float_rhs(I); if (frc) return frc; }
+    if (!I || !I->F.p) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    Field &U = result(I), &O = I->result_in_U1 ? I->U0 : I->U1;
+    // the partner buffer receives the interior; give it the ring as well so it is a complete field
+    SC_HIP(I, hipMemcpyAsync(O.p, U.p, U.bytes(), hipMemcpyDeviceToDevice, I->stream));
+    int rc = lowmode_correct(I, U, O);
+    if (rc) return rc;
+    I->result_in_U1 = !I->result_in_U1;
     SC_HIP(I, hipStreamSynchronize(I->stream));
     return SC_OK;
 }

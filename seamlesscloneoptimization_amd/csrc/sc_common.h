@@ -65,7 +65,7 @@ void launch_preprocess_group(const ImageJob *jobs, int n, int mpitch, Field U0, 
 void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s);
 void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_t s);
 
-void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag = false);
+void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag = false, int lds_tile_rows = 0);
 void launch_rb_half(Field U, Field F, int color, float omega, hipStream_t s, bool tag = false);
 // fused temporally-blocked kernels (sc_sweep_tb.hip); return false when the shape is unsupported
 bool launch_jacobi_tb(Field Uin, Field Uout, Field F, int sweeps, hipStream_t s, bool tag = false);

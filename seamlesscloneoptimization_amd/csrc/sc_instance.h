@@ -22,6 +22,14 @@ struct FD1 {
     std::vector<double> lam, q, ee;          // eigenvalues; q[k*n + i] = component i of eigenvector k; diagonal of E
 };
 
+// float-table correction (sc_lowmode.hip): sine tables and coefficient buffers for the current ROI size
+struct LowMode {
+    int w = 0, h = 0, C = 0;               // interior size the tables were built for; channels the buffers hold
+    int Kx = 0, Ky = 0, Kxp = 0, Kyp = 0;  // modes per direction, padded to the register block
+    DevBuf Sx, Sy, R, P, E;                // Sx[w][Kxp], Sy[h][Kyp], R[Kyp][Kxp], P[chunks][C][Kyp][pitch], E[C][Kyp][pitch]
+    DevBuf hR;                             // pinned staging of R
+};
+
 struct MGLevel {
     Field U, F, T;   // correction, RHS, scratch (residual field); level 0 aliases the instance fields
     MGGeom g;        // geometry of this level and of its transfer to the next coarser one
@@ -74,6 +82,7 @@ struct Instance {
     // direct (fast-diagonalisation) solve inside the bottom kernel: level index relative to mg_bottom, or -1
     int fd_level = -1, fd_nxp = 0, fd_nyp = 0;
     DevBuf mg_fd, h_fd;    // its matrices: device copy and pinned staging
+    LowMode lm;
     std::vector<FD1> fd_cache;   // recent 1-D decompositions (a geometry seen before costs no eigen-solve)
     size_t fd_cache_next = 0;
     // reductions / mailboxes
@@ -113,6 +122,10 @@ int setup_fields(Instance *I, int W, int H, int C);
 int solve(Instance *I);
 bool mg_reads_half_rhs(const Instance *I);
 bool mg_composes_level1(const Instance *I);   // sc_multigrid.cpp   // sc_multigrid.cpp: would the solve configured in I->opts read a float16 F?
+int lowmode_correct(Instance *I, const Field &U, const Field &Out);   // sc_lowmode.hip: Out = U + float-table correction
+int lowmode_count(int n);
+bool wants_float_tables(const Instance *I);
+int output_field(Instance *I, Field &out);   // sc_solver.cpp: result(I), or result(I) + float-table correction in the partner buffer
 int run_sweeps(Instance *I, int method, int sweeps, float omega, int sweeps_per_launch);
 int fused_depth(int method, int sweeps_per_launch); // 0 = plain kernels
 int eval_residual(Instance *I, double out[2]);

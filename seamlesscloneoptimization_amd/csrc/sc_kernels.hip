@@ -711,12 +711,10 @@ __global__ __launch_bounds__(256) void k_jacobi_roll(Field Uin, Field Uout, Fiel
 // 5.7 / 5.45, 32 rows 4.8 / 4.6, 64 rows 3.2 / 3.3.  A bare out = a + b kernel with the same tiling and
 // a one-row halo (tools/stream_probe.hip) reaches 6.9 / 5.9 TB/s on the same data, so the sweep runs
 // at 90 / 97 % of what this GPU streams; dropping the two outside-column loads would close most of the
-// rest (measured 6.7 TB/s without them).  SC_JT_TH=<16|32|64> selects the LDS-tiled kernel and
-// SC_JROLL=<4|8|12|16> another segment height, for tuning.
-void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag)
+// rest (measured 6.7 TB/s without them).  lds_th = 16, 32 or 64 (sc_solver_opts.jacobi_tile_rows) selects the
+// LDS-tiled kernel.
+void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag, int lds_th)
 {
-    static const int lds_th = [] { const char *e = getenv("SC_JT_TH"); return e ? atoi(e) : 0; }();
-    static const int roll = [] { const char *e = getenv("SC_JROLL"); return e ? atoi(e) : 4; }();
     if (lds_th) {
         const int th = lds_th == 64 ? 64 : (lds_th == 32 ? 32 : 16);
         dim3 grid((Uin.W + JT_TW - 1) / JT_TW, (Uin.H + th - 1) / th, Uin.C);
@@ -725,12 +723,9 @@ void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag)
         else hipLaunchKernelGGL((k_jacobi<16, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
         return;
     }
-    const int S = (roll == 8 || roll == 12 || roll == 16) ? roll : 4;
+    constexpr int S = 4;
     const dim3 grid(((Uin.W + 255) / 256) * ((Uin.H + 4 * S - 1) / (4 * S)) * Uin.C);
-    if (S == 8) hipLaunchKernelGGL((k_jacobi_roll<8, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
-    else if (S == 12) hipLaunchKernelGGL((k_jacobi_roll<12, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
-    else if (S == 16) hipLaunchKernelGGL((k_jacobi_roll<16, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
-    else if (tag) hipLaunchKernelGGL((k_jacobi_roll<4, 1>), grid, dim3(256), 0, s, Uin, Uout, F);
+    if (tag) hipLaunchKernelGGL((k_jacobi_roll<4, 1>), grid, dim3(256), 0, s, Uin, Uout, F);
     else hipLaunchKernelGGL((k_jacobi_roll<4, 0>), grid, dim3(256), 0, s, Uin, Uout, F);
 }
 

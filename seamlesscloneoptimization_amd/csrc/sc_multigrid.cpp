@@ -187,8 +187,7 @@ double fd_selftest_error()
 static int build_fd(Instance *I)
 {
     I->fd_level = -1;
-    static const int fd_on = [] { const char *e = getenv("SC_BOTTOM_FD"); return e ? atoi(e) : 1; }();
-    if (!fd_on || I->mg_bottom >= I->mg.size()) return SC_OK;
+    if ((I->opts.flags & SC_FLAG_VCYCLE_BOTTOM) || I->mg_bottom >= I->mg.size()) return SC_OK;
     long planes = 0;
     for (size_t l = I->mg_bottom; l < I->mg.size(); ++l) {
         const MGLevel &L = I->mg[l];
@@ -355,8 +354,7 @@ static int vcycle(Instance *I, size_t l, int pre, int post, unsigned no_post = 0
     // a level without post-smoothing does all its sweeps before the restriction
     int pre_here = pre;
     if (skip_post) {
-        static const int extra = [] { const char *e = getenv("SC_COMPOSE_PRE"); return e ? atoi(e) : 4; }();
-        pre_here = std::max(pre, std::min(extra, pre + post));
+        pre_here = std::max(pre, std::min(4, pre + post));
     }
     // ---- pre-smoothing (levels >= 1 start from a zero correction), residual + restriction
     bool restricted = false;
@@ -414,18 +412,16 @@ static bool fused_level0(const sc_solver_opts &o)
 // (oracle/mg_np.py runs the same schedule); one launch per cycle less is worth ~10 % of the clone throughput.
 bool mg_composes_level1(const Instance *I)
 {
-    static const int off = [] { const char *e = getenv("SC_NO_COMPOSE_L1"); return e ? atoi(e) : 0; }();
     const sc_solver_opts &o = I->opts;
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
-    return !off && I->mg.size() >= 3 && I->mg_bottom >= 2 && pre == 2 && post == 2;
+    return !(o.flags & SC_FLAG_NO_COMPOSE_L1) && I->mg.size() >= 3 && I->mg_bottom >= 2 && pre == 2 && post == 2;
 }
 
 bool mg_reads_half_rhs(const Instance *I)
 {
-    static const int off = [] { const char *e = getenv("SC_NO_HALF_RHS"); return e ? atoi(e) : 0; }();
     const sc_solver_opts &o = I->opts;
     // at least two levels: min(W, H) - 2 > 3 (build_levels)
-    return !off && o.method == SC_METHOD_MULTIGRID && o.tol <= 0.f && fused_level0(o) && std::min(I->F.W, I->F.H) - 2 > 3;
+    return !(o.flags & SC_FLAG_FLOAT_RHS) && o.method == SC_METHOD_MULTIGRID && o.tol <= 0.f && fused_level0(o) && std::min(I->F.W, I->F.H) - 2 > 3;
 }
 
 int mg_solve(Instance *I)
@@ -498,10 +494,12 @@ int mg_solve(Instance *I)
                 // the post-process goes in FIRST (see Instance::spec_post): enqueued while the cycle launch is still running it
                 // starts without a gap, and the read-back of the maxima follows it
                 if (I->spec_post.armed && o.tol <= 0.f) {
+                    Field outf;
+                    if ((rc = output_field(I, outf))) return rc;
                     if (I->spec_post.group.empty()) {
-                        launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
+                        launch_postprocess(outf, I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
                     } else {
-                        launch_postprocess_group(result(I), I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream);
+                        launch_postprocess_group(outf, I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream);
                     }
                     I->spec_post.done = true;
                 }

@@ -11,6 +11,26 @@ namespace sc {
 Field &result(Instance *I) { return I->result_in_U1 ? I->U1 : I->U0; }
 static Field &other(Instance *I) { return I->result_in_U1 ? I->U0 : I->U1; }
 
+// The field the post-process reads.  For the converged multigrid solve that is, by default, the solution plus the
+// float-table correction (sc_lowmode.hip: the answer OpenCV and the reference compute), written into the ping-pong
+// partner so the solution itself stays untouched (the solve may continue if the stop rule rejects the cycle, and the
+// diagnostic hooks read it).  SC_FLAG_EXACT_TABLES, the sweep solvers (fixed counts, not converged fields) and ROIs
+// without unknowns: the solution itself.
+bool wants_float_tables(const Instance *I)
+{
+    return I->opts.method == SC_METHOD_MULTIGRID && !(I->opts.flags & SC_FLAG_EXACT_TABLES) && I->F.W >= 3 && I->F.H >= 3;
+}
+
+int output_field(Instance *I, Field &out)
+{
+    out = result(I);
+    if (!wants_float_tables(I)) return SC_OK;
+    const int rc = lowmode_correct(I, result(I), other(I));
+    if (rc) return rc;
+    out = other(I);
+    return SC_OK;
+}
+
 float optimal_omega(int W, int H)
 {
     const double w = W - 2, h = H - 2;
@@ -69,7 +89,7 @@ int run_sweeps(Instance *I, int method, int sweeps, float omega, int spl)
         if (!done) {
             T = 1;
             if (method == SC_METHOD_JACOBI) {
-                launch_jacobi(result(I), other(I), I->F, I->stream, I->bench_tag);
+                launch_jacobi(result(I), other(I), I->F, I->stream, I->bench_tag, I->opts.jacobi_tile_rows);
                 I->result_in_U1 = !I->result_in_U1;
                 I->info.sweep_launches += 1;
             } else {

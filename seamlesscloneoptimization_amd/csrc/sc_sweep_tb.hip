@@ -295,8 +295,7 @@ int tb_blocks_level0(int W, int H, int C, int sweeps)
 // never selects the 8-row form; SC_BIG_SIDE overrides for tuning runs.
 long tb_big_side()
 {
-    static const long v = [] { const char *e = getenv("SC_BIG_SIDE"); return e ? atol(e) : 1000000L; }();
-    return v;
+    return 1000000L;
 }
 
 // coarse multigrid levels: Gauss-Seidel only (omega = 1); smaller workgroups on small levels so
@@ -308,8 +307,6 @@ long tb_big_side()
 // short 4-row bands won every measurement (tools/bench_configs.py c3/c4).  SC_GEN_R overrides for tuning.
 int tb_gen_rows(int W, int H, int C, int hx, int hy)
 {
-    static const int forced = [] { const char *e = getenv("SC_GEN_R"); return e ? atoi(e) : 0; }();
-    if (forced == 4 || forced == 6 || forced == 8) return forced;
     if ((long)W * H >= tb_big_side() * tb_big_side()) return 8;
     const int nbx = (W + (256 - 2 * hx) - 1) / (256 - 2 * hx);
     for (int R = 4; R <= 8; R += 2) {
@@ -328,8 +325,7 @@ int tb_gen_rows_deep(int W, int H, int C, int hx, int hy)
     const int R = tb_gen_rows(W, H, C, hx, hy);
     if (R != 4) return 6;
     const int nbx = (W + (256 - 2 * hx) - 1) / (256 - 2 * hx), rows = 8 * 4 - 2 * hy;
-    static const int forced = [] { const char *e = getenv("SC_GEN_R"); return e ? atoi(e) : 0; }();
-    return (forced == 4 || nbx * ((H + rows - 1) / rows) * C <= 512) ? 4 : 6;
+    return (nbx * ((H + rows - 1) / rows) * C <= 512) ? 4 : 6;
 }
 
 // coarse multigrid levels: Gauss-Seidel only (omega = 1).  mode: 0 plain, TB_ZEROIN, TB_PROLONG (with E).

@@ -1,0 +1,241 @@
+"""GPU parity tests added in round 2 (through the C ABI, against the CPU oracle):
+the float-table correction (OpenCV's / the reference's own float32 eigenvalue tables), every per-instance variant flag,
+the LDS-tiled Jacobi kernel, the post-process hook, caller-pinned strided images and BASELINE config 5."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracles():
+    from oracle import oracle_np, oracle_c
+    oracle_c.build()
+    return oracle_np, oracle_c
+
+
+def _solution_field(oc, W, H, seed=0, margin=32):
+    from oracle import oracle_np as o
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=1001 + seed, seed_patch=2002 + seed, margin=margin)
+    geo, M = oc.mask_stage(mask, cx, cy)
+    B, lap = oc.build_rhs(dst, patch, geo, M)
+    g = oc.fold(B, lap)
+    nt = min(16, oc.max_threads())
+    ue, uf = oc.solve_dst(g, nt, exact_den=True), oc.solve_dst(g, nt, exact_den=False)
+    U = B.copy()
+    U[:, 1:-1, 1:-1] = ue
+    return U, lap, ue, uf
+
+
+@pytest.mark.parametrize("W,H", [(130, 70), (700, 300), (1100, 900), (2048, 600)])
+def test_float_table_correction_alone(hip, oracles, W, H):
+    """sc_hip_field_lowmode on the exact solution: equals the numpy restatement of the same K-mode correction to
+    float32 rounding, and lands on the reference's float-table answer (C oracle, exact_den=0) to a few 1e-3."""
+    from oracle import lowmode_np as lm
+    _, oc = oracles
+    U, lap, ue, uf = _solution_field(oc, W, H)
+    hip.field_load(U, lap)
+    hip.field_lowmode()
+    got = hip.field_store()
+    assert np.array_equal(got[:, 0, :], U[:, 0, :]) and np.array_equal(got[:, :, -1], U[:, :, -1])     # ring untouched
+    assert np.array_equal(got[:, -1, :], U[:, -1, :]) and np.array_equal(got[:, :, 0], U[:, :, 0])
+    for c in range(3):
+        d = got[c, 1:-1, 1:-1].astype(np.float64) - ue[c]
+        want = lm.correction(ue[c])
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(d - want).max() < 3e-4 * scale + 1e-4, (c, np.abs(d - want).max(), scale)
+        assert np.abs(got[c, 1:-1, 1:-1] - uf[c]).max() < 5e-3 + 2e-3 * scale, c
+
+
+def test_default_is_the_reference_arithmetic_and_the_flag_gives_the_exact_system(hip, oracles):
+    """BASELINE config 3 size.  The reference (and OpenCV) divide by float32 eigenvalue tables
+    (seamlessClone_imp.cpp:596-599, :1651-1653); at 2048^2 that answer is 3 grey levels away from the exact solution of
+    the 5-point system.  Default = the reference's answer; SC_FLAG_EXACT_TABLES = the exact system's."""
+    from seamlesscloneoptimization_amd import capi, compare
+    o, oc = oracles
+    W = H = 2048
+    nt = min(16, oc.max_threads())
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H)
+    want_f = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=nt, exact_den=False)
+    want_e = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=nt, exact_den=True)
+    assert compare.image_diff_stats(want_f, want_e)["max"] >= 2          # the distinction is real at this size
+    body = dst.copy()
+    assert hip.run(patch, body, mask, cx, cy) == 0
+    s = compare.image_diff_stats(want_f, body)
+    assert s["max"] <= 1 and s["percent"] < 0.5, compare.format_stats(s)
+    assert compare.image_diff_stats(want_e, body)["max"] >= 2
+    try:
+        hip.set_solver(flags=capi.SC_FLAG_EXACT_TABLES)
+        body = dst.copy()
+        assert hip.run(patch, body, mask, cx, cy) == 0
+        s = compare.image_diff_stats(want_e, body)
+        assert s["max"] <= 1 and s["percent"] < 0.5, compare.format_stats(s)
+    finally:
+        hip.set_solver(flags=0)
+
+
+@pytest.mark.parametrize("W,H", [(517, 400), (1030, 1000)])
+def test_variant_flags(hip, oracles, W, H):
+    """Every sc_solver_opts.flags variant in one process: the bit-identical ones equal the default path byte for byte,
+    the ones with different iterates stay within one grey level of the oracle."""
+    from seamlesscloneoptimization_amd import capi, compare
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=40)
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+    base = dst.copy()
+    assert hip.run(patch, base, mask, cx, cy) == 0
+    cycles = hip.info().sweeps
+    assert compare.image_diff_stats(want, base)["max"] <= 1
+    try:
+        for flags in (capi.SC_FLAG_NO_SPECULATE, capi.SC_FLAG_FLOAT_RHS, capi.SC_FLAG_FLOAT_U0,
+                      capi.SC_FLAG_FLOAT_RHS | capi.SC_FLAG_NO_SPECULATE):
+            hip.set_solver(flags=flags)
+            for _ in range(2):                                   # twice: the second call reuses the instance state
+                body = dst.copy()
+                assert hip.run(patch, body, mask, cx, cy) == 0
+                assert hip.info().sweeps == cycles
+                assert np.array_equal(body, base), flags
+        for flags in (capi.SC_FLAG_NO_COMPOSE_L1, capi.SC_FLAG_VCYCLE_BOTTOM,
+                      capi.SC_FLAG_NO_COMPOSE_L1 | capi.SC_FLAG_VCYCLE_BOTTOM | capi.SC_FLAG_FLOAT_RHS):
+            hip.set_solver(flags=flags)
+            body = dst.copy()
+            assert hip.run(patch, body, mask, cx, cy) == 0
+            s = compare.image_diff_stats(want, body)
+            assert s["max"] <= 1 and s["percent"] < 0.5, (flags, compare.format_stats(s))
+    finally:
+        hip.set_solver(flags=0)
+    body = dst.copy()
+    assert hip.run(patch, body, mask, cx, cy) == 0 and np.array_equal(body, base)
+
+
+@pytest.mark.parametrize("rows", [16, 32, 64])
+def test_lds_tiled_jacobi_bit_exact(hip, oracles, rows):
+    """k_jacobi<rows>: the LDS-staged 256 x rows tile with a 1-pixel halo (the form the north-star names) against the
+    CPU sweeps, bit for bit, across tile seams and ragged edges."""
+    from seamlesscloneoptimization_amd import capi
+    _, oc = oracles
+    try:
+        hip.set_solver(jacobi_tile_rows=rows)
+        for W, H in [(33, 17), (298, 192), (513, 129), (1030, 70), (257, 65), (3, 3)]:
+            rng = np.random.default_rng(W * 31 + H)
+            U = rng.normal(100, 50, (3, H, W)).astype(np.float32)
+            F = rng.normal(0, 30, (3, H, W)).astype(np.float32)
+            for n in (1, 6):
+                hip.field_load(U, F)
+                hip.field_sweep(capi.SC_METHOD_JACOBI, n, 1.0, 1)
+                assert np.array_equal(hip.field_store(), oc.jacobi(U, F, n)), (rows, W, H, n)
+    finally:
+        hip.set_solver(jacobi_tile_rows=0)
+    with pytest.raises(capi.SeamlessCloneError):
+        hip.set_solver(jacobi_tile_rows=48)
+
+
+def test_postprocess_hook_byte_exact(hip, oracles):
+    """sc_hip_field_finish = k_postprocess alone: clamp, then TRUNCATE (not round), interleave, interior only --
+    byte for byte against sco_finish (seamlessClone_imp.cpp:2091-2096, :470-483), including the values where a
+    rounding conversion would differ."""
+    _, oc = oracles
+    rng = np.random.default_rng(11)
+    for W, H, ltx, lty in [(37, 21, 5, 3), (300, 70, 0, 0), (258, 33, 11, 2), (1027, 19, 1, 1)]:
+        U = rng.uniform(-40, 300, (3, H, W)).astype(np.float32)
+        edge = np.array([99.9996, 100.0003, -0.5, 255.5, 254.99998, 255.0, 0.0, -0.0, 0.99999994, 1e-30, 1e9, -1e9,
+                         127.5, 128.49999], np.float32)
+        U[:, 1:-1, 1:-1].reshape(3, -1)[:, :edge.size] = edge
+        U[1, H // 2, 1:1 + min(edge.size, W - 2)] = edge[:min(edge.size, W - 2)]
+        body = rng.integers(0, 256, (H + lty + 4, W + ltx + 7, 3), dtype=np.uint8)
+        want = body.copy()
+        oc.finish(want, U, [0, 0, W, H, ltx, lty])
+        hip.field_load(U, np.zeros_like(U))
+        got = body.copy()
+        hip.field_finish(got, ltx, lty)
+        assert np.array_equal(got, want), (W, H)
+        # a strided (non-contiguous rows) destination view
+        big = rng.integers(0, 256, (H + lty + 4, W + ltx + 40, 3), dtype=np.uint8)
+        view = big[:, 9:9 + W + ltx + 7]
+        want2 = np.ascontiguousarray(view).copy()
+        oc.finish(want2, U, [0, 0, W, H, ltx, lty])
+        keep = big.copy()
+        hip.field_finish(view, ltx, lty)
+        assert np.array_equal(view, want2)
+        keep[:, 9:9 + W + ltx + 7] = want2
+        assert np.array_equal(big, keep)                       # nothing outside the view was touched
+
+
+def test_caller_pinned_and_strided_images(hip, oracles):
+    """run() with page-locked caller images: dense ones whose row step happens to equal the device pitch are copied in
+    place, strided ones are packed like pageable memory (the library issues no 2-D copies) -- same bytes either way."""
+    o, _ = oracles
+    W, H = 766, 300                       # 3 * 768 = 2304 = 9 * 256: the patch ROI rows can have the device pitch
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=64)
+    want = dst.copy()
+    assert hip.run(patch, want, mask, cx, cy) == 0
+    handles = []
+    try:
+        def pinned_copy(a, pad_cols):
+            shape = (a.shape[0], a.shape[1] + pad_cols) + a.shape[2:]
+            buf, h = hip.pinned_array(shape)
+            handles.append(h)
+            buf[...] = 7
+            view = buf[:, 3:3 + a.shape[1]] if pad_cols else buf
+            view[...] = a
+            return buf, view
+        for pad in (0, 29):
+            _, p_v = pinned_copy(patch, pad)
+            d_buf, d_v = pinned_copy(dst, pad)
+            _, m_v = pinned_copy(mask, pad)
+            assert hip.run(p_v, d_v, m_v, cx, cy) == 0
+            assert np.array_equal(d_v, want), pad
+            if pad:
+                assert np.all(d_buf[:, :3] == 7) and np.all(d_buf[:, 3 + dst.shape[1]:] == 7)
+    finally:
+        for h in handles:
+            hip.free_pinned(h)
+
+
+def test_config5_batch_of_64_clones_of_1024(oracles):
+    """BASELINE config 5 on one GPU: 64 independent 1024 x 1024 clones through the native pool (4 streams, groups of 8
+    sharing one set of solver launches).  A sample of members is compared with the C oracle (reference arithmetic) and
+    with the same clone run alone."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    N, W, H = 64, 1024, 1024
+    pool = capi.Pool(0, 4, group=8)
+    inst = pool.instances[0]
+    jobs = pool.make_jobs(N)
+    keep = []
+    for i, j in enumerate(jobs):
+        dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=3000 + i, seed_patch=4000 + i, margin=128)
+        f, b0, b, m = inst.to_device(patch), inst.to_device(dst), inst.to_device(dst), inst.to_device(mask)
+        keep.append((f, b0, b, m, dst.shape, (dst, patch, mask, cx, cy) if i % 9 == 0 or i == N - 1 else None))
+        j.face, j.face_cols, j.face_rows, j.face_step = f, patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+        j.body, j.body_cols, j.body_rows, j.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+        j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
+        j.centerX, j.centerY, j.body_restore = cx, cy, b0
+    for _ in range(2):
+        pool.run(jobs, device_resident=True)
+    assert all(j.rc == 0 for j in jobs)
+    group_cycles = {i.info().sweeps for i in pool.instances}
+    solo = capi.Instance(0)
+    checked = 0
+    for k, (f, b0, b, m, shape, host) in enumerate(keep):
+        if host is None:
+            continue
+        dst, patch, mask, cx, cy = host
+        got = inst.from_device(b, shape)
+        want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1 and (d > 0).mean() < 0.005, (k, int(d.max()), float((d > 0).mean()))
+        assert not np.array_equal(got, dst)
+        alone = dst.copy()
+        assert solo.run(patch, alone, mask, cx, cy) == 0
+        if group_cycles == {solo.info().sweeps}:
+            assert np.array_equal(got, alone), k
+        else:
+            assert np.abs(got.astype(np.int16) - alone.astype(np.int16)).max() <= 1, k
+        checked += 1
+    assert checked >= 8
+    for f, b0, b, m, _, _ in keep:
+        for p in (f, b0, b, m):
+            inst.free(p)
+    solo.destroy()
+    pool.close()
