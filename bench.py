@@ -1,46 +1,54 @@
 #!/usr/bin/env python3
 """bench.py -- seamless-clone throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W          (N > 1: spawns one rank per GPU itself)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks from the environment)
 
 A "step" is one pass of the hot path over one batch: `--batch` (default 32) independent
-NORMAL_CLONEs of a 2048x2048 ROI per GPU (mask stage + fused pre-process + Poisson solve to +-1
-grey-level parity + fused post-process), through the C ABI with their images already resident in HBM,
-issued by the library's native pool (sc_hip_pool_run: `--streams`, default 4, instances = HIP streams,
-one C++ worker thread each) so one clone's latency-bound phases overlap another's bandwidth-bound
-ones.  Each worker takes `--group` (default 8) clones at a time and solves them as ONE field of 3n
-channels (sc_hip_run_device_batch: same-size ROIs share one set of solver launches); `--group 1` is
-one clone per set of launches (sc_hip_run_device).  Every rank
+NORMAL_CLONEs of a 2048x2048 ROI per GPU (mask stage + fused pre-process + Poisson solve + float-table
+correction + fused post-process; result = the reference's arithmetic, +-1 grey level), through the C ABI with
+their images already resident in HBM, issued by the library's native pool (sc_hip_pool_run: `--streams`,
+default 4, instances = HIP streams, one C++ worker thread each).  Each worker takes `--group` (default 8)
+clones at a time and solves them as ONE field of 3n channels (sc_hip_run_device_batch: same-size ROIs share
+one set of solver launches); `--group 1` is one clone per set of launches (sc_hip_run_device).  Every rank
 owns its own synthetic images (weak scaling: independent images, no data-path collective);
 value = total ROI Mpix / max-over-ranks wall time.  Each destination is restored from a pristine
-device copy before every clone (inside the timed region) so no clone starts from an
-already-converged field.
+device copy before every clone (inside the timed region) so no clone starts from an already-converged field.
 
-The same JSON line carries `roofline` (dominant sweep kernel, HIP-event timed on the library's
-stream) and `cpu_baseline` (the C restatement of what cv::seamlessClone computes, timed on the
-host cores; rank 0, N=1 only).
+The same JSON line carries `roofline` (the dominant kernel AS THE TIMED REGION RUNS IT -- the grouped level-0
+multigrid launch -- HIP-event timed on the library's stream), `pcie` (the drop-in host-image call) and
+`cpu_baseline` (the C restatement of what cv::seamlessClone computes, timed on the host cores; rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The HIP library must be loaded before anything pulls in torch's bundled ROCm runtime.
-from seamlesscloneoptimization_amd import capi  # noqa: E402
-capi.load()   # bind /opt/rocm's HIP runtime now; torch (gloo only, N>1) is imported later inside Comm()
-from seamlesscloneoptimization_amd.batch import Comm, timed_region  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
-METHODS = {"mg": capi.SC_METHOD_MULTIGRID, "sor": capi.SC_METHOD_SOR, "rbgs": capi.SC_METHOD_RBGS,
-           "jacobi": capi.SC_METHOD_JACOBI}
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--roi", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=32, help="independent images per GPU per step")
+    ap.add_argument("--streams", type=int, default=4, help="concurrent library instances (HIP streams) per GPU")
+    ap.add_argument("--group", type=int, default=8, help="clones of one ROI size a worker solves as ONE field of 3n channels (sc_hip_run_device_batch)")
+    ap.add_argument("--method", default="mg", choices=["jacobi", "mg", "rbgs", "sor"])
+    ap.add_argument("--sweeps-per-launch", type=int, default=0)
+    ap.add_argument("--exact-tables", action="store_true", help="time the exact 5-point solution (SC_FLAG_EXACT_TABLES) instead of the reference's float-table answer")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
+    ap.add_argument("--kernel-launches", type=int, default=100, help="launches in the roofline micro-region")
+    return ap.parse_args(argv)
 
 
 def synth(roi, rank):
@@ -63,9 +71,11 @@ def synth(roi, rank):
     return dst, patch, mask, Wd // 2, Hd // 2
 
 
-def cpu_baseline(dst, patch, mask, cx, cy, gpu_out, budget_s):
-    """OpenCV-equivalent CPU restatement (oracle/sc_oracle.c), single thread (OpenCV's DFT
-    path is serial), 1 warm-up + timed repeats inside `budget_s`."""
+def cpu_baseline(dst, patch, mask, cx, cy, gpu_out, gpu_out_exact, budget_s):
+    """OpenCV-equivalent CPU restatement (oracle/sc_oracle.c, float32 eigenvalue tables exactly as the reference builds
+    them), single thread (OpenCV's DFT path is serial), 1 warm-up + timed repeats inside `budget_s`.  The parity numbers
+    compare like with like: the GPU's default output with the float-table port (the variant that is timed, = what the
+    reference computes), the GPU's SC_FLAG_EXACT_TABLES output with the exact-denominator port."""
     from oracle import oracle_c as oc
     import numpy as np
     oc.build()
@@ -80,9 +90,13 @@ def cpu_baseline(dst, patch, mask, cx, cy, gpu_out, budget_s):
     dt = (time.perf_counter() - t0) / reps
     nthr = max(1, min(oc.max_threads(), len(os.sched_getaffinity(0)), 16))  # the GPU box gives 16 cores per GPU
     t0 = time.perf_counter()
-    ref = oc.seamless_clone(dst, patch, mask, cx, cy, nthr, True)  # exact-denominator variant, all cores
+    ref_f = oc.seamless_clone(dst, patch, mask, cx, cy, nthr, False)  # the reference's arithmetic, all cores
     dt_all = time.perf_counter() - t0
-    d = np.abs(ref.astype(np.int16) - gpu_out.astype(np.int16))
+    ref_e = oc.seamless_clone(dst, patch, mask, cx, cy, nthr, True)   # exact denominators
+
+    def diff(a, b):
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        return {"maxdiff": int(d.max()), "percent_differing": round(float((d > 0).mean() * 100.0), 4)}
     # apples-to-apples for the fixed-iteration stencil config (512^2 ROI, 1000 Jacobi sweeps):
     # the same sweeps in C on one core, 200 timed and scaled to 1000
     rng = np.random.default_rng(5)
@@ -92,50 +106,62 @@ def cpu_baseline(dst, patch, mask, cx, cy, gpu_out, budget_s):
     oc.jacobi(Uj, Fj, 200)
     tj = (time.perf_counter() - t0) * 5.0
     return {
-        "jacobi_512x512_1000_sweeps": {"ms": round(tj * 1e3, 1), "Gpix_updates_per_s": round(510 * 510 * 1000 / tj / 1e9, 3),
-                                       "cores": 1, "note": "CPU counterpart of tools/bench_configs.py c2 (GPU: 1.2 ms)"},
         "value": round(W * H / dt / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
         "sample": f"{reps} timed + 1 warm-up full clones of the same {W}x{H} ROI, C restatement of "
-                  f"cv::seamlessClone (DST-direct, float32 tables), {dt * 1e3:.0f} ms each",
+                  f"cv::seamlessClone (DST-direct, float32 tables as the reference builds them), {dt * 1e3:.0f} ms each",
         "all_cores": {"value": round(W * H / dt_all / 1e6, 3), "cores": nthr, "note": "OpenMP over rows, 1 run"},
-        "gpu_vs_port_maxdiff": int(d.max()), "gpu_vs_port_diff_percent": float((d > 0).mean() * 100.0),
+        "gpu_vs_float_table_port": dict(diff(gpu_out, ref_f), note="GPU default output vs the port that is timed above (float32 "
+                                        "eigenvalue tables = the reference's / OpenCV's arithmetic; the port's FFT internals are double, "
+                                        "real OpenCV runs a float32 DFT whose own rounding is unknown here)"),
+        "gpu_exact_tables_vs_exact_den_port": dict(diff(gpu_out_exact, ref_e), note="GPU with SC_FLAG_EXACT_TABLES vs the port with "
+                                                   "double denominators (the exact 5-point system)"),
+        "float_table_port_vs_exact_den_port": dict(diff(ref_f, ref_e), note="how far the reference's own float tables are from the "
+                                                   "exact system at this size"),
+        "jacobi_512x512_1000_sweeps": {"ms": round(tj * 1e3, 1), "Gpix_updates_per_s": round(510 * 510 * 1000 / tj / 1e9, 3),
+                                       "cores": 1, "note": "CPU counterpart of tools/bench_configs.py c2"},
     }
 
 
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: one fresh child process per rank, started BEFORE this process touches HIP
+    (it never does: the library is only loaded by the children).  Rank 0's JSON line is forwarded."""
+    from seamlesscloneoptimization_amd.batch import spawn_ranks
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    rc, out0 = spawn_ranks(args.gpus, cmd)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--roi", type=int, default=2048)
-    ap.add_argument("--batch", type=int, default=32, help="independent images per GPU per step")
-    ap.add_argument("--streams", type=int, default=4, help="concurrent library instances (HIP streams) per GPU")
-    ap.add_argument("--group", type=int, default=8, help="clones of one ROI size a worker solves as ONE field of 3n channels (sc_hip_run_device_batch)")
-    ap.add_argument("--method", default="mg", choices=sorted(METHODS))
-    ap.add_argument("--sweeps-per-launch", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
-    ap.add_argument("--kernel-launches", type=int, default=200, help="launches in the roofline micro-region")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    # The HIP library must be loaded before anything pulls in torch's bundled ROCm runtime.
+    from seamlesscloneoptimization_amd import capi
+    capi.load()   # bind /opt/rocm's HIP runtime now; torch (gloo only, N>1) is imported later inside Comm()
+    from seamlesscloneoptimization_amd.batch import Comm, timed_region
+    methods = {"mg": capi.SC_METHOD_MULTIGRID, "sor": capi.SC_METHOD_SOR, "rbgs": capi.SC_METHOD_RBGS,
+               "jacobi": capi.SC_METHOD_JACOBI}
 
     comm = Comm()
     if comm.world != args.gpus:
-        if comm.world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = comm.world
     import numpy as np
 
     ndev = capi.device_count()
     if ndev < 1:
         sys.exit("bench.py: no MI355X visible (there is no CPU fallback)")
-    opts = dict(method=METHODS[args.method])
+    opts = dict(method=methods[args.method], flags=capi.SC_FLAG_EXACT_TABLES if args.exact_tables else 0)
     if args.method == "sor":
         opts.update(tol=2e-5, max_sweeps=200000, check_every=64)
     if args.sweeps_per_launch:
         opts.update(sweeps_per_launch=args.sweeps_per_launch)
     streams = max(1, min(args.streams, args.batch))
-    # % ndev only matters when rehearsing N ranks on a 1-GPU box
     group = max(1, min(args.group, args.batch))
     streams = max(1, min(streams, (args.batch + group - 1) // group))
+    # % ndev only matters when rehearsing N ranks on a 1-GPU box
     pool = capi.Pool(comm.local_rank % ndev, streams, group=group, **opts)      # native C++ workers, one per HIP stream
     inst = pool.instances[0]
 
@@ -144,7 +170,7 @@ def main():
     cjobs = pool.make_jobs(args.batch)          # one C job per image: D2D restore + device-resident clone
     for b in range(args.batch):
         dst, patch, mask, cx, cy = synth(args.roi, comm.rank * args.batch + b)
-        j = dict(host=(dst, patch, mask, cx, cy), f=inst.to_device(patch), fs=patch.shape[:2],
+        j = dict(host=(dst, patch, mask, cx, cy) if b in (0, args.batch - 1) else None, f=inst.to_device(patch), fs=patch.shape[:2],
                  b0=inst.to_device(dst), b=inst.to_device(dst), n=dst.nbytes, bs=dst.shape[:2],
                  m=inst.to_device(mask), ms=mask.shape[:2], cx=cx, cy=cy)
         jobs.append(j)
@@ -169,10 +195,20 @@ def main():
     for _ in range(args.warmup):
         step()
     elapsed = timed_region(comm, sync_all, lambda: [step() for _ in range(args.steps)])
+    group_cycles = max(i.info().sweeps for i in pool.instances)
     dst, patch, mask, cx, cy = jobs[0]["host"]
     out = inst.from_device(jobs[0]["b"], dst.shape)
     if not all(i.info().converged for i in pool.instances) or np.array_equal(out, dst):
         sys.exit("bench.py: the clone did not converge / did not modify the destination")
+
+    # ---- roofline of the dominant kernel AS TIMED: the level-0 multigrid launch of a group (3 x group channels), on the
+    #      fields the last group of the timed region left on instance 0; HIP events on the library's stream around
+    #      back-to-back launches.  (The isolated launches run the same kernel under a second symbol -- template tag -- so
+    #      the rocprofv3 statistics of this command keep them apart from the launches inside the clones.)
+    unknowns = (W - 2) * (H - 2) * 3
+    grp_ch = inst.field_shape()[0] if args.method == "mg" else 3
+    ms_c0 = inst.time_cycle0(args.kernel_launches) if args.method == "mg" else None
+
     # the last image of the batch once more, alone: what the pool (groups, several streams) wrote must be the clone's result
     jl = jobs[-1]
     pooled_last = inst.from_device(jl["b"], jl["host"][0].shape)
@@ -185,16 +221,35 @@ def main():
     clone(inst, jobs[0], sync=True)
     clone(inst, jobs[0], sync=True)
     info = inst.info()
+    # the same clone with the exact tables (parity pair of the CPU baseline leg)
+    if args.method == "mg":
+        inst.set_solver(flags=opts["flags"] ^ capi.SC_FLAG_EXACT_TABLES)
+        clone(inst, jobs[0], sync=True)
+        other_tables = inst.from_device(jobs[0]["b"], dst.shape)
+        inst.set_solver(flags=opts["flags"])
+    else:
+        other_tables = out
+    out_float, out_exact = (other_tables, out) if args.exact_tables else (out, other_tables)
 
-    # ---- roofline of the dominant sweep kernel: HIP events on the library's stream, over a
-    #      region of back-to-back launches on the very fields the clone just used
-    unknowns = (W - 2) * (H - 2) * 3
+    # ---- the drop-in call itself: pageable host images in, result in the caller's image (PCIe inclusive)
+    body = dst.copy()
+    inst.run(patch, body, mask, cx, cy)
+    t0 = time.perf_counter()
+    body[...] = dst
+    t_restore = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    inst.run(patch, body, mask, cx, cy)
+    t_host = time.perf_counter() - t0
+    hi = inst.info()
+    pcie = {"h2d_ms": round(hi.ms_h2d, 4), "d2h_ms": round(hi.ms_d2h, 4), "device_ms": round(hi.ms_device_total, 4),
+            "call_ms": round(t_host * 1e3, 4), "Mpix_per_s_inclusive": round(W * H / t_host / 1e6, 1),
+            "note": "my_seamlessclone_api_imp_run on pageable numpy images, one clone, one stream: pack into pinned staging + H2D of "
+                    "the ROI of face/body and the mask, clone, D2H + splice of the interior (never `value`)"}
+
+    # ---- sweep kernels named by the north-star, on freshly built float fields of the same images (single clone, 3 channels)
     spl = args.sweeps_per_launch            # 0: library default = fused kernels at their deepest depth
     rb_depth = {0: 4, 1: 0, -1: 1}.get(spl, min(spl, 4))        # sweeps per launch of the red-black kernel
     j_depth = {0: 8, 1: 0, -1: 1, 5: 4, 7: 6}.get(spl, min(spl, 8))
-    # the fused multigrid cycle first, on the state the clone left (its right-hand side is stored as float16);
-    # the sweep kernels then run on freshly built float fields of the same images
-    ms_c0 = inst.time_cycle0(args.kernel_launches) if args.method == "mg" else None
     inst.build_rhs(patch, dst, mask, cx, cy)
     ms_rb = inst.field_time_sweeps(capi.SC_METHOD_RBGS, args.kernel_launches, spl, 1.0)
     ms_j = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, args.kernel_launches, spl, 1.0)
@@ -202,57 +257,71 @@ def main():
     rb_bytes = 12.0 * unknowns * (0.5 if rb_depth == 0 else rb_depth)   # plain kernel: one colour per launch
     j_bytes = 12.0 * unknowns * max(j_depth, 1)
 
-    def pmc_traffic(symbol):
-        """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
-        WRITE_SIZE, tools/pmc_traffic.py); null when no pass exists for this ROI size."""
-        path = os.path.join(ROOT, "profiles", f"pmc_traffic_roi{args.roi}.json")
+    profile = None
+    for name in ("r2_pmc_traffic_bench.json",):
         try:
-            ks = json.load(open(path))["kernels"]
+            profile = json.load(open(os.path.join(ROOT, "profiles", name)))
+            profile["_file"] = "profiles/" + name
+            break
         except Exception:
+            pass
+
+    def pmc_traffic(symbol, channels):
+        """Fabric-side bytes per launch from the committed rocprofv3 PMC passes of this command (2 x FETCH_SIZE + WRITE_SIZE,
+        tools/pmc_traffic.py; collected per MI355X_MICROARCH.md's HBM section); None when no pass covers this configuration."""
+        if not profile or profile.get("roi") != args.roi:
             return None
-        for k, v in ks.items():
-            if symbol in k:
+        for k, v in profile.get("kernels", {}).items():
+            if symbol in k and v.get("channels", channels) == channels:
                 return v["traffic_bytes_per_launch"]
         return None
 
-    def roof(name, symbol, bytes_per_launch, ms, note):
+    def roof(name, symbol, bytes_per_launch, ms, note, channels=3):
         ach = bytes_per_launch / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": name, "profiler_symbol": "sc::" + symbol, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(symbol), "us_per_launch": round(ms * 1e3, 2),
-                "algorithmic_bytes_per_launch": int(bytes_per_launch), "note": note}
+        tr = pmc_traffic(symbol, channels)
+        r = {"bound": "hbm", "kernel": name, "profiler_symbol": "sc::" + symbol, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "frac_effective": round(ach / HBM_PEAK_GBS, 4),
+             "traffic": tr, "frac_traffic": round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
+             "traffic_source": (f"{profile['_file']} @ {profile.get('git', '?')}" if tr else None),
+             "us_per_launch": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch), "note": note}
+        return r
 
     rb_name = "k_rb_half (one colour, in place)" if rb_depth == 0 else \
         f"k_rb_tb<{rb_depth},8,8> ({rb_depth} fused red-black sweeps per launch, register blocked)"
     j_name = "k_jacobi_roll (register-rolling 5-point, 1 sweep)" if j_depth == 0 else \
         f"k_jacobi_tb<{j_depth},8,8> ({j_depth} fused Jacobi sweeps per launch, register blocked)"
-    cache_note = ("working set %.0f MB %s the 256 MB Infinity Cache" %
-                  (unknowns * 12 / 1e6, "fits" if unknowns * 12 < 256e6 else "exceeds"))
-    # the isolated launches below run the same kernels under a second symbol (template tag) so the
-    # rocprofv3 statistics of this command keep them apart from the concurrent in-clone launches
+
+    def cache_note(ch):
+        ws = (W - 2) * (H - 2) * ch * 12
+        return "working set %.0f MB %s the 256 MB Infinity Cache" % (ws / 1e6, "fits" if ws < 256e6 else "exceeds")
     rb_sym = "k_rb_half<false, 1>" if rb_depth == 0 else f"k_rb_tb<{rb_depth}, 8, 8, false, false, 8, {1 if rb_depth <= 2 else 2}>"
     j_sym = "k_jacobi_roll<4, 1>" if j_depth == 0 else f"k_jacobi_tb<{j_depth}, 8, 8, 1, {1 if j_depth <= 4 else 2}>"
     roofline_rb = roof(rb_name, rb_sym, rb_bytes, ms_rb,
-                       "red-black GS/SOR sweeps alone; algorithmic bytes = 12 B/unknown/channel/sweep x sweeps per launch "
-                       "(SURVEY 8d), so >1.0 is 'effective' bandwidth from temporal blocking; " + cache_note)
-    # the dominant kernel of the timed clone: the fused level-0 multigrid cycle.  Algorithmic bytes per
+                       "red-black GS/SOR sweeps alone, single clone (3 channels); algorithmic bytes = 12 B/unknown/channel/sweep x sweeps "
+                       "per launch (SURVEY 8d): frac > 1 is 'effective' bandwidth from temporal blocking, frac_traffic is what crosses the fabric; "
+                       + cache_note(3))
+    # the dominant kernel of the timed region: the fused level-0 multigrid cycle of a GROUP.  Algorithmic bytes per
     # unknown and channel = the SURVEY 8d figures of the operations it fuses: 4 red-black sweeps (4 x 12 B),
     # residual (8 B read) + restricted RHS (1/4 x 4 B written), prolongation (1/4 x 4 B read + 4 B read + 4 B written)
-    c0_bytes = (4 * 12.0 + 8.0 + 1.0 + 9.0) * unknowns
     if args.method == "mg":
-        roofline = roof("k_cycle0<4,8,8,PRO> (prolongation + 4 red-black sweeps + residual + restriction, one launch)",
-                        "k_cycle0<4, 8, 8, true, false, false, 19>", c0_bytes, ms_c0,
-                        "dominant kernel of the timed clone (whole level-0 part of a V-cycle); algorithmic bytes = sum of the "
-                        "SURVEY 8d figures of the fused operations = 66 B/unknown/channel, so >1.0 is 'effective' bandwidth; "
-                        + cache_note)
+        c0_bytes = (4 * 12.0 + 8.0 + 1.0 + 9.0) * (W - 2) * (H - 2) * grp_ch
+        roofline = roof(f"k_cycle0<4,8,8,PRO> on a group of {grp_ch // 3} clones = {grp_ch} channels (prolongation + 4 red-black sweeps + "
+                        "residual + restriction, one launch)", "k_cycle0<4, 8, 8, true, false, false, 19>", c0_bytes, ms_c0,
+                        "dominant kernel of the timed region, in the form the timed region launches it; algorithmic bytes = sum of the "
+                        "SURVEY 8d figures of the fused operations = 66 B/unknown/channel: frac (= frac_effective) > 1 is 'effective' "
+                        "bandwidth from temporal blocking; frac_traffic = counter-measured fabric bytes / time / 8 TB/s; "
+                        + cache_note(grp_ch), channels=grp_ch)
     else:
         roofline = roofline_rb
-    roofline_j = roof(j_name, j_sym, j_bytes, ms_j, "the Jacobi stencil named by the north-star, same field; effective "
-                      "bandwidth (temporal blocking); " + cache_note)
-    roofline_j1 = roof("k_jacobi_roll<4> (5-point sweep, rows rolling through registers, 1 sweep per launch)", "k_jacobi_roll<4, 1>", 12.0 * unknowns, ms_j1,
-                       "single-sweep Jacobi: algorithmic == actual traffic; " + cache_note)
+    roofline_j = roof(j_name, j_sym, j_bytes, ms_j, "the Jacobi stencil named by the north-star, same field, single clone; effective "
+                      "bandwidth (temporal blocking); " + cache_note(3))
+    roofline_j1 = roof("k_jacobi_roll<4> (5-point sweep, rows rolling through registers, 1 sweep per launch)", "k_jacobi_roll<4, 1>",
+                       12.0 * unknowns, ms_j1, "single-sweep Jacobi, single clone: algorithmic == actual traffic; " + cache_note(3))
 
     total_pix = comm.sum(float(W * H * args.batch)) * args.steps
     value = total_pix / elapsed / 1e6
+    step_traffic = profile.get("step_traffic_bytes") if profile and profile.get("roi") == args.roi and \
+        profile.get("batch") == args.batch and profile.get("group") == group else None
     line = {
         "metric": "Mpix/s seamlessClone (ROI 2048^2)" if args.roi == 2048 else f"Mpix/s seamlessClone (ROI {args.roi}^2)",
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -260,18 +329,27 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.batch} independent {W}x{H}-ROI NORMAL_CLONEs per GPU per step on {streams} HIP "
                                f"streams, {group} clones per set of solver launches, 3-channel u8 images resident in HBM, solver={args.method}, "
-                               f"parity +-1 grey level vs the float64 oracle",
+                               + ("result = exact 5-point solution (SC_FLAG_EXACT_TABLES), +-1 grey level vs the exact-denominator port"
+                                  if args.exact_tables else
+                                  "result = the reference's / OpenCV's float32-table arithmetic (multigrid + float-table correction), "
+                                  "+-1 grey level vs the float-table CPU port"),
                    "roi": [W, H], "dst": list(dst.shape[:2]), "batch_per_gpu": args.batch, "streams_per_gpu": streams,
                    "clones_per_launch_group": group,
                    "parallelism": f"{args.gpus} GPU(s) x {args.batch} independent images, no collective",
-                   "cycles_or_sweeps": int(info.sweeps)},
+                   "cycles_or_sweeps": int(group_cycles)},
         "single_clone_stages_ms": {"mask": round(info.ms_mask, 4), "pre": round(info.ms_pre, 4), "solve": round(info.ms_solve, 4),
-                      "post": round(info.ms_post, 4), "device_total": round(info.ms_device_total, 4)},
+                                   "post": round(info.ms_post, 4), "device_total": round(info.ms_device_total, 4),
+                                   "note": "one clone alone on the GPU, hipEvent marks; solve includes the float-table correction and, "
+                                           "when post = 0, the post-process enqueued directly behind it"},
         "roofline": roofline, "roofline_red_black": roofline_rb, "roofline_jacobi": roofline_j,
         "roofline_jacobi_single_sweep": roofline_j1,
+        "whole_step_fabric": ({"bytes_per_step": int(step_traffic), "TB_per_s": round(step_traffic / (elapsed / args.steps) / 1e12, 3),
+                               "frac_of_peak": round(step_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                               "traffic_source": f"{profile['_file']} @ {profile.get('git', '?')}"} if step_traffic else None),
+        "pcie": pcie,
     }
     if comm.rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:
-        line["cpu_baseline"] = cpu_baseline(dst, patch, mask, cx, cy, out, args.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(dst, patch, mask, cx, cy, out_float, out_exact, args.cpu_seconds)
     elif comm.rank == 0:
         line["cpu_baseline"] = None
     for j in jobs:

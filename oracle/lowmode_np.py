@@ -7,8 +7,11 @@ Relative to the exact solution u of the 5-point system that is
 
     u_ref - u = S^-1[ S(u) * (den_exact / den_float - 1) ],      S = 2-D DST-I,
 
-restricted here to the first K modes per direction, exactly as the HIP kernels do (K = lowmode_count(n)).
-`full_correction` keeps every mode (what K -> n converges to) and is what the tests use to bound the truncation.
+restricted here to the first K modes per direction, exactly as the HIP kernels do (K = lowmode_count(n)), and -- also
+as the kernels do -- with both sine tables represented by their values at the NODES, every 8th field row / column
+(field position 8Y = interior index 8Y - 1; node 0 is the Dirichlet ring), and linear interpolation between them
+(`hat=8`; `hat=1` is the plain table).  `full_correction` keeps every mode and the plain tables (what K -> n
+converges to) and is what the tests use to bound both approximations.
 """
 from __future__ import annotations
 
@@ -39,13 +42,26 @@ def ratio(w: int, h: int, Kx: int, Ky: int) -> np.ndarray:
     return den_e / den_f - 1.0
 
 
-def correction(u: np.ndarray, Kx: int | None = None, Ky: int | None = None) -> np.ndarray:
+def sine_table(n: int, K: int, hat: int = 8) -> np.ndarray:
+    """n x K: sin(pi (i+1)(k+1)/(n+1)) for the interior points i, exact (hat=1) or interpolated linearly from the nodes
+    at field positions 0, hat, 2 hat, ... (field position = i + 1; the last node may lie past the far ring)."""
+    k = np.arange(1, K + 1)
+    pos = np.arange(1, n + 1)                                    # field position of interior point i
+    if hat == 1:
+        return np.sin(np.pi * np.outer(pos, k) / (n + 1.0))
+    nodes = n // hat + 2
+    SN = np.sin(np.pi * np.outer(hat * np.arange(nodes), k) / (n + 1.0))
+    Y, t = pos // hat, (pos % hat) / float(hat)
+    return (1.0 - t)[:, None] * SN[Y] + t[:, None] * SN[Y + 1]
+
+
+def correction(u: np.ndarray, Kx: int | None = None, Ky: int | None = None, hat: int = 8) -> np.ndarray:
     """u: interior field (h x w, float).  Returns the K-mode correction (float64, h x w)."""
     h, w = u.shape
     Kx = lowmode_count(w) if Kx is None else Kx
     Ky = lowmode_count(h) if Ky is None else Ky
-    Sx = np.sin(np.pi * np.outer(np.arange(1, w + 1), np.arange(1, Kx + 1)) / (w + 1.0))   # w x Kx
-    Sy = np.sin(np.pi * np.outer(np.arange(1, h + 1), np.arange(1, Ky + 1)) / (h + 1.0))   # h x Ky
+    Sx = sine_table(w, Kx, hat)                                                            # w x Kx
+    Sy = sine_table(h, Ky, hat)                                                            # h x Ky
     uh = Sy.T @ u.astype(np.float64) @ Sx * (4.0 / ((w + 1.0) * (h + 1.0)))
     return Sy @ (uh * ratio(w, h, Kx, Ky)) @ Sx.T
 

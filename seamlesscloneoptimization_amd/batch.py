@@ -19,6 +19,46 @@ def shard_indices(n_items: int, rank: int, world: int) -> list[int]:
     return list(range(rank, n_items, world))
 
 
+def spawn_ranks(world: int, cmd: list[str], extra_env: dict | None = None, poll_s: float = 0.05):
+    """Start `world` fresh processes running `cmd`, one per rank, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set (what torch.distributed.run would export), and wait for them.  Returns (rc, rank-0 stdout): rc is 0
+    only if every rank exited 0; when one fails the others are terminated (they would wait in a barrier for ever).
+    The caller must not have initialised the GPU -- nothing in here does: the children are plain subprocesses started
+    with Popen (fork + exec of a process that never loaded the HIP library), never an exec of an initialised process."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc = 0
+    pending = set(range(world))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in pending:                      # a rank died: the rest would hang in the next barrier
+                    procs[q].terminate()
+        if pending:
+            if rc == 0 and 0 not in pending:
+                pass
+            time.sleep(poll_s)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    return rc, out0
+
+
 class Comm:
     """Barrier + max-reduction over ranks.  world == 1 needs no torch at all."""
 

@@ -315,9 +315,9 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
         if (!I->spec_post.done) {          // otherwise the solver already enqueued it behind its last cycle
             if (pass == passes - 1 && (rc = tmark(I, 6))) return rc;
-            Field outf;
-            if ((rc = output_field(I, outf))) return rc;
-            launch_postprocess(outf, body_org, bstep, I->stream, I->guard);
+            LmNodes lm;
+            if ((rc = output_nodes(I, lm))) return rc;
+            launch_postprocess(result(I), body_org, bstep, I->stream, I->guard, lm);
         } else if (pass == passes - 1) {
             I->tm[6] = nullptr;            // no mark between the last cycle and the post-process (an event there costs a
         }                                  // ~5 us bubble): ms_post is reported as 0 and ms_solve includes it
@@ -410,7 +410,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
     if (I->mg_partial.p) (void)hipFree(I->mg_partial.p);
     if (I->h_partial.p) (void)hipHostFree(I->h_partial.p);
-    for (DevBuf *b : { &I->lm.Sx, &I->lm.Sy, &I->lm.R, &I->lm.P, &I->lm.E }) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : { &I->lm.Sx, &I->lm.Sy, &I->lm.R, &I->lm.P, &I->lm.E, &I->lm.CN }) if (b->p) (void)hipFree(b->p);
     if (I->lm.hR.p) (void)hipHostFree(I->lm.hR.p);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
     if (I->h_fd.p) (void)hipHostFree(I->h_fd.p);
@@ -862,9 +862,9 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     I->spec_post.group.clear();
     if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
     if (!spliced) {
-        Field outf;
-        if ((rc = output_field(I, outf))) return rc;
-        launch_postprocess_group(outf, ij.data(), n, I->stream);
+        LmNodes lm;
+        if ((rc = output_nodes(I, lm))) return rc;
+        launch_postprocess_group(result(I), ij.data(), n, I->stream, lm);
     }
     for (int i = 0; i < n; ++i) jobs[i].rc = solve_rc;
     SC_HIP(I, hipGetLastError());

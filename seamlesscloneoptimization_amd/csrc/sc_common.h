@@ -59,10 +59,23 @@ void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_o
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false);
 // bounding box the host assumed when it launched a clone before the device's answer was back (d_rect == nullptr: none)
 struct RectGuard { const int *d_rect = nullptr; int x0 = 0, x1 = 0, y0 = 0, y1 = 0; };
-void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard());
+// float-table correction at the nodes = every 8th field row and column (sc_lowmode.hip): CN[c][Y][X], ny rows of npitch
+// floats per channel; the post-process adds the bilinear interpolation between the four nodes around a pixel.
+// CN == nullptr: none.
+struct LmNodes { const float *CN = nullptr; int ny = 0, npitch = 0; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ float lm_bilinear(const LmNodes &lm, int c, int x, int y)
+{
+    const float *__restrict__ p = lm.CN + ((size_t)c * lm.ny + (y >> 3)) * lm.npitch + (x >> 3);
+    const float tx = 0.125f * (float)(x & 7), ty = 0.125f * (float)(y & 7);
+    const float top = __builtin_fmaf(tx, p[1] - p[0], p[0]), bot = __builtin_fmaf(tx, p[lm.npitch + 1] - p[lm.npitch], p[lm.npitch]);
+    return __builtin_fmaf(ty, bot - top, top);
+}
+#endif
+void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard(), LmNodes lm = LmNodes());
 // the same for a group (fields of 3n channels), one launch per 16 members
 void launch_preprocess_group(const ImageJob *jobs, int n, int mpitch, Field U0, Field F, hipStream_t s, bool f_half, bool u_half);
-void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s);
+void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s, LmNodes lm = LmNodes());
 void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_t s);
 
 void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag = false, int lds_tile_rows = 0);

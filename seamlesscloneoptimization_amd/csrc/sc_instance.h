@@ -26,7 +26,8 @@ struct FD1 {
 struct LowMode {
     int w = 0, h = 0, C = 0;               // interior size the tables were built for; channels the buffers hold
     int Kx = 0, Ky = 0, Kxp = 0, Kyp = 0;  // modes per direction, padded to the register block
-    DevBuf Sx, Sy, R, P, E;                // Sx[w][Kxp], Sy[h][Kyp], R[Kyp][Kxp], P[chunks][C][Kyp][pitch], E[C][Kyp][pitch]
+    int nx = 0, ny = 0, npitch = 0;        // nodes (every 8th field column / row) and the row pitch of CN
+    DevBuf Sx, Sy, R, P, E, CN;            // Sx[nx][Kxp], Sy[ny][Kyp] (sines at the nodes), R[Kyp][Kxp], P = cell shares float4[C][cells_y][cells_x], E = partial products of the coarse projection [parts][C][Kyp][Kxp], CN[C][ny][npitch]
     DevBuf hR;                             // pinned staging of R
 };
 
@@ -123,9 +124,10 @@ int solve(Instance *I);
 bool mg_reads_half_rhs(const Instance *I);
 bool mg_composes_level1(const Instance *I);   // sc_multigrid.cpp   // sc_multigrid.cpp: would the solve configured in I->opts read a float16 F?
 int lowmode_correct(Instance *I, const Field &U, const Field &Out);   // sc_lowmode.hip: Out = U + float-table correction
+int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm);          // the correction of U at the node rows (what the post-process adds)
 int lowmode_count(int n);
 bool wants_float_tables(const Instance *I);
-int output_field(Instance *I, Field &out);   // sc_solver.cpp: result(I), or result(I) + float-table correction in the partner buffer
+int output_nodes(Instance *I, LmNodes &lm);  // sc_solver.cpp: the float-table correction the post-process of result(I) has to add (none: lm.CN == nullptr)
 int run_sweeps(Instance *I, int method, int sweeps, float omega, int sweeps_per_launch);
 int fused_depth(int method, int sweeps_per_launch); // 0 = plain kernels
 int eval_residual(Instance *I, double out[2]);

@@ -507,7 +507,8 @@ void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_
 // guard: when the host launched this clone on a PREDICTED bounding box (RectGuard, sc_common.h) the output is only
 // written if the bounding box the device found is the predicted one; otherwise the destination stays untouched
 // and the host repeats the clone with the true geometry.
-__device__ __forceinline__ void postprocess_block(const Field &U, uint8_t *__restrict__ body, int bstep, int c0)
+template <bool LM>
+__device__ __forceinline__ void postprocess_block(const Field &U, uint8_t *__restrict__ body, int bstep, int c0, const LmNodes &lm)
 {
     // four pixels per lane: one 16-byte load per channel, twelve output bytes; a lane whose twelve bytes are all interior
     // pixels and start on a 4-byte boundary (the same for every lane of a row) writes three words, the others bytes
@@ -519,6 +520,21 @@ __device__ __forceinline__ void postprocess_block(const Field &U, uint8_t *__res
     float4 v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = *reinterpret_cast<const float4 *>(U.at(c0 + c) + o);      // x < pitch, pitch % 4 == 0
+    if (LM) {
+        // float-table correction (sc_lowmode.hip): bilinear interpolation between the four nodes around the pixel; the
+        // lane's four pixels lie in one 8-column cell (x is a multiple of 4)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float *__restrict__ p = lm.CN + ((size_t)(c0 + c) * lm.ny + (y >> 3)) * lm.npitch + (x >> 3);
+            const float ty = 0.125f * (float)(y & 7);
+            const float l = __builtin_fmaf(ty, p[lm.npitch] - p[0], p[0]), r = __builtin_fmaf(ty, p[lm.npitch + 1] - p[1], p[1]);
+            const float dx = 0.125f * (r - l), a0 = __builtin_fmaf((float)(x & 7), dx, l);
+            v[c].x += a0;
+            v[c].y += a0 + dx;
+            v[c].z += __builtin_fmaf(2.0f, dx, a0);
+            v[c].w += __builtin_fmaf(3.0f, dx, a0);
+        }
+    }
     unsigned char px[12];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -546,23 +562,25 @@ __device__ __forceinline__ void postprocess_block(const Field &U, uint8_t *__res
     }
 }
 
-__global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restrict__ body, int bstep, RectGuard guard)
+template <bool LM>
+__global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restrict__ body, int bstep, RectGuard guard, LmNodes lm)
 {
     if (guard.d_rect) {
         const int *__restrict__ r = guard.d_rect;
         if (r[0] != guard.x0 || r[1] != guard.x1 || r[2] != guard.y0 || r[3] != guard.y1) return;
     }
-    postprocess_block(U, body, bstep, 0);
+    postprocess_block<LM>(U, body, bstep, 0, lm);
 }
 
-__global__ __launch_bounds__(256) void k_postprocess_group(Field U, ImageJobs t)
+template <bool LM>
+__global__ __launch_bounds__(256) void k_postprocess_group(Field U, ImageJobs t, LmNodes lm)
 {
     const ImageJob &j = t.j[blockIdx.z];
     if (j.d_rect && (j.d_rect[0] != j.rx0 || j.d_rect[1] != j.rx1 || j.d_rect[2] != j.ry0 || j.d_rect[3] != j.ry1)) return;
-    postprocess_block(U, j.body_org, j.bstep, 3 * blockIdx.z);
+    postprocess_block<LM>(U, j.body_org, j.bstep, 3 * blockIdx.z, lm);
 }
 
-void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s)
+void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s, LmNodes lm)
 {
     for (int i0 = 0; i0 < n; i0 += ImageJobs::MAX) {
         ImageJobs t{};
@@ -570,15 +588,19 @@ void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t 
         for (int i = 0; i < cnt; ++i) t.j[i] = jobs[i0 + i];
         Field u = U;
         u.p = U.p + (size_t)3 * i0 * U.plane;
+        LmNodes l = lm;
+        if (l.CN) l.CN += (size_t)3 * i0 * l.ny * l.npitch;
         dim3 grid(((U.W + 3) / 4 + 63) / 64, (U.H + 3) / 4, cnt);
-        hipLaunchKernelGGL(k_postprocess_group, grid, dim3(256), 0, s, u, t);
+        if (l.CN) hipLaunchKernelGGL(k_postprocess_group<true>, grid, dim3(256), 0, s, u, t, l);
+        else hipLaunchKernelGGL(k_postprocess_group<false>, grid, dim3(256), 0, s, u, t, l);
     }
 }
 
-void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard)
+void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard, LmNodes lm)
 {
     dim3 grid(((U.W + 3) / 4 + 63) / 64, (U.H + 3) / 4);
-    hipLaunchKernelGGL(k_postprocess, grid, dim3(256), 0, s, U, body_org, bstep, guard);
+    if (lm.CN) hipLaunchKernelGGL(k_postprocess<true>, grid, dim3(256), 0, s, U, body_org, bstep, guard, lm);
+    else hipLaunchKernelGGL(k_postprocess<false>, grid, dim3(256), 0, s, U, body_org, bstep, guard, lm);
 }
 
 // ------------------------------------------------------------------------------------------

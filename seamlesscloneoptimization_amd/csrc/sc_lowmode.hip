@@ -8,181 +8,264 @@
 // a few percent off: the reference's answer is up to 3 grey levels (2048^2) or 7 (4096^2) away from the exact
 // solution of the system -- which is what the multigrid solver converges to.  Only the low modes are affected:
 //     u_ref - u_exact = S^-1[ S(u_exact) * (den_exact / den_float - 1) ],        S = 2-D DST-I,
-// and the factor is below 1e-4 beyond the first ~n/64 modes per direction.  So the correction is three small kernels
-// on K = Kx x Ky modes (K ~ n/64 per direction; measured residual vs all modes: < 0.002 grey levels):
-//   k_lm_project : T[k][x]  = sum_y Sy[y][k] U[y][x]                  (per row chunk; a second stage adds the chunks)
-//   k_lm_coeffs  : Uh[k][l] = sum_x T[k][x] Sx[x][l];  E[k][x] = sum_l Uh[k][l] R[k][l] Sx[x][l]
-//   k_lm_expand  : Out[y][x] = U[y][x] + sum_k Sy[y][k] E[k][x]
-// Sy / Sx = sin tables (built on the device in double, sinpi with exact integer argument reduction), R = (den_exact /
-// den_float - 1) * 4/((w+1)(h+1)) built on the host in double with the reference's float expressions.
-// All sums run in a fixed order (no atomics): results are reproducible bit for bit, alone or in a group.
-// Accuracy needed: the correction is a few grey levels and must be good to ~1e-3 of that, so float32 is ample.
+// and the factor is below 1e-4 beyond the first ~n/64 modes per direction (K = lowmode_count(n) modes are kept; measured
+// residual against all modes < 0.002 grey levels).  Such a field is very smooth -- its shortest
+// wavelength is 128 pixels -- so both the projection and the expansion go through a coarse grid of NODES, every 8th field
+// row and column, with bilinear interpolation in between (and its transpose for the projection):
+//   k_lm_restrict : every 8 x 8 cell of U sends its hat-weighted sums to its four corner nodes        (one pass over U)
+//   k_lm_cproject : V = node values;  Chat[k][l] = R[k][l] sum_YX SyN[Y][k] V[Y][X] SxN[X][l]           (coarse grid)
+//   k_lm_cexpand  : CN[Y][X] = sum_kl SyN[Y][k] Chat[k][l] SxN[X][l]: the correction at the nodes       (coarse grid)
+//   post-process  : out = clamp/truncate( U[y][x] + bilinear(CN) )                                      (sc_kernels.hip)
+// SyN[Y][k] = sin(pi 8Y (k+1)/(h+1)) are the rows of the DST matrix at the nodes (field row 8Y = interior index 8Y - 1).
+// Representing a sine of mode k by linear interpolation from every 8th sample is off by at most 8 (pi (k+1)/(n+1))^2:
+// 2e-5 for the first mode and 2e-2 for mode n/64, whose share of the correction is itself ~1e-3 -- measured: the residual
+// against the full-table correction does not move in the 4th decimal (oracle/lowmode_np.py, hat = 1 vs 8).
+// Tables: built on the device in double (sinpi with exact integer argument reduction); R = (den_exact / den_float - 1) *
+// 4/((w+1)(h+1)) built on the host in double with the reference's float expressions.
+// All sums run in a fixed order (no float atomics): results are reproducible bit for bit, alone or in a group.
 #include "sc_instance.h"
-#include <cmath>
-#include <vector>
-#include <cstring>
 #include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
 
 namespace sc {
 
 constexpr int LM_KB = 32;          // modes per register block
-constexpr int LM_ROWS = 128;       // rows per projection chunk (4 waves x 32 rows)
+constexpr int LM_HAT = 8;          // node spacing (field rows / columns)
+constexpr int LM_NPW = 8;          // node rows per wave in k_lm_cexpand
+constexpr int LM_RS = 4;           // row splits of the coarse projection (workgroups per column tile and channel)
 
 int lowmode_count(int n)
 {
     int k = (n + 63) / 64;
     k = (std::max(k, 8) + 7) & ~7;
-    return std::min(std::min(k, n), 256);          // 256: k_lm_coeffs keeps one coefficient row in LDS (n <= 16384 is unaffected)
+    return std::min(std::min(k, n), 256);
 }
 
-// S[i][l] = sin(pi (i+1)(l+1) / (n+1)), i < n, l < K; row pitch Kp floats, pad columns zero
-__global__ __launch_bounds__(256) void k_lm_table(float *__restrict__ S, int n, int K, int Kp)
+// S[r][l] = sin(pi (LM_HAT r)(l+1) / (n+1)), r < rows, l < K: the sine of mode l at the node in FIELD position LM_HAT r
+// (interior index LM_HAT r - 1; node 0 is the Dirichlet ring, where every mode vanishes; the last node may lie past the
+// far ring: the analytic continuation).  Row pitch Kp floats, pad columns zero.  Double, exact integer argument reduction.
+__global__ __launch_bounds__(256) void k_lm_table(float *__restrict__ S, int n, int rows, int K, int Kp)
 {
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (long)n * Kp) return;
-    const int i = (int)(id / Kp), l = (int)(id % Kp);
+    if (id >= (long)rows * Kp) return;
+    const int r = (int)(id / Kp), l = (int)(id % Kp);
     float v = 0.f;
     if (l < K) {
         const long m = 2L * (n + 1);
-        const long r = ((long)(i + 1) * (l + 1)) % m;           // sin(pi r / (n+1)) has period 2(n+1) in r
-        v = (float)sinpi((double)r / (double)(n + 1));
+        const long q = ((long)LM_HAT * r * (l + 1)) % m;          // sin(pi q / (n+1)) has period 2(n+1) in q
+        v = (float)sinpi((double)q / (double)(n + 1));
     }
     S[id] = v;
 }
 
-// T chunk: P[chunk][c][k][x] = sum over the chunk's rows y of Sy[y-1][k] * U[c][y][x]   (field coordinates: interior
-// rows 1..H-2, every column of the pitch; ring / pad columns produce values nobody reads).
-// Workgroup = 4 waves x 64 columns; wave v takes rows r0 + v, r0 + v + 4, ...; lane = one column; the Sy row is
-// wave-uniform (scalar loads), the accumulators are LM_KB registers; the 4 waves are added through LDS in a fixed order.
-__global__ __launch_bounds__(256) void k_lm_project(Field U, const float *__restrict__ Sy, int Kyp, int nkb, float *__restrict__ P)
+// Restriction with the transpose of the bilinear interpolation: every 8 x 8 cell of the field (field rows 8Yc.., columns
+// 8Xc..) sends its hat-weighted sums to its four corner nodes: Cell[c][Yc][Xc] = (a00, a01, a10, a11) for the nodes
+// (Yc,Xc), (Yc,Xc+1), (Yc+1,Xc), (Yc+1,Xc+1).  Interior values only (ring and pads count as zero).  One pass over U:
+// lane = 8 columns of one cell (two 16-byte loads per row, 8 rows in flight), no communication between lanes.
+__global__ __launch_bounds__(256) void k_lm_restrict(Field U, float4 *__restrict__ Cell, int cells_x, int cells_y)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.z;
+    const int Xc = blockIdx.x * 64 + lane, Yc = blockIdx.y * 4 + wv;
+    if (Xc >= cells_x || Yc >= cells_y) return;
+    const int x0 = 8 * Xc, y0 = 8 * Yc;
+    const float *__restrict__ u = U.at(c) + x0;
+    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+    float4 lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int y = min(y0 + i, U.H - 1);                       // clamped address (x0 + 7 < pitch always), masked below
+        lo[i] = *reinterpret_cast<const float4 *>(u + (size_t)y * U.pitch);
+        hi[i] = *reinterpret_cast<const float4 *>(u + (size_t)y * U.pitch + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int y = y0 + i;
+        float v[8] = { lo[i].x, lo[i].y, lo[i].z, lo[i].w, hi[i].x, hi[i].y, hi[i].z, hi[i].w };
+        float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool in = (x0 + j >= 1) && (x0 + j <= U.W - 2);
+            const float val = in ? v[j] : 0.f;
+            r0 = __builtin_fmaf(1.0f - 0.125f * j, val, r0);
+            r1 = __builtin_fmaf(0.125f * j, val, r1);
+        }
+        if (y >= 1 && y <= U.H - 2) {
+            a00 = __builtin_fmaf(1.0f - 0.125f * i, r0, a00); a01 = __builtin_fmaf(1.0f - 0.125f * i, r1, a01);
+            a10 = __builtin_fmaf(0.125f * i, r0, a10);        a11 = __builtin_fmaf(0.125f * i, r1, a11);
+        }
+    }
+    Cell[((size_t)c * cells_y + Yc) * cells_x + Xc] = make_float4(a00, a01, a10, a11);
+}
+
+// Coarse projection.  Node value V[Y][X] = the four cell shares that meet there; T[k][X] = sum_Y SyN[Y][k] V[Y][X];
+// Upart[part][k][l] = sum_{X in tile} T[k][X] SxN[X][l] (part = column tile x row split; the expansion kernel adds the parts
+// in a fixed order).  Workgroup = 64 node columns (lane = X), the four waves split the node rows and meet in LDS.
+__global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ Cell, int cells_x, int cells_y, int nx, int ny, int C,
+                                                      const float *__restrict__ SyN, int Kyp, const float *__restrict__ SxN, int Kxp,
+                                                      float *__restrict__ Upart)
 {
     __shared__ float red[4][LM_KB][64];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = blockIdx.z, chunk = blockIdx.y;
-    const int x = blockIdx.x * 64 + lane;                        // < pitch (grid covers the pitch exactly: pitch % 64 == 0)
-    const int y0 = 1 + chunk * LM_ROWS, y1 = min(U.H - 1, y0 + LM_ROWS);
-    const float *__restrict__ u = U.at(c) + x;
-    const size_t P_ = U.pitch;
-    for (int kb = 0; kb < nkb; ++kb) {
+    __shared__ float Tt[LM_KB][64 + 1];
+    __shared__ float St[64][LM_KB + 1];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x;
+    const int xt = blockIdx.x, nxt = gridDim.x, rs = blockIdx.y, nrs = gridDim.y, c = blockIdx.z;
+    const int part = rs * nxt + xt;                              // this workgroup's partial product
+    const int X = xt * 64 + lane;
+    const float4 *__restrict__ cell = Cell + (size_t)c * cells_y * cells_x;
+    const int rows_per = (ny + 4 * nrs - 1) / (4 * nrs), Ya = (rs * 4 + wv) * rows_per, Yb = min(ny, Ya + rows_per);
+    // clamped cell coordinates, masked values: the loads stay branch-free and all of a batch are in flight together
+    const int Xc0 = min(X, cells_x - 1), Xc1 = min(max(X - 1, 0), cells_x - 1);
+    const bool mx0 = X < nx && X < cells_x, mx1 = X < nx && X >= 1 && X - 1 < cells_x;
+    for (int kb = 0; kb < Kyp; kb += LM_KB) {
         float acc[LM_KB];
 #pragma unroll
         for (int k = 0; k < LM_KB; ++k) acc[k] = 0.f;
-        for (int y = y0 + wv; y < y1; y += 4) {
-            const float v = u[(size_t)y * P_];
-            const float *__restrict__ s = Sy + (size_t)(y - 1) * Kyp + kb * LM_KB;
+        for (int Yq = Ya; Yq < Yb; Yq += 8) {
+            float v[8];
+            float4 c00[8], c01[8], c10[8], c11[8];
 #pragma unroll
-            for (int k = 0; k < LM_KB; ++k) acc[k] = __builtin_fmaf(s[k], v, acc[k]);
+            for (int q = 0; q < 8; ++q) {
+                const int Y = Yq + q, Yc0 = min(Y, cells_y - 1), Yc1 = min(max(Y - 1, 0), cells_y - 1);
+                c00[q] = cell[(size_t)Yc0 * cells_x + Xc0]; c01[q] = cell[(size_t)Yc0 * cells_x + Xc1];
+                c10[q] = cell[(size_t)Yc1 * cells_x + Xc0]; c11[q] = cell[(size_t)Yc1 * cells_x + Xc1];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int Y = Yq + q;
+                const bool my0 = Y < Yb && Y < cells_y, my1 = Y < Yb && Y >= 1 && Y - 1 < cells_y;
+                const float s00 = (my0 && mx0) ? c00[q].x : 0.f, s01 = (my0 && mx1) ? c01[q].y : 0.f;
+                const float s10 = (my1 && mx0) ? c10[q].z : 0.f, s11 = (my1 && mx1) ? c11[q].w : 0.f;
+                v[q] = (s00 + s01) + (s10 + s11);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int Y = min(Yq + q, ny - 1);               // rows past Yb carry v = 0
+                const float *__restrict__ s = SyN + (size_t)Y * Kyp + kb;
+#pragma unroll
+                for (int k = 0; k < LM_KB; ++k) acc[k] = __builtin_fmaf(s[k], v[q], acc[k]);
+            }
         }
-        if (kb) __syncthreads();
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < LM_KB; ++k) red[wv][k][lane] = acc[k];
         __syncthreads();
-        float *__restrict__ out = P + (((size_t)chunk * U.C + c) * Kyp + (size_t)kb * LM_KB) * P_ + blockIdx.x * 64;
-        for (int i = threadIdx.x; i < LM_KB * 64; i += 256) {
+        for (int i = t; i < LM_KB * 64; i += 256) {
             const int k = i >> 6, xx = i & 63;
-            out[(size_t)k * P_ + xx] = ((red[0][k][xx] + red[1][k][xx]) + (red[2][k][xx] + red[3][k][xx]));
+            Tt[k][xx] = ((red[0][k][xx] + red[1][k][xx]) + (red[2][k][xx] + red[3][k][xx]));
         }
-    }
-}
-
-// One workgroup per (mode row k, channel c):  T[x] = sum_chunks P;  Uh[l] = sum_x T[x] Sx[x-1][l];
-// E[c][k][x] = sum_l Uh[l] R[k][l] Sx[x-1][l].  Everything in a fixed order.
-__global__ __launch_bounds__(256) void k_lm_coeffs(const float *__restrict__ P, int nchunks, int C, int W, int pitch, int Ky, int Kyp,
-                                                    const float *__restrict__ Sx, int Kx, int Kxp,
-                                                    const float *__restrict__ R, float *__restrict__ E)
-{
-    __shared__ float part[LM_KB][257];
-    __shared__ float chat[256];                                  // Kx <= 256
-    const int k = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
-    float *__restrict__ e = E + ((size_t)c * Kyp + k) * pitch;
-    if (k >= Ky) {                                               // pad rows of the register blocks: no mode, no contribution
-        for (int x = t; x < pitch; x += 256) e[x] = 0.f;
-        return;
-    }
-    // T row (chunks added in order), parked in E's own row: each thread only ever touches its own columns
-    for (int x = 1 + t; x <= W - 2; x += 256) {
-        float s = 0.f;
-        for (int ch = 0; ch < nchunks; ++ch) s += P[(((size_t)ch * C + c) * Kyp + k) * pitch + x];
-        e[x] = s;
-    }
-    for (int lb = 0; lb < Kx; lb += LM_KB) {
-        float acc[LM_KB];
-#pragma unroll
-        for (int j = 0; j < LM_KB; ++j) acc[j] = 0.f;
-        for (int x = 1 + t; x <= W - 2; x += 256) {
-            const float tv = e[x];
-            const float4 *__restrict__ row = reinterpret_cast<const float4 *>(Sx + (size_t)(x - 1) * Kxp + lb);
-#pragma unroll
-            for (int j = 0; j < LM_KB / 4; ++j) {
-                const float4 s4 = row[j];
-                acc[4 * j + 0] = __builtin_fmaf(tv, s4.x, acc[4 * j + 0]);
-                acc[4 * j + 1] = __builtin_fmaf(tv, s4.y, acc[4 * j + 1]);
-                acc[4 * j + 2] = __builtin_fmaf(tv, s4.z, acc[4 * j + 2]);
-                acc[4 * j + 3] = __builtin_fmaf(tv, s4.w, acc[4 * j + 3]);
+        __syncthreads();
+        const int tk = t >> 4, tl = t & 15;                      // this thread's 2 x 2 block of the 32 x 32 product
+        for (int lb = 0; lb < Kxp; lb += LM_KB) {
+            __syncthreads();
+            for (int i = t; i < 64 * LM_KB; i += 256) {
+                const int xx = i >> 5, l = i & 31;
+                St[xx][l] = SxN[(size_t)min(xt * 64 + xx, nx - 1) * Kxp + lb + l];          // columns past nx carry T = 0
             }
+            __syncthreads();
+            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+#pragma unroll 8
+            for (int xx = 0; xx < 64; ++xx) {
+                const float s0 = St[xx][2 * tl], s1 = St[xx][2 * tl + 1];
+                const float t0 = Tt[2 * tk][xx], t1 = Tt[2 * tk + 1][xx];
+                a00 = __builtin_fmaf(t0, s0, a00); a01 = __builtin_fmaf(t0, s1, a01);
+                a10 = __builtin_fmaf(t1, s0, a10); a11 = __builtin_fmaf(t1, s1, a11);
+            }
+            float *__restrict__ o = Upart + (((size_t)part * C + c) * Kyp + kb + 2 * tk) * Kxp + lb + 2 * tl;
+            o[0] = a00; o[1] = a01; o[Kxp] = a10; o[Kxp + 1] = a11;
         }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < LM_KB; ++j) part[j][t] = acc[j];
-        __syncthreads();
-        // 256 partials per mode: thread t adds 32 of them for mode t/8, then the 8 lanes of a mode are added in a fixed tree
-        {
-            const int j = t >> 3, seg = t & 7;
-            float s = 0.f;
-            for (int i = 0; i < 32; ++i) s += part[j][seg * 32 + i];
-            s += __shfl_down(s, 4, 8);
-            s += __shfl_down(s, 2, 8);
-            s += __shfl_down(s, 1, 8);
-            if (seg == 0 && lb + j < Kx) chat[lb + j] = s * R[(size_t)k * Kxp + lb + j];
-        }
-    }
-    __syncthreads();
-    for (int x = 1 + t; x <= W - 2; x += 256) {
-        const float *__restrict__ row = Sx + (size_t)(x - 1) * Kxp;
-        float s = 0.f;
-        for (int l = 0; l < Kx; ++l) s = __builtin_fmaf(chat[l], row[l], s);
-        e[x] = s;
     }
 }
 
-// Out[c][y][x] = U[c][y][x] + sum_k Sy[y-1][k] E[c][k][x] on the interior; same tiling as the projection (lane = column,
-// the E column lives in registers, Sy rows are scalar loads).
-__global__ __launch_bounds__(256) void k_lm_expand(Field U, Field Out, const float *__restrict__ Sy, int Kyp, int nkb,
-                                                   const float *__restrict__ E)
+// Coarse expansion: Chat[k][l] = R[k][l] * (sum of the projection's parts, in order);  E[k][X] = sum_l Chat[k][l] SxN[X][l];
+// CN[c][Y][X] = sum_k SyN[Y][k] E[k][X] -- the correction at the nodes.  Workgroup = 64 node columns x (4 waves x LM_NPW node rows); E of the 64 columns is formed once per workgroup
+// (wave v takes 8 of every 32 modes, through LDS); then lane = X with the E column in registers, SyN rows as scalar loads.
+__global__ __launch_bounds__(256) void k_lm_cexpand(const float *__restrict__ Upart, int nparts, int C, const float *__restrict__ R,
+                                                    const float *__restrict__ SxN, int Kxp,
+                                                    const float *__restrict__ SyN, int Kyp, int nx, int ny, int npitch,
+                                                    float *__restrict__ CN)
 {
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float Ch[LM_KB][LM_KB + 4];
+    __shared__ float Es[LM_KB][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x;
     const int c = blockIdx.z;
-    const int x = blockIdx.x * 64 + lane;
-    const int y0 = 1 + blockIdx.y * LM_ROWS, y1 = min(U.H - 1, y0 + LM_ROWS);
-    const size_t P_ = U.pitch;
-    const float *__restrict__ u = U.at(c) + x;
-    float *__restrict__ o = Out.at(c) + x;
-    const bool inside = x >= 1 && x <= U.W - 2;
-    float corr[LM_ROWS / 4];
+    const int X = blockIdx.x * 64 + lane, Xs = min(X, nx - 1);
+    const int Y0 = (blockIdx.y * 4 + wv) * LM_NPW;
+    float cn[LM_NPW];
 #pragma unroll
-    for (int i = 0; i < LM_ROWS / 4; ++i) corr[i] = 0.f;
-    for (int kb = 0; kb < nkb; ++kb) {
-        float e[LM_KB];
-        const float *__restrict__ ep = E + ((size_t)c * Kyp + (size_t)kb * LM_KB) * P_ + x;
+    for (int q = 0; q < LM_NPW; ++q) cn[q] = 0.f;
+    for (int kb = 0; kb < Kyp; kb += LM_KB) {
+        float ek[LM_KB / 4];                                     // this wave's 8 modes of the block
 #pragma unroll
-        for (int k = 0; k < LM_KB; ++k) e[k] = ep[(size_t)k * P_];
+        for (int q = 0; q < LM_KB / 4; ++q) ek[q] = 0.f;
+        for (int lb = 0; lb < Kxp; lb += LM_KB) {
+            __syncthreads();
+            {
+                float sum[LM_KB * LM_KB / 256];
 #pragma unroll
-        for (int i = 0; i < LM_ROWS / 4; ++i) {
-            const int y = y0 + wv + 4 * i;
-            if (y < y1) {
-                const float *__restrict__ s = Sy + (size_t)(y - 1) * Kyp + kb * LM_KB;
-                float a = corr[i];
+                for (int j = 0; j < LM_KB * LM_KB / 256; ++j) sum[j] = 0.f;
+                for (int q = 0; q < nparts; ++q) {
+                    const float *__restrict__ up = Upart + (((size_t)q * C + c) * Kyp + kb) * Kxp + lb;
 #pragma unroll
-                for (int k = 0; k < LM_KB; ++k) a = __builtin_fmaf(s[k], e[k], a);
-                corr[i] = a;
+                    for (int j = 0; j < LM_KB * LM_KB / 256; ++j) {
+                        const int idx = t + 256 * j;
+                        sum[j] += up[(size_t)(idx >> 5) * Kxp + (idx & 31)];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < LM_KB * LM_KB / 256; ++j) {
+                    const int idx = t + 256 * j;
+                    Ch[idx >> 5][idx & 31] = sum[j] * R[(size_t)(kb + (idx >> 5)) * Kxp + lb + (idx & 31)];
+                }
+            }
+            float sx[LM_KB];
+#pragma unroll
+            for (int q = 0; q < LM_KB / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(SxN + (size_t)Xs * Kxp + lb + 4 * q);
+                sx[4 * q] = v.x; sx[4 * q + 1] = v.y; sx[4 * q + 2] = v.z; sx[4 * q + 3] = v.w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < LM_KB / 4; ++q) {
+                float a = ek[q];
+#pragma unroll
+                for (int l = 0; l < LM_KB; ++l) a = __builtin_fmaf(Ch[wv * (LM_KB / 4) + q][l], sx[l], a);
+                ek[q] = a;
             }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < LM_ROWS / 4; ++i) {
-        const int y = y0 + wv + 4 * i;
-        if (y < y1 && inside) o[(size_t)y * P_] = u[(size_t)y * P_] + corr[i];
+        for (int q = 0; q < LM_KB / 4; ++q) Es[wv * (LM_KB / 4) + q][lane] = ek[q];
+        __syncthreads();
+        float e[LM_KB];
+#pragma unroll
+        for (int k = 0; k < LM_KB; ++k) e[k] = Es[k][lane];
+#pragma unroll
+        for (int q = 0; q < LM_NPW; ++q) {
+            const int Y = min(Y0 + q, ny - 1);
+            const float *__restrict__ s = SyN + (size_t)Y * Kyp + kb;
+            float a = cn[q];
+#pragma unroll
+            for (int k = 0; k < LM_KB; ++k) a = __builtin_fmaf(s[k], e[k], a);
+            cn[q] = a;
+        }
     }
+    if (X >= npitch) return;
+    float *__restrict__ o = CN + (size_t)c * ny * npitch + X;
+#pragma unroll
+    for (int q = 0; q < LM_NPW; ++q)
+        if (Y0 + q < ny) o[(size_t)(Y0 + q) * npitch] = (X < nx) ? cn[q] : 0.f;
+}
+
+// Out = U + bilinearly interpolated node correction on the interior, as float (diagnostic hook; the clone itself applies
+// the correction inside the post-process, sc_kernels.hip, with the same formula: lm_bilinear)
+__global__ __launch_bounds__(256) void k_lm_apply(Field U, Field Out, LmNodes lm)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
+    if (x < 1 || x > U.W - 2 || y < 1 || y > U.H - 2) return;
+    const size_t o = (size_t)y * U.pitch + x;
+    Out.at(c)[o] = U.at(c)[o] + lm_bilinear(lm, c, x, y);
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
@@ -215,40 +298,59 @@ static int lm_prepare(Instance *I)
     const int w = W - 2, h = H - 2;
     const int Kx = lowmode_count(w), Ky = lowmode_count(h);
     const int Kxp = round_up(Kx, LM_KB), Kyp = round_up(Ky, LM_KB);
-    const int nchunks = (h + LM_ROWS - 1) / LM_ROWS;
+    const int cells_x = pitch / LM_HAT, cells_y = (H + LM_HAT - 1) / LM_HAT;      // 8 x 8 cells covering the field
+    const int nx = ((W - 2) >> 3) + 2, ny = ((H - 2) >> 3) + 2;                   // nodes: every cell with interior points has both its corners
+    const int npitch = round_up(nx, 4);
+    const int nxt = (nx + 63) / 64;
     int rc;
-    if ((rc = ensure(I, L.P, sizeof(float) * (size_t)nchunks * C * Kyp * pitch))) return rc;
-    if ((rc = ensure(I, L.E, sizeof(float) * (size_t)C * Kyp * pitch))) return rc;
+    if ((rc = ensure(I, L.P, sizeof(float4) * (size_t)C * cells_y * cells_x))) return rc;           // cell shares
+    if ((rc = ensure(I, L.E, sizeof(float) * (size_t)nxt * LM_RS * C * Kyp * Kxp))) return rc;       // partial products of the coarse projection
+    if ((rc = ensure(I, L.CN, sizeof(float) * (size_t)C * ny * npitch))) return rc;
     L.C = C;
     if (L.w == w && L.h == h && L.Sx.p && L.Sy.p && L.R.p) return SC_OK;
-    if ((rc = ensure(I, L.Sx, sizeof(float) * (size_t)w * Kxp))) return rc;
-    if ((rc = ensure(I, L.Sy, sizeof(float) * (size_t)h * Kyp))) return rc;
+    if ((rc = ensure(I, L.Sx, sizeof(float) * (size_t)nx * Kxp))) return rc;
+    if ((rc = ensure(I, L.Sy, sizeof(float) * (size_t)ny * Kyp))) return rc;
     if ((rc = ensure(I, L.R, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
     if ((rc = ensure_pinned(I, L.hR, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
     std::memset(L.hR.p, 0, sizeof(float) * (size_t)Kyp * Kxp);
     build_ratio(w, h, Kx, Ky, Kxp, (float *)L.hR.p);
     SC_HIP(I, hipMemcpyAsync(L.R.p, L.hR.p, sizeof(float) * (size_t)Kyp * Kxp, hipMemcpyHostToDevice, I->stream));
-    hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)w * Kxp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sx.p, w, Kx, Kxp);
-    hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)h * Kyp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sy.p, h, Ky, Kyp);
+    hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)nx * Kxp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sx.p, w, nx, Kx, Kxp);
+    hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)ny * Kyp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sy.p, h, ny, Ky, Kyp);
     SC_HIP(I, hipGetLastError());
-    L.w = w; L.h = h; L.Kx = Kx; L.Ky = Ky; L.Kxp = Kxp; L.Kyp = Kyp;
+    L.w = w; L.h = h; L.Kx = Kx; L.Ky = Ky; L.Kxp = Kxp; L.Kyp = Kyp; L.nx = nx; L.ny = ny; L.npitch = npitch;
     return SC_OK;
 }
 
-// Out = U + correction (interior; ring and pads of Out are left as they are).  U and Out are fields of the instance's
-// current shape; Out may not alias U.
-int lowmode_correct(Instance *I, const Field &U, const Field &Out)
+// Node corrections of the field U (the instance's current shape): what the post-process adds (lm.CN == nullptr: nothing).
+int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm)
 {
+    lm = LmNodes();
     if (U.W < 3 || U.H < 3) return SC_OK;
     int rc = lm_prepare(I);
     if (rc) return rc;
     const LowMode &L = I->lm;
-    const int nchunks = (L.h + LM_ROWS - 1) / LM_ROWS, nkb = L.Kyp / LM_KB;
-    const dim3 grid(U.pitch / 64, nchunks, U.C);
-    hipLaunchKernelGGL(k_lm_project, grid, dim3(256), 0, I->stream, U, (const float *)L.Sy.p, L.Kyp, nkb, (float *)L.P.p);
-    hipLaunchKernelGGL(k_lm_coeffs, dim3(L.Kyp, U.C), dim3(256), 0, I->stream, (const float *)L.P.p, nchunks, U.C, U.W, U.pitch,
-                       L.Ky, L.Kyp, (const float *)L.Sx.p, L.Kx, L.Kxp, (const float *)L.R.p, (float *)L.E.p);
-    hipLaunchKernelGGL(k_lm_expand, grid, dim3(256), 0, I->stream, U, Out, (const float *)L.Sy.p, L.Kyp, nkb, (const float *)L.E.p);
+    const int cells_x = U.pitch / LM_HAT, cells_y = (U.H + LM_HAT - 1) / LM_HAT, nxt = (L.nx + 63) / 64;
+    float *upart = (float *)L.E.p;
+    hipLaunchKernelGGL(k_lm_restrict, dim3((cells_x + 63) / 64, (cells_y + 3) / 4, U.C), dim3(256), 0, I->stream, U, (float4 *)L.P.p, cells_x, cells_y);
+    hipLaunchKernelGGL(k_lm_cproject, dim3(nxt, LM_RS, U.C), dim3(256), 0, I->stream, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
+                       (const float *)L.Sy.p, L.Kyp, (const float *)L.Sx.p, L.Kxp, upart);
+    hipLaunchKernelGGL(k_lm_cexpand, dim3(nxt, (L.ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, I->stream, (const float *)upart,
+                       nxt * LM_RS, U.C, (const float *)L.R.p, (const float *)L.Sx.p, L.Kxp, (const float *)L.Sy.p, L.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p);
+    SC_HIP(I, hipGetLastError());
+    lm.CN = (const float *)L.CN.p;
+    lm.ny = L.ny;
+    lm.npitch = L.npitch;
+    return SC_OK;
+}
+
+// Out = U + correction as a float field (interior; ring and pads of Out are left as they are).  Out may not alias U.
+int lowmode_correct(Instance *I, const Field &U, const Field &Out)
+{
+    LmNodes lm;
+    int rc = lowmode_nodes(I, U, lm);
+    if (rc || !lm.CN) return rc;
+    hipLaunchKernelGGL(k_lm_apply, dim3((U.W + 255) / 256, U.H, U.C), dim3(256), 0, I->stream, U, Out, lm);
     SC_HIP(I, hipGetLastError());
     return SC_OK;
 }

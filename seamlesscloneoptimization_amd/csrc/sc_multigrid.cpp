@@ -494,12 +494,12 @@ int mg_solve(Instance *I)
                 // the post-process goes in FIRST (see Instance::spec_post): enqueued while the cycle launch is still running it
                 // starts without a gap, and the read-back of the maxima follows it
                 if (I->spec_post.armed && o.tol <= 0.f) {
-                    Field outf;
-                    if ((rc = output_field(I, outf))) return rc;
+                    LmNodes lm;
+                    if ((rc = output_nodes(I, lm))) return rc;
                     if (I->spec_post.group.empty()) {
-                        launch_postprocess(outf, I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
+                        launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard, lm);
                     } else {
-                        launch_postprocess_group(outf, I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream);
+                        launch_postprocess_group(result(I), I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream, lm);
                     }
                     I->spec_post.done = true;
                 }

@@ -11,24 +11,20 @@ namespace sc {
 Field &result(Instance *I) { return I->result_in_U1 ? I->U1 : I->U0; }
 static Field &other(Instance *I) { return I->result_in_U1 ? I->U0 : I->U1; }
 
-// The field the post-process reads.  For the converged multigrid solve that is, by default, the solution plus the
-// float-table correction (sc_lowmode.hip: the answer OpenCV and the reference compute), written into the ping-pong
-// partner so the solution itself stays untouched (the solve may continue if the stop rule rejects the cycle, and the
-// diagnostic hooks read it).  SC_FLAG_EXACT_TABLES, the sweep solvers (fixed counts, not converged fields) and ROIs
-// without unknowns: the solution itself.
+// What the post-process adds to result(I).  For the converged multigrid solve that is, by default, the float-table
+// correction (sc_lowmode.hip: result + correction = the answer OpenCV and the reference compute); the solution itself
+// stays untouched (the solve may continue if the stop rule rejects the cycle, and the diagnostic hooks read it).
+// SC_FLAG_EXACT_TABLES, the sweep solvers (fixed counts, not converged fields) and ROIs without unknowns: nothing.
 bool wants_float_tables(const Instance *I)
 {
     return I->opts.method == SC_METHOD_MULTIGRID && !(I->opts.flags & SC_FLAG_EXACT_TABLES) && I->F.W >= 3 && I->F.H >= 3;
 }
 
-int output_field(Instance *I, Field &out)
+int output_nodes(Instance *I, LmNodes &lm)
 {
-    out = result(I);
+    lm = LmNodes();
     if (!wants_float_tables(I)) return SC_OK;
-    const int rc = lowmode_correct(I, result(I), other(I));
-    if (rc) return rc;
-    out = other(I);
-    return SC_OK;
+    return lowmode_nodes(I, result(I), lm);
 }
 
 float optimal_omega(int W, int H)

@@ -192,3 +192,60 @@ def test_compare_cli(tmp_path, golden_dir):
     img2[5, 5, 0] = (int(img2[5, 5, 0]) + 9) % 256
     ymlio.write_bmp(tmp_path / "b.bmp", img2)
     assert compare.main([str(tmp_path / "a.bmp"), str(tmp_path / "b.bmp")]) == 1
+
+
+_STUB = r'''
+import json, os, sys, time
+sys.path.insert(0, os.environ["SC_ROOT"])
+from seamlesscloneoptimization_amd.batch import Comm, timed_region
+comm = Comm()                                   # gloo over 127.0.0.1 from the launcher's environment
+if os.environ.get("STUB_FAIL_RANK") == str(comm.rank):
+    sys.exit(7)                                 # dies before the first barrier: the others must not hang
+dt = timed_region(comm, lambda: None, lambda: time.sleep(0.02 * (comm.rank + 1)))
+tot = comm.sum(10.0)
+comm.barrier()
+if comm.rank == 0:
+    print(json.dumps({"n_gpus": comm.world, "value": tot / dt, "ranks_seen": int(tot / 10)}), flush=True)
+comm.close()
+'''
+
+
+def test_self_launcher_spawns_ranks_and_forwards_rank0(tmp_path):
+    """bench.py --gpus N without torchrun: spawn_ranks starts one fresh process per rank (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, 127.0.0.1), forwards rank 0's line, and reports failure -- without hanging -- when a rank dies."""
+    import json
+    from seamlesscloneoptimization_amd.batch import spawn_ranks
+    stub = tmp_path / "stub.py"
+    stub.write_text(_STUB)
+    rc, out = spawn_ranks(2, [sys.executable, str(stub)], extra_env={"SC_ROOT": ROOT})
+    assert rc == 0, out
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    rc, out = spawn_ranks(2, [sys.executable, str(stub)], extra_env={"SC_ROOT": ROOT, "STUB_FAIL_RANK": "1"})
+    assert rc != 0
+
+
+def test_bench_parent_never_loads_the_hip_library(tmp_path):
+    """The launcher branch of bench.py must run before anything loads libseamlessclone_hip.so / libamdhip64 in the
+    parent (a process that has initialised the GPU must not spawn-and-exec, and must not hold the device)."""
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import os, sys, runpy\n"
+        "sys.argv = ['bench.py', '--gpus', '2']\n"
+        "import seamlesscloneoptimization_amd.batch as b\n"
+        "def fake(world, cmd, extra_env=None, poll_s=0.05):\n"
+        "    maps = open('/proc/self/maps').read()\n"
+        "    assert 'libseamlessclone_hip' not in maps and 'libamdhip64' not in maps, 'HIP loaded in the launcher'\n"
+        "    assert world == 2 and cmd[1].endswith('bench.py') and '--gpus' in cmd\n"
+        "    return 0, '{\"n_gpus\": 2}\\n'\n"
+        "b.spawn_ranks = fake\n"
+        "os.environ.pop('WORLD_SIZE', None)\n"
+        "try:\n"
+        "    runpy.run_path(os.path.join(os.environ['SC_ROOT'], 'bench.py'), run_name='__main__')\n"
+        "except SystemExit as e:\n"
+        "    assert e.code == 0, e.code\n")
+    env = dict(os.environ, SC_ROOT=ROOT, PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(probe)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert '"n_gpus": 2' in r.stdout
