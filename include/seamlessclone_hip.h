@@ -53,7 +53,11 @@ enum sc_method {
     SC_METHOD_JACOBI = 0,    /* U' = 1/4 (l+r+u+d - lap), ping-pong                         */
     SC_METHOD_RBGS   = 1,    /* red-black Gauss-Seidel (omega = 1)                          */
     SC_METHOD_SOR    = 2,    /* red-black SOR, omega from opts (<=0: optimal for the ROI)   */
-    SC_METHOD_MULTIGRID = 3  /* V-cycles with red-black GS smoothing (converges at any ROI)  */
+    SC_METHOD_MULTIGRID = 3, /* V-cycles with red-black GS smoothing (converges at any ROI)  */
+    SC_METHOD_DST    = 4     /* the reference's direct solve (seamlessClone_imp.cpp:1814-1896; matrix form :1266-1334):
+                                u = S_h ((S_h g S_w) / den) S_w with den = filter_X + filter_Y - 4 from the float
+                                tables of :596-599, four double-precision products on the matrix cores.  O(n^3):
+                                milliseconds at 2048^2; the non-iterative cross-check of the default path          */
 };
 
 typedef struct sc_solver_opts {

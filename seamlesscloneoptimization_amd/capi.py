@@ -29,6 +29,7 @@ SC_METHOD_JACOBI = 0
 SC_METHOD_RBGS = 1
 SC_METHOD_SOR = 2
 SC_METHOD_MULTIGRID = 3
+SC_METHOD_DST = 4
 
 SC_FLAG_NO_SPECULATE = 1 << 0
 SC_FLAG_FLOAT_RHS = 1 << 1

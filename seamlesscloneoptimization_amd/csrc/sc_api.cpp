@@ -412,6 +412,8 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->h_partial.p) (void)hipHostFree(I->h_partial.p);
     for (DevBuf *b : { &I->lm.Sx, &I->lm.Sy, &I->lm.R, &I->lm.P, &I->lm.E, &I->lm.CN }) if (b->p) (void)hipFree(b->p);
     if (I->lm.hR.p) (void)hipHostFree(I->lm.hR.p);
+    for (DevBuf *b : { &I->dst.Sw, &I->dst.Sh, &I->dst.fxy, &I->dst.G, &I->dst.T1, &I->dst.T2 }) if (b->p) (void)hipFree(b->p);
+    if (I->dst.hfxy.p) (void)hipHostFree(I->dst.hfxy.p);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
     if (I->h_fd.p) (void)hipHostFree(I->h_fd.p);
     if (I->d_rect) (void)hipFree(I->d_rect);
@@ -446,7 +448,7 @@ int sc_hip_set_solver(void *p, const sc_solver_opts *o)
 {
     Instance *I = get(p);
     if (!I || !o) return SC_ERR_BAD_ARG;
-    if (o->method < SC_METHOD_JACOBI || o->method > SC_METHOD_MULTIGRID || o->max_sweeps < 0) {
+    if (o->method < SC_METHOD_JACOBI || o->method > SC_METHOD_DST || o->max_sweeps < 0) {
         I->err = "bad solver options";
         return SC_ERR_BAD_ARG;
     }

@@ -31,6 +31,13 @@ struct LowMode {
     DevBuf hR;                             // pinned staging of R
 };
 
+// direct DST solve (sc_dst.hip): DST matrices, the reference's float tables and the double work planes
+struct DstState {
+    int w = 0, h = 0, wp = 0, hp = 0;      // interior size the tables were built for, padded to the 128 x 128 tiles
+    DevBuf Sw, Sh, fxy, G, T1, T2;         // Sw[wp][wp], Sh[hp][hp] double; fx[wp] + fy[hp] float; G, T1, T2: [C][hp][wp] double
+    DevBuf hfxy;                           // pinned staging of the float tables
+};
+
 struct MGLevel {
     Field U, F, T;   // correction, RHS, scratch (residual field); level 0 aliases the instance fields
     MGGeom g;        // geometry of this level and of its transfer to the next coarser one
@@ -84,6 +91,7 @@ struct Instance {
     int fd_level = -1, fd_nxp = 0, fd_nyp = 0;
     DevBuf mg_fd, h_fd;    // its matrices: device copy and pinned staging
     LowMode lm;
+    DstState dst;
     std::vector<FD1> fd_cache;   // recent 1-D decompositions (a geometry seen before costs no eigen-solve)
     size_t fd_cache_next = 0;
     // reductions / mailboxes
@@ -126,6 +134,7 @@ bool mg_composes_level1(const Instance *I);   // sc_multigrid.cpp   // sc_multig
 int lowmode_correct(Instance *I, const Field &U, const Field &Out);   // sc_lowmode.hip: Out = U + float-table correction
 int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm);          // the correction of U at the node rows (what the post-process adds)
 int lowmode_count(int n);
+int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST
 bool wants_float_tables(const Instance *I);
 int output_nodes(Instance *I, LmNodes &lm);  // sc_solver.cpp: the float-table correction the post-process of result(I) has to add (none: lm.CN == nullptr)
 int run_sweeps(Instance *I, int method, int sweeps, float omega, int sweeps_per_launch);

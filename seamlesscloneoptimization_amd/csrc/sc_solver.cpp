@@ -110,6 +110,7 @@ int solve(Instance *I)
     I->info.rel_residual = NAN;
     if (I->F.W < 3 || I->F.H < 3) { I->info.converged = 1; return SC_OK; } // no unknowns
     if (o.method == SC_METHOD_MULTIGRID) return mg_solve(I);
+    if (o.method == SC_METHOD_DST) return dst_solve(I);
     if (o.tol <= 0.f) {
         int rc = run_sweeps(I, o.method, o.max_sweeps, o.omega, o.sweeps_per_launch);
         if (rc) return rc;

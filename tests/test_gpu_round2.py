@@ -239,3 +239,50 @@ def test_config5_batch_of_64_clones_of_1024(oracles):
             inst.free(p)
     solo.destroy()
     pool.close()
+
+
+@pytest.mark.parametrize("W,H", [(19, 11), (130, 70), (298, 192), (1030, 500)])
+def test_direct_dst_solver_field_level(hip, oracles, W, H):
+    """SC_METHOD_DST (sc_dst.hip): the reference's direct solve -- four double-precision products with the DST matrix on
+    the matrix cores, division by the reference's float tables -- against the C oracle's float-table solve, as fields."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=32)
+    geo, M = oc.mask_stage(mask, cx, cy)
+    B, lap = oc.build_rhs(dst, patch, geo, M)
+    want = oc.solve_dst(oc.fold(B, lap), min(16, oc.max_threads()), exact_den=False)
+    try:
+        hip.set_solver(method=capi.SC_METHOD_DST)
+        hip.field_load(B, lap)
+        hip.field_solve()
+        got = hip.field_store()
+    finally:
+        hip.set_solver(method=capi.SC_METHOD_MULTIGRID)
+    assert np.array_equal(got[:, 0, :], B[:, 0, :]) and np.array_equal(got[:, :, 0], B[:, :, 0])       # ring untouched
+    assert np.array_equal(got[:, -1, :], B[:, -1, :]) and np.array_equal(got[:, :, -1], B[:, :, -1])
+    err = np.abs(got[:, 1:-1, 1:-1] - want).max()
+    assert err < 2e-3, err                          # both are float32 fields of magnitude ~300 with double transforms inside
+
+
+@pytest.mark.parametrize("W,H", [(298, 192), (2048, 2048), (4096, 4096)])
+def test_direct_dst_solver_end_to_end(hip, oracles, W, H):
+    """The whole clone with solver = DST against the float-table CPU port (BASELINE configs 1, 3 and 4 sizes), and against
+    the default path (multigrid + float-table correction), which must land on the same image within one grey level."""
+    from seamlesscloneoptimization_amd import capi, compare
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=64)
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+    default = dst.copy()
+    assert hip.run(patch, default, mask, cx, cy) == 0
+    try:
+        hip.set_solver(method=capi.SC_METHOD_DST)
+        body = dst.copy()
+        assert hip.run(patch, body, mask, cx, cy) == 0
+        info = hip.info()
+    finally:
+        hip.set_solver(method=capi.SC_METHOD_MULTIGRID)
+    assert (info.W, info.H) == (W, H) and info.converged == 1
+    s = compare.image_diff_stats(want, body)
+    assert s["max"] <= 1 and s["percent"] < 0.05, compare.format_stats(s)
+    s = compare.image_diff_stats(default, body)
+    assert s["max"] <= 1 and s["percent"] < 0.5, compare.format_stats(s)
