@@ -231,6 +231,26 @@ def main():
         other_tables = out
     out_float, out_exact = (other_tables, out) if args.exact_tables else (out, other_tables)
 
+    # ---- the reference's direct solve on the matrix cores (SC_METHOD_DST, sc_dst.hip): four double-precision products with the
+    #      DST matrix per channel, 2 n^3 multiply-adds each; timed as the solve stage of one synchronous clone
+    inst.set_solver(method=capi.SC_METHOD_DST)
+    clone(inst, jobs[0], sync=True)                  # builds the DST matrices for this size
+    clone(inst, jobs[0], sync=True)
+    di = inst.info()
+    out_dst = inst.from_device(jobs[0]["b"], dst.shape)
+    inst.set_solver(method=methods[args.method])
+    wp = hp = -(-(W - 2) // 128) * 128
+    dst_flop = 3 * (2.0 * hp * wp * wp * 2 + 2.0 * hp * hp * wp * 2)
+    dd = np.abs(out_dst.astype(np.int16) - out_float.astype(np.int16))
+    roofline_dst = {"bound": "mfma", "kernel": "k_dgemm<EPI> x 4 (v_mfma_f64_16x16x4_f64, 128x128x16 LDS tiles) + fold, SC_METHOD_DST",
+                    "achieved": round(dst_flop / (di.ms_solve * 1e-3) / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s",
+                    "frac": round(dst_flop / (di.ms_solve * 1e-3) / 1e12 / 78.6, 4), "traffic": None,
+                    "ms_solve": round(di.ms_solve, 4), "ms_device_total": round(di.ms_device_total, 4),
+                    "flop_per_clone": int(dst_flop),
+                    "vs_default_path": {"maxdiff": int(dd.max()), "percent_differing": round(float((dd > 0).mean() * 100), 4)},
+                    "note": "the reference's own algorithm (direct DST, float tables), padded to 128-multiples; peak = MI355X FP64 "
+                            "matrix spec; solve stage of one clone by hipEvents (includes the fold kernel)"}
+
     # ---- the drop-in call itself: pageable host images in, result in the caller's image (PCIe inclusive)
     body = dst.copy()
     inst.run(patch, body, mask, cx, cy)
@@ -342,7 +362,7 @@ def main():
                                    "note": "one clone alone on the GPU, hipEvent marks; solve includes the float-table correction and, "
                                            "when post = 0, the post-process enqueued directly behind it"},
         "roofline": roofline, "roofline_red_black": roofline_rb, "roofline_jacobi": roofline_j,
-        "roofline_jacobi_single_sweep": roofline_j1,
+        "roofline_jacobi_single_sweep": roofline_j1, "roofline_direct_dst": roofline_dst,
         "whole_step_fabric": ({"bytes_per_step": int(step_traffic), "TB_per_s": round(step_traffic / (elapsed / args.steps) / 1e12, 3),
                                "frac_of_peak": round(step_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                                "traffic_source": f"{profile['_file']} @ {profile.get('git', '?')}"} if step_traffic else None),
