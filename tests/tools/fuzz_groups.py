@@ -2,7 +2,7 @@
 and ordinary ROI sizes; rectangular / elliptic / speckled masks; different positions), every member against the numpy oracle.
 python tools/fuzz_groups.py [groups] [seed] [big]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from seamlesscloneoptimization_amd import capi
 from oracle import oracle_np as o
@@ -48,7 +48,7 @@ for gi in range(ngroups):
     for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
         members += 1
         try:
-            want = o.seamless_clone(*it)
+            want = o.seamless_clone(*it, float_tables=True)
         except Exception:
             want = None
         if want is None or jobs[k].rc not in (0, capi.SC_ERR_NOT_CONVERGED):

@@ -1,7 +1,7 @@
 """Long-running shape fuzz (not part of the test suite): random ROI shapes incl. tiny, thin and level-boundary sizes,
 random rectangular / elliptic / speckled masks, every result against the numpy oracle.  python tools/fuzz_shapes.py [n] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from seamlesscloneoptimization_amd import capi, compare
 from oracle import oracle_np as o
@@ -28,7 +28,7 @@ for case in range(n):
         mask = mask.copy(); mask[rng.integers(0, H + 2, 6), rng.integers(0, W + 2, 6)] = rng.integers(0, 255, 6)
     body = dst.copy()
     try:
-        want = o.seamless_clone(dst, patch, mask, cx, cy)
+        want = o.seamless_clone(dst, patch, mask, cx, cy, float_tables=True)
     except Exception as e:           # the oracle rejects what the reference asserts on (empty / degenerate box)
         try:
             inst.run(patch, body, mask, cx, cy); print("case", case, W, H, "oracle rejected, GPU accepted:", e); fails += 1

@@ -1,7 +1,7 @@
 """Soak: many clones of random sizes and masks through the native pool (host path, several in flight) against the same
 clones run one by one on a single instance -- results must be bit-identical.  python tools/soak.py [rounds] [jobs] [streams]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from seamlesscloneoptimization_amd import capi
 from oracle import oracle_np as o

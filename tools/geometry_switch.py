@@ -3,7 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from seamlesscloneoptimization_amd import capi
-from oracle import oracle_np as o
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _synth as o
 inst = capi.Instance(0)
 cases = {k: o.synth_inputs(*k, margin=64) for k in [(298, 192), (260, 200), (1024, 1024), (1000, 900)]}
 def call(k):

@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from seamlesscloneoptimization_amd import capi
-from oracle import oracle_np as o
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _synth as o
 roi = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 inst = capi.Instance(0)
 dst, patch, mask, cx, cy = o.synth_inputs(roi, roi, margin=64)
