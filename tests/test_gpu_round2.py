@@ -286,3 +286,60 @@ def test_direct_dst_solver_end_to_end(hip, oracles, W, H):
     assert s["max"] <= 1 and s["percent"] < 0.05, compare.format_stats(s)
     s = compare.image_diff_stats(default, body)
     assert s["max"] <= 1 and s["percent"] < 0.5, compare.format_stats(s)
+
+
+@pytest.mark.parametrize("kind", ["checkerboard", "impulses", "offset_ramp", "speckle_mask", "stripes_vs_flat", "saturated_blocks"])
+def test_stop_rule_on_adversarial_images(hip, oracles, kind):
+    """The multigrid stop rule (predicted error from two successive corrections) on inputs built to stress it: the highest
+    frequency the grid carries, isolated impulses, a large smooth offset (slowest modes), a mask full of holes (irregular
+    Dirichlet set inside the ROI), stripes against a flat destination, saturated blocks.  Within one grey level of the
+    float-table oracle, few channels off, and no runaway cycle count."""
+    from seamlesscloneoptimization_amd import compare
+    o, oc = oracles
+    W, H = 777, 530
+    rng = np.random.default_rng(sum(ord(ch) for ch in kind))
+    Hd, Wd = H + 80, W + 80
+    yy, xx = np.mgrid[0:H + 2, 0:W + 2]
+    dst = np.clip(128 + 40 * np.sin(np.mgrid[0:Hd, 0:Wd][1] / 97.0)[:, :, None] + rng.normal(0, 6, (Hd, Wd, 3)), 0, 255).astype(np.uint8)
+    mask = np.full((H + 2, W + 2), 255, np.uint8)
+    if kind == "checkerboard":
+        patch = np.repeat((((xx + yy) & 1) * 255).astype(np.uint8)[:, :, None], 3, axis=2)
+    elif kind == "impulses":
+        patch = np.full((H + 2, W + 2, 3), 90, np.uint8)
+        idx = rng.integers(8, min(H, W) - 8, (60, 2))
+        patch[idx[:, 0], idx[:, 1]] = 255
+    elif kind == "offset_ramp":
+        patch = np.clip(20 + 200.0 * xx / W, 0, 255).astype(np.uint8)[:, :, None].repeat(3, axis=2)
+        dst[...] = 250
+    elif kind == "speckle_mask":
+        patch = np.clip(110 + 50 * np.cos(xx / 31.0)[:, :, None] + rng.normal(0, 20, (H + 2, W + 2, 3)), 0, 255).astype(np.uint8)
+        mask[rng.random((H + 2, W + 2)) < 0.02] = 0
+    elif kind == "stripes_vs_flat":
+        patch = np.repeat((((xx // 3) & 1) * 200 + 20).astype(np.uint8)[:, :, None], 3, axis=2)
+        dst[...] = 128
+    else:
+        patch = np.repeat(((((xx // 64) + (yy // 64)) & 1) * 255).astype(np.uint8)[:, :, None], 3, axis=2)
+    cx, cy = Wd // 2, Hd // 2
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+    body = dst.copy()
+    assert hip.run(patch, body, mask, cx, cy) == 0
+    info = hip.info()
+    s = compare.image_diff_stats(want, body)
+    assert s["max"] <= 1 and s["percent"] < 1.0, (kind, compare.format_stats(s))
+    assert info.converged == 1 and info.sweeps <= 6, (kind, info.sweeps)
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` started directly (no torchrun): the parent spawns two ranks that share this box's GPU
+    (local_rank % device count), rank 0 prints ONE JSON line with n_gpus = 2 and the aggregate of both ranks."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--roi", "512", "--batch", "8", "--steps", "2",
+                        "--warmup", "1", "--cpu-seconds", "0", "--kernel-launches", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["batch_per_gpu"] == 8 and d["cpu_baseline"] is None
