@@ -64,16 +64,18 @@ __global__ __launch_bounds__(256) void k_dst_fold(Field U, Field F, double *__re
 // C = A * B in double on the matrix cores.  Row-major, every dimension padded (M, N to 128, K to 16): no edge handling in
 // the main loop.  blockIdx.z = channel; a stride of 0 shares an operand (the DST matrix) between channels.
 // EPI 0: C double.  EPI 1: C double, divided by the reference's float denominator fx[col] + fy[row] - 4 (zero outside
-// h x w).  EPI 2: C * scale as float into the interior of the planar field Uf (row r -> field row r+1).
-struct DgemmEpi { const float *fx, *fy; int h, w; double scale; Field Uf; };
+// eh x ew).  EPI 2: C * scale as float into the interior of the planar field Uf (row r -> field row r+1).
 
 template <int EPI>
 __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C,
                                                int lda, int ldb, int ldc, int K, size_t strideA, size_t strideB, size_t strideC,
-                                               DgemmEpi epi)
+                                               const float *__restrict__ fx, const float *__restrict__ fy, int eh, int ew, double scale,
+                                               float *__restrict__ Uf, int upitch, size_t uplane)
 {
-    __shared__ double As[DG_BK][DG_BM + DG_PAD];
-    __shared__ double Bs[DG_BK][DG_BN + DG_PAD];
+    // two LDS stages: while stage s is multiplied, the next K-tile (already in registers) is written to stage s^1 -- one
+    // barrier per K-tile
+    __shared__ double As[2][DG_BK][DG_BM + DG_PAD];
+    __shared__ double Bs[2][DG_BK][DG_BN + DG_PAD];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
     const int m0 = blockIdx.y * DG_BM, n0 = blockIdx.x * DG_BN, z = blockIdx.z;
     A += (size_t)z * strideA; B += (size_t)z * strideB;
@@ -81,41 +83,55 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, con
     const int ar = t >> 1, ak = (t & 1) * 8, bk = t >> 4, bc = (t & 15) * 8;
     const double *__restrict__ ap = A + (size_t)(m0 + ar) * lda + ak;
     const double *__restrict__ bp = B + (size_t)bk * ldb + n0 + bc;
-    double2 ra[4], rb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { ra[q] = *reinterpret_cast<const double2 *>(ap + 2 * q); rb[q] = *reinterpret_cast<const double2 *>(bp + 2 * q); }
+    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define DG_LOAD(k0)                                                                                          \
+    {                                                                                                        \
+        const double *a_ = ap + (k0);                                                                        \
+        const double *b_ = bp + (size_t)(k0) * ldb;                                                          \
+        ra0 = *reinterpret_cast<const double2 *>(a_); ra1 = *reinterpret_cast<const double2 *>(a_ + 2);      \
+        ra2 = *reinterpret_cast<const double2 *>(a_ + 4); ra3 = *reinterpret_cast<const double2 *>(a_ + 6);  \
+        rb0 = *reinterpret_cast<const double2 *>(b_); rb1 = *reinterpret_cast<const double2 *>(b_ + 2);      \
+        rb2 = *reinterpret_cast<const double2 *>(b_ + 4); rb3 = *reinterpret_cast<const double2 *>(b_ + 6);  \
+    }
+#define DG_STORE(s)                                                                                          \
+    {                                                                                                        \
+        As[s][ak + 0][ar] = ra0.x; As[s][ak + 1][ar] = ra0.y; As[s][ak + 2][ar] = ra1.x; As[s][ak + 3][ar] = ra1.y;  \
+        As[s][ak + 4][ar] = ra2.x; As[s][ak + 5][ar] = ra2.y; As[s][ak + 6][ar] = ra3.x; As[s][ak + 7][ar] = ra3.y;  \
+        *reinterpret_cast<double2 *>(&Bs[s][bk][bc + 0]) = rb0; *reinterpret_cast<double2 *>(&Bs[s][bk][bc + 2]) = rb1;  \
+        *reinterpret_cast<double2 *>(&Bs[s][bk][bc + 4]) = rb2; *reinterpret_cast<double2 *>(&Bs[s][bk][bc + 6]) = rb3;  \
+    }
     v4f64 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){ 0.0, 0.0, 0.0, 0.0 };
     const int fr = lane & 15, fk = lane >> 4;
-    for (int k0 = 0; k0 < K; k0 += DG_BK) {
-        __syncthreads();                                         // the previous tile has been consumed
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            As[ak + 2 * q][ar] = ra[q].x; As[ak + 2 * q + 1][ar] = ra[q].y;
-            *reinterpret_cast<double2 *>(&Bs[bk][bc + 2 * q]) = rb[q];
-        }
-        __syncthreads();
-        if (k0 + DG_BK < K) {                                    // next tile's loads fly while this one is multiplied
-            ap += DG_BK; bp += (size_t)DG_BK * ldb;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { ra[q] = *reinterpret_cast<const double2 *>(ap + 2 * q); rb[q] = *reinterpret_cast<const double2 *>(bp + 2 * q); }
-        }
+    DG_LOAD(0);
+    DG_STORE(0);
+    __syncthreads();
+    const int ntiles = K / DG_BK;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int s = kt & 1;
+        // the next tile's loads fly while this one is multiplied (the last iteration re-reads the last tile: no branch)
+        DG_LOAD(min(kt + 1, ntiles - 1) * DG_BK);
 #pragma unroll
         for (int kk = 0; kk < DG_BK; kk += 4) {
             double a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[kk + fk][wm * 64 + i * 16 + fr];
+            for (int i = 0; i < 4; ++i) a[i] = As[s][kk + fk][wm * 64 + i * 16 + fr];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[kk + fk][wn * 64 + j * 16 + fr];
+            for (int j = 0; j < 4; ++j) b[j] = Bs[s][kk + fk][wn * 64 + j * 16 + fr];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the stores BEHIND the products: the compiler otherwise hoists them (and the wait for the loads) above
+        DG_STORE(s ^ 1);                 // stage s^1 was last read in iteration kt-1: every wave passed the barrier below since
+        __syncthreads();
     }
+#undef DG_LOAD
+#undef DG_STORE
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -126,12 +142,12 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, con
                 const int row = m0 + wm * 64 + i * 16 + fk + 4 * r, col = n0 + wn * 64 + j * 16 + fr;
                 double v = acc[i][j][r];
                 if (EPI == 1) {
-                    const bool in = row < epi.h && col < epi.w;
-                    const float den = in ? (epi.fx[col] + epi.fy[row]) - 4.0f : 1.0f;       // seamlessClone_imp.cpp:1651-1653, in float
+                    const bool in = row < eh && col < ew;
+                    const float den = in ? (fx[col] + fy[row]) - 4.0f : 1.0f;       // seamlessClone_imp.cpp:1651-1653, in float
                     v = in ? v / (double)den : 0.0;
                 }
                 if (EPI == 2) {
-                    if (row < epi.h && col < epi.w) epi.Uf.at(z)[(size_t)(row + 1) * epi.Uf.pitch + col + 1] = (float)(v * epi.scale);
+                    if (row < eh && col < ew) Uf[(size_t)z * uplane + (size_t)(row + 1) * upitch + col + 1] = (float)(v * scale);
                 } else {
                     C[(size_t)z * strideC + (size_t)row * ldc + col] = v;
                 }
@@ -179,17 +195,17 @@ int dst_solve(Instance *I)
     double *G = (double *)D.G.p, *T1 = (double *)D.T1.p, *T2 = (double *)D.T2.p;
     const double *Sw = (const double *)D.Sw.p, *Sh = (const double *)D.Sh.p;
     const size_t plane = (size_t)hp * wp;
-    DgemmEpi e{};
-    e.fx = (const float *)D.fxy.p; e.fy = e.fx + wp; e.h = D.h; e.w = D.w;
-    e.scale = 4.0 / ((D.w + 1.0) * (D.h + 1.0));
-    e.Uf = U;
+    const float *fx = (const float *)D.fxy.p, *fy = fx + wp;
+    const double scale = 4.0 / ((D.w + 1.0) * (D.h + 1.0));
     const dim3 grid(wp / DG_BN, hp / DG_BM, C);
     hipLaunchKernelGGL(k_dst_fold, dim3((wp + 255) / 256, hp, C), dim3(256), 0, I->stream, U, I->F, G, hp, wp);
     // T1 = G Sw ; T2 = (Sh T1) / den ; T1 = T2 Sw ; U = Sh T1 * scale
-    hipLaunchKernelGGL(k_dgemm<0>, grid, dim3(256), 0, I->stream, G, Sw, T1, wp, wp, wp, wp, plane, (size_t)0, plane, e);
-    hipLaunchKernelGGL(k_dgemm<1>, grid, dim3(256), 0, I->stream, Sh, T1, T2, hp, wp, wp, hp, (size_t)0, plane, plane, e);
-    hipLaunchKernelGGL(k_dgemm<0>, grid, dim3(256), 0, I->stream, T2, Sw, T1, wp, wp, wp, wp, plane, (size_t)0, plane, e);
-    hipLaunchKernelGGL(k_dgemm<2>, grid, dim3(256), 0, I->stream, Sh, T1, T2, hp, wp, wp, hp, (size_t)0, plane, plane, e);
+#define DG_EPI fx, fy, D.h, D.w, scale, U.p, U.pitch, U.plane
+    hipLaunchKernelGGL(k_dgemm<0>, grid, dim3(256), 0, I->stream, G, Sw, T1, wp, wp, wp, wp, plane, (size_t)0, plane, DG_EPI);
+    hipLaunchKernelGGL(k_dgemm<1>, grid, dim3(256), 0, I->stream, Sh, T1, T2, hp, wp, wp, hp, (size_t)0, plane, plane, DG_EPI);
+    hipLaunchKernelGGL(k_dgemm<0>, grid, dim3(256), 0, I->stream, T2, Sw, T1, wp, wp, wp, wp, plane, (size_t)0, plane, DG_EPI);
+    hipLaunchKernelGGL(k_dgemm<2>, grid, dim3(256), 0, I->stream, Sh, T1, T2, hp, wp, wp, hp, (size_t)0, plane, plane, DG_EPI);
+#undef DG_EPI
     SC_HIP(I, hipGetLastError());
     I->info.sweeps = 1;
     I->info.converged = 1;
