@@ -301,17 +301,18 @@ def main():
     di = inst.info()
     out_dst = inst.from_device(jobs[0]["b"], dst.shape)
     inst.set_solver(method=methods[args.method])
-    wp = hp = -(-(W - 2) // 128) * 128
-    dst_flop = 3 * (2.0 * hp * wp * wp * 2 + 2.0 * hp * hp * wp * 2)
+    wp = hp = 2 * (-(-((W - 2 + 1) // 2) // 128) * 128)       # two parity halves, each padded to 128
+    dst_flop = 3 * (2.0 * hp * wp * wp + 2.0 * hp * hp * wp)      # the even/odd fold halves the plain matrix form's 2 n^3 per product
     dd = np.abs(out_dst.astype(np.int16) - out_float.astype(np.int16))
-    roofline_dst = {"bound": "mfma", "kernel": "k_dgemm<EPI> x 4 (v_mfma_f64_16x16x4_f64, 128x128x16 LDS tiles) + fold, SC_METHOD_DST",
+    roofline_dst = {"bound": "mfma", "kernel": "k_dgemm<EPI> x 4 on parity-folded halves (v_mfma_f64_16x16x4_f64, 128x128x16 LDS tiles) + fold / unfold, SC_METHOD_DST",
                     "achieved": round(dst_flop / (di.ms_solve * 1e-3) / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s",
                     "frac": round(dst_flop / (di.ms_solve * 1e-3) / 1e12 / 78.6, 4), "traffic": None,
                     "ms_solve": round(di.ms_solve, 4), "ms_device_total": round(di.ms_device_total, 4),
                     "flop_per_clone": int(dst_flop),
                     "vs_default_path": {"maxdiff": int(dd.max()), "percent_differing": round(float((dd > 0).mean() * 100), 4)},
-                    "note": "the reference's own algorithm (direct DST, float tables), padded to 128-multiples; peak = MI355X FP64 "
-                            "matrix spec; solve stage of one clone by hipEvents (includes the fold kernel)"}
+                    "note": "the reference's own algorithm (direct DST, float tables); the DST matrix's mirror symmetry splits every product "
+                            "into two of half the size (flop_per_clone counts what is executed: half of the plain matrix form); peak = MI355X "
+                            "FP64 matrix spec; solve stage of one clone by hipEvents (includes the fold / unfold kernels)"}
 
     # ---- the drop-in call itself: pageable host images in, result in the caller's image (PCIe inclusive)
     body = dst.copy()
