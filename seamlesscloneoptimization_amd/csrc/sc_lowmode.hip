@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void k_lm_cexpand(const float *__restrict__ Up
                 float sum[LM_KB * LM_KB / 256];
 #pragma unroll
                 for (int j = 0; j < LM_KB * LM_KB / 256; ++j) sum[j] = 0.f;
-                for (int q = 0; q < nparts; ++q) {
+#pragma unroll 2
+                for (int q = 0; q < nparts; ++q) {               // nparts is a multiple of LM_RS
                     const float *__restrict__ up = Upart + (((size_t)q * C + c) * Kyp + kb) * Kxp + lb;
 #pragma unroll
                     for (int j = 0; j < LM_KB * LM_KB / 256; ++j) {
