@@ -343,3 +343,32 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["batch_per_gpu"] == 8 and d["cpu_baseline"] is None
+
+
+def test_config3_literal_rule_red_black_to_1e_4(hip, oracles):
+    """BASELINE config 3 as written: a 2048 x 2048 ROI, red-black Gauss-Seidel / SOR until ||f - Au|| / ||f|| <= 1e-4, residual
+    checked every 32 sweeps.  SOR with the optimal factor gets there in a few thousand sweeps and lands within one grey level of the
+    exact system (sweep solvers return the exact system's iterate: the float-table correction belongs to the converged multigrid
+    solve); plain red-black GS meets the same residual after a few hundred sweeps with tens of grey levels of smooth error left --
+    a 1e-4 residual does not bound the pixel error at this size, which is why the default is multigrid."""
+    from seamlesscloneoptimization_amd import capi, compare
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(2048, 2048)
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=True)
+    try:
+        hip.set_solver(method=capi.SC_METHOD_SOR, tol=1e-4, max_sweeps=20000, check_every=32, omega=0.0)
+        body = dst.copy()
+        assert hip.run(patch, body, mask, cx, cy) == 0
+        i = hip.info()
+        assert i.converged == 1 and i.rel_residual <= 1e-4 and 500 < i.sweeps < 8000, (i.sweeps, i.rel_residual)
+        s = compare.image_diff_stats(want, body)
+        assert s["max"] <= 1 and s["percent"] < 3.0, compare.format_stats(s)
+        hip.set_solver(method=capi.SC_METHOD_RBGS, tol=1e-4, max_sweeps=4096, check_every=32)
+        body = dst.copy()
+        assert hip.run(patch, body, mask, cx, cy) == 0
+        i = hip.info()
+        assert i.converged == 1 and i.rel_residual <= 1e-4
+        assert compare.image_diff_stats(want, body)["max"] > 5           # converged by the residual rule, far from the solution
+    finally:
+        d = hip.default_opts()
+        hip.set_solver(method=d.method, tol=d.tol, max_sweeps=d.max_sweeps, check_every=d.check_every, omega=d.omega)

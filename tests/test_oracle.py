@@ -197,3 +197,29 @@ def test_frozen_golden_vectors(golden_dir, c1_inputs):
         B, lap = oc.build_rhs(dst, patch, geo, M)
         assert np.array_equal(M, syn[name + "_eroded"]) and np.array_equal(lap.transpose(1, 2, 0), syn[name + "_lap_f32"])
         assert np.abs(oc.seamless_clone(dst, patch, mask, cx, cy, 1, True).astype(int) - syn[name + "_out"].astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("W,H", [(130, 70), (333, 207), (515, 300)])
+def test_float_table_correction_spec_against_the_float_table_solve(W, H):
+    """oracle/lowmode_np.py (the restatement the GPU correction is checked against) against the C oracle's two direct
+    solves: float-table minus exact-denominator solve == S^-1[S(u) (den_e/den_f - 1)] with every mode and the plain tables,
+    and the K-mode / node-table form the kernels use stays within a few 1e-3 of it.  The numpy float-table solve agrees too."""
+    from oracle import lowmode_np as lm
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=32)
+    geo, M = oc.mask_stage(mask, cx, cy)
+    B, lap = oc.build_rhs(dst, patch, geo, M)
+    g = oc.fold(B, lap)
+    uf, ue = oc.solve_dst(g, 2, exact_den=False), oc.solve_dst(g, 2, exact_den=True)
+    un = o.solve_dst(g.transpose(1, 2, 0), float_tables=True).transpose(2, 0, 1)
+    assert np.abs(un - uf).max() < 2e-3
+    for c in range(3):
+        d = uf[c].astype(np.float64) - ue[c]
+        full = lm.full_correction(ue[c])
+        assert np.abs(d - full).max() < 3e-4 + 1e-3 * np.abs(d).max()           # float32 storage of the two fields
+        for hat in (1, 8):
+            k = lm.correction(ue[c], hat=hat)
+            assert np.abs(full - k).max() < 3e-3, (c, hat)
+    assert lm.lowmode_count(2046) == 32 and lm.lowmode_count(4094) == 64 and lm.lowmode_count(190) == 8 and lm.lowmode_count(5) == 5
+    # the float tables themselves: double cosine of the FLOAT literal pi, stored as float (seamlessClone_imp.cpp:596-599)
+    t = lm.float_table(2046, 4)
+    assert t.dtype == np.float32 and np.array_equal(t, (2.0 * np.cos(lm.PI_F / 2047.0 * np.arange(1.0, 5.0))).astype(np.float32))
