@@ -91,7 +91,9 @@ typedef struct sc_solver_opts {
     int   jacobi_tile_rows;  /* single-sweep Jacobi launches (sweeps_per_launch = 1): 0 = rows rolling through
                                 registers (k_jacobi_roll, default); 16, 32 or 64 = the LDS-staged 256 x rows tile
                                 with a 1-pixel halo (k_jacobi<rows>).  Bit-identical fields.              */
-    int   reserved[3];
+    int   mg_level1_sweeps;  /* multigrid, default schedule (level 1 without post-smoothing, SC_FLAG_NO_COMPOSE_L1 clear): sweeps
+                                level 1 does before its restriction; 0 = default (4), 2..4                        */
+    int   reserved[2];
 } sc_solver_opts;
 
 /* ---- sc_solver_opts.flags: non-default variants of the same path, selectable per instance so one process (one

@@ -456,6 +456,10 @@ int sc_hip_set_solver(void *p, const sc_solver_opts *o)
         I->err = "jacobi_tile_rows must be 0, 16, 32 or 64";
         return SC_ERR_BAD_ARG;
     }
+    if (o->mg_level1_sweeps != 0 && (o->mg_level1_sweeps < 2 || o->mg_level1_sweeps > 4)) {
+        I->err = "mg_level1_sweeps must be 0 or 2..4";
+        return SC_ERR_BAD_ARG;
+    }
     if (o->flags != I->opts.flags) I->mg.clear();   // the hierarchy (direct bottom solve or not) depends on the flags
     I->opts = *o;
     return SC_OK;

@@ -354,7 +354,8 @@ static int vcycle(Instance *I, size_t l, int pre, int post, unsigned no_post = 0
     // a level without post-smoothing does all its sweeps before the restriction
     int pre_here = pre;
     if (skip_post) {
-        pre_here = std::max(pre, std::min(4, pre + post));
+        const int want = I->opts.mg_level1_sweeps > 0 ? I->opts.mg_level1_sweeps : 4;   // measured (tests/tools/level1_sweeps.py): 3 sweeps are 5 % faster per cycle but full-range noise then needs a 4th cycle
+        pre_here = std::max(pre, std::min(want, pre + post));
     }
     // ---- pre-smoothing (levels >= 1 start from a zero correction), residual + restriction
     bool restricted = false;
