@@ -3,7 +3,7 @@ u0 = (eroded mask ? patch : dst); e = u - u0 solves A e = r0 (zero Dirichlet), r
 the mask's edges.  Levels 0 and 1 exist only in a band around the driven pixels; level 2 is dense and solved exactly here."""
 import sys, time
 import numpy as np
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import oracle_np as o, mg_np as mg
 
 def coefs(dx, dy):
