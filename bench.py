@@ -8,7 +8,7 @@ A "step" is one pass of the hot path over one batch: `--batch` (default 32) inde
 NORMAL_CLONEs of a 2048x2048 ROI per GPU (mask stage + fused pre-process + Poisson solve + float-table
 correction + fused post-process; result = the reference's arithmetic, +-1 grey level), through the C ABI with
 their images already resident in HBM, issued by the library's native pool (sc_hip_pool_run: `--streams`,
-default 4, instances = HIP streams, one C++ worker thread each).  Each worker takes `--group` (default 8)
+default 2, instances = HIP streams, one C++ worker thread each).  Each worker takes `--group` (default 16)
 clones at a time and solves them as ONE field of 3n channels (sc_hip_run_device_batch: same-size ROIs share
 one set of solver launches); `--group 1` is one clone per set of launches (sc_hip_run_device).  Every rank
 owns its own synthetic images (weak scaling: independent images, no data-path collective);
@@ -41,8 +41,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--roi", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=32, help="independent images per GPU per step")
-    ap.add_argument("--streams", type=int, default=4, help="concurrent library instances (HIP streams) per GPU")
-    ap.add_argument("--group", type=int, default=8, help="clones of one ROI size a worker solves as ONE field of 3n channels (sc_hip_run_device_batch)")
+    ap.add_argument("--streams", type=int, default=2, help="concurrent library instances (HIP streams) per GPU")
+    ap.add_argument("--group", type=int, default=16, help="clones of one ROI size a worker solves as ONE field of 3n channels (sc_hip_run_device_batch)")
     ap.add_argument("--method", default="mg", choices=["jacobi", "mg", "rbgs", "sor"])
     ap.add_argument("--sweeps-per-launch", type=int, default=0)
     ap.add_argument("--exact-tables", action="store_true", help="time the exact 5-point solution (SC_FLAG_EXACT_TABLES) instead of the reference's float-table answer")

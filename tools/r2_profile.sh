@@ -17,6 +17,6 @@ for pass in "f3 FETCH_SIZE 3" "w3 WRITE_SIZE 3" "f1 FETCH_SIZE 1" "w1 WRITE_SIZE
       > /dev/null 2> $R/gpurun_out/${T}_$1.err || { echo "pmc pass $1 failed"; tail -5 $R/gpurun_out/${T}_$1.err; exit 1; }
   echo "pass $1 done"
 done
-cd $R && python3 tools/pmc_traffic_bench.py gpurun_out/${T}_f3 gpurun_out/${T}_w3 gpurun_out/${T}_f1 gpurun_out/${T}_w1 gpurun_out/${T}_pmc_traffic_bench.json 2048 32 8 $GIT
+cd $R && python3 tools/pmc_traffic_bench.py gpurun_out/${T}_f3 gpurun_out/${T}_w3 gpurun_out/${T}_f1 gpurun_out/${T}_w1 gpurun_out/${T}_pmc_traffic_bench.json 2048 32 16 $GIT
 rm -rf gpurun_out/${T}_f3 gpurun_out/${T}_w3 gpurun_out/${T}_f1 gpurun_out/${T}_w1
 find gpurun_out/${T}_stats -name "*kernel_trace.csv" -delete
