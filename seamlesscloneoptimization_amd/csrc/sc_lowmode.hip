@@ -13,8 +13,8 @@
 // wavelength is 128 pixels -- so both the projection and the expansion go through a coarse grid of NODES, every 8th field
 // row and column, with bilinear interpolation in between (and its transpose for the projection):
 //   k_lm_restrict : every 8 x 8 cell of U sends its hat-weighted sums to its four corner nodes        (one pass over U)
-//   k_lm_cproject : V = node values;  Chat[k][l] = R[k][l] sum_YX SyN[Y][k] V[Y][X] SxN[X][l]           (coarse grid)
-//   k_lm_cexpand  : CN[Y][X] = sum_kl SyN[Y][k] Chat[k][l] SxN[X][l]: the correction at the nodes       (coarse grid)
+//   k_lm_cproject : V = node values;  parts of Uh[k][l] = sum_YX SyN[Y][k] V[Y][X] SxN[X][l], one per column tile and row split
+//   k_lm_cexpand  : Chat = R (.) (the parts, added in order);  CN[Y][X] = sum_kl SyN[Y][k] Chat[k][l] SxN[X][l]: the correction at the nodes
 //   post-process  : out = clamp/truncate( U[y][x] + bilinear(CN) )                                      (sc_kernels.hip)
 // SyN[Y][k] = sin(pi 8Y (k+1)/(h+1)) are the rows of the DST matrix at the nodes (field row 8Y = interior index 8Y - 1).
 // Representing a sine of mode k by linear interpolation from every 8th sample is off by at most 8 (pi (k+1)/(n+1))^2:
