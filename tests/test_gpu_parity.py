@@ -489,6 +489,12 @@ def test_native_cli_binary(tmp_path, golden_dir, c1_inputs, oracles):
     assert "patch size=298x192" in r.stdout and "argv[6]: 0" in r.stdout
     want = o.seamless_clone(c1_inputs["dst"], c1_inputs["patch"], c1_inputs["mask"], 800, 150, float_tables=True)
     assert compare.image_diff_stats(want, ymlio.read_bmp(out))["max"] <= 1
+    # optional 8th argument: the reference's direct DST solve instead of the default path -- the same image within one grey level
+    out2 = tmp_path / "dst_solver.bmp"
+    r2 = subprocess.run([exe, str(tmp_path / "src.yml"), str(tmp_path / "dst.yml"), str(tmp_path / "src_mask.yml"),
+                         "800", "150", "0", str(out2), "dst"], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and "solver dst" in r2.stdout, r2.stderr
+    assert compare.image_diff_stats(want, ymlio.read_bmp(out2))["max"] <= 1
     bad = subprocess.run([exe, str(tmp_path / "src.yml"), str(tmp_path / "dst.yml"), str(tmp_path / "src_mask.yml"),
                           "5", "5", "0"], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "ROI leaves the destination" in bad.stderr
