@@ -260,6 +260,12 @@ SC_API int   sc_hip_pool_set_group(void *pool, int group);
  * MULTIGRID run (values are discarded; bench.py roofline) */
 SC_API int sc_hip_time_cycle0(void *instance, int launches, float *ms_per_launch);
 
+/* Host-only (needs no GPU): 1 when the reference's float32 eigenvalue tables are singular for an ROI of w x h unknowns --
+ * (float)(2 cos(PI/(n+1))) is exactly 2.0f in both directions (n >= ~12 870), so the reference's denominator
+ * filter_X[0] + filter_Y[0] - 4 (seamlessClone_imp.cpp:1651-1653) is zero and its result undefined.  For such ROIs the
+ * default path and SC_METHOD_DST return the exact system's solution (as SC_FLAG_EXACT_TABLES does). */
+SC_API int sc_hip_reference_tables_singular(int w, int h);
+
 /* host-only self test (needs no GPU): the parked-thread row copier of the host path and the tridiagonal
  * eigen-solver behind the direct bottom solve (residual of T V = V L for level operators with an irregular
  * last interval).  Returns 0, or the number of the check that failed. */

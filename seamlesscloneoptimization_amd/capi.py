@@ -179,6 +179,8 @@ def load():
     L.sc_hip_run_device_batch.restype = C.c_int
     L.sc_hip_time_cycle0.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.sc_hip_time_cycle0.restype = C.c_int
+    L.sc_hip_reference_tables_singular.argtypes = [C.c_int, C.c_int]
+    L.sc_hip_reference_tables_singular.restype = C.c_int
     L.sc_hip_selftest_host.argtypes = []
     L.sc_hip_selftest_host.restype = C.c_int
     _lib = L

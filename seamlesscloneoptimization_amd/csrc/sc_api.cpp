@@ -898,6 +898,14 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     return worst;
 }
 
+int sc_hip_reference_tables_singular(int w, int h)
+{
+    if (w < 1 || h < 1) return 0;
+    const double PIf = (double)3.14159265358979323846f;           // seamlessClone_imp.h:17
+    const float fx0 = (float)(2.0 * std::cos(PIf / (w + 1.0))), fy0 = (float)(2.0 * std::cos(PIf / (h + 1.0)));
+    return ((fx0 + fy0) - 4.0f < 0.0f) ? 0 : 1;
+}
+
 int sc_hip_selftest_host(void)
 {
     // 1: row copier -- strided copy of an awkward shape through the parked helpers, twice (reuse of the pool)

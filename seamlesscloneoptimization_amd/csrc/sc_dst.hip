@@ -116,7 +116,8 @@ template <int EPI>
 __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C,
                                                int lda, int ldb, int ldc, int K, size_t strideAc, size_t strideAp, size_t strideBc,
                                                size_t strideBp, size_t strideCc, size_t strideCp,
-                                               const float *__restrict__ fx, const float *__restrict__ fy, int eh, int ew, int mph, int mpw)
+                                               const float *__restrict__ fx, const float *__restrict__ fy, int eh, int ew, int mph, int mpw,
+                                               int exact_den)
 {
     // two LDS stages: while stage s is multiplied, the next K-tile (already in registers) is written to stage s^1 -- one
     // barrier per K-tile
@@ -192,8 +193,13 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, con
                     // this launch is a LEFT product: its rows are one parity half (zp) of the modes in y, its columns run over both halves in x
                     const int i = 2 * row + zp, j = 2 * (col % mpw) + col / mpw;
                     const bool in = row < mph && i < eh && j < ew;
-                    const float den = in ? (fx[j] + fy[i]) - 4.0f : 1.0f;           // seamlessClone_imp.cpp:1651-1653, in float
-                    v = in ? v / (double)den : 0.0;
+                    if (exact_den) {           // the float tables are singular at this size (the reference divides by zero): exact system
+                        const double sa = sinpi(0.5 * (j + 1.0) / (ew + 1.0)), sb = sinpi(0.5 * (i + 1.0) / (eh + 1.0));
+                        v = in ? v / (-4.0 * (sa * sa + sb * sb)) : 0.0;
+                    } else {
+                        const float den = in ? (fx[j] + fy[i]) - 4.0f : 1.0f;       // seamlessClone_imp.cpp:1651-1653, in float
+                        v = in ? v / (double)den : 0.0;
+                    }
                 }
                 C[(size_t)row * ldc + col] = v;
             }
@@ -220,6 +226,7 @@ static int dst_prepare(Instance *I)
     float *fx = (float *)D.hfxy.p, *fy = fx + w;
     for (int i = 0; i < w; ++i) fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
     for (int j = 0; j < h; ++j) fy[j] = (float)(2.0 * std::cos(PIf / (h + 1.0) * (j + 1.0)));
+    D.singular = !((fx[0] + fy[0]) - 4.0f < 0.0f);     // 2 cos(pi/(n+1)) rounds to 2.0f in both directions (n >= ~12 870): the reference divides by zero
     SC_HIP(I, hipMemcpyAsync(D.fxy.p, D.hfxy.p, (size_t)(w + h) * sizeof(float), hipMemcpyHostToDevice, I->stream));
     hipLaunchKernelGGL(k_dst_table, dim3((unsigned)(((size_t)4 * mpw * mpw + 255) / 256)), dim3(256), 0, I->stream, (double *)D.Sw.p, w, mpw);
     hipLaunchKernelGGL(k_dst_table, dim3((unsigned)(((size_t)4 * mph * mph + 255) / 256)), dim3(256), 0, I->stream, (double *)D.Sh.p, h, mph);
@@ -247,7 +254,7 @@ int dst_solve(Instance *I)
     // Right products work on one column half (all 2 mph rows), left products on one row half (all 2 mpw columns); the half is
     // the low bit of blockIdx.z.   forward: T1 = G [Se|So]_w ; T2 = ([Se^T;So^T]_h T1) / den     inverse: T1 = T2 [Se^T|So^T]_w ; T2 = [Se;So]_h T1
     const dim3 gr(mpw / DG_BN, 2 * mph / DG_BM, 2 * C), gl(2 * mpw / DG_BN, mph / DG_BM, 2 * C);
-#define DG_EPI fx, fy, D.h, D.w, mph, mpw
+#define DG_EPI fx, fy, D.h, D.w, mph, mpw, D.singular ? 1 : 0
     hipLaunchKernelGGL(k_dgemm<0>, gr, dim3(256), 0, I->stream, G, Tw, T1, ld, mpw, ld, mpw, plane, (size_t)mpw, (size_t)0, bw, plane, (size_t)mpw, DG_EPI);
     hipLaunchKernelGGL(k_dgemm<1>, gl, dim3(256), 0, I->stream, Th + 2 * bh, T1, T2, mph, ld, ld, mph, (size_t)0, bh, plane, (size_t)mph * ld, plane, (size_t)mph * ld, DG_EPI);
     hipLaunchKernelGGL(k_dgemm<0>, gr, dim3(256), 0, I->stream, T2, Tw + 2 * bw, T1, ld, mpw, ld, mpw, plane, (size_t)mpw, (size_t)0, bw, plane, (size_t)mpw, DG_EPI);

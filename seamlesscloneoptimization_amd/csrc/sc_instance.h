@@ -27,6 +27,7 @@ struct LowMode {
     int w = 0, h = 0, C = 0;               // interior size the tables were built for; channels the buffers hold
     int Kx = 0, Ky = 0, Kxp = 0, Kyp = 0;  // modes per direction, padded to the register block
     int nx = 0, ny = 0, npitch = 0;        // nodes (every 8th field column / row) and the row pitch of CN
+    bool singular = false;                 // the reference's float denominator of the lowest mode is zero at this size: no correction
     DevBuf Sx, Sy, R, P, E, CN;            // Sx[nx][Kxp], Sy[ny][Kyp] (sines at the nodes), R[Kyp][Kxp], P = cell shares float4[C][cells_y][cells_x], E = partial products of the coarse projection [parts][C][Kyp][Kxp], CN[C][ny][npitch]
     DevBuf hR;                             // pinned staging of R
 };
@@ -34,6 +35,7 @@ struct LowMode {
 // direct DST solve (sc_dst.hip): DST matrices, the reference's float tables and the double work planes
 struct DstState {
     int w = 0, h = 0, wp = 0, hp = 0;      // interior size the tables were built for, padded to the 128 x 128 tiles
+    bool singular = false;                 // the reference's float tables are singular at this size: exact denominators instead
     DevBuf Sw, Sh, fxy, G, T1, T2;         // Sw[wp][wp], Sh[hp][hp] double; fx[wp] + fy[hp] float; G, T1, T2: [C][hp][wp] double
     DevBuf hfxy;                           // pinned staging of the float tables
 };

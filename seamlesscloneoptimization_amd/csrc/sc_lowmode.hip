@@ -274,7 +274,10 @@ __global__ __launch_bounds__(256) void k_lm_apply(Field U, Field Out, LmNodes lm
 // R[k][l] = (den_exact / den_float - 1) * 4 / ((w+1)(h+1)).  den_float follows the reference to the letter:
 // filter_X[i] = (float)(2.0 * cos(PI/(n+1.0) * (i+1.0))) with the FLOAT literal PI (seamlessClone_imp.h:17, .cpp:596-599),
 // den = filter_X[i] + filter_Y[j] - 4 in float (:1651-1653).  den_exact = -4 (sin^2(a/2) + sin^2(b/2)) in double.
-static void build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R)
+// Returns false when the reference's arithmetic is SINGULAR for this size: beyond ~12 870 pixels in both directions
+// 2 cos(pi/(n+1)) rounds to 2.0f, the float denominator of the lowest mode is zero and the reference divides by zero
+// (its result is NaN).  There is nothing to reproduce then: the caller applies no correction (exact system).
+static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R)
 {
     const double PIf = (double)3.14159265358979323846f;
     std::vector<float> fx(Kx), fy(Ky);
@@ -287,8 +290,9 @@ static void build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R)
             const double sa = std::sin(0.5 * M_PI * (i + 1.0) / (w + 1.0)), sb = std::sin(0.5 * M_PI * (j + 1.0) / (h + 1.0));
             const double den_e = -4.0 * (sa * sa + sb * sb);
             const float den_f = (fx[i] + fy[j]) - 4.0f;
-            R[(size_t)j * Kxp + i] = (float)((den_e / (double)den_f - 1.0) * scale);
+            R[(size_t)j * Kxp + i] = (den_f < 0.0f) ? (float)((den_e / (double)den_f - 1.0) * scale) : 0.0f;
         }
+    return (fx[0] + fy[0]) - 4.0f < 0.0f;          // the lowest mode has the denominator closest to zero
 }
 
 // (Re)builds the tables for the fields currently bound to the instance; no-op when the geometry is unchanged.
@@ -314,7 +318,7 @@ static int lm_prepare(Instance *I)
     if ((rc = ensure(I, L.R, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
     if ((rc = ensure_pinned(I, L.hR, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
     std::memset(L.hR.p, 0, sizeof(float) * (size_t)Kyp * Kxp);
-    build_ratio(w, h, Kx, Ky, Kxp, (float *)L.hR.p);
+    L.singular = !build_ratio(w, h, Kx, Ky, Kxp, (float *)L.hR.p);
     SC_HIP(I, hipMemcpyAsync(L.R.p, L.hR.p, sizeof(float) * (size_t)Kyp * Kxp, hipMemcpyHostToDevice, I->stream));
     hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)nx * Kxp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sx.p, w, nx, Kx, Kxp);
     hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)ny * Kyp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sy.p, h, ny, Ky, Kyp);
@@ -331,6 +335,7 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm)
     int rc = lm_prepare(I);
     if (rc) return rc;
     const LowMode &L = I->lm;
+    if (L.singular) return SC_OK;                  // the reference's float tables divide by zero at this size: exact system
     const int cells_x = U.pitch / LM_HAT, cells_y = (U.H + LM_HAT - 1) / LM_HAT, nxt = (L.nx + 63) / 64;
     float *upart = (float *)L.E.p;
     hipLaunchKernelGGL(k_lm_restrict, dim3((cells_x + 63) / 64, (cells_y + 3) / 4, U.C), dim3(256), 0, I->stream, U, (float4 *)L.P.p, cells_x, cells_y);

@@ -249,3 +249,21 @@ def test_bench_parent_never_loads_the_hip_library(tmp_path):
     r = subprocess.run([sys.executable, str(probe)], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert '"n_gpus": 2' in r.stdout
+
+
+def test_reference_tables_singular_threshold():
+    """Beyond ~12 870 unknowns per side the reference's float tables give a zero denominator for the lowest mode
+    (seamlessClone_imp.cpp:596-599, :1651-1653); the library reports that (host-only entry point) and then returns the
+    exact system's solution.  The threshold is checked against the float32 arithmetic itself."""
+    from seamlesscloneoptimization_amd import capi
+    L = capi.load()
+    pif = float(np.float32(3.14159265358979323846))
+
+    def singular(w, h):
+        fx0 = np.float32(2.0 * np.cos(pif / (w + 1.0))); fy0 = np.float32(2.0 * np.cos(pif / (h + 1.0)))
+        return not (np.float32(np.float32(fx0 + fy0) - np.float32(4.0)) < 0)
+    for w, h in [(296, 190), (2046, 2046), (4094, 4094), (8190, 8190), (12000, 7000), (12860, 12860), (12880, 12880), (12880, 5000),
+                 (16382, 16382), (20000, 13000)]:
+        assert bool(L.sc_hip_reference_tables_singular(w, h)) == singular(w, h), (w, h)
+    assert L.sc_hip_reference_tables_singular(2046, 2046) == 0 and L.sc_hip_reference_tables_singular(16382, 16382) == 1
+    assert L.sc_hip_reference_tables_singular(16382, 2046) == 0          # one short side keeps the denominator negative
