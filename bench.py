@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--roi", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=32, help="independent images per GPU per step")
     ap.add_argument("--streams", type=int, default=2, help="concurrent library instances (HIP streams) per GPU")
