@@ -304,7 +304,7 @@ def main():
     wp = hp = 2 * (-(-((W - 2 + 1) // 2) // 128) * 128)       # two parity halves, each padded to 128
     dst_flop = 3 * (2.0 * hp * wp * wp + 2.0 * hp * hp * wp)      # the even/odd fold halves the plain matrix form's 2 n^3 per product
     dd = np.abs(out_dst.astype(np.int16) - out_float.astype(np.int16))
-    roofline_dst = {"bound": "mfma", "kernel": "k_dgemm<EPI> x 4 on parity-folded halves (v_mfma_f64_16x16x4_f64, 128x128x16 LDS tiles) + fold / unfold, SC_METHOD_DST",
+    roofline_dst = {"bound": "mfma", "kernel": "k_dgemm<EPI> x 4 on parity-folded halves (v_mfma_f64_16x16x4_f64, 128x128x16 LDS tiles, 8 waves) + fold / unfold, SC_METHOD_DST",
                     "achieved": round(dst_flop / (di.ms_solve * 1e-3) / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s",
                     "frac": round(dst_flop / (di.ms_solve * 1e-3) / 1e12 / 78.6, 4), "traffic": None,
                     "ms_solve": round(di.ms_solve, 4), "ms_device_total": round(di.ms_device_total, 4),

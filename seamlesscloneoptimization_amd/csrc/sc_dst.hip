@@ -113,44 +113,40 @@ __global__ __launch_bounds__(256) void k_dst_unfold(const double *__restrict__ R
 // mode 2 (r % mp) + r / mp (zero outside eh x ew).
 
 template <int EPI>
-__global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C,
+__global__ __launch_bounds__(512) void k_dgemm(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C,
                                                int lda, int ldb, int ldc, int K, size_t strideAc, size_t strideAp, size_t strideBc,
                                                size_t strideBp, size_t strideCc, size_t strideCp,
                                                const float *__restrict__ fx, const float *__restrict__ fy, int eh, int ew, int mph, int mpw,
                                                int exact_den)
 {
-    // two LDS stages: while stage s is multiplied, the next K-tile (already in registers) is written to stage s^1 -- one
-    // barrier per K-tile
+    // Eight waves, two per SIMD (their MFMAs interleave in the pipe), each owns a 32 x 64 part of the 128 x 128 tile: 2 x 4 MFMA tiles.
+    // Two LDS stages: while stage s is multiplied, the next K-tile (already in registers) is written to stage s^1 -- one barrier per K-tile.
     __shared__ double As[2][DG_BK][DG_BM + DG_PAD];
     __shared__ double Bs[2][DG_BK][DG_BN + DG_PAD];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;       // wm 0..3 (32 rows each), wn 0..1 (64 columns each)
     const int m0 = blockIdx.y * DG_BM, n0 = blockIdx.x * DG_BN, zc = blockIdx.z >> 1, zp = blockIdx.z & 1;
     A += (size_t)zc * strideAc + (size_t)zp * strideAp; B += (size_t)zc * strideBc + (size_t)zp * strideBp;
     C += (size_t)zc * strideCc + (size_t)zp * strideCp;
-    // global -> register staging: A tile 128 x 16 (thread: one row, 8 consecutive k), B tile 16 x 128 (one k row, 8 columns)
-    const int ar = t >> 1, ak = (t & 1) * 8, bk = t >> 4, bc = (t & 15) * 8;
+    // global -> register staging: A tile 128 x 16 (thread: one row, 4 consecutive k), B tile 16 x 128 (one k row, 4 columns)
+    const int ar = t >> 2, ak = (t & 3) * 4, bk = t >> 5, bc = (t & 31) * 4;
     const double *__restrict__ ap = A + (size_t)(m0 + ar) * lda + ak;
     const double *__restrict__ bp = B + (size_t)bk * ldb + n0 + bc;
-    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    double2 ra0, ra1, rb0, rb1;
 #define DG_LOAD(k0)                                                                                          \
     {                                                                                                        \
         const double *a_ = ap + (k0);                                                                        \
         const double *b_ = bp + (size_t)(k0) * ldb;                                                          \
         ra0 = *reinterpret_cast<const double2 *>(a_); ra1 = *reinterpret_cast<const double2 *>(a_ + 2);      \
-        ra2 = *reinterpret_cast<const double2 *>(a_ + 4); ra3 = *reinterpret_cast<const double2 *>(a_ + 6);  \
         rb0 = *reinterpret_cast<const double2 *>(b_); rb1 = *reinterpret_cast<const double2 *>(b_ + 2);      \
-        rb2 = *reinterpret_cast<const double2 *>(b_ + 4); rb3 = *reinterpret_cast<const double2 *>(b_ + 6);  \
     }
 #define DG_STORE(s)                                                                                          \
     {                                                                                                        \
         As[s][ak + 0][ar] = ra0.x; As[s][ak + 1][ar] = ra0.y; As[s][ak + 2][ar] = ra1.x; As[s][ak + 3][ar] = ra1.y;  \
-        As[s][ak + 4][ar] = ra2.x; As[s][ak + 5][ar] = ra2.y; As[s][ak + 6][ar] = ra3.x; As[s][ak + 7][ar] = ra3.y;  \
         *reinterpret_cast<double2 *>(&Bs[s][bk][bc + 0]) = rb0; *reinterpret_cast<double2 *>(&Bs[s][bk][bc + 2]) = rb1;  \
-        *reinterpret_cast<double2 *>(&Bs[s][bk][bc + 4]) = rb2; *reinterpret_cast<double2 *>(&Bs[s][bk][bc + 6]) = rb3;  \
     }
-    v4f64 acc[4][4];
+    v4f64 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){ 0.0, 0.0, 0.0, 0.0 };
     const int fr = lane & 15, fk = lane >> 4;
@@ -164,13 +160,13 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, con
         DG_LOAD(min(kt + 1, ntiles - 1) * DG_BK);
 #pragma unroll
         for (int kk = 0; kk < DG_BK; kk += 4) {
-            double a[4], b[4];
+            double a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[s][kk + fk][wm * 64 + i * 16 + fr];
+            for (int i = 0; i < 2; ++i) a[i] = As[s][kk + fk][wm * 32 + i * 16 + fr];
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = Bs[s][kk + fk][wn * 64 + j * 16 + fr];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
@@ -182,12 +178,12 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, con
 #undef DG_STORE
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + fk + 4 * r, col = n0 + wn * 64 + j * 16 + fr;
+                const int row = m0 + wm * 32 + i * 16 + fk + 4 * r, col = n0 + wn * 64 + j * 16 + fr;
                 double v = acc[i][j][r];
                 if (EPI == 1) {
                     // this launch is a LEFT product: its rows are one parity half (zp) of the modes in y, its columns run over both halves in x
@@ -255,10 +251,10 @@ int dst_solve(Instance *I)
     // the low bit of blockIdx.z.   forward: T1 = G [Se|So]_w ; T2 = ([Se^T;So^T]_h T1) / den     inverse: T1 = T2 [Se^T|So^T]_w ; T2 = [Se;So]_h T1
     const dim3 gr(mpw / DG_BN, 2 * mph / DG_BM, 2 * C), gl(2 * mpw / DG_BN, mph / DG_BM, 2 * C);
 #define DG_EPI fx, fy, D.h, D.w, mph, mpw, D.singular ? 1 : 0
-    hipLaunchKernelGGL(k_dgemm<0>, gr, dim3(256), 0, I->stream, G, Tw, T1, ld, mpw, ld, mpw, plane, (size_t)mpw, (size_t)0, bw, plane, (size_t)mpw, DG_EPI);
-    hipLaunchKernelGGL(k_dgemm<1>, gl, dim3(256), 0, I->stream, Th + 2 * bh, T1, T2, mph, ld, ld, mph, (size_t)0, bh, plane, (size_t)mph * ld, plane, (size_t)mph * ld, DG_EPI);
-    hipLaunchKernelGGL(k_dgemm<0>, gr, dim3(256), 0, I->stream, T2, Tw + 2 * bw, T1, ld, mpw, ld, mpw, plane, (size_t)mpw, (size_t)0, bw, plane, (size_t)mpw, DG_EPI);
-    hipLaunchKernelGGL(k_dgemm<0>, gl, dim3(256), 0, I->stream, Th, T1, T2, mph, ld, ld, mph, (size_t)0, bh, plane, (size_t)mph * ld, plane, (size_t)mph * ld, DG_EPI);
+    hipLaunchKernelGGL(k_dgemm<0>, gr, dim3(512), 0, I->stream, G, Tw, T1, ld, mpw, ld, mpw, plane, (size_t)mpw, (size_t)0, bw, plane, (size_t)mpw, DG_EPI);
+    hipLaunchKernelGGL(k_dgemm<1>, gl, dim3(512), 0, I->stream, Th + 2 * bh, T1, T2, mph, ld, ld, mph, (size_t)0, bh, plane, (size_t)mph * ld, plane, (size_t)mph * ld, DG_EPI);
+    hipLaunchKernelGGL(k_dgemm<0>, gr, dim3(512), 0, I->stream, T2, Tw + 2 * bw, T1, ld, mpw, ld, mpw, plane, (size_t)mpw, (size_t)0, bw, plane, (size_t)mpw, DG_EPI);
+    hipLaunchKernelGGL(k_dgemm<0>, gl, dim3(512), 0, I->stream, Th, T1, T2, mph, ld, ld, mph, (size_t)0, bh, plane, (size_t)mph * ld, plane, (size_t)mph * ld, DG_EPI);
 #undef DG_EPI
     hipLaunchKernelGGL(k_dst_unfold, dim3(((D.w + 1) / 2 + 255) / 256, (D.h + 1) / 2, C), dim3(256), 0, I->stream, (const double *)T2, mph, mpw, scale, U);
     SC_HIP(I, hipGetLastError());
