@@ -5,7 +5,7 @@ The reference ships no lossless output, so these vectors are produce
 oracle (oracle/oracle_np.py) -- itself pinned against the reference's committed JPEG -- and frozen
 here so that neither the oracle, the C restatement nor the HIP path can drift unnoticed.
 
-    python tests/golden/make_golden.py        # rewrites c1_expected.npz and synthetic_cases.npz
+    python tests/golden/make_golden.py        # rewrites c1_expected.npz, synthetic_cases.npz and float_table_case.npz
 """
 import hashlib
 import os
@@ -43,7 +43,20 @@ def main():
         cases[name + "_lap_f32"] = inf["lap"].astype(np.float32)
         cases[name + "_eroded"] = inf["geo"]["M"]
     np.savez_compressed(os.path.join(HERE, "synthetic_cases.npz"), **cases)
-    print("wrote c1_expected.npz, synthetic_cases.npz")
+    # The reference's own arithmetic (float32 eigenvalue tables, seamlessClone_imp.cpp:596-599, :1651-1653) at a size where it is
+    # visibly NOT the exact system's: inputs are regenerated from their seeds (not stored); frozen are a 96 x 96 crop of the
+    # float-table result, a digest of the whole image and how many channels the two answers differ in.
+    W, H = 1024, 700
+    dst, patch, m, cx, cy = o.synth_inputs(W, H, margin=48)
+    ft = o.seamless_clone(dst, patch, m, cx, cy, float_tables=True)
+    ex = o.seamless_clone(dst, patch, m, cx, cy)
+    y0, x0 = dst.shape[0] // 2 - 48, dst.shape[1] // 2 - 48
+    np.savez_compressed(os.path.join(HERE, "float_table_case.npz"),
+                        size=np.array([W, H, 48], np.int32), crop_origin=np.array([y0, x0], np.int32),
+                        crop_float_tables=ft[y0:y0 + 96, x0:x0 + 96], crop_exact=ex[y0:y0 + 96, x0:x0 + 96],
+                        sha256_float_tables=np.frombuffer(hashlib.sha256(ft.tobytes()).digest(), np.uint8),
+                        channels_differing=np.int64((ft != ex).sum()), maxdiff=np.int64(np.abs(ft.astype(int) - ex.astype(int)).max()))
+    print("wrote c1_expected.npz, synthetic_cases.npz, float_table_case.npz")
 
 
 if __name__ == "__main__":

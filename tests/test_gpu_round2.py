@@ -1,6 +1,8 @@
 """GPU parity tests added in round 2 (through the C ABI, against the CPU oracle):
 the float-table correction (OpenCV's / the reference's own float32 eigenvalue tables), every per-instance variant flag,
 the LDS-tiled Jacobi kernel, the post-process hook, caller-pinned strided images and BASELINE config 5."""
+import os
+
 import numpy as np
 import pytest
 
@@ -372,3 +374,28 @@ def test_config3_literal_rule_red_black_to_1e_4(hip, oracles):
     finally:
         d = hip.default_opts()
         hip.set_solver(method=d.method, tol=d.tol, max_sweeps=d.max_sweeps, check_every=d.check_every, omega=d.omega)
+
+
+def test_frozen_float_table_case_on_the_gpu(hip, golden_dir):
+    """The committed float-table fixture (tests/golden/float_table_case.npz) through the C ABI: default path and SC_METHOD_DST
+    against the frozen float-table crop, SC_FLAG_EXACT_TABLES against the frozen exact crop; the two crops differ."""
+    from seamlesscloneoptimization_amd import capi
+    from oracle import oracle_np as o
+    f = np.load(os.path.join(golden_dir, "float_table_case.npz"))
+    W, H, margin = (int(v) for v in f["size"])
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=margin)
+    y0, x0 = (int(v) for v in f["crop_origin"])
+    assert (f["crop_float_tables"] != f["crop_exact"]).mean() > 0.05
+
+    def crop_of(**solver):
+        try:
+            hip.set_solver(**solver)
+            body = dst.copy()
+            assert hip.run(patch, body, mask, cx, cy) == 0
+        finally:
+            hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=0)
+        return body[y0:y0 + 96, x0:x0 + 96].astype(int)
+    for solver, want in (({}, f["crop_float_tables"]), ({"method": capi.SC_METHOD_DST}, f["crop_float_tables"]),
+                         ({"flags": capi.SC_FLAG_EXACT_TABLES}, f["crop_exact"])):
+        d = np.abs(crop_of(**solver) - want.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01, (solver, int(d.max()), float((d > 0).mean()))
