@@ -46,6 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--method", default="mg", choices=["jacobi", "mg", "rbgs", "sor"])
     ap.add_argument("--sweeps-per-launch", type=int, default=0)
     ap.add_argument("--exact-tables", action="store_true", help="time the exact 5-point solution (SC_FLAG_EXACT_TABLES) instead of the reference's float-table answer")
+    ap.add_argument("--extra-flags", type=int, default=0, help="further sc_solver_opts.flags bits (A/B runs of a variant, e.g. 64 = SC_FLAG_SEPARATE_RESTRICT)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--kernel-launches", type=int, default=100, help="launches in the roofline micro-region")
     ap.add_argument("--reference-table", action="store_true",
@@ -215,7 +216,7 @@ def main():
     ndev = capi.device_count()
     if ndev < 1:
         sys.exit("bench.py: no MI355X visible (there is no CPU fallback)")
-    opts = dict(method=methods[args.method], flags=capi.SC_FLAG_EXACT_TABLES if args.exact_tables else 0)
+    opts = dict(method=methods[args.method], flags=(capi.SC_FLAG_EXACT_TABLES if args.exact_tables else 0) | args.extra_flags)
     if args.method == "sor":
         opts.update(tol=2e-5, max_sweeps=200000, check_every=64)
     if args.sweeps_per_launch:

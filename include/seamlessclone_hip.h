@@ -116,6 +116,10 @@ typedef struct sc_solver_opts {
                                             eigenvalue tables are stored and combined in float32
                                             (seamlessClone_imp.cpp:596-599, :1651-1653) -- see DESIGN.md sec. 5,
                                             "float-table correction"                                            */
+#define SC_FLAG_SEPARATE_RESTRICT (1 << 6) /* float-table correction: restrict the finished field in a pass of its own
+                                            (k_lm_restrict); default: the final level-0 multigrid launch leaves the cell
+                                            shares behind.  Same cells, different order of the additions (differences at
+                                            float rounding level)                                               */
 
 /* ---- statistics of the last run */
 typedef struct sc_run_info {

@@ -148,6 +148,7 @@ static Field make_field(void *p, int W, int H, int C)
 
 int setup_fields(Instance *I, int W, int H, int C)
 {
+    field_moved(I);
     Field proto = make_field(nullptr, W, H, C);
     const size_t bytes = proto.bytes() + 4096;
     int rc;
@@ -410,8 +411,9 @@ void my_seamlessclone_api_imp_destroy(void *p)
     for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
     if (I->mg_partial.p) (void)hipFree(I->mg_partial.p);
     if (I->h_partial.p) (void)hipHostFree(I->h_partial.p);
-    for (DevBuf *b : { &I->lm.Sx, &I->lm.Sy, &I->lm.R, &I->lm.P, &I->lm.E, &I->lm.CN }) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : { &I->lm.Sx, &I->lm.Sy, &I->lm.R, &I->lm.P, &I->lm.E, &I->lm.CN, &I->lm.B, &I->lm.map }) if (b->p) (void)hipFree(b->p);
     if (I->lm.hR.p) (void)hipHostFree(I->lm.hR.p);
+    if (I->lm.hmap.p) (void)hipHostFree(I->lm.hmap.p);
     for (DevBuf *b : { &I->dst.Sw, &I->dst.Sh, &I->dst.fxy, &I->dst.G, &I->dst.T1, &I->dst.T2 }) if (b->p) (void)hipFree(b->p);
     if (I->dst.hfxy.p) (void)hipHostFree(I->dst.hfxy.p);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
@@ -1005,6 +1007,7 @@ int sc_hip_build_rhs(void *p, const uint8_t *face, int fc, int fr, int fs, const
 int sc_hip_field_load(void *p, int W, int H, int C, const float *U, const float *lap)
 {
     Instance *I = get(p);
+    if (I) field_moved(I);
     if (!I || !U || !lap) return SC_ERR_BAD_ARG;
     I->err.clear();
     SC_HIP(I, hipSetDevice(I->gpu));
@@ -1119,6 +1122,7 @@ int sc_hip_field_lowmode(void *p)
 int sc_hip_field_time_sweeps(void *p, int method, int launches, int spl, float omega, float *ms_per_launch)
 {
     Instance *I = get(p);
+    if (I) field_moved(I);
     if (I && I->f_half) { int frc = float_rhs(I); if (frc) return frc; }
     if (!I || !I->F.p || !ms_per_launch || launches < 1) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));
@@ -1146,6 +1150,7 @@ int sc_hip_field_time_sweeps(void *p, int method, int launches, int spl, float o
 int sc_hip_time_cycle0(void *p, int launches, float *ms_per_launch)
 {
     Instance *I = get(p);
+    if (I) field_moved(I);
     if (!I || !ms_per_launch || launches < 1) return SC_ERR_BAD_ARG;
     if (!I->F.p || I->mg.size() < 2 || !I->mg_partial.p) { I->err = "time_cycle0: run a multigrid clone first"; return SC_ERR_BAD_ARG; }
     SC_HIP(I, hipSetDevice(I->gpu));

@@ -99,12 +99,15 @@ void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_
 // residual + restriction into Fc.  Returns #partials written, 0 without prolong, -1 if unsupported.
 int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
                    float *partial, hipStream_t s, bool tag = false, bool f_half = false, bool u_half = false,
-                   bool final_cycle = false);
+                   bool final_cycle = false, float4 *bands = nullptr);
+// bands (final form only): receives the cell shares of the float-table correction, two float4 per (channel, tile row, wave,
+// 8-column cell) -- see k_cycle0 and sc_lowmode.hip
+void cycle0_row_geometry(int H, int sweeps, int &nby, int &step, int &hy);
 int  cycle0_blocks(int W, int H, int C, int sweeps);
 // the same launch with its prolongation source composed on the fly from level 1 (before post-smoothing) and level 2
 // (sc_cycle0.hip, ComposeArgs); -1: combination not instantiated
 int  launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
-                            hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1);
+                            hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands = nullptr);
 // coarse level: zero-guess pre-smoothing + residual + restriction fused (Uout = smoothed correction, Fc = next RHS)
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s);
 

@@ -135,7 +135,7 @@ __device__ __forceinline__ float c0_comp(const float4 &v, int k) { return k == 0
 // ZEROIN = the incoming correction is identically zero and is not read (first visit of a level).
 template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG bit 0: second symbol for isolated timing; bit 1: F is float16; bit 2: Uin is float16; bit 3: last cycle (no residual / restriction)
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
-                                                    float *__restrict__ partial, ComposeArgs comp)
+                                                    float *__restrict__ partial, ComposeArgs comp, float4 *__restrict__ bands)
 {
     constexpr int HY = 2 * T + 2, RH = NW * R;
     constexpr bool COMP = (TAG & 16) != 0;      // E is U1; the interpolated level-2 correction is added on the fly (ComposeArgs)
@@ -408,6 +408,48 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
 #undef SC_C0_ROWS
 
+    // ------------------------------------------------------------------ cell shares for the float-table correction
+    // (FINAL form, level 0, when the caller asks: `bands`).  The correction's restriction (sc_lowmode.hip: every 8 x 8 cell of
+    // the finished field sends hat-weighted sums to its four corner nodes) needs one more pass over U; the finished field is
+    // in registers right here.  A lane's four columns are half of one cell, its band of R = 8 rows (y0 is even, never a
+    // multiple of 8) spans two cell rows: each lane pair writes two cell shares per band, part A for cell row y0 >> 3 and
+    // part B for the next; k_lm_bands_to_cells adds the (at most four) parts of a cell in a fixed order.  Rows outside the
+    // tile's exact output and everything outside the interior count as zero, exactly as in k_lm_restrict.
+    if constexpr (FINAL && !GEN) {
+        if (bands) {
+            const bool lane_out = (lane >= C0_HXQ) && (lane < 64 - C0_HXQ);
+            const int jo = x & 7;                                  // 0: left half of the cell, 4: right half
+            const float wl0 = 1.0f - 0.125f * (float)jo;           // weight of column x towards the cell's left nodes; -1/8 per column
+            float a0[4] = { 0.f, 0.f, 0.f, 0.f }, a1[4] = { 0.f, 0.f, 0.f, 0.f };
+            const int Yc0 = y0 >> 3;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int yr = wv * R + r, y = y0 + r;
+                const bool rowok = lane_out && yr >= HY && yr < RH - HY && y >= 1 && y <= H - 2;
+                const float v0 = (rowok && x0ok) ? u[r].x : 0.f, v1 = (rowok && x1ok) ? u[r].y : 0.f;
+                const float v2 = (rowok && x2ok) ? u[r].z : 0.f, v3 = (rowok && x3ok) ? u[r].w : 0.f;
+                const float r0 = __builtin_fmaf(wl0 - 0.375f, v3, __builtin_fmaf(wl0 - 0.25f, v2, __builtin_fmaf(wl0 - 0.125f, v1, wl0 * v0)));
+                const float r1 = __builtin_fmaf(1.375f - wl0, v3, __builtin_fmaf(1.25f - wl0, v2, __builtin_fmaf(1.125f - wl0, v1, (1.0f - wl0) * v0)));
+                const float tb = 0.125f * (float)(y & 7), tt = 1.0f - tb;
+                if ((y >> 3) == Yc0) {
+                    a0[0] = __builtin_fmaf(tt, r0, a0[0]); a0[1] = __builtin_fmaf(tt, r1, a0[1]);
+                    a0[2] = __builtin_fmaf(tb, r0, a0[2]); a0[3] = __builtin_fmaf(tb, r1, a0[3]);
+                } else {
+                    a1[0] = __builtin_fmaf(tt, r0, a1[0]); a1[1] = __builtin_fmaf(tt, r1, a1[1]);
+                    a1[2] = __builtin_fmaf(tb, r0, a1[2]); a1[3] = __builtin_fmaf(tb, r1, a1[3]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0[k] += wave_from_right(a0[k]); a1[k] += wave_from_right(a1[k]); }   // left half + right half of the cell
+            const int Xc = x >> 3;
+            if (jo == 0 && lane_out && x >= 0 && x < W && Xc < (P >> 3)) {
+                float4 *o = bands + 2 * ((((size_t)c * nby + by) * NW + wv) * (size_t)(P >> 3) + Xc);
+                o[0] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                o[1] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+            }
+        }
+    }
+
     // ------------------------------------------------------------------ residual + restriction
 #undef SC_C0_GS
     if (!FINAL) {
@@ -518,12 +560,12 @@ constexpr int C0_NW = 8, C0_R = 8;
 
 template <int T, bool PRO, int TAG = 0>
 static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s,
-                     const ComposeArgs &comp = ComposeArgs())
+                     const ComposeArgs &comp = ComposeArgs(), float4 *bands = nullptr)
 {
     constexpr int RH = C0_NW * C0_R, HY = 2 * T + 2;
     const int blocks = ((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
     hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false, TAG>), dim3(blocks), dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E,
-                       g, partial, comp);
+                       g, partial, comp, bands);
     return blocks;
 }
 
@@ -531,13 +573,13 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
 // has no post-smoothing and no prolongation launch of its own), E2 = finished level-2 correction, g1 = level-1 geometry.
 // sweeps = post + pre (4) or, final_cycle, post (2).  Returns the number of partial maxima, -1 if not instantiated.
 int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
-                           hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1)
+                           hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands)
 {
     ComposeArgs ca;
     ca.E2 = E2; ca.g1 = g1;
     if (final_cycle) {
         if (sweeps != 2) return -1;
-        return f_half ? launch_c0<2, true, 26>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<2, true, 24>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
+        return f_half ? launch_c0<2, true, 26>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : launch_c0<2, true, 24>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
     }
     if (sweeps != 4) return -1;
     if (tag) return f_half ? launch_c0<4, true, 19>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 17>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
@@ -548,13 +590,14 @@ int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, c
 // Uin hold float16 values (same element layout).  Returns the number of partial maxima written (0 without prolong), or -1
 // for an unsupported depth.
 int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle)
+                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle, float4 *bands)
 {
     if (final_cycle) {   // prolongation + `sweeps` post-smoothing sweeps, nothing restricted
         if (!prolong || u_half) return -1;
+        const ComposeArgs nc = ComposeArgs();
         switch (sweeps) {
-        case 1: return f_half ? launch_c0<1, true, 10>(Uin, Uout, F, Fc, E, g, partial, s) : launch_c0<1, true, 8>(Uin, Uout, F, Fc, E, g, partial, s);
-        case 2: return f_half ? launch_c0<2, true, 10>(Uin, Uout, F, Fc, E, g, partial, s) : launch_c0<2, true, 8>(Uin, Uout, F, Fc, E, g, partial, s);
+        case 1: return f_half ? launch_c0<1, true, 10>(Uin, Uout, F, Fc, E, g, partial, s, nc, bands) : launch_c0<1, true, 8>(Uin, Uout, F, Fc, E, g, partial, s, nc, bands);
+        case 2: return f_half ? launch_c0<2, true, 10>(Uin, Uout, F, Fc, E, g, partial, s, nc, bands) : launch_c0<2, true, 8>(Uin, Uout, F, Fc, E, g, partial, s, nc, bands);
         default: return -1;
         }
     }
@@ -586,6 +629,14 @@ int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeo
 #undef SC_C0
 }
 
+// tiling in y of a level-0 launch with `sweeps` sweeps: nby tile rows, tile row b processes field rows [b step - hy, + 64) in
+// eight 8-row bands (one per wave) and owns the output rows [b step, (b + 1) step)
+void cycle0_row_geometry(int H, int sweeps, int &nby, int &step, int &hy)
+{
+    const int RH = C0_NW * C0_R;
+    hy = 2 * sweeps + 2; step = RH - 2 * hy; nby = (H + step - 1) / step;
+}
+
 int cycle0_blocks(int W, int H, int C, int sweeps)
 {
     const int RH = C0_NW * C0_R, HY = 2 * sweeps + 2;
@@ -601,7 +652,7 @@ static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_
     Field none{};
     const int blocks = ((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * F.C;
     hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true>), dim3(blocks), dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
-                       Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs());
+                       Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs(), (float4 *)nullptr);
 }
 
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s)

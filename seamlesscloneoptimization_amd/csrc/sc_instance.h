@@ -28,6 +28,9 @@ struct LowMode {
     int Kx = 0, Ky = 0, Kxp = 0, Kyp = 0;  // modes per direction, padded to the register block
     int nx = 0, ny = 0, npitch = 0;        // nodes (every 8th field column / row) and the row pitch of CN
     bool singular = false;                 // the reference's float denominator of the lowest mode is zero at this size: no correction
+    DevBuf B, map, hmap;                   // cell-share parts left by the final level-0 launch [C][band rows][cells_x][2] float4; parts of each cell row (device, pinned)
+    int band_rows = 0, map_H = 0, map_sweeps = 0;
+    const float *bands_of = nullptr;       // the field whose parts B holds (nullptr: none); cleared whenever a solve starts or moves on
     DevBuf Sx, Sy, R, P, E, CN;            // Sx[nx][Kxp], Sy[ny][Kyp] (sines at the nodes), R[Kyp][Kxp], P = cell shares float4[C][cells_y][cells_x], E = partial products of the coarse projection [parts][C][Kyp][Kxp], CN[C][ny][npitch]
     DevBuf hR;                             // pinned staging of R
 };
@@ -135,6 +138,9 @@ bool mg_reads_half_rhs(const Instance *I);
 bool mg_composes_level1(const Instance *I);   // sc_multigrid.cpp   // sc_multigrid.cpp: would the solve configured in I->opts read a float16 F?
 int lowmode_correct(Instance *I, const Field &U, const Field &Out);   // sc_lowmode.hip: Out = U + float-table correction
 int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm);          // the correction of U at the node rows (what the post-process adds)
+float4 *lowmode_bands_buffer(Instance *I, int sweeps);               // where a final level-0 launch leaves the correction's cell shares (nullptr: not wanted)
+inline void field_moved(Instance *I) { I->lm.bands_of = nullptr; }   // anything that writes the solution field outside the judged multigrid launch calls this
+void lowmode_bands_written(Instance *I, const float *field);       // the launch went in: B describes `field` (nullptr: nothing)
 int lowmode_count(int n);
 int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST
 bool wants_float_tables(const Instance *I);

@@ -101,6 +101,25 @@ __global__ __launch_bounds__(256) void k_lm_restrict(Field U, float4 *__restrict
 }
 
 // Coarse projection.  Node value V[Y][X] = the four cell shares that meet there; T[k][X] = sum_Y SyN[Y][k] V[Y][X];
+// The same cell shares from the parts the final level-0 multigrid launch left (k_cycle0, `bands`): cell row Yc receives part A of
+// the bands that start in it and part B of the bands that start in the cell row above; map[Yc][e] = 2 * band row + part, or -1,
+// in ascending order (built on the host from the launch's tiling) -- a fixed order of at most four additions.
+__global__ __launch_bounds__(256) void k_lm_bands_to_cells(const float4 *__restrict__ bands, int band_rows, const int *__restrict__ map,
+                                                           float4 *__restrict__ Cell, int cells_x, int cells_y, int W)
+{
+    const int Xc = blockIdx.x * 256 + threadIdx.x, Yc = blockIdx.y, c = blockIdx.z;
+    if (Xc >= cells_x) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = map[4 * Yc + e];
+        if (m < 0 || LM_HAT * Xc >= W) continue;       // cells right of the field: pad columns, nothing was written for them
+        const float4 v = bands[2 * (((size_t)c * band_rows + (m >> 1)) * cells_x + Xc) + (m & 1)];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    Cell[((size_t)c * cells_y + Yc) * cells_x + Xc] = s;
+}
+
 // Upart[part][k][l] = sum_{X in tile} T[k][X] SxN[X][l] (part = column tile x row split; the expansion kernel adds the parts
 // in a fixed order).  Workgroup = 64 node columns (lane = X), the four waves split the node rows and meet in LDS.
 __global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ Cell, int cells_x, int cells_y, int nx, int ny, int C,
@@ -327,6 +346,45 @@ static int lm_prepare(Instance *I)
     return SC_OK;
 }
 
+// Buffer for the cell-share parts of a final level-0 launch with `sweeps` sweeps on the instance's current fields (k_cycle0's
+// `bands` argument), or nullptr when no correction will be applied.  The caller passes it to that launch and then calls
+// lowmode_bands_written(); the next lowmode_nodes() builds the cells from the parts instead of reading the field again.
+float4 *lowmode_bands_buffer(Instance *I, int sweeps)
+{
+    LowMode &L = I->lm;
+    L.bands_of = nullptr;
+    if (!wants_float_tables(I) || lm_prepare(I) != SC_OK || L.singular) return nullptr;
+    const int H = I->F.H, C = I->F.C, cells_x = I->F.pitch / LM_HAT, cells_y = (H + LM_HAT - 1) / LM_HAT;
+    int nby, step, hy;
+    cycle0_row_geometry(H, sweeps, nby, step, hy);
+    const int band_rows = nby * 8;
+    if (ensure(I, L.B, sizeof(float4) * 2 * (size_t)C * band_rows * cells_x) != SC_OK) return nullptr;
+    if (L.map_H != H || L.map_sweeps != sweeps || !L.map.p) {
+        if (ensure(I, L.map, sizeof(int) * 4 * (size_t)cells_y) != SC_OK) return nullptr;
+        if (ensure_pinned(I, L.hmap, sizeof(int) * 4 * (size_t)cells_y) != SC_OK) return nullptr;
+        int *m = (int *)L.hmap.p;
+        for (int i = 0; i < 4 * cells_y; ++i) m[i] = -1;
+        std::vector<int> fill(cells_y, 0);
+        bool fits = true;
+        auto add = [&](int Yc, int v) {
+            if (Yc < 0 || Yc >= cells_y) return;
+            if (fill[Yc] < 4) m[4 * Yc + fill[Yc]++] = v; else fits = false;
+        };
+        for (int b = 0; b < band_rows; ++b) {                   // ascending band rows: a fixed order of additions per cell
+            const int y0 = (b >> 3) * step - hy + 8 * (b & 7);
+            const int Yc0 = y0 >= 0 ? y0 >> 3 : -((-y0 + 7) >> 3);          // floor(y0 / 8)
+            add(Yc0, 2 * b); add(Yc0 + 1, 2 * b + 1);
+        }
+        if (!fits) return nullptr;          // a tiling with more than four parts per cell row: the separate pass serves
+        if (hipMemcpyAsync(L.map.p, L.hmap.p, sizeof(int) * 4 * (size_t)cells_y, hipMemcpyHostToDevice, I->stream) != hipSuccess) return nullptr;
+        L.map_H = H; L.map_sweeps = sweeps;
+    }
+    L.band_rows = band_rows;
+    return (float4 *)L.B.p;
+}
+
+void lowmode_bands_written(Instance *I, const float *field) { I->lm.bands_of = field; }
+
 // Node corrections of the field U (the instance's current shape): what the post-process adds (lm.CN == nullptr: nothing).
 int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm)
 {
@@ -334,10 +392,15 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm)
     if (U.W < 3 || U.H < 3) return SC_OK;
     int rc = lm_prepare(I);
     if (rc) return rc;
-    const LowMode &L = I->lm;
+    LowMode &L = I->lm;
     if (L.singular) return SC_OK;                  // the reference's float tables divide by zero at this size: exact system
     const int cells_x = U.pitch / LM_HAT, cells_y = (U.H + LM_HAT - 1) / LM_HAT, nxt = (L.nx + 63) / 64;
     float *upart = (float *)L.E.p;
+    if (L.bands_of && L.bands_of == U.p) {       // the final level-0 launch left the cell shares in parts: no further pass over U
+        hipLaunchKernelGGL(k_lm_bands_to_cells, dim3((cells_x + 255) / 256, cells_y, U.C), dim3(256), 0, I->stream, (const float4 *)L.B.p,
+                           L.band_rows, (const int *)L.map.p, (float4 *)L.P.p, cells_x, cells_y, U.W);
+        L.bands_of = nullptr;  // used once: whoever touches the field afterwards need not know about the parts
+    } else
     hipLaunchKernelGGL(k_lm_restrict, dim3((cells_x + 63) / 64, (cells_y + 3) / 4, U.C), dim3(256), 0, I->stream, U, (float4 *)L.P.p, cells_x, cells_y);
     hipLaunchKernelGGL(k_lm_cproject, dim3(nxt, LM_RS, U.C), dim3(256), 0, I->stream, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
                        (const float *)L.Sy.p, L.Kyp, (const float *)L.Sx.p, L.Kxp, upart);
@@ -357,6 +420,7 @@ int lowmode_correct(Instance *I, const Field &U, const Field &Out)
     int rc = lowmode_nodes(I, U, lm);
     if (rc || !lm.CN) return rc;
     hipLaunchKernelGGL(k_lm_apply, dim3((U.W + 255) / 256, U.H, U.C), dim3(256), 0, I->stream, U, Out, lm);
+    field_moved(I);
     SC_HIP(I, hipGetLastError());
     return SC_OK;
 }

@@ -469,15 +469,19 @@ int mg_solve(Instance *I)
             const bool judged = !(cyc + 1 < 3 && cyc + 1 < budget && o.tol <= 0.f);
             const int nb_cap = cycle0_blocks(I->F.W, I->F.H, I->F.C, 4);   // deepest form = largest halo = most workgroups
             float *const part_now = (float *)I->mg_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;    // this cycle's maxima; the previous cycle's sit in the other half
+            // the judged cycle runs in its final form; when the float-table correction will follow it leaves the correction's
+            // cell shares behind (sc_lowmode.hip), which saves the correction its own pass over the field
+            float4 *const bands = (judged && !(o.flags & SC_FLAG_SEPARATE_RESTRICT)) ? lowmode_bands_buffer(I, post) : nullptr;
             const int nb = comp1
                 ? launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
                                          judged ? post : post + pre, part_now, I->stream, false, I->f_half, judged,
-                                         I->mg[2].U, I->mg[1].g)
+                                         I->mg[2].U, I->mg[1].g, bands)
                 : launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
                                 I->mg[0].g, judged ? post : post + pre, true, part_now, I->stream,
-                                false, I->f_half, false, judged);
+                                false, I->f_half, false, judged, bands);
             if (nb <= 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
             I->result_in_U1 = !I->result_in_U1;
+            lowmode_bands_written(I, bands ? result(I).p : nullptr);
             I->info.sweep_launches += 1;
             ++cyc;
             SC_HIP(I, hipGetLastError());
@@ -544,6 +548,7 @@ int mg_solve(Instance *I)
                 if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false,
                                   nullptr, I->stream, false, I->f_half, false) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
                 I->result_in_U1 = !I->result_in_U1;
+                lowmode_bands_written(I, nullptr);
                 I->info.sweep_launches += 1;
             }
         }

@@ -63,6 +63,7 @@ int fused_depth(int method, int spl)
 
 int run_sweeps(Instance *I, int method, int sweeps, float omega, int spl)
 {
+    field_moved(I);
     if (sweeps <= 0) return SC_OK;
     if (method != SC_METHOD_JACOBI && method != SC_METHOD_RBGS && method != SC_METHOD_SOR) {
         I->err = "run_sweeps: unknown method";
@@ -105,6 +106,7 @@ int mg_solve(Instance *I); // sc_multigrid.cpp
 int solve(Instance *I)
 {
     const sc_solver_opts &o = I->opts;
+    field_moved(I);
     I->info.sweeps = 0;
     I->info.converged = 0;
     I->info.rel_residual = NAN;

@@ -399,3 +399,77 @@ def test_frozen_float_table_case_on_the_gpu(hip, golden_dir):
                          ({"flags": capi.SC_FLAG_EXACT_TABLES}, f["crop_exact"])):
         d = np.abs(crop_of(**solver) - want.astype(int))
         assert d.max() <= 1 and (d > 0).mean() < 0.01, (solver, int(d.max()), float((d > 0).mean()))
+
+
+@pytest.mark.parametrize("W,H", [(9, 9), (64, 71), (233, 59), (240, 53), (517, 400), (1030, 1000), (1856, 1700), (2048, 2048)])
+def test_restriction_fused_into_the_final_cycle_equals_the_separate_pass(hip, oracles, W, H):
+    """The correction's restriction comes out of the final level-0 multigrid launch by default (k_cycle0 `bands` +
+    k_lm_bands_to_cells); SC_FLAG_SEPARATE_RESTRICT reads the finished field again (k_lm_restrict).  Same cells, another
+    order of additions: the corrected fields agree to float rounding, the images within the rounding of a handful of pixels,
+    both within one grey level of the float-table port.  Sizes: a single tile, tile seams in x (232-column step) and y
+    (52-row step), ragged last cells, the BASELINE config 3 size."""
+    from seamlesscloneoptimization_amd import capi, compare
+    o, oc = oracles
+    margin = 2 if min(W, H) < 64 else 24
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=margin)
+    geo, M = oc.mask_stage(mask, cx, cy)
+    B, lap = oc.build_rhs(dst, patch, geo, M)
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+    out, fields = {}, {}
+    try:
+        for flags in (0, capi.SC_FLAG_SEPARATE_RESTRICT, capi.SC_FLAG_NO_SPECULATE):
+            hip.set_solver(flags=flags)
+            for rep in range(2):                                     # the second call reuses buffers and the part map
+                body = dst.copy()
+                assert hip.run(patch, body, mask, cx, cy) == 0
+                assert rep == 0 or np.array_equal(body, out[flags])
+                out[flags] = body
+            hip.field_load(B, lap)
+            hip.field_solve()
+            hip.field_lowmode()
+            fields[flags] = hip.field_store()
+    finally:
+        hip.set_solver(flags=0)
+    assert np.array_equal(out[0], out[capi.SC_FLAG_NO_SPECULATE])
+    scale = max(1.0, float(np.abs(fields[0]).max()))
+    assert np.abs(fields[0] - fields[capi.SC_FLAG_SEPARATE_RESTRICT]).max() <= 2e-5 * scale
+    assert np.array_equal(fields[0], fields[capi.SC_FLAG_NO_SPECULATE])
+    s = compare.image_diff_stats(out[0], out[capi.SC_FLAG_SEPARATE_RESTRICT])
+    assert s["max"] <= 1 and s["percent"] < 0.01, compare.format_stats(s)
+    for flags, body in out.items():
+        s = compare.image_diff_stats(want, body)
+        assert s["max"] <= 1 and s["percent"] < 0.5, (flags, compare.format_stats(s))
+
+
+def test_restriction_parts_are_not_reused_after_the_field_moved(hip, oracles):
+    """The parts describe the field the final cycle wrote.  A sweep, a reload or a correction applied in between
+    invalidates them: the correction then restricts the field it is given."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    W, H = 300, 180
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=24)
+    geo, M = oc.mask_stage(mask, cx, cy)
+    B, lap = oc.build_rhs(dst, patch, geo, M)
+    hip.field_load(B, lap)
+    hip.field_solve()
+    hip.field_sweep(capi.SC_METHOD_JACOBI, 3, 1.0, 1)                # moves the field away from what the parts describe
+    moved = hip.field_store()
+    hip.field_lowmode()
+    got = hip.field_store()
+    try:
+        hip.set_solver(flags=capi.SC_FLAG_SEPARATE_RESTRICT)
+        hip.field_load(moved, lap)
+        hip.field_lowmode()
+        ref = hip.field_store()
+    finally:
+        hip.set_solver(flags=0)
+    assert np.array_equal(got, ref)
+    hip.field_load(B, lap)
+    hip.field_solve()
+    hip.field_lowmode()
+    once = hip.field_store()
+    hip.field_lowmode()                                               # second correction: of the corrected field
+    twice = hip.field_store()
+    hip.field_load(once, lap)
+    hip.field_lowmode()
+    assert np.array_equal(twice, hip.field_store())
