@@ -38,6 +38,7 @@ SC_FLAG_NO_COMPOSE_L1 = 1 << 3
 SC_FLAG_VCYCLE_BOTTOM = 1 << 4
 SC_FLAG_EXACT_TABLES = 1 << 5
 SC_FLAG_SEPARATE_RESTRICT = 1 << 6
+SC_FLAG_KEEP_FIELD = 1 << 7
 
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",

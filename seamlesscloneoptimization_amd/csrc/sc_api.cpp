@@ -411,9 +411,9 @@ void my_seamlessclone_api_imp_destroy(void *p)
     for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
     if (I->mg_partial.p) (void)hipFree(I->mg_partial.p);
     if (I->h_partial.p) (void)hipHostFree(I->h_partial.p);
-    for (DevBuf *b : { &I->lm.Sx, &I->lm.Sy, &I->lm.R, &I->lm.P, &I->lm.E, &I->lm.CN, &I->lm.B, &I->lm.map }) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : { &I->lm.Sx, &I->lm.Sy, &I->lm.R, &I->lm.P, &I->lm.E, &I->lm.CN, &I->lm.B, &I->lm.maps[0].d, &I->lm.maps[1].d }) if (b->p) (void)hipFree(b->p);
     if (I->lm.hR.p) (void)hipHostFree(I->lm.hR.p);
-    if (I->lm.hmap.p) (void)hipHostFree(I->lm.hmap.p);
+    for (auto &m : I->lm.maps) if (m.h.p) (void)hipHostFree(m.h.p);
     for (DevBuf *b : { &I->dst.Sw, &I->dst.Sh, &I->dst.fxy, &I->dst.G, &I->dst.T1, &I->dst.T2 }) if (b->p) (void)hipFree(b->p);
     if (I->dst.hfxy.p) (void)hipHostFree(I->dst.hfxy.p);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
@@ -1008,6 +1008,7 @@ int sc_hip_field_load(void *p, int W, int H, int C, const float *U, const float 
 {
     Instance *I = get(p);
     if (I) field_moved(I);
+    if (I) I->out_direct = false;
     if (!I || !U || !lap) return SC_ERR_BAD_ARG;
     I->err.clear();
     SC_HIP(I, hipSetDevice(I->gpu));
@@ -1030,6 +1031,7 @@ int sc_hip_field_load(void *p, int W, int H, int C, const float *U, const float 
 int sc_hip_field_sweep(void *p, int method, int sweeps, float omega, int spl)
 {
     Instance *I = get(p);
+    if (I && I->out_direct) { I->err = "the last clone kept no solution field (set SC_FLAG_KEEP_FIELD to keep it)"; return SC_ERR_BAD_ARG; }
     if (I && I->f_half) { int frc = float_rhs(I); if (frc) return frc; }
     if (!I || !I->F.p) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));
@@ -1043,6 +1045,7 @@ int sc_hip_field_sweep(void *p, int method, int sweeps, float omega, int spl)
 int sc_hip_field_residual(void *p, double out[2])
 {
     Instance *I = get(p);
+    if (I && I->out_direct) { I->err = "the last clone kept no solution field (set SC_FLAG_KEEP_FIELD to keep it)"; return SC_ERR_BAD_ARG; }
     if (I && I->f_half) { int frc = float_rhs(I); if (frc) return frc; }
     if (!I || !I->F.p || !out) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));
@@ -1073,6 +1076,7 @@ int sc_hip_field_shape(void *p, int whc[3])
 int sc_hip_field_store(void *p, float *U_out, size_t capacity_floats)
 {
     Instance *I = get(p);
+    if (I && I->out_direct) { I->err = "the last clone kept no solution field (set SC_FLAG_KEEP_FIELD to keep it)"; return SC_ERR_BAD_ARG; }
     if (!I || !I->F.p || !U_out) return SC_ERR_BAD_ARG;
     if (capacity_floats < (size_t)I->F.W * I->F.H * I->F.C) { I->err = "field_store: buffer too small"; return SC_ERR_BAD_SIZE; }
     SC_HIP(I, hipSetDevice(I->gpu));
@@ -1085,6 +1089,7 @@ int sc_hip_field_store(void *p, float *U_out, size_t capacity_floats)
 int sc_hip_field_finish(void *p, uint8_t *body, int bc, int br, int bs, int ltx, int lty)
 {
     Instance *I = get(p);
+    if (I && I->out_direct) { I->err = "the last clone kept no solution field (set SC_FLAG_KEEP_FIELD to keep it)"; return SC_ERR_BAD_ARG; }
     if (!I || !I->F.p || !body) return SC_ERR_BAD_ARG;
     I->err.clear();
     SC_HIP(I, hipSetDevice(I->gpu));
@@ -1106,6 +1111,7 @@ int sc_hip_field_finish(void *p, uint8_t *body, int bc, int br, int bs, int ltx,
 int sc_hip_field_lowmode(void *p)
 {
     Instance *I = get(p);
+    if (I && I->out_direct) { I->err = "the last clone kept no solution field (set SC_FLAG_KEEP_FIELD to keep it)"; return SC_ERR_BAD_ARG; }
     if (I && I->f_half) { int frc = float_rhs(I); if (frc) return frc; }
     if (!I || !I->F.p) return SC_ERR_BAD_ARG;
     SC_HIP(I, hipSetDevice(I->gpu));

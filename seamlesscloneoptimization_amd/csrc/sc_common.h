@@ -64,6 +64,26 @@ struct RectGuard { const int *d_rect = nullptr; int x0 = 0, x1 = 0, y0 = 0, y1 =
 // CN == nullptr: none.
 struct LmNodes { const float *CN = nullptr; int ny = 0, npitch = 0; };
 #if defined(__HIPCC__)
+// the correction at the four pixels x .. x + 3 (x a multiple of 4: one 8-column cell) of row y, added to v; and the output
+// byte of a value: clamp to [0, 255], truncate (seamlessClone_imp.cpp:2091-2096).  One definition for the post-process and for
+// the multigrid launch that writes output bytes itself: the same operations in the same order.
+__device__ __forceinline__ void lm_add4(const LmNodes &lm, int c, int x, int y, float4 &v)
+{
+    const float *__restrict__ p = lm.CN + ((size_t)c * lm.ny + (y >> 3)) * lm.npitch + (x >> 3);
+    const float ty = 0.125f * (float)(y & 7);
+    const float l = __builtin_fmaf(ty, p[lm.npitch] - p[0], p[0]), r = __builtin_fmaf(ty, p[lm.npitch + 1] - p[1], p[1]);
+    const float dx = 0.125f * (r - l), a0 = __builtin_fmaf((float)(x & 7), dx, l);
+    v.x += a0;
+    v.y += a0 + dx;
+    v.z += __builtin_fmaf(2.0f, dx, a0);
+    v.w += __builtin_fmaf(3.0f, dx, a0);
+}
+__device__ __forceinline__ unsigned lm_byte(float d)
+{
+    d = d > 255.0f ? 255.0f : d;
+    d = d < 0.0f ? 0.0f : d;
+    return (unsigned)(unsigned char)d;
+}
 __device__ __forceinline__ float lm_bilinear(const LmNodes &lm, int c, int x, int y)
 {
     const float *__restrict__ p = lm.CN + ((size_t)c * lm.ny + (y >> 3)) * lm.npitch + (x >> 3);
@@ -76,6 +96,9 @@ void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, Re
 // the same for a group (fields of 3n channels), one launch per 16 members
 void launch_preprocess_group(const ImageJob *jobs, int n, int mpitch, Field U0, Field F, hipStream_t s, bool f_half, bool u_half);
 void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s, LmNodes lm = LmNodes());
+// splice of output bytes a multigrid launch left planar in Q's memory (launch_cycle0_out): interleave into the destination
+void launch_splice_planar(Field Q, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard());
+void launch_splice_planar_group(Field Q, const ImageJob *jobs, int n, hipStream_t s);
 void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_t s);
 
 void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag = false, int lds_tile_rows = 0);
@@ -100,14 +123,17 @@ void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_
 int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
                    float *partial, hipStream_t s, bool tag = false, bool f_half = false, bool u_half = false,
                    bool final_cycle = false, float4 *bands = nullptr);
-// bands (final form only): receives the cell shares of the float-table correction, two float4 per (channel, tile row, wave,
-// 8-column cell) -- see k_cycle0 and sc_lowmode.hip
+// bands (final form, or 4 sweeps with prolongation): receives the cell shares of the float-table correction of the field the
+// launch writes, two float4 per (channel, tile row, wave, 8-column cell) -- see k_cycle0 and sc_lowmode.hip
 void cycle0_row_geometry(int H, int sweeps, int &nby, int &step, int &hy);
 int  cycle0_blocks(int W, int H, int C, int sweeps);
 // the same launch with its prolongation source composed on the fly from level 1 (before post-smoothing) and level 2
 // (sc_cycle0.hip, ComposeArgs); -1: combination not instantiated
 int  launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
                             hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands = nullptr);
+// the last cycle with its result leaving as output bytes (planar, in Q's memory) instead of as a field; see sc_cycle0.hip
+int  launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
+                       bool composed, Field E2, const MGGeom &g1, const LmNodes &lm);
 // coarse level: zero-guess pre-smoothing + residual + restriction fused (Uout = smoothed correction, Fc = next RHS)
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s);
 

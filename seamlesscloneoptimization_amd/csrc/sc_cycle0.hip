@@ -133,14 +133,22 @@ __device__ __forceinline__ float c0_comp(const float4 &v, int k) { return k == 0
 // GEN    = coarse multigrid level: general stencil coefficients at the last column / row (MGDim)
 //          and the interpolation-tail weights in the restriction of the last coarse column / row.
 // ZEROIN = the incoming correction is identically zero and is not read (first visit of a level).
-template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>   // TAG bit 0: second symbol for isolated timing; bit 1: F is float16; bit 2: Uin is float16; bit 3: last cycle (no residual / restriction)
+// TAG bit 0: second symbol for isolated timing; bit 1: F is float16; bit 2: Uin is float16; bit 3: last cycle (no residual /
+// restriction); bit 4: composed prolongation; bit 5: last cycle whose result leaves as bytes (Uout's memory receives planar
+// 8-bit output values: float-table node correction added, clamped, truncated) instead of as a field; bit 6: the launch
+// leaves the float-table correction's cell shares of the field it writes in `bands` (the last-cycle form does so whenever
+// `bands` is not null)
+template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
-                                                    float *__restrict__ partial, ComposeArgs comp, float4 *__restrict__ bands)
+                                                    float *__restrict__ partial, ComposeArgs comp, float4 *__restrict__ bands, LmNodes lm)
 {
     constexpr int HY = 2 * T + 2, RH = NW * R;
     constexpr bool COMP = (TAG & 16) != 0;      // E is U1; the interpolated level-2 correction is added on the fly (ComposeArgs)
     static_assert(!COMP || (PRO && !GEN && R % 2 == 0), "composition of two prolongations exists on level 0 only");
     constexpr bool FINAL = (TAG & 8) != 0;      // prolongation + post-smoothing only: the cycle the stop rule is expected to accept
+    constexpr bool OUT = (TAG & 32) != 0, BANDS = ((TAG & 64) != 0 || FINAL) && !OUT;
+    static_assert(!OUT || (FINAL && !GEN), "bytes leave from the last level-0 launch only");
+    static_assert(!(TAG & 64) || !GEN, "cell shares exist on level 0 only");
     constexpr bool HF = (TAG & 2) != 0, HU = (TAG & 4) != 0;   // HU: the first launch of a clone reads the 8-bit destination values the pre-process stored as float16
     static_assert(!(HF && GEN), "float16 right-hand sides exist on level 0 only");
     static_assert(!(PRO && GEN), "the in-kernel prolongation relies on level 0's regular last interval");
@@ -409,13 +417,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 #undef SC_C0_ROWS
 
     // ------------------------------------------------------------------ cell shares for the float-table correction
-    // (FINAL form, level 0, when the caller asks: `bands`).  The correction's restriction (sc_lowmode.hip: every 8 x 8 cell of
+    // (level 0, when the caller asks: `bands`; the last-cycle form and the forms with TAG bit 6).  The correction's restriction (sc_lowmode.hip: every 8 x 8 cell of
     // the finished field sends hat-weighted sums to its four corner nodes) needs one more pass over U; the finished field is
     // in registers right here.  A lane's four columns are half of one cell, its band of R = 8 rows (y0 is even, never a
     // multiple of 8) spans two cell rows: each lane pair writes two cell shares per band, part A for cell row y0 >> 3 and
     // part B for the next; k_lm_bands_to_cells adds the (at most four) parts of a cell in a fixed order.  Rows outside the
     // tile's exact output and everything outside the interior count as zero, exactly as in k_lm_restrict.
-    if constexpr (FINAL && !GEN) {
+    if constexpr (BANDS && !GEN) {
         if (bands) {
             const bool lane_out = (lane >= C0_HXQ) && (lane < 64 - C0_HXQ);
             const int jo = x & 7;                                  // 0: left half of the cell, 4: right half
@@ -548,6 +556,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 
     // ------------------------------------------------------------------ write back the exact inner tile
     if (lane < C0_HXQ || lane >= 64 - C0_HXQ || x >= P || x >= W) return;
+    if constexpr (OUT) {
+        // the result leaves as output values: u + node correction (the arithmetic of the post-process, sc_kernels.hip),
+        // clamped to [0, 255], truncated; plane c of Uout's memory, rows of P bytes.  The splice kernel interleaves.
+        uint8_t *__restrict__ q = reinterpret_cast<uint8_t *>(Uout.p) + (size_t)c * Uout.plane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int yr = wv * R + r, y = y0 + r;
+            if (!(yr >= HY && yr < RH - HY && y >= 1 && y <= H - 2)) continue;
+            float4 v = u[r];
+            if (lm.CN) lm_add4(lm, c, x, y, v);
+            *reinterpret_cast<unsigned *>(q + (size_t)y * P + x) = lm_byte(v.x) | (lm_byte(v.y) << 8) | (lm_byte(v.z) << 16) | (lm_byte(v.w) << 24);
+        }
+        return;
+    }
     float *__restrict__ out = Uout.at(c);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -560,12 +582,12 @@ constexpr int C0_NW = 8, C0_R = 8;
 
 template <int T, bool PRO, int TAG = 0>
 static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s,
-                     const ComposeArgs &comp = ComposeArgs(), float4 *bands = nullptr)
+                     const ComposeArgs &comp = ComposeArgs(), float4 *bands = nullptr, const LmNodes &lm = LmNodes())
 {
     constexpr int RH = C0_NW * C0_R, HY = 2 * T + 2;
     const int blocks = ((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
     hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false, TAG>), dim3(blocks), dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E,
-                       g, partial, comp, bands);
+                       g, partial, comp, bands, lm);
     return blocks;
 }
 
@@ -582,6 +604,7 @@ int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, c
         return f_half ? launch_c0<2, true, 26>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : launch_c0<2, true, 24>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
     }
     if (sweeps != 4) return -1;
+    if (bands && !tag) return f_half ? launch_c0<4, true, 82>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : launch_c0<4, true, 80>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
     if (tag) return f_half ? launch_c0<4, true, 19>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 17>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
     return f_half ? launch_c0<4, true, 18>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 16>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
 }
@@ -613,6 +636,8 @@ int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeo
                                        : launch_c0<T_, PRO_, 2>(Uin, Uout, F, Fc, E, g, partial, s))      \
                                 : (tag ? launch_c0<T_, PRO_, 1>(Uin, Uout, F, Fc, E, g, partial, s)      \
                                        : launch_c0<T_, PRO_, 0>(Uin, Uout, F, Fc, E, g, partial, s)))
+    if (prolong && bands && sweeps == 4 && !tag)
+        return f_half ? launch_c0<4, true, 66>(Uin, Uout, F, Fc, E, g, partial, s, ComposeArgs(), bands) : launch_c0<4, true, 64>(Uin, Uout, F, Fc, E, g, partial, s, ComposeArgs(), bands);
     if (prolong) {
         switch (sweeps) {
         case 2: return SC_C0(2, true);
@@ -627,6 +652,20 @@ int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeo
     default: return -1;
     }
 #undef SC_C0
+}
+
+// The last cycle of a clone with its output leaving as bytes (TAG bit 5): prolongation (composed: E = U1 with E2 / g1, else
+// E = the finished level-1 correction) + two post-smoothing sweeps; Q (a field's memory: plane c at Q.p + c Q.plane BYTES,
+// rows of Q.pitch bytes) receives the output values, lm the node correction to add (CN == nullptr: none).
+int launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
+                      bool composed, Field E2, const MGGeom &g1, const LmNodes &lm)
+{
+    ComposeArgs ca;
+    if (composed) {
+        ca.E2 = E2; ca.g1 = g1;
+        return f_half ? launch_c0<2, true, 58>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm) : launch_c0<2, true, 56>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
+    }
+    return f_half ? launch_c0<2, true, 42>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm) : launch_c0<2, true, 40>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
 }
 
 // tiling in y of a level-0 launch with `sweeps` sweeps: nby tile rows, tile row b processes field rows [b step - hy, + 64) in
@@ -652,7 +691,7 @@ static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_
     Field none{};
     const int blocks = ((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * F.C;
     hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true>), dim3(blocks), dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
-                       Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs(), (float4 *)nullptr);
+                       Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs(), (float4 *)nullptr, LmNodes());
 }
 
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s)

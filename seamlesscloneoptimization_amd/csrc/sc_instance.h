@@ -28,8 +28,11 @@ struct LowMode {
     int Kx = 0, Ky = 0, Kxp = 0, Kyp = 0;  // modes per direction, padded to the register block
     int nx = 0, ny = 0, npitch = 0;        // nodes (every 8th field column / row) and the row pitch of CN
     bool singular = false;                 // the reference's float denominator of the lowest mode is zero at this size: no correction
-    DevBuf B, map, hmap;                   // cell-share parts left by the final level-0 launch [C][band rows][cells_x][2] float4; parts of each cell row (device, pinned)
-    int band_rows = 0, map_H = 0, map_sweeps = 0;
+    double max_ratio = 0.0;                // max |den_exact / den_float - 1| over the corrected modes
+    DevBuf B;                              // cell-share parts left by a level-0 launch [C][band rows][cells_x][2] float4
+    struct PartMap { DevBuf d, h; int H = 0, sweeps = 0; } maps[2];      // parts of each cell row (device, pinned) for the 2- and the 4-sweep tiling
+    PartMap *map_used = nullptr;
+    int band_rows = 0;
     const float *bands_of = nullptr;       // the field whose parts B holds (nullptr: none); cleared whenever a solve starts or moves on
     DevBuf Sx, Sy, R, P, E, CN;            // Sx[nx][Kxp], Sy[ny][Kyp] (sines at the nodes), R[Kyp][Kxp], P = cell shares float4[C][cells_y][cells_x], E = partial products of the coarse projection [parts][C][Kyp][Kxp], CN[C][ny][npitch]
     DevBuf hR;                             // pinned staging of R
@@ -71,6 +74,7 @@ struct Instance {
     DevBuf d_U0, d_U1, d_F;
     Field U0, U1, F;      // current views into the buffers above
     bool result_in_U1 = false;
+    bool out_direct = false;               // the last solve wrote output bytes from its last cycle: result(I) is the iterate before it, not the solution
     bool f_half = false;      // F currently holds float16 values (written by the pre-process for the fused multigrid path)
     bool u_half = false;      // ... and so does the initial field U0 until the first cycle has consumed it
     // Speculative epilogue: the multigrid driver enqueues the post-process right behind the cycle whose
@@ -140,6 +144,7 @@ int lowmode_correct(Instance *I, const Field &U, const Field &Out);   // sc_lowm
 int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm);          // the correction of U at the node rows (what the post-process adds)
 float4 *lowmode_bands_buffer(Instance *I, int sweeps);               // where a final level-0 launch leaves the correction's cell shares (nullptr: not wanted)
 inline void field_moved(Instance *I) { I->lm.bands_of = nullptr; }   // anything that writes the solution field outside the judged multigrid launch calls this
+int lowmode_early_kind(Instance *I, float update_tol);                // see sc_lowmode.hip
 void lowmode_bands_written(Instance *I, const float *field);       // the launch went in: B describes `field` (nullptr: nothing)
 int lowmode_count(int n);
 int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST

@@ -524,28 +524,14 @@ __device__ __forceinline__ void postprocess_block(const Field &U, uint8_t *__res
         // float-table correction (sc_lowmode.hip): bilinear interpolation between the four nodes around the pixel; the
         // lane's four pixels lie in one 8-column cell (x is a multiple of 4)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float *__restrict__ p = lm.CN + ((size_t)(c0 + c) * lm.ny + (y >> 3)) * lm.npitch + (x >> 3);
-            const float ty = 0.125f * (float)(y & 7);
-            const float l = __builtin_fmaf(ty, p[lm.npitch] - p[0], p[0]), r = __builtin_fmaf(ty, p[lm.npitch + 1] - p[1], p[1]);
-            const float dx = 0.125f * (r - l), a0 = __builtin_fmaf((float)(x & 7), dx, l);
-            v[c].x += a0;
-            v[c].y += a0 + dx;
-            v[c].z += __builtin_fmaf(2.0f, dx, a0);
-            v[c].w += __builtin_fmaf(3.0f, dx, a0);
-        }
+        for (int c = 0; c < 3; ++c) lm_add4(lm, c0 + c, x, y, v[c]);
     }
     unsigned char px[12];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float e[4] = { v[c].x, v[c].y, v[c].z, v[c].w };
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float d = e[k];
-            d = d > 255.0f ? 255.0f : d;
-            d = d < 0.0f ? 0.0f : d;
-            px[3 * k + c] = (unsigned char)d;
-        }
+        for (int k = 0; k < 4; ++k) px[3 * k + c] = (unsigned char)lm_byte(e[k]);
     }
     if (x >= 1 && x + 3 <= U.W - 2 && ((uintptr_t)b & 3) == 0) {
         unsigned w[3];
@@ -578,6 +564,72 @@ __global__ __launch_bounds__(256) void k_postprocess_group(Field U, ImageJobs t,
     const ImageJob &j = t.j[blockIdx.z];
     if (j.d_rect && (j.d_rect[0] != j.rx0 || j.d_rect[1] != j.rx1 || j.d_rect[2] != j.ry0 || j.d_rect[3] != j.ry1)) return;
     postprocess_block<LM>(U, j.body_org, j.bstep, 3 * blockIdx.z, lm);
+}
+
+// The same splice for output values that already exist as bytes: the last multigrid launch of a clone wrote them planar into
+// the memory of its partner field (k_cycle0, TAG bit 5: plane c at Q.p + c Q.plane bytes, rows of Q.pitch bytes).  Eight
+// pixels per lane: two words per channel in, six words (or 24 bytes) out.
+__device__ __forceinline__ void splice_block(const Field &Q, uint8_t *__restrict__ body, int bstep, int c0)
+{
+    const int x = 8 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x > Q.W - 2 || y < 1 || y > Q.H - 2) return;
+    const uint8_t *__restrict__ q = reinterpret_cast<const uint8_t *>(Q.p) + (size_t)y * Q.pitch + x;    // pitch % 64 == 0: x + 7 < pitch
+    uint2 v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = *reinterpret_cast<const uint2 *>(q + (size_t)(c0 + c) * Q.plane);
+    unsigned char px[24];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) px[3 * k + c] = (unsigned char)(((k < 4 ? v[c].x : v[c].y) >> (8 * (k & 3))) & 255u);
+    uint8_t *b = body + (size_t)y * bstep + 3 * x;
+    if (x >= 1 && x + 7 <= Q.W - 2 && ((uintptr_t)b & 3) == 0) {
+        unsigned *d32 = reinterpret_cast<unsigned *>(b);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d32[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (x + k < 1 || x + k > Q.W - 2) continue;
+            b[3 * k + 0] = px[3 * k + 0]; b[3 * k + 1] = px[3 * k + 1]; b[3 * k + 2] = px[3 * k + 2];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_splice_planar(Field Q, uint8_t *__restrict__ body, int bstep, RectGuard guard)
+{
+    if (guard.d_rect) {
+        const int *__restrict__ r = guard.d_rect;
+        if (r[0] != guard.x0 || r[1] != guard.x1 || r[2] != guard.y0 || r[3] != guard.y1) return;
+    }
+    splice_block(Q, body, bstep, 0);
+}
+
+__global__ __launch_bounds__(256) void k_splice_planar_group(Field Q, ImageJobs t)
+{
+    const ImageJob &j = t.j[blockIdx.z];
+    if (j.d_rect && (j.d_rect[0] != j.rx0 || j.d_rect[1] != j.rx1 || j.d_rect[2] != j.ry0 || j.d_rect[3] != j.ry1)) return;
+    splice_block(Q, j.body_org, j.bstep, 3 * blockIdx.z);
+}
+
+void launch_splice_planar(Field Q, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard)
+{
+    dim3 grid(((Q.W + 7) / 8 + 63) / 64, (Q.H + 3) / 4);
+    hipLaunchKernelGGL(k_splice_planar, grid, dim3(256), 0, s, Q, body_org, bstep, guard);
+}
+
+void launch_splice_planar_group(Field Q, const ImageJob *jobs, int n, hipStream_t s)
+{
+    for (int i0 = 0; i0 < n; i0 += ImageJobs::MAX) {
+        ImageJobs t{};
+        const int cnt = std::min(n - i0, (int)ImageJobs::MAX);
+        for (int i = 0; i < cnt; ++i) t.j[i] = jobs[i0 + i];
+        Field q = Q;
+        q.p = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(Q.p) + (size_t)3 * i0 * Q.plane);      // planes are Q.plane BYTES apart here
+        dim3 grid(((Q.W + 7) / 8 + 63) / 64, (Q.H + 3) / 4, cnt);
+        hipLaunchKernelGGL(k_splice_planar_group, grid, dim3(256), 0, s, q, t);
+    }
 }
 
 void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s, LmNodes lm)

@@ -296,8 +296,9 @@ __global__ __launch_bounds__(256) void k_lm_apply(Field U, Field Out, LmNodes lm
 // Returns false when the reference's arithmetic is SINGULAR for this size: beyond ~12 870 pixels in both directions
 // 2 cos(pi/(n+1)) rounds to 2.0f, the float denominator of the lowest mode is zero and the reference divides by zero
 // (its result is NaN).  There is nothing to reproduce then: the caller applies no correction (exact system).
-static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R)
+static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double &max_ratio)
 {
+    max_ratio = 0.0;
     const double PIf = (double)3.14159265358979323846f;
     std::vector<float> fx(Kx), fy(Ky);
     for (int i = 0; i < Kx; ++i) fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
@@ -310,6 +311,7 @@ static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R)
             const double den_e = -4.0 * (sa * sa + sb * sb);
             const float den_f = (fx[i] + fy[j]) - 4.0f;
             R[(size_t)j * Kxp + i] = (den_f < 0.0f) ? (float)((den_e / (double)den_f - 1.0) * scale) : 0.0f;
+            if (den_f < 0.0f) max_ratio = std::max(max_ratio, std::fabs(den_e / (double)den_f - 1.0));
         }
     return (fx[0] + fy[0]) - 4.0f < 0.0f;          // the lowest mode has the denominator closest to zero
 }
@@ -337,7 +339,7 @@ static int lm_prepare(Instance *I)
     if ((rc = ensure(I, L.R, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
     if ((rc = ensure_pinned(I, L.hR, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
     std::memset(L.hR.p, 0, sizeof(float) * (size_t)Kyp * Kxp);
-    L.singular = !build_ratio(w, h, Kx, Ky, Kxp, (float *)L.hR.p);
+    L.singular = !build_ratio(w, h, Kx, Ky, Kxp, (float *)L.hR.p, L.max_ratio);
     SC_HIP(I, hipMemcpyAsync(L.R.p, L.hR.p, sizeof(float) * (size_t)Kyp * Kxp, hipMemcpyHostToDevice, I->stream));
     hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)nx * Kxp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sx.p, w, nx, Kx, Kxp);
     hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)ny * Kyp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sy.p, h, ny, Ky, Kyp);
@@ -359,10 +361,13 @@ float4 *lowmode_bands_buffer(Instance *I, int sweeps)
     cycle0_row_geometry(H, sweeps, nby, step, hy);
     const int band_rows = nby * 8;
     if (ensure(I, L.B, sizeof(float4) * 2 * (size_t)C * band_rows * cells_x) != SC_OK) return nullptr;
-    if (L.map_H != H || L.map_sweeps != sweeps || !L.map.p) {
-        if (ensure(I, L.map, sizeof(int) * 4 * (size_t)cells_y) != SC_OK) return nullptr;
-        if (ensure_pinned(I, L.hmap, sizeof(int) * 4 * (size_t)cells_y) != SC_OK) return nullptr;
-        int *m = (int *)L.hmap.p;
+    LowMode::PartMap &M = L.maps[sweeps > 2];              // the two tilings a solve uses (2 and 4 sweeps) keep a map each
+    L.map_used = &M;
+    if (M.H != H || M.sweeps != sweeps || !M.d.p) {
+        M.H = 0;
+        if (ensure(I, M.d, sizeof(int) * 4 * (size_t)cells_y) != SC_OK) return nullptr;
+        if (ensure_pinned(I, M.h, sizeof(int) * 4 * (size_t)cells_y) != SC_OK) return nullptr;
+        int *m = (int *)M.h.p;
         for (int i = 0; i < 4 * cells_y; ++i) m[i] = -1;
         std::vector<int> fill(cells_y, 0);
         bool fits = true;
@@ -376,14 +381,27 @@ float4 *lowmode_bands_buffer(Instance *I, int sweeps)
             add(Yc0, 2 * b); add(Yc0 + 1, 2 * b + 1);
         }
         if (!fits) return nullptr;          // a tiling with more than four parts per cell row: the separate pass serves
-        if (hipMemcpyAsync(L.map.p, L.hmap.p, sizeof(int) * 4 * (size_t)cells_y, hipMemcpyHostToDevice, I->stream) != hipSuccess) return nullptr;
-        L.map_H = H; L.map_sweeps = sweeps;
+        if (hipMemcpyAsync(M.d.p, M.h.p, sizeof(int) * 4 * (size_t)cells_y, hipMemcpyHostToDevice, I->stream) != hipSuccess) return nullptr;
+        M.H = H; M.sweeps = sweeps;
     }
     L.band_rows = band_rows;
     return (float4 *)L.B.p;
 }
 
 void lowmode_bands_written(Instance *I, const float *field) { I->lm.bands_of = field; }
+
+// Can the correction of the NEXT cycle's result be taken from the current iterate?  The correction is linear in the field:
+// corr(u_next) - corr(u_now) = corr(u_next - u_now), at most max_ratio x the low-mode content of the next cycle's update,
+// which the stop rule bounds by update_tol when it accepts that cycle.  0: no correction is applied at all (exact tables,
+// singular float tables, no unknowns); 1: yes, the difference stays below 0.01 grey levels (0.012 x 0.25 at 2048^2,
+// 0.029 x 0.25 at 4096^2); 2: no (ROIs beyond ~5000^2, where the float tables approach their singularity).
+int lowmode_early_kind(Instance *I, float update_tol)
+{
+    if (!wants_float_tables(I)) return 0;
+    if (lm_prepare(I) != SC_OK) return 2;
+    if (I->lm.singular) return 0;
+    return I->lm.max_ratio * (double)update_tol <= 0.01 ? 1 : 2;
+}
 
 // Node corrections of the field U (the instance's current shape): what the post-process adds (lm.CN == nullptr: nothing).
 int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm)
@@ -398,7 +416,7 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm)
     float *upart = (float *)L.E.p;
     if (L.bands_of && L.bands_of == U.p) {       // the final level-0 launch left the cell shares in parts: no further pass over U
         hipLaunchKernelGGL(k_lm_bands_to_cells, dim3((cells_x + 255) / 256, cells_y, U.C), dim3(256), 0, I->stream, (const float4 *)L.B.p,
-                           L.band_rows, (const int *)L.map.p, (float4 *)L.P.p, cells_x, cells_y, U.W);
+                           L.band_rows, (const int *)L.map_used->d.p, (float4 *)L.P.p, cells_x, cells_y, U.W);
         L.bands_of = nullptr;  // used once: whoever touches the field afterwards need not know about the parts
     } else
     hipLaunchKernelGGL(k_lm_restrict, dim3((cells_x + 63) / 64, (cells_y + 3) / 4, U.C), dim3(256), 0, I->stream, U, (float4 *)L.P.p, cells_x, cells_y);

@@ -107,6 +107,7 @@ int solve(Instance *I)
 {
     const sc_solver_opts &o = I->opts;
     field_moved(I);
+    I->out_direct = false;
     I->info.sweeps = 0;
     I->info.converged = 0;
     I->info.rel_residual = NAN;

@@ -717,7 +717,11 @@ def test_full_size_properties_2048(hip, oracles):
     W = H = 2048
     dst, patch, mask, cx, cy = o.synth_inputs(W, H)
     body = dst.copy()
-    assert hip.run(patch, body, mask, cx, cy, sync=True) == 0
+    hip.set_solver(flags=capi.SC_FLAG_KEEP_FIELD)           # the test looks at the solution field after the clone
+    try:
+        assert hip.run(patch, body, mask, cx, cy, sync=True) == 0
+    finally:
+        hip.set_solver(flags=0)
     info = hip.info()
     assert (info.W, info.H) == (W, H) and info.converged == 1 and info.sweeps <= 6
     r2, f2 = hip.field_residual()

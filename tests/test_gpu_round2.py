@@ -402,12 +402,14 @@ def test_frozen_float_table_case_on_the_gpu(hip, golden_dir):
 
 
 @pytest.mark.parametrize("W,H", [(9, 9), (64, 71), (233, 59), (240, 53), (517, 400), (1030, 1000), (1856, 1700), (2048, 2048)])
-def test_restriction_fused_into_the_final_cycle_equals_the_separate_pass(hip, oracles, W, H):
-    """The correction's restriction comes out of the final level-0 multigrid launch by default (k_cycle0 `bands` +
-    k_lm_bands_to_cells); SC_FLAG_SEPARATE_RESTRICT reads the finished field again (k_lm_restrict).  Same cells, another
-    order of additions: the corrected fields agree to float rounding, the images within the rounding of a handful of pixels,
-    both within one grey level of the float-table port.  Sizes: a single tile, tile seams in x (232-column step) and y
-    (52-row step), ragged last cells, the BASELINE config 3 size."""
+def test_output_and_restriction_variants_agree(hip, oracles, W, H):
+    """Default: the last multigrid cycle writes output bytes itself (node correction of the iterate one cycle earlier, whose
+    cell shares the launch before it leaves behind: k_cycle0 `bands` + k_lm_bands_to_cells).  SC_FLAG_KEEP_FIELD: that cycle
+    writes the field (and the cell shares of that field), a post-process launch reads it.  SC_FLAG_SEPARATE_RESTRICT: the cell
+    shares come from a pass of their own over the field (k_lm_restrict).  Same arithmetic in another order / one cycle
+    earlier: the corrected fields agree to float rounding, the images in all but a handful of pixels, each within one grey
+    level of the float-table port.  Sizes: a single tile, tile seams in x (232-column step) and y (52- and 44-row steps),
+    ragged last cells, the BASELINE config 3 size."""
     from seamlesscloneoptimization_amd import capi, compare
     o, oc = oracles
     margin = 2 if min(W, H) < 64 else 24
@@ -415,27 +417,35 @@ def test_restriction_fused_into_the_final_cycle_equals_the_separate_pass(hip, or
     geo, M = oc.mask_stage(mask, cx, cy)
     B, lap = oc.build_rhs(dst, patch, geo, M)
     want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+    KEEP, SEP, NOSPEC = capi.SC_FLAG_KEEP_FIELD, capi.SC_FLAG_SEPARATE_RESTRICT, capi.SC_FLAG_NO_SPECULATE
     out, fields = {}, {}
     try:
-        for flags in (0, capi.SC_FLAG_SEPARATE_RESTRICT, capi.SC_FLAG_NO_SPECULATE):
+        for flags in (0, SEP, NOSPEC, KEEP, KEEP | SEP, KEEP | NOSPEC):
             hip.set_solver(flags=flags)
-            for rep in range(2):                                     # the second call reuses buffers and the part map
+            for rep in range(2):                                     # the second call reuses buffers and the part maps
                 body = dst.copy()
                 assert hip.run(patch, body, mask, cx, cy) == 0
                 assert rep == 0 or np.array_equal(body, out[flags])
                 out[flags] = body
+            if flags & KEEP:
+                assert hip.field_store().shape == (3, hip.info().H, hip.info().W)      # the solution field is there
+            elif min(W, H) >= 64:
+                with pytest.raises(capi.SeamlessCloneError):          # no final field exists
+                    hip.field_store()
             hip.field_load(B, lap)
             hip.field_solve()
             hip.field_lowmode()
             fields[flags] = hip.field_store()
     finally:
         hip.set_solver(flags=0)
-    assert np.array_equal(out[0], out[capi.SC_FLAG_NO_SPECULATE])
+    assert np.array_equal(out[0], out[NOSPEC]) and np.array_equal(out[KEEP], out[KEEP | NOSPEC])
     scale = max(1.0, float(np.abs(fields[0]).max()))
-    assert np.abs(fields[0] - fields[capi.SC_FLAG_SEPARATE_RESTRICT]).max() <= 2e-5 * scale
-    assert np.array_equal(fields[0], fields[capi.SC_FLAG_NO_SPECULATE])
-    s = compare.image_diff_stats(out[0], out[capi.SC_FLAG_SEPARATE_RESTRICT])
-    assert s["max"] <= 1 and s["percent"] < 0.01, compare.format_stats(s)
+    for flags in (SEP, KEEP | SEP):
+        assert np.abs(fields[0] - fields[flags]).max() <= 2e-5 * scale
+    assert np.array_equal(fields[0], fields[KEEP])
+    for flags in (SEP, KEEP, KEEP | SEP):
+        s = compare.image_diff_stats(out[0], out[flags])
+        assert s["max"] <= 1 and s["percent"] < 0.02, (flags, compare.format_stats(s))
     for flags, body in out.items():
         s = compare.image_diff_stats(want, body)
         assert s["max"] <= 1 and s["percent"] < 0.5, (flags, compare.format_stats(s))
