@@ -380,6 +380,9 @@ void *my_seamlessclone_api_imp_create_instance(int gpu_id)
     I->gpu = gpu_id;
     sc_hip_default_opts(&I->opts);
     bool ok = hipStreamCreateWithFlags(&I->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&I->aux, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&I->ev_fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&I->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_rect, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_red, 2 * sizeof(double), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_rect, 4 * sizeof(int)) == hipSuccess;
@@ -406,6 +409,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (!I) return;
     (void)hipSetDevice(I->gpu);
     if (I->stream) (void)hipStreamSynchronize(I->stream);
+    if (I->aux) (void)hipStreamSynchronize(I->aux);
     DevBuf *bufs[] = { &I->d_face, &I->d_body_roi, &I->d_mask, &I->d_M, &I->d_U0, &I->d_U1, &I->d_F };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
@@ -433,6 +437,9 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->ev_k0) (void)hipEventDestroy(I->ev_k0);
     if (I->ev_k1) (void)hipEventDestroy(I->ev_k1);
     if (I->ev_rects) (void)hipEventDestroy(I->ev_rects);
+    if (I->ev_fork) (void)hipEventDestroy(I->ev_fork);
+    if (I->ev_join) (void)hipEventDestroy(I->ev_join);
+    if (I->aux) (void)hipStreamDestroy(I->aux);
     if (I->stream) (void)hipStreamDestroy(I->stream);
     I->magic = 0;
     delete I;

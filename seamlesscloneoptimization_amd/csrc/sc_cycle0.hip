@@ -430,12 +430,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             const float wl0 = 1.0f - 0.125f * (float)jo;           // weight of column x towards the cell's left nodes; -1/8 per column
             float a0[4] = { 0.f, 0.f, 0.f, 0.f }, a1[4] = { 0.f, 0.f, 0.f, 0.f };
             const int Yc0 = y0 >> 3;
+            // (a lane outside the exact output columns is never the left half of a written cell nor the partner of one: no
+            // lane mask; rows outside the exact output are skipped as a whole, the test is wave-uniform)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int yr = wv * R + r, y = y0 + r;
-                const bool rowok = lane_out && yr >= HY && yr < RH - HY && y >= 1 && y <= H - 2;
-                const float v0 = (rowok && x0ok) ? u[r].x : 0.f, v1 = (rowok && x1ok) ? u[r].y : 0.f;
-                const float v2 = (rowok && x2ok) ? u[r].z : 0.f, v3 = (rowok && x3ok) ? u[r].w : 0.f;
+                if (!(yr >= HY && yr < RH - HY && y >= 1 && y <= H - 2)) continue;
+                const float v0 = (inner || x0ok) ? u[r].x : 0.f, v1 = (inner || x1ok) ? u[r].y : 0.f;
+                const float v2 = (inner || x2ok) ? u[r].z : 0.f, v3 = (inner || x3ok) ? u[r].w : 0.f;
                 const float r0 = __builtin_fmaf(wl0 - 0.375f, v3, __builtin_fmaf(wl0 - 0.25f, v2, __builtin_fmaf(wl0 - 0.125f, v1, wl0 * v0)));
                 const float r1 = __builtin_fmaf(1.375f - wl0, v3, __builtin_fmaf(1.25f - wl0, v2, __builtin_fmaf(1.125f - wl0, v1, (1.0f - wl0) * v0)));
                 const float tb = 0.125f * (float)(y & 7), tt = 1.0f - tb;

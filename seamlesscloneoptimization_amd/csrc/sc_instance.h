@@ -56,6 +56,11 @@ struct Instance {
     uint32_t magic = 0x5C10E001u;
     int gpu = 0;
     hipStream_t stream = nullptr;
+    // second stream of the instance: the float-table node correction of the next-to-last iterate (three latency-bound launches)
+    // runs here beside the coarse levels of the last cycle; forked and joined with events, see mg_solve
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool aux_pending = false;              // work on aux that `stream` has not waited for yet
     sc_solver_opts opts{};
     sc_run_info info{};
     std::string err;
@@ -141,7 +146,7 @@ int solve(Instance *I);
 bool mg_reads_half_rhs(const Instance *I);
 bool mg_composes_level1(const Instance *I);   // sc_multigrid.cpp   // sc_multigrid.cpp: would the solve configured in I->opts read a float16 F?
 int lowmode_correct(Instance *I, const Field &U, const Field &Out);   // sc_lowmode.hip: Out = U + float-table correction
-int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm);          // the correction of U at the node rows (what the post-process adds)
+int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on = nullptr);      // on: another stream than the instance's          // the correction of U at the node rows (what the post-process adds)
 float4 *lowmode_bands_buffer(Instance *I, int sweeps);               // where a final level-0 launch leaves the correction's cell shares (nullptr: not wanted)
 inline void field_moved(Instance *I) { I->lm.bands_of = nullptr; }   // anything that writes the solution field outside the judged multigrid launch calls this
 int lowmode_early_kind(Instance *I, float update_tol);                // see sc_lowmode.hip

@@ -404,9 +404,10 @@ int lowmode_early_kind(Instance *I, float update_tol)
 }
 
 // Node corrections of the field U (the instance's current shape): what the post-process adds (lm.CN == nullptr: nothing).
-int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm)
+int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on)
 {
     lm = LmNodes();
+    hipStream_t const st = on ? on : I->stream;
     if (U.W < 3 || U.H < 3) return SC_OK;
     int rc = lm_prepare(I);
     if (rc) return rc;
@@ -415,14 +416,14 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm)
     const int cells_x = U.pitch / LM_HAT, cells_y = (U.H + LM_HAT - 1) / LM_HAT, nxt = (L.nx + 63) / 64;
     float *upart = (float *)L.E.p;
     if (L.bands_of && L.bands_of == U.p) {       // the final level-0 launch left the cell shares in parts: no further pass over U
-        hipLaunchKernelGGL(k_lm_bands_to_cells, dim3((cells_x + 255) / 256, cells_y, U.C), dim3(256), 0, I->stream, (const float4 *)L.B.p,
+        hipLaunchKernelGGL(k_lm_bands_to_cells, dim3((cells_x + 255) / 256, cells_y, U.C), dim3(256), 0, st, (const float4 *)L.B.p,
                            L.band_rows, (const int *)L.map_used->d.p, (float4 *)L.P.p, cells_x, cells_y, U.W);
         L.bands_of = nullptr;  // used once: whoever touches the field afterwards need not know about the parts
     } else
-    hipLaunchKernelGGL(k_lm_restrict, dim3((cells_x + 63) / 64, (cells_y + 3) / 4, U.C), dim3(256), 0, I->stream, U, (float4 *)L.P.p, cells_x, cells_y);
-    hipLaunchKernelGGL(k_lm_cproject, dim3(nxt, LM_RS, U.C), dim3(256), 0, I->stream, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
+    hipLaunchKernelGGL(k_lm_restrict, dim3((cells_x + 63) / 64, (cells_y + 3) / 4, U.C), dim3(256), 0, st, U, (float4 *)L.P.p, cells_x, cells_y);
+    hipLaunchKernelGGL(k_lm_cproject, dim3(nxt, LM_RS, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
                        (const float *)L.Sy.p, L.Kyp, (const float *)L.Sx.p, L.Kxp, upart);
-    hipLaunchKernelGGL(k_lm_cexpand, dim3(nxt, (L.ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, I->stream, (const float *)upart,
+    hipLaunchKernelGGL(k_lm_cexpand, dim3(nxt, (L.ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, st, (const float *)upart,
                        nxt * LM_RS, U.C, (const float *)L.R.p, (const float *)L.Sx.p, L.Kxp, (const float *)L.Sy.p, L.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p);
     SC_HIP(I, hipGetLastError());
     lm.CN = (const float *)L.CN.p;

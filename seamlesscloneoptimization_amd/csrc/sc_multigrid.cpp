@@ -493,6 +493,10 @@ int mg_solve(Instance *I)
             float4 *const bands = (o.flags & SC_FLAG_SEPARATE_RESTRICT) ? nullptr
                                   : judged ? lowmode_bands_buffer(I, post) : early == 1 ? lowmode_bands_buffer(I, post + pre) : nullptr;
             if (judged && early_ready) {
+                if (I->aux_pending) {          // the node correction is ready when the launch that adds it starts
+                    SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_join, 0));
+                    I->aux_pending = false;
+                }
                 const int nbo = launch_cycle0_out(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, part_now,
                                                   I->stream, I->f_half, comp1, comp1 ? I->mg[2].U : Field(), comp1 ? I->mg[1].g : MGGeom(), early_lm);
                 early_ready = false;
@@ -546,7 +550,15 @@ int mg_solve(Instance *I)
             lowmode_bands_written(I, bands ? result(I).p : nullptr);
             if (!judged && early != 2) {       // the node correction the next cycle's output will carry, from this launch's field
                 early_lm = LmNodes();
-                if (early == 1 && (rc = lowmode_nodes(I, result(I), early_lm))) return rc;       // from the parts, or by a pass of its own
+                if (early == 1 && I->F.C > 3) {        // a group of clones: its coarse levels fill the chip, nothing to overlap (measured: -2 %)
+                    if ((rc = lowmode_nodes(I, result(I), early_lm))) return rc;
+                } else if (early == 1) {       // one clone: on the second stream, beside the coarse levels of the next cycle (-15 us of 500)
+                    SC_HIP(I, hipEventRecord(I->ev_fork, I->stream));
+                    SC_HIP(I, hipStreamWaitEvent(I->aux, I->ev_fork, 0));
+                    if ((rc = lowmode_nodes(I, result(I), early_lm, I->aux))) return rc;
+                    SC_HIP(I, hipEventRecord(I->ev_join, I->aux));
+                    I->aux_pending = true;
+                }
                 early_ready = true;            // (early == 0: nothing to add)
             }
             I->info.sweep_launches += 1;

@@ -107,6 +107,10 @@ int solve(Instance *I)
 {
     const sc_solver_opts &o = I->opts;
     field_moved(I);
+    if (I->aux_pending) {      // a solve that ended early left work on the second stream: order it before anything new
+        SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_join, 0));
+        I->aux_pending = false;
+    }
     I->out_direct = false;
     I->info.sweeps = 0;
     I->info.converged = 0;
