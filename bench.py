@@ -155,7 +155,7 @@ def reference_table(args):
                "destination restored on the host between rounds (restore time reported, not included)", "published": published[f"{pw}x{ph}"]}
         outs = {}
         for name, method in (("default_multigrid_plus_float_table_correction", capi.SC_METHOD_MULTIGRID), ("direct_dst", capi.SC_METHOD_DST)):
-            inst.set_solver(method=method)
+            inst.set_solver(method=method, flags=args.extra_flags)
             body = dst.copy()
             inst.run(patch, body, mask, cx, cy)
             t_run = t_restore = 0.0

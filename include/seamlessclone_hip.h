@@ -116,15 +116,17 @@ typedef struct sc_solver_opts {
                                             eigenvalue tables are stored and combined in float32
                                             (seamlessClone_imp.cpp:596-599, :1651-1653) -- see DESIGN.md sec. 5,
                                             "float-table correction"                                            */
-#define SC_FLAG_KEEP_FIELD (1 << 7)        /* a clone keeps its solution field on the device (sc_hip_field_store / _residual after
-                                            sc_hip_run*): the last multigrid cycle writes the field and a post-process launch reads
-                                            it.  Default: that cycle writes output bytes itself and no final field exists; the
-                                            float-table node correction it adds is taken one cycle earlier (difference below
-                                            0.01 grey levels; ROIs where that bound fails take this flag's path by themselves) */
-#define SC_FLAG_SEPARATE_RESTRICT (1 << 6) /* float-table correction: restrict the finished field in a pass of its own
-                                            (k_lm_restrict); default: the final level-0 multigrid launch leaves the cell
-                                            shares behind.  Same cells, different order of the additions (differences at
-                                            float rounding level)                                               */
+#define SC_FLAG_SEPARATE_RESTRICT (1 << 6) /* float-table correction: the hat-weighted cell sums of the field come from
+                                            a pass of their own over it (k_lm_restrict); default: the level-0 multigrid
+                                            launch that writes the field leaves them behind.  Same cells, another order
+                                            of the additions (differences at float rounding level)               */
+#define SC_FLAG_KEEP_FIELD     (1 << 7)  /* sc_hip_run*: keep the solution field on the device (sc_hip_field_store,
+                                            _residual, _finish after a run): the last multigrid cycle writes the field
+                                            and a post-process launch reads it.  Default: that cycle writes the output
+                                            bytes itself and no final field exists (those hooks then fail with
+                                            SC_ERR_BAD_ARG); the float-table node correction it adds is the one of the
+                                            iterate one cycle earlier (difference below 0.01 grey levels; ROIs where
+                                            that bound does not hold take this flag's path by themselves)        */
 
 /* ---- statistics of the last run */
 typedef struct sc_run_info {
