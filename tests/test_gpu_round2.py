@@ -483,3 +483,26 @@ def test_restriction_parts_are_not_reused_after_the_field_moved(hip, oracles):
     hip.field_load(once, lap)
     hip.field_lowmode()
     assert np.array_equal(twice, hip.field_store())
+
+
+@pytest.mark.parametrize("W,H", [(300, 180), (1030, 1000)])
+def test_rejected_last_cycle_is_relaunched_with_its_field(hip, oracles, W, H):
+    """A tight update tolerance makes the stop rule reject the cycle that wrote output bytes: that cycle is launched again in
+    the form that keeps the field and the solve goes on exactly as with SC_FLAG_KEEP_FIELD -- same cycle count, same bytes."""
+    from seamlesscloneoptimization_amd import capi, compare
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=24)
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+    out, cycles = {}, {}
+    try:
+        for flags in (0, capi.SC_FLAG_KEEP_FIELD):
+            hip.set_solver(flags=flags, update_tol=0.002)
+            body = dst.copy()
+            assert hip.run(patch, body, mask, cx, cy) == 0
+            out[flags], cycles[flags] = body, hip.info().sweeps
+    finally:
+        hip.set_solver(flags=0, update_tol=0.0)
+    assert cycles[0] == cycles[capi.SC_FLAG_KEEP_FIELD] >= 4, cycles
+    assert np.array_equal(out[0], out[capi.SC_FLAG_KEEP_FIELD])
+    s = compare.image_diff_stats(want, out[0])
+    assert s["max"] <= 1 and s["percent"] < 0.5, compare.format_stats(s)
