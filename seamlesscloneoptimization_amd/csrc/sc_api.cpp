@@ -941,6 +941,8 @@ int sc_hip_selftest_host(void)
     }
     // 2: eigen-decomposition of the 1-D level operators
     if (!(sc::fd_selftest_error() < 1e-11)) return 2;
+    // 3: which parts of a level-0 launch make up each cell row of the float-table correction (sc_lowmode.hip)
+    if (sc::lowmode_part_map_selftest() != 0) return 3;
     return 0;
 }
 

@@ -149,6 +149,7 @@ int lowmode_correct(Instance *I, const Field &U, const Field &Out);   // sc_lowm
 int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on = nullptr);      // on: another stream than the instance's          // the correction of U at the node rows (what the post-process adds)
 float4 *lowmode_bands_buffer(Instance *I, int sweeps);               // where a final level-0 launch leaves the correction's cell shares (nullptr: not wanted)
 inline void field_moved(Instance *I) { I->lm.bands_of = nullptr; }   // anything that writes the solution field outside the judged multigrid launch calls this
+int lowmode_part_map_selftest();                                     // host-only check of the parts-per-cell-row map against the launch geometry
 int lowmode_early_kind(Instance *I, float update_tol);                // see sc_lowmode.hip
 void lowmode_bands_written(Instance *I, const float *field);       // the launch went in: B describes `field` (nullptr: nothing)
 int lowmode_count(int n);

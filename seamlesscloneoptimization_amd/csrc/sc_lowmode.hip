@@ -348,6 +348,63 @@ static int lm_prepare(Instance *I)
     return SC_OK;
 }
 
+// Which parts make up each cell row.  A level-0 launch with `sweeps` sweeps leaves, per 8-row band b (tile row b / 8, wave b % 8)
+// and 8-column cell, part 2b for the cell row the band starts in and part 2b + 1 for the next one (k_cycle0, `bands`);
+// m[4 Yc + e] lists the parts of cell row Yc in ascending order, -1 = none.  False: a tiling with more than four parts in a
+// cell row (none of the instantiated ones).  Pure host arithmetic on the launch geometry (cycle0_row_geometry).
+bool lowmode_part_map(int H, int sweeps, std::vector<int> &m, int &band_rows)
+{
+    const int cells_y = (H + LM_HAT - 1) / LM_HAT;
+    int nby, step, hy;
+    cycle0_row_geometry(H, sweeps, nby, step, hy);
+    band_rows = nby * 8;
+    m.assign(4 * (size_t)cells_y, -1);
+    std::vector<int> fill(cells_y, 0);
+    bool fits = true;
+    auto add = [&](int Yc, int v) {
+        if (Yc < 0 || Yc >= cells_y) return;
+        if (fill[Yc] < 4) m[4 * Yc + fill[Yc]++] = v; else fits = false;
+    };
+    for (int b = 0; b < band_rows; ++b) {                       // ascending band rows: a fixed order of additions per cell
+        const int y0 = (b >> 3) * step - hy + 8 * (b & 7);
+        const int Yc0 = y0 >= 0 ? y0 >> 3 : -((-y0 + 7) >> 3);  // floor(y0 / 8)
+        add(Yc0, 2 * b); add(Yc0 + 1, 2 * b + 1);
+    }
+    return fits;
+}
+
+// Host check of the map against the launch geometry it describes (sc_hip_selftest_host): every interior field row lies in the
+// exact output rows of exactly one band, and the part that band forms for the row's cell row is in the map.  0 = fine.
+int lowmode_part_map_selftest()
+{
+    const int sizes[] = { 3, 4, 9, 10, 11, 53, 54, 55, 64, 105, 300, 517, 1000, 1025, 2048, 2049, 4096, 6000 };
+    for (int sweeps : { 1, 2, 3, 4 })
+        for (int H : sizes) {
+            std::vector<int> m;
+            int band_rows = 0;
+            if (!lowmode_part_map(H, sweeps, m, band_rows)) return 1;
+            int nby, step, hy;
+            cycle0_row_geometry(H, sweeps, nby, step, hy);
+            for (int y = 1; y <= H - 2; ++y) {
+                int owners = 0, part = -1;
+                for (int b = 0; b < band_rows; ++b) {
+                    const int y0 = (b >> 3) * step - hy + 8 * (b & 7), yr = y - ((b >> 3) * step - hy);      // row inside the tile
+                    if (y < y0 || y >= y0 + 8 || yr < hy || yr >= 64 - hy) continue;
+                    ++owners;
+                    const int Yc0 = y0 >= 0 ? y0 >> 3 : -((-y0 + 7) >> 3);
+                    part = 2 * b + ((y >> 3) == Yc0 ? 0 : 1);
+                }
+                if (owners != 1) return 2;
+                bool listed = false;
+                for (int e = 0; e < 4; ++e) listed = listed || m[4 * (y >> 3) + e] == part;
+                if (!listed) return 3;
+            }
+            for (size_t i = 0; i + 1 < m.size(); ++i)               // ascending inside a cell row, -1 only at the end
+                if ((i & 3) != 3 && m[i + 1] != -1 && (m[i] == -1 || m[i] >= m[i + 1])) return 4;
+        }
+    return 0;
+}
+
 // Buffer for the cell-share parts of a final level-0 launch with `sweeps` sweeps on the instance's current fields (k_cycle0's
 // `bands` argument), or nullptr when no correction will be applied.  The caller passes it to that launch and then calls
 // lowmode_bands_written(); the next lowmode_nodes() builds the cells from the parts instead of reading the field again.
@@ -359,7 +416,7 @@ float4 *lowmode_bands_buffer(Instance *I, int sweeps)
     const int H = I->F.H, C = I->F.C, cells_x = I->F.pitch / LM_HAT, cells_y = (H + LM_HAT - 1) / LM_HAT;
     int nby, step, hy;
     cycle0_row_geometry(H, sweeps, nby, step, hy);
-    const int band_rows = nby * 8;
+    int band_rows = nby * 8;
     if (ensure(I, L.B, sizeof(float4) * 2 * (size_t)C * band_rows * cells_x) != SC_OK) return nullptr;
     LowMode::PartMap &M = L.maps[sweeps > 2];              // the two tilings a solve uses (2 and 4 sweeps) keep a map each
     L.map_used = &M;
@@ -367,20 +424,9 @@ float4 *lowmode_bands_buffer(Instance *I, int sweeps)
         M.H = 0;
         if (ensure(I, M.d, sizeof(int) * 4 * (size_t)cells_y) != SC_OK) return nullptr;
         if (ensure_pinned(I, M.h, sizeof(int) * 4 * (size_t)cells_y) != SC_OK) return nullptr;
-        int *m = (int *)M.h.p;
-        for (int i = 0; i < 4 * cells_y; ++i) m[i] = -1;
-        std::vector<int> fill(cells_y, 0);
-        bool fits = true;
-        auto add = [&](int Yc, int v) {
-            if (Yc < 0 || Yc >= cells_y) return;
-            if (fill[Yc] < 4) m[4 * Yc + fill[Yc]++] = v; else fits = false;
-        };
-        for (int b = 0; b < band_rows; ++b) {                   // ascending band rows: a fixed order of additions per cell
-            const int y0 = (b >> 3) * step - hy + 8 * (b & 7);
-            const int Yc0 = y0 >= 0 ? y0 >> 3 : -((-y0 + 7) >> 3);          // floor(y0 / 8)
-            add(Yc0, 2 * b); add(Yc0 + 1, 2 * b + 1);
-        }
-        if (!fits) return nullptr;          // a tiling with more than four parts per cell row: the separate pass serves
+        std::vector<int> m;
+        if (!lowmode_part_map(H, sweeps, m, band_rows)) return nullptr;      // more than four parts per cell row: the separate pass serves
+        std::memcpy(M.h.p, m.data(), sizeof(int) * m.size());
         if (hipMemcpyAsync(M.d.p, M.h.p, sizeof(int) * 4 * (size_t)cells_y, hipMemcpyHostToDevice, I->stream) != hipSuccess) return nullptr;
         M.H = H; M.sweeps = sweeps;
     }
