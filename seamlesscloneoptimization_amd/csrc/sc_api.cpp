@@ -149,6 +149,7 @@ static Field make_field(void *p, int W, int H, int C)
 int setup_fields(Instance *I, int W, int H, int C)
 {
     field_moved(I);
+    I->out_direct = false;             // new fields are about to be built (a clone's pre-process, sc_hip_build_rhs, sc_hip_field_load)
     Field proto = make_field(nullptr, W, H, C);
     const size_t bytes = proto.bytes() + 4096;
     int rc;
