@@ -7,6 +7,7 @@
 #include "sc_instance.h"
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <cstring>
 #include <cstdlib>
 
@@ -475,6 +476,39 @@ int mg_solve(Instance *I)
             }
             return m <= utol;
         };
+        // max |correction| of the cycle just launched = max over its per-workgroup maxima (at part_now; `cyc` already counts the
+        // cycle), and of the cycle before when its maxima are at hand.  A few thousand maxima are folded here on the host (the
+        // read-back is needed anyway and a reduction launch costs ~5 us of GPU time) -- both cycles' halves in ONE copy, a second
+        // small D2H costs ~5 us on the critical path; large grids (groups of clones) reduce on the device first and leave
+        // m_prev unknown (< 0).  `output` (the splice or post-process of the result, or nothing) is enqueued between the launch
+        // and the read-back: it then starts without a gap while the host waits.
+        auto correction_maxima = [&](int nb, int nb_prev, int nb_cap, float *part_now, const std::function<int()> &output, float &m, float &m_prev) -> int {
+            m = 0.f; m_prev = -1.f;
+            int orc;
+            if (nb <= 16384) {
+                const bool have_prev = nb_prev > 0 && nb_prev <= 16384;   // the launch of the previous cycle wrote the other half
+                if ((orc = ensure_pinned(I, I->h_partial, 2 * sizeof(float) * (size_t)nb_cap))) return orc;
+                if ((orc = output())) return orc;
+                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap : ((cyc & 1) * nb_cap + nb)),
+                                         hipMemcpyDeviceToHost, I->stream));
+                SC_HIP(I, hipStreamSynchronize(I->stream));
+                const float *hp = (const float *)I->h_partial.p + (size_t)(cyc & 1) * nb_cap;            // this cycle's half
+                const float *hq = (const float *)I->h_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;      // the previous cycle's
+                for (int i = 0; i < nb; ++i) m = hp[i] > m ? hp[i] : m;
+                if (have_prev) {
+                    m_prev = 0.f;
+                    for (int i = 0; i < nb_prev; ++i) m_prev = hq[i] > m_prev ? hq[i] : m_prev;
+                }
+            } else {
+                launch_max_final(part_now, nb, I->d_maxcorr, I->stream);
+                if ((orc = output())) return orc;
+                SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
+                SC_HIP(I, hipStreamSynchronize(I->stream));
+                unsigned bits = *I->h_maxcorr;
+                memcpy(&m, &bits, sizeof(float));
+            }
+            return SC_OK;
+        };
         bool early_ready = false;          // the node correction for the judged cycle's output is on its way (early_lm; CN == nullptr: none to add)
         LmNodes early_lm;
         while (cyc < budget) {
@@ -504,33 +538,13 @@ int mg_solve(Instance *I)
                     I->info.sweep_launches += 1;
                     ++cyc;
                     SC_HIP(I, hipGetLastError());
-                    const int nb_prev = nb_last;
                     const Field Q = I->result_in_U1 ? I->U0 : I->U1;
-                    float m = 0.f, m_prev = -1.f;
-                    if (nbo <= 16384) {            // maxima folded on the host, as below
-                        const bool have_prev = nb_prev > 0 && nb_prev <= 16384;
-                        if ((rc = ensure_pinned(I, I->h_partial, 2 * sizeof(float) * (size_t)nb_cap))) return rc;
-                        if (I->spec_post.group.empty()) launch_splice_planar(Q, I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
-                        else launch_splice_planar_group(Q, I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream);
-                        SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap : ((cyc & 1) * nb_cap + nbo)),
-                                                 hipMemcpyDeviceToHost, I->stream));
-                        SC_HIP(I, hipStreamSynchronize(I->stream));
-                        const float *hp = (const float *)I->h_partial.p + (size_t)(cyc & 1) * nb_cap;
-                        const float *hq = (const float *)I->h_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;
-                        for (int i = 0; i < nbo; ++i) m = hp[i] > m ? hp[i] : m;
-                        if (have_prev) {
-                            m_prev = 0.f;
-                            for (int i = 0; i < nb_prev; ++i) m_prev = hq[i] > m_prev ? hq[i] : m_prev;
-                        }
-                    } else {                       // large grids (groups of clones): reduced on the device, plain threshold
-                        launch_max_final(part_now, nbo, I->d_maxcorr, I->stream);
-                        if (I->spec_post.group.empty()) launch_splice_planar(Q, I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
-                        else launch_splice_planar_group(Q, I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream);
-                        SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
-                        SC_HIP(I, hipStreamSynchronize(I->stream));
-                        unsigned bits = *I->h_maxcorr;
-                        memcpy(&m, &bits, sizeof(float));
-                    }
+                    float m, m_prev;
+                    if ((rc = correction_maxima(nbo, nb_last, nb_cap, part_now, [&]() -> int {
+                            if (I->spec_post.group.empty()) launch_splice_planar(Q, I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
+                            else launch_splice_planar_group(Q, I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream);
+                            return SC_OK;
+                        }, m, m_prev))) return rc;
                     I->info.last_update = m;
                     if (stop_rule(m, m_prev)) { I->spec_post.done = true; I->out_direct = true; ok = true; break; }
                     // rejected: the same cycle again in the form that keeps the field, then on as usual
@@ -569,43 +583,18 @@ int mg_solve(Instance *I)
             const int nb_prev = nb_last;
             nb_last = nb;
             if (!judged) continue;
-            // max |correction| = max over the per-workgroup maxima.  A few thousand of them are folded here
-            // on the host (the read-back is needed anyway and a reduction launch costs ~5 us of GPU time);
-            // large grids reduce on the device first.
-            float m = 0.f, m_prev = -1.f;          // m_prev < 0: unknown
-            if (nb <= 16384) {
-                const bool have_prev = nb_prev > 0 && nb_prev <= 16384;   // the launch of the previous cycle wrote the other half
-                // both halves in ONE copy (a second small D2H costs ~5 us on the critical path)
-                if ((rc = ensure_pinned(I, I->h_partial, 2 * sizeof(float) * (size_t)nb_cap))) return rc;
-                // the post-process goes in FIRST (see Instance::spec_post): enqueued while the cycle launch is still running it
-                // starts without a gap, and the read-back of the maxima follows it
-                if (I->spec_post.armed && o.tol <= 0.f) {
+            // the post-process goes in FIRST (see Instance::spec_post), the read-back of the maxima follows it
+            float m, m_prev;
+            if ((rc = correction_maxima(nb, nb_prev, nb_cap, part_now, [&]() -> int {
+                    if (!(I->spec_post.armed && o.tol <= 0.f)) return SC_OK;
                     LmNodes lm;
-                    if ((rc = output_nodes(I, lm))) return rc;
-                    if (I->spec_post.group.empty()) {
-                        launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard, lm);
-                    } else {
-                        launch_postprocess_group(result(I), I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream, lm);
-                    }
+                    const int lrc = output_nodes(I, lm);
+                    if (lrc) return lrc;
+                    if (I->spec_post.group.empty()) launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard, lm);
+                    else launch_postprocess_group(result(I), I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream, lm);
                     I->spec_post.done = true;
-                }
-                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap : ((cyc & 1) * nb_cap + nb)),
-                                         hipMemcpyDeviceToHost, I->stream));
-                SC_HIP(I, hipStreamSynchronize(I->stream));
-                const float *hp = (const float *)I->h_partial.p + (size_t)(cyc & 1) * nb_cap;            // this cycle's half (cyc is already incremented)
-                const float *hq = (const float *)I->h_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;      // the previous cycle's
-                for (int i = 0; i < nb; ++i) m = hp[i] > m ? hp[i] : m;
-                if (have_prev) {
-                    m_prev = 0.f;
-                    for (int i = 0; i < nb_prev; ++i) m_prev = hq[i] > m_prev ? hq[i] : m_prev;
-                }
-            } else {
-                launch_max_final(part_now, nb, I->d_maxcorr, I->stream);
-                SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
-                SC_HIP(I, hipStreamSynchronize(I->stream));
-                unsigned bits = *I->h_maxcorr;
-                memcpy(&m, &bits, sizeof(float));
-            }
+                    return SC_OK;
+                }, m, m_prev))) return rc;
             I->info.last_update = m;
             if (o.tol > 0.f) {
                 double r[2];
