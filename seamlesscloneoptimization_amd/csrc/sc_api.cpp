@@ -389,8 +389,8 @@ void *my_seamlessclone_api_imp_create_instance(int gpu_id)
     ok = ok && hipMalloc((void **)&I->d_rect, 4 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_partials, 2 * sizeof(double) * residual_max_blocks()) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_red, 2 * sizeof(double)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&I->d_maxcorr, sizeof(unsigned)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&I->h_maxcorr, sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void **)&I->d_maxcorr, 2 * sizeof(unsigned)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&I->h_maxcorr, 2 * sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
     ok = ok && mg_bottom_prepare() == hipSuccess;   // opt in to >64 KiB dynamic LDS for the bottom kernel
     for (int i = 0; ok && i < 8; ++i) ok = hipEventCreate(&I->ev[i]) == hipSuccess;
     ok = ok && hipEventCreate(&I->ev_k0) == hipSuccess && hipEventCreate(&I->ev_k1) == hipSuccess;

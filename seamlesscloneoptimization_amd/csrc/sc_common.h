@@ -118,6 +118,7 @@ bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &
 int  launch_rb_tb_prolong0(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, Field E, float *partial, hipStream_t s);
 int  tb_blocks_level0(int W, int H, int C, int sweeps);
 void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_t s);
+void launch_max_final2(const float *d_a, int na, const float *d_b, int nb, unsigned *d_out2, hipStream_t s);   // out[0] = max a, out[1] = max b (-1: b empty)
 // whole level-0 part of a V-cycle in one launch (sc_cycle0.hip): [prolong E] + `sweeps` RBGS sweeps +
 // residual + restriction into Fc.  Returns #partials written, 0 without prolong, -1 if unsupported.
 int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,

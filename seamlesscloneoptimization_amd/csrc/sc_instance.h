@@ -117,8 +117,8 @@ struct Instance {
     double *d_partials = nullptr;
     double *d_red = nullptr;
     double *h_red = nullptr;     // pinned
-    unsigned *d_maxcorr = nullptr;
-    unsigned *h_maxcorr = nullptr; // pinned
+    unsigned *d_maxcorr = nullptr;     // two words: max correction of the last cycle and of the one before (bits of a float)
+    unsigned *h_maxcorr = nullptr;     // pinned, two words
     hipEvent_t ev[8]{};
     bool stage_marks = true;   // record the stage marks (synchronous calls); tmark() in sc_api.cpp
     hipEvent_t tm[8]{};   // stage marks of the current run: ev[k], or the previous mark where a stage is empty (no record call)

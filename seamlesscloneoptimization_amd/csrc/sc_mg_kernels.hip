@@ -196,6 +196,28 @@ __global__ __launch_bounds__(256) void k_max_final(const float *__restrict__ par
     if (threadIdx.x == 0) *out = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
+// two lists in one launch (this cycle's maxima and the previous cycle's): block b folds list b into out[b]; an empty list
+// gives -1 ("unknown")
+__global__ __launch_bounds__(256) void k_max_final2(const float *__restrict__ pa, int na, const float *__restrict__ pb, int nb,
+                                                    unsigned *__restrict__ out)
+{
+    const float *__restrict__ partial = blockIdx.x ? pb : pa;
+    const int n = blockIdx.x ? nb : na;
+    float m = n > 0 ? 0.f : -1.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, partial[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+void launch_max_final2(const float *d_a, int na, const float *d_b, int nb, unsigned *d_out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_max_final2, dim3(2), dim3(256), 0, s, d_a, na, d_b, nb, d_out2);
+}
+
 void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, s, d_partial, n, d_out);

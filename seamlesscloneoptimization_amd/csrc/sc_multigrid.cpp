@@ -479,8 +479,8 @@ int mg_solve(Instance *I)
         // max |correction| of the cycle just launched = max over its per-workgroup maxima (at part_now; `cyc` already counts the
         // cycle), and of the cycle before when its maxima are at hand.  A few thousand maxima are folded here on the host (the
         // read-back is needed anyway and a reduction launch costs ~5 us of GPU time) -- both cycles' halves in ONE copy, a second
-        // small D2H costs ~5 us on the critical path; large grids (groups of clones) reduce on the device first and leave
-        // m_prev unknown (< 0).  `output` (the splice or post-process of the result, or nothing) is enqueued between the launch
+        // small D2H costs ~5 us on the critical path; large grids (groups of clones) reduce both lists on the device first (one
+        // launch).  m_prev < 0: unknown.  `output` (the splice or post-process of the result, or nothing) is enqueued between the launch
         // and the read-back: it then starts without a gap while the host waits.
         auto correction_maxima = [&](int nb, int nb_prev, int nb_cap, float *part_now, const std::function<int()> &output, float &m, float &m_prev) -> int {
             m = 0.f; m_prev = -1.f;
@@ -500,12 +500,13 @@ int mg_solve(Instance *I)
                     for (int i = 0; i < nb_prev; ++i) m_prev = hq[i] > m_prev ? hq[i] : m_prev;
                 }
             } else {
-                launch_max_final(part_now, nb, I->d_maxcorr, I->stream);
+                const float *part_prev = (const float *)I->mg_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;
+                launch_max_final2(part_now, nb, part_prev, nb_prev > 0 ? nb_prev : 0, I->d_maxcorr, I->stream);
                 if ((orc = output())) return orc;
-                SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
+                SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
                 SC_HIP(I, hipStreamSynchronize(I->stream));
-                unsigned bits = *I->h_maxcorr;
-                memcpy(&m, &bits, sizeof(float));
+                memcpy(&m, &I->h_maxcorr[0], sizeof(float));
+                memcpy(&m_prev, &I->h_maxcorr[1], sizeof(float));
             }
             return SC_OK;
         };

@@ -521,3 +521,38 @@ def test_field_hooks_work_again_once_new_fields_are_built(hip, oracles):
     _, B, lap = hip.build_rhs(patch, dst, mask, cx, cy)
     hip.field_sweep(capi.SC_METHOD_JACOBI, 3, 1.0, 1)
     assert np.array_equal(hip.field_store(), oc.jacobi(B, lap, 3))
+
+
+def test_groups_stop_by_the_same_rule_as_single_clones(oracles):
+    """Large grids (groups of clones) reduce the per-workgroup maxima on the device; they hand the stop rule this cycle's AND
+    the previous cycle's largest correction, as the host fold does for a single clone.  With a tight tolerance (more than
+    three cycles) a group of identical clones therefore runs exactly as many cycles as the clone alone and produces its bytes."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    W, H, N = 2048, 2048, 16                                  # 48 channels at 2048^2: 20 304 workgroups per launch, above the host fold's 16 384
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=64)
+    pool = capi.Pool(0, 1, group=N, update_tol=0.004)
+    inst = pool.instances[0]
+    jobs = pool.make_jobs(N)
+    keep = []
+    for j in jobs:
+        f, b0, b, m = inst.to_device(patch), inst.to_device(dst), inst.to_device(dst), inst.to_device(mask)
+        keep.append((f, b0, b, m))
+        j.face, j.face_cols, j.face_rows, j.face_step = f, patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+        j.body, j.body_cols, j.body_rows, j.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+        j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
+        j.centerX, j.centerY, j.body_restore = cx, cy, b0
+    pool.run(jobs, device_resident=True)
+    assert all(j.rc == 0 for j in jobs)
+    group_cycles = inst.info().sweeps
+    solo = capi.Instance(0)
+    solo.set_solver(update_tol=0.004)
+    alone = dst.copy()
+    assert solo.run(patch, alone, mask, cx, cy) == 0
+    assert group_cycles == solo.info().sweeps >= 4, (group_cycles, solo.info().sweeps)
+    for f, b0, b, m in keep:
+        assert np.array_equal(inst.from_device(b, dst.shape), alone)
+        for p in (f, b0, b, m):
+            inst.free(p)
+    solo.destroy()
+    pool.close()
