@@ -141,6 +141,7 @@ def reference_table(args):
                  "592x592": {"V100_ms_fft_gemm": [5.401, 5.621], "T4_ms_fft_gemm": [9.047, 7.424]},
                  "2400x1552": {"V100_ms_fft_gemm": [63.988, 56.412], "T4_ms_fft_gemm": [91.306, 79.462]}}
     inst = capi.Instance(0)
+    nthr = max(1, min(oc.max_threads(), len(os.sched_getaffinity(0)), 16))
     for pw, ph in ((154, 100), (300, 194), (592, 592), (2400, 1552)):
         # destination 1600 x 898 as in the reference (PDF p4) where the patch fits, else patch + 256
         dw, dh = (1600, 898) if pw + 2 <= 1600 and ph + 2 <= 898 else (pw + 256, ph + 256)
@@ -154,7 +155,8 @@ def reference_table(args):
         row = {"patch": f"{pw}x{ph}", "dst": [dw, dh], "protocol": "1 warm-up + 50 rounds, pageable host images, one application per call, "
                "destination restored on the host between rounds (restore time reported, not included)", "published": published[f"{pw}x{ph}"]}
         outs = {}
-        for name, method in (("default_multigrid_plus_float_table_correction", capi.SC_METHOD_MULTIGRID), ("direct_dst", capi.SC_METHOD_DST)):
+        for name, method in (("default_auto", capi.SC_METHOD_AUTO), ("multigrid_plus_float_table_correction", capi.SC_METHOD_MULTIGRID),
+                             ("direct_dst", capi.SC_METHOD_DST)):
             inst.set_solver(method=method, flags=args.extra_flags)
             body = dst.copy()
             inst.run(patch, body, mask, cx, cy)
@@ -168,17 +170,32 @@ def reference_table(args):
             outs[name] = body.copy()
             row[name] = {"ms_per_clone_end_to_end": round(t_run / 50 * 1e3, 4), "h2d_ms": round(i.ms_h2d, 4), "device_ms": round(i.ms_device_total, 4),
                          "d2h_ms": round(i.ms_d2h, 4), "restore_ms_not_included": round(t_restore / 50 * 1e3, 4), "roi": [i.W, i.H],
-                         "device_bytes": int(i.device_bytes)}
-        inst.set_solver(method=capi.SC_METHOD_MULTIGRID)
+                         "device_bytes": int(i.device_bytes), "method_that_ran": {3: "multigrid", 4: "dst"}.get(i.method, i.method)}
+        inst.set_solver(method=capi.SC_METHOD_AUTO)
         t0 = time.perf_counter(); ref = oc.seamless_clone(dst, patch, mask, cx, cy, 1, False); one = time.perf_counter() - t0
         reps = max(1, min(20, int(args.cpu_seconds / 4 / max(one, 1e-4))))
         t0 = time.perf_counter()
         for _ in range(reps):
             oc.seamless_clone(dst, patch, mask, cx, cy, 1, False)
         row["cpu_port_1_core_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+
+        def dstat(a, b):
+            d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+            return {"maxdiff": int(d.max()), "diff_sum": int(d.sum()), "percent_differing": round(float((d > 0).mean() * 100), 4)}
         for name, img in outs.items():
-            d = np.abs(img.astype(np.int16) - ref.astype(np.int16))
-            row[name]["vs_float_table_port"] = {"maxdiff": int(d.max()), "diff_sum": int(d.sum()), "percent_differing": round(float((d > 0).mean() * 100), 4)}
+            row[name]["vs_float_table_port"] = dstat(img, ref)
+        # How far is "+-1 against the port" from "+-1 against OpenCV"?  The port transforms in double; OpenCV's dft and cuFFT
+        # transform in float32.  The same port with float32 transform internals (mixed radix; Bluestein) beside it:
+        ref32 = oc.seamless_clone(dst, patch, mask, cx, cy, nthr, False, "f32")
+        ref32b = oc.seamless_clone(dst, patch, mask, cx, cy, nthr, False, "f32_bluestein")
+        row["float32_transform_bound"] = {
+            "gpu_default_vs_f64_port": dstat(outs["default_auto"], ref), "gpu_default_vs_f32_port": dstat(outs["default_auto"], ref32),
+            "f32_port_vs_f64_port": dstat(ref32, ref), "f32_bluestein_port_vs_f64_port": dstat(ref32b, ref),
+            "f32_port_vs_f32_bluestein_port": dstat(ref32, ref32b),
+            "reference_cufft_vs_opencv_published": {"300x194": {"maxdiff": 1, "diff_sum": 44}, "2400x1552": {"maxdiff": 1, "diff_sum": 17631}}.get(f"{pw}x{ph}"),
+            "note": "all ports use the reference's float32 eigenvalue tables; f64 / f32 = precision of the two 1-D transforms (oracle/sc_oracle.c "
+                    "sco_solve_dst3).  Two float32 transforms differ from each other as much as either differs from the double one, and "
+                    "as much as the reference's float32 cuFFT path differed from OpenCV's float32 dft (published)"}
         print(json.dumps(row), flush=True)
     inst.destroy()
 

@@ -54,11 +54,17 @@ enum sc_method {
     SC_METHOD_RBGS   = 1,    /* red-black Gauss-Seidel (omega = 1)                          */
     SC_METHOD_SOR    = 2,    /* red-black SOR, omega from opts (<=0: optimal for the ROI)   */
     SC_METHOD_MULTIGRID = 3, /* V-cycles with red-black GS smoothing (converges at any ROI)  */
-    SC_METHOD_DST    = 4     /* the reference's direct solve (seamlessClone_imp.cpp:1814-1896; matrix form :1266-1334):
+    SC_METHOD_DST    = 4,    /* the reference's direct solve (seamlessClone_imp.cpp:1814-1896; matrix form :1266-1334):
                                 u = S_h ((S_h g S_w) / den) S_w with den = filter_X + filter_Y - 4 from the float
                                 tables of :596-599, four double-precision products on the matrix cores.  O(n^3):
                                 milliseconds at 2048^2; the non-iterative cross-check of the default path          */
+    SC_METHOD_AUTO   = 5     /* DEFAULT.  SC_METHOD_DST for ROIs of at most SC_AUTO_DIRECT_MAX unknowns per side (there it
+                                costs what the multigrid path costs and has no iteration error: diff sum against the
+                                float-table CPU port 2 instead of 129 at the reference's 300x194 patch, whose own published
+                                deviation from OpenCV is 44, PDF p3), SC_METHOD_MULTIGRID above and whenever tol > 0
+                                asks for a residual-based stop.  sc_run_info.method says which one ran.           */
 };
+#define SC_AUTO_DIRECT_MAX 640
 
 typedef struct sc_solver_opts {
     int   method;            /* enum sc_method                                              */
@@ -111,8 +117,8 @@ typedef struct sc_solver_opts {
 #define SC_FLAG_VCYCLE_BOTTOM  (1 << 4)  /* multigrid: cycle down to the coarsest level inside the bottom kernel
                                             instead of solving its first level directly (fast diagonalisation).
                                             Same fixed point, slightly different iterates                       */
-#define SC_FLAG_EXACT_TABLES   (1 << 5)  /* MULTIGRID / sweep solvers: return the exact solution of the 5-point
-                                            system.  Default: the answer OpenCV and the reference compute, whose
+#define SC_FLAG_EXACT_TABLES   (1 << 5)  /* MULTIGRID / DST: return the exact solution of the 5-point
+                                            system (DST: double denominators 2cos + 2cos - 4 instead of the float tables).  Default: the answer OpenCV and the reference compute, whose
                                             eigenvalue tables are stored and combined in float32
                                             (seamlessClone_imp.cpp:596-599, :1651-1653) -- see DESIGN.md sec. 5,
                                             "float-table correction"                                            */
@@ -125,7 +131,8 @@ typedef struct sc_solver_opts {
                                             and a post-process launch reads it.  Default: that cycle writes the output
                                             bytes itself and no final field exists (those hooks then fail with
                                             SC_ERR_BAD_ARG); the float-table node correction it adds is the one of the
-                                            iterate one cycle earlier (difference below 0.01 grey levels; ROIs where
+                                            iterate one cycle earlier (difference at most 0.05 grey levels in the worst case the stop rule admits,
+                                            0.001-0.003 measured; ROIs where
                                             that bound does not hold take this flag's path by themselves)        */
 
 /* ---- statistics of the last run */
@@ -142,6 +149,7 @@ typedef struct sc_run_info {
     int    sweep_launches;          /* launches of the dominant sweep kernel in the last run */
     float  last_update;             /* MULTIGRID: max |coarse-grid correction| of the last checked cycle (grey levels) */
     size_t device_bytes;            /* arena bytes owned by the instance                    */
+    int    method;                  /* enum sc_method that ran (what SC_METHOD_AUTO resolved to) */
 } sc_run_info;
 
 /* ---- the reference's four entry points ------------------------------------------------- */

@@ -58,6 +58,10 @@ def lib():
         L.sco_seamless_clone2.restype = C.c_int
         L.sco_solve_dst2.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int]
         L.sco_solve_dst2.restype = None
+        L.sco_solve_dst3.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int]
+        L.sco_solve_dst3.restype = None
+        L.sco_seamless_clone3.argtypes = L.sco_seamless_clone2.argtypes + [C.c_int]
+        L.sco_seamless_clone3.restype = C.c_int
         L.sco_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -105,12 +109,17 @@ def fold(B, lap):
     return g
 
 
-def solve_dst(g, nthreads=1, exact_den=False):
-    """exact_den=False reproduces OpenCV's float32 eigenvalue tables (see sc_oracle.c)."""
+INTERNALS = {"f64": 0, "f32": 1, "f32_bluestein": 2}
+
+
+def solve_dst(g, nthreads=1, exact_den=False, internals="f64"):
+    """exact_den=False reproduces OpenCV's float32 eigenvalue tables (see sc_oracle.c).
+    internals: "f64" = transforms in double; "f32" = float32 mixed-radix transforms (what OpenCV's dft / cuFFT run),
+    "f32_bluestein" = float32 chirp-z transforms (cuFFT's route for lengths with large prime factors)."""
     g = np.ascontiguousarray(g, np.float32)
     Cc, h, w = g.shape
     u = np.zeros_like(g)
-    lib().sco_solve_dst2(_f32(g), w, h, Cc, _f32(u), nthreads, int(exact_den))
+    lib().sco_solve_dst3(_f32(g), w, h, Cc, _f32(u), nthreads, int(exact_den), INTERNALS[internals])
     return u
 
 
@@ -148,15 +157,15 @@ def finish(dst, U, geo):
     return dst
 
 
-def seamless_clone(dst, patch, mask, cx, cy, nthreads=1, exact_den=False):
-    """Returns a new blended image (input dst is not modified)."""
+def seamless_clone(dst, patch, mask, cx, cy, nthreads=1, exact_den=False, internals="f64"):
+    """Returns a new blended image (input dst is not modified).  internals: see solve_dst."""
     out = np.array(dst, np.uint8, copy=True, order="C")
     patch = np.ascontiguousarray(patch, np.uint8)
     mask = np.ascontiguousarray(mask, np.uint8)
-    rc = lib().sco_seamless_clone2(_u8(patch), patch.shape[1], patch.shape[0], patch.strides[0],
+    rc = lib().sco_seamless_clone3(_u8(patch), patch.shape[1], patch.shape[0], patch.strides[0],
                                    _u8(out), out.shape[1], out.shape[0], out.strides[0],
                                    _u8(mask), mask.shape[1], mask.shape[0], mask.strides[0], cx, cy, nthreads,
-                                   int(exact_den))
+                                   int(exact_den), INTERNALS[internals])
     if rc:
         raise ValueError(f"sco_seamless_clone rc={rc}")
     return out

@@ -331,6 +331,231 @@ SCO_API void sco_solve_dst2(const float *g, int w, int h, int C, float *u, int n
     plan_destroy(pw); plan_destroy(ph);
 }
 
+/* ------------------------------------------------------------------ float32 transform internals
+ *
+ * OpenCV's dft() and cuFFT (cufftExecC2C, IMP.cpp:1740,1791) run the two batched 1-D complex transforms of the DST in
+ * FLOAT32; the port above transforms in double.  The variants below bound what that costs: the same odd-extension
+ * construction, every buffer float, with
+ *   internals 1: a mixed-radix Cooley-Tukey transform (radix 4 / 2 and a generic O(p^2) butterfly for every other prime
+ *                factor, twiddle table computed in double and stored float) -- the kind of transform OpenCV's dft and
+ *                cuFFT run for composite lengths; lengths with a prime factor > 127 go through Bluestein, as in cuFFT;
+ *   internals 2: Bluestein's chirp-z over a power-of-two float transform for every length.
+ * Neither is bit-identical to OpenCV or cuFFT (their butterfly order is not published to that level); they show the size
+ * of float32 transform rounding in the 8-bit result.  The sequence of steps is the reference's (IMP.cpp:1694-1896):
+ * odd extension [0, s, 0, -reverse(s)] as complex with zero imaginary part (:1342-1351), transform of length 2n+2,
+ * imaginary part of bin j+1 transposed and odd-extended along the other axis (:1465-1478), second transform,
+ * transposed copy of the imaginary part (:1797-1801), divide (:1646-1655), the same again with the inverse flag,
+ * one final scale 1.0f/((2w+2)(2h+2)) (:1893). */
+typedef struct { float re, im; } cpxf;
+static inline cpxf cmulf(cpxf a, cpxf b) { cpxf r = { a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re }; return r; }
+
+typedef struct fftf_plan {
+    int n, inverse;
+    int fac[2 * 40];       /* (radix, remaining length) pairs */
+    cpxf *tw;              /* n twiddles exp(-/+ 2 pi i k / n) */
+    int maxp;              /* largest generic radix */
+    /* Bluestein */
+    int blue, m;
+    struct fftf_plan *sub_f, *sub_i;
+    cpxf *chirp, *bfft;
+} fftf_plan;
+
+static void fftf_factor(int n, int *fac, int *maxp)
+{
+    int p = 4, i = 0;
+    *maxp = 1;
+    while (n > 1) {
+        while (n % p) {
+            if (p == 4) p = 2; else if (p == 2) p = 3; else p += 2;
+            if ((long long)p * p > n) p = n;
+        }
+        n /= p;
+        fac[i++] = p; fac[i++] = n;
+        if (p != 4 && p != 2 && p > *maxp) *maxp = p;
+    }
+}
+
+static int largest_prime_factor(int n)
+{
+    int best = 1;
+    for (int p = 2; (long long)p * p <= n; ++p) while (n % p == 0) { best = p; n /= p; }
+    return n > 1 ? n : best;
+}
+
+static void fftf_work(cpxf *out, const cpxf *in, int fstride, const int *fac, const fftf_plan *P, cpxf *scratch)
+{
+    const int p = fac[0], m = fac[1];
+    if (m == 1) { for (int q = 0; q < p; ++q) out[q] = in[(size_t)q * fstride]; }
+    else for (int q = 0; q < p; ++q) fftf_work(out + (size_t)q * m, in + (size_t)q * fstride, fstride * p, fac + 2, P, scratch);
+    const cpxf *tw = P->tw;
+    const int N = P->n;
+    if (p == 2) {
+        for (int k = 0; k < m; ++k) {
+            cpxf t = cmulf(out[k + m], tw[(size_t)k * fstride]);
+            cpxf a = out[k];
+            out[k + m].re = a.re - t.re; out[k + m].im = a.im - t.im;
+            out[k].re = a.re + t.re; out[k].im = a.im + t.im;
+        }
+    } else if (p == 4) {
+        for (int k = 0; k < m; ++k) {
+            cpxf a0 = out[k];
+            cpxf a1 = cmulf(out[k + m], tw[(size_t)k * fstride]);
+            cpxf a2 = cmulf(out[k + 2 * m], tw[(size_t)k * fstride * 2]);
+            cpxf a3 = cmulf(out[k + 3 * m], tw[(size_t)k * fstride * 3]);
+            cpxf s02 = { a0.re + a2.re, a0.im + a2.im }, d02 = { a0.re - a2.re, a0.im - a2.im };
+            cpxf s13 = { a1.re + a3.re, a1.im + a3.im }, d13 = { a1.re - a3.re, a1.im - a3.im };
+            out[k].re = s02.re + s13.re; out[k].im = s02.im + s13.im;
+            out[k + 2 * m].re = s02.re - s13.re; out[k + 2 * m].im = s02.im - s13.im;
+            /* forward: -i * d13 ; inverse: +i * d13 */
+            cpxf r = P->inverse ? (cpxf){ -d13.im, d13.re } : (cpxf){ d13.im, -d13.re };
+            out[k + m].re = d02.re + r.re; out[k + m].im = d02.im + r.im;
+            out[k + 3 * m].re = d02.re - r.re; out[k + 3 * m].im = d02.im - r.im;
+        }
+    } else {
+        for (int u = 0; u < m; ++u) {
+            int k = u;
+            for (int q1 = 0; q1 < p; ++q1) { scratch[q1] = out[k]; k += m; }
+            k = u;
+            for (int q1 = 0; q1 < p; ++q1) {
+                long long twidx = 0;
+                cpxf acc = scratch[0];
+                for (int q = 1; q < p; ++q) {
+                    twidx += (long long)fstride * k;
+                    if (twidx >= N) twidx %= N;
+                    cpxf t = cmulf(scratch[q], tw[twidx]);
+                    acc.re += t.re; acc.im += t.im;
+                }
+                out[k] = acc;
+                k += m;
+            }
+        }
+    }
+}
+
+static fftf_plan *fftf_create(int n, int inverse, int force_bluestein);
+static void fftf_destroy(fftf_plan *P)
+{
+    if (!P) return;
+    free(P->tw); free(P->chirp); free(P->bfft);
+    fftf_destroy(P->sub_f); fftf_destroy(P->sub_i);
+    free(P);
+}
+
+static fftf_plan *fftf_create(int n, int inverse, int force_bluestein)
+{
+    fftf_plan *P = (fftf_plan *)calloc(1, sizeof(fftf_plan));
+    P->n = n; P->inverse = inverse;
+    const int pow2 = (n & (n - 1)) == 0;
+    if (!pow2 && (force_bluestein || largest_prime_factor(n) > 127)) {
+        P->blue = 1;
+        int m = 1; while (m < 2 * n - 1) m <<= 1;
+        P->m = m;
+        P->sub_f = fftf_create(m, 0, 0);
+        P->sub_i = fftf_create(m, 1, 0);
+        P->chirp = (cpxf *)malloc(sizeof(cpxf) * n);
+        const double sgn = inverse ? 1.0 : -1.0;
+        for (int k = 0; k < n; ++k) {
+            long long k2 = ((long long)k * k) % (2LL * n);
+            double a = sgn * M_PI * (double)k2 / n;
+            P->chirp[k].re = (float)cos(a); P->chirp[k].im = (float)sin(a);
+        }
+        cpxf *b = (cpxf *)calloc(m, sizeof(cpxf));
+        for (int k = 0; k < n; ++k) {
+            cpxf c = { P->chirp[k].re, -P->chirp[k].im };
+            b[k] = c;
+            if (k) b[m - k] = c;
+        }
+        P->bfft = (cpxf *)malloc(sizeof(cpxf) * m);
+        cpxf *scr = (cpxf *)malloc(sizeof(cpxf) * (P->sub_f->maxp + 1));
+        fftf_work(P->bfft, b, 1, P->sub_f->fac, P->sub_f, scr);
+        free(scr); free(b);
+        return P;
+    }
+    fftf_factor(n, P->fac, &P->maxp);
+    P->tw = (cpxf *)malloc(sizeof(cpxf) * n);
+    for (int k = 0; k < n; ++k) {
+        double a = (inverse ? 2.0 : -2.0) * M_PI * (double)k / n;
+        P->tw[k].re = (float)cos(a); P->tw[k].im = (float)sin(a);
+    }
+    return P;
+}
+
+static int fftf_work_len(const fftf_plan *P) { return P->blue ? 2 * P->m + 8 : P->maxp + 1; }
+
+/* out[0..n) = unnormalised DFT of in[0..n) (sign per plan); work holds fftf_work_len entries */
+static void fftf_exec(const fftf_plan *P, const cpxf *in, cpxf *out, cpxf *work)
+{
+    if (!P->blue) { fftf_work(out, in, 1, P->fac, P, work); return; }
+    const int n = P->n, m = P->m;
+    cpxf *a = work, *b = work + m, *scr = work + 2 * m;
+    for (int k = 0; k < n; ++k) a[k] = cmulf(in[k], P->chirp[k]);
+    for (int k = n; k < m; ++k) { a[k].re = 0.f; a[k].im = 0.f; }
+    fftf_work(b, a, 1, P->sub_f->fac, P->sub_f, scr);
+    for (int k = 0; k < m; ++k) b[k] = cmulf(b[k], P->bfft[k]);
+    fftf_work(a, b, 1, P->sub_i->fac, P->sub_i, scr);
+    const float s = 1.0f / (float)m;
+    for (int k = 0; k < n; ++k) {
+        cpxf v = { a[k].re * s, a[k].im * s };
+        out[k] = cmulf(v, P->chirp[k]);
+    }
+}
+
+/* one pass of the reference's dst() (IMP.cpp:1694-1811) over `rows` rows of length n held in `src` (row-major,
+ * rows x n): odd extension, complex transform, imaginary part of bins 1..n written TRANSPOSED into dst (n x rows). */
+static void dstf_pass(const fftf_plan *P, const float *src, float *dst, int rows, int n, int nthreads)
+{
+    const int N = 2 * n + 2;
+#pragma omp parallel num_threads(nthreads)
+    {
+        cpxf *t = (cpxf *)malloc(sizeof(cpxf) * N), *o = (cpxf *)malloc(sizeof(cpxf) * N);
+        cpxf *work = (cpxf *)malloc(sizeof(cpxf) * fftf_work_len(P));
+#pragma omp for schedule(static)
+        for (int r = 0; r < rows; ++r) {
+            const float *s = src + (size_t)r * n;
+            t[0].re = t[0].im = 0.f; t[n + 1].re = t[n + 1].im = 0.f;
+            for (int j = 0; j < n; ++j) {
+                t[1 + j].re = s[j]; t[1 + j].im = 0.f;
+                t[n + 2 + j].re = -s[n - 1 - j]; t[n + 2 + j].im = 0.f;
+            }
+            fftf_exec(P, t, o, work);
+            for (int j = 0; j < n; ++j) dst[(size_t)j * rows + r] = o[j + 1].im;
+        }
+        free(t); free(o); free(work);
+    }
+}
+
+/* internals: 0 = double transforms (sco_solve_dst2), 1 = float32 mixed radix, 2 = float32 Bluestein */
+SCO_API void sco_solve_dst3(const float *g, int w, int h, int C, float *u, int nthreads, int exact_den, int internals)
+{
+    if (internals == 0) { sco_solve_dst2(g, w, h, C, u, nthreads, exact_den); return; }
+    if (nthreads < 1) nthreads = 1;
+    const int fb = internals == 2;
+    fftf_plan *pwf = fftf_create(2 * w + 2, 0, fb), *phf = fftf_create(2 * h + 2, 0, fb);
+    fftf_plan *pwi = fftf_create(2 * w + 2, 1, fb), *phi = fftf_create(2 * h + 2, 1, fb);
+    float *fx = (float *)malloc(sizeof(float) * w), *fy = (float *)malloc(sizeof(float) * h);
+    const double PIf = (double)3.14159265358979323846f;     /* seamlessClone_imp.h:17 */
+    for (int i = 0; i < w; ++i) fx[i] = (float)(2.0 * cos(PIf / (w + 1.0) * (i + 1.0)));   /* IMP.cpp:596-599 */
+    for (int j = 0; j < h; ++j) fy[j] = (float)(2.0 * cos(PIf / (h + 1.0) * (j + 1.0)));
+    const size_t pl = (size_t)w * h;
+    float *a = (float *)malloc(sizeof(float) * pl), *b = (float *)malloc(sizeof(float) * pl);
+    const float scale = 1.0f / (float)((w * 2 + 2) * (h * 2 + 2));                        /* IMP.cpp:1893 */
+    for (int c = 0; c < C; ++c) {
+        dstf_pass(pwf, g + c * pl, b, h, w, nthreads);        /* rows of length w -> b[x][y] */
+        dstf_pass(phf, b, a, w, h, nthreads);                 /* rows of length h -> a[y][x] */
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                if (exact_den) a[(size_t)y * w + x] = (float)((double)a[(size_t)y * w + x] /
+                    (2.0 * cos(M_PI * (x + 1.0) / (w + 1.0)) + 2.0 * cos(M_PI * (y + 1.0) / (h + 1.0)) - 4.0));
+                else a[(size_t)y * w + x] /= (fx[x] + fy[y] - 4.0f);                      /* IMP.cpp:1651-1653 */
+            }
+        dstf_pass(pwi, a, b, h, w, nthreads);
+        dstf_pass(phi, b, a, w, h, nthreads);
+        for (size_t i = 0; i < pl; ++i) u[c * pl + i] = a[i] * scale;
+    }
+    free(a); free(b); free(fx); free(fy);
+    fftf_destroy(pwf); fftf_destroy(phf); fftf_destroy(pwi); fftf_destroy(phi);
+}
+
 /* ------------------------------------------------------------------ stencil sweeps (A.5) */
 
 /* Jacobi: U' = 0.25f*(((l+r)+(u+d)) - f); ring fixed; `sweeps` ping-pong passes. */
@@ -416,10 +641,10 @@ SCO_API void sco_finish(uint8_t *dst, int dstride, const float *U, const int *ge
 
 /* Whole NORMAL_CLONE path with the direct DST solve, in place on dst (reference
  * semantics, IMP.cpp:470).  Returns 0 or a negative error. */
-SCO_API int sco_seamless_clone2(const uint8_t *patch, int pw, int ph, int pstride,
+SCO_API int sco_seamless_clone3(const uint8_t *patch, int pw, int ph, int pstride,
                                 uint8_t *dst, int dw, int dh, int dstride,
                                 const uint8_t *mask, int mw, int mh, int mstride,
-                                int cx, int cy, int nthreads, int exact_den)
+                                int cx, int cy, int nthreads, int exact_den, int internals)
 {
     if (pw != mw || ph != mh) return -2;
     int geo[6];
@@ -434,7 +659,7 @@ SCO_API int sco_seamless_clone2(const uint8_t *patch, int pw, int ph, int pstrid
     if (rc == 0 && w > 0 && h > 0) {
         float *g = (float *)malloc(sizeof(float) * (size_t)w * h * 3);
         sco_fold(B, lap, W, H, g);
-        sco_solve_dst2(g, w, h, 3, g, nthreads, exact_den);
+        sco_solve_dst3(g, w, h, 3, g, nthreads, exact_den, internals);
         for (int c = 0; c < 3; ++c)
             for (int y = 1; y < H - 1; ++y)
                 for (int x = 1; x < W - 1; ++x)
@@ -444,6 +669,15 @@ SCO_API int sco_seamless_clone2(const uint8_t *patch, int pw, int ph, int pstrid
     }
     free(B); free(lap); free(M);
     return rc;
+}
+
+SCO_API int sco_seamless_clone2(const uint8_t *patch, int pw, int ph, int pstride,
+                                uint8_t *dst, int dw, int dh, int dstride,
+                                const uint8_t *mask, int mw, int mh, int mstride,
+                                int cx, int cy, int nthreads, int exact_den)
+{
+    return sco_seamless_clone3(patch, pw, ph, pstride, dst, dw, dh, dstride, mask, mw, mh, mstride,
+                               cx, cy, nthreads, exact_den, 0);
 }
 
 SCO_API int sco_seamless_clone(const uint8_t *patch, int pw, int ph, int pstride,

@@ -19,43 +19,56 @@ def shard_indices(n_items: int, rank: int, world: int) -> list[int]:
     return list(range(rank, n_items, world))
 
 
-def spawn_ranks(world: int, cmd: list[str], extra_env: dict | None = None, poll_s: float = 0.05):
-    """Start `world` fresh processes running `cmd`, one per rank, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
-    MASTER_PORT set (what torch.distributed.run would export), and wait for them.  Returns (rc, rank-0 stdout): rc is 0
-    only if every rank exited 0; when one fails the others are terminated (they would wait in a barrier for ever).
-    The caller must not have initialised the GPU -- nothing in here does: the children are plain subprocesses started
-    with Popen (fork + exec of a process that never loaded the HIP library), never an exec of an initialised process."""
+def _spawn_once(world: int, cmd: list[str], extra_env: dict | None, poll_s: float):
     import socket
     import subprocess
+    import tempfile
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(world):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
-                    "MASTER_PORT": str(port)})
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if extra_env:
-            env.update(extra_env)
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    rc = 0
-    pending = set(range(world))
-    while pending:
-        for r in sorted(pending):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            pending.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                for q in pending:                      # a rank died: the rest would hang in the next barrier
-                    procs[q].terminate()
-        if pending:
-            if rc == 0 and 0 not in pending:
-                pass
-            time.sleep(poll_s)
-    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    # rank 0's stdout goes to a temporary FILE, not a pipe: a pipe is only read after every rank has exited, so a rank 0 that
+    # prints more than the pipe buffer (64 KiB: a long JSON line, library warnings) would block in write() while the others
+    # wait for it in a barrier
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(world):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                        "MASTER_PORT": str(port)})
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if extra_env:
+                env.update(extra_env)
+            procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+        rc = 0
+        pending = set(range(world))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in pending:                      # a rank died: the rest would hang in the next barrier
+                        procs[q].terminate()
+            if pending:
+                time.sleep(poll_s)
+        out0.seek(0)
+        return rc, out0.read()
+
+
+def spawn_ranks(world: int, cmd: list[str], extra_env: dict | None = None, poll_s: float = 0.05, retries: int = 1):
+    """Start `world` fresh processes running `cmd`, one per rank, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set (what torch.distributed.run would export), and wait for them.  Returns (rc, rank-0 stdout): rc is 0
+    only if every rank exited 0; when one fails the others are terminated (they would wait in a barrier for ever).
+    The rendezvous port is found by binding port 0 and closing the socket, so another process can take it before the
+    ranks bind it: a launch that fails before rank 0 has printed anything is repeated (`retries` times) on a new port.
+    The caller must not have initialised the GPU -- nothing in here does: the children are plain subprocesses started
+    with Popen (fork + exec of a process that never loaded the HIP library), never an exec of an initialised process."""
+    rc, out0 = _spawn_once(world, cmd, extra_env, poll_s)
+    while rc != 0 and not out0.strip() and retries > 0:
+        retries -= 1
+        rc, out0 = _spawn_once(world, cmd, extra_env, poll_s)
     return rc, out0
 
 

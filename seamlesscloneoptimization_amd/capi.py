@@ -30,6 +30,8 @@ SC_METHOD_RBGS = 1
 SC_METHOD_SOR = 2
 SC_METHOD_MULTIGRID = 3
 SC_METHOD_DST = 4
+SC_METHOD_AUTO = 5      # default: DST up to SC_AUTO_DIRECT_MAX unknowns per side, MULTIGRID above
+SC_AUTO_DIRECT_MAX = 640
 
 SC_FLAG_NO_SPECULATE = 1 << 0
 SC_FLAG_FLOAT_RHS = 1 << 1
@@ -57,7 +59,7 @@ class RunInfo(C.Structure):
                 ("sweeps", C.c_int), ("converged", C.c_int), ("rel_residual", C.c_double),
                 ("ms_h2d", C.c_float), ("ms_mask", C.c_float), ("ms_pre", C.c_float), ("ms_solve", C.c_float),
                 ("ms_post", C.c_float), ("ms_d2h", C.c_float), ("ms_device_total", C.c_float),
-                ("sweep_launches", C.c_int), ("last_update", C.c_float), ("device_bytes", C.c_size_t)]
+                ("sweep_launches", C.c_int), ("last_update", C.c_float), ("device_bytes", C.c_size_t), ("method", C.c_int)]
 
 
 class BatchJob(C.Structure):

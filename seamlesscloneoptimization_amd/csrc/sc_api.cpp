@@ -349,7 +349,7 @@ void sc_hip_default_opts(sc_solver_opts *o)
 {
     if (!o) return;
     memset(o, 0, sizeof(*o));
-    o->method = SC_METHOD_MULTIGRID;
+    o->method = SC_METHOD_AUTO;
     o->max_sweeps = 30;      // V-cycles
     o->tol = 0.f;            // MULTIGRID stops on update_tol; the sweep methods on tol
     o->check_every = 1;
@@ -458,7 +458,7 @@ int sc_hip_set_solver(void *p, const sc_solver_opts *o)
 {
     Instance *I = get(p);
     if (!I || !o) return SC_ERR_BAD_ARG;
-    if (o->method < SC_METHOD_JACOBI || o->method > SC_METHOD_DST || o->max_sweeps < 0) {
+    if (o->method < SC_METHOD_JACOBI || o->method > SC_METHOD_AUTO || o->max_sweeps < 0) {
         I->err = "bad solver options";
         return SC_ERR_BAD_ARG;
     }

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             const int yr = wv * R + r, y = y0 + r;
             if (!(yr >= HY && yr < RH - HY && y >= 1 && y <= H - 2)) continue;
             float4 v = u[r];
-            if (lm.CN) lm_add4(lm, c, x, y, v);
+            if (lm.CN && x <= W - 2) lm_add4(lm, c, x, y, v);   // the lane that holds only the ring column x = W - 1 would read node (x >> 3) + 1 == nx, one past the row (its byte is never spliced)
             *reinterpret_cast<unsigned *>(q + (size_t)y * P + x) = lm_byte(v.x) | (lm_byte(v.y) << 8) | (lm_byte(v.z) << 16) | (lm_byte(v.w) << 24);
         }
         return;

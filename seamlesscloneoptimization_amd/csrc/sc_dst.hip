@@ -250,7 +250,7 @@ int dst_solve(Instance *I)
     // Right products work on one column half (all 2 mph rows), left products on one row half (all 2 mpw columns); the half is
     // the low bit of blockIdx.z.   forward: T1 = G [Se|So]_w ; T2 = ([Se^T;So^T]_h T1) / den     inverse: T1 = T2 [Se^T|So^T]_w ; T2 = [Se;So]_h T1
     const dim3 gr(mpw / DG_BN, 2 * mph / DG_BM, 2 * C), gl(2 * mpw / DG_BN, mph / DG_BM, 2 * C);
-#define DG_EPI fx, fy, D.h, D.w, mph, mpw, D.singular ? 1 : 0
+#define DG_EPI fx, fy, D.h, D.w, mph, mpw, (D.singular || (I->opts.flags & SC_FLAG_EXACT_TABLES)) ? 1 : 0
     hipLaunchKernelGGL(k_dgemm<0>, gr, dim3(512), 0, I->stream, G, Tw, T1, ld, mpw, ld, mpw, plane, (size_t)mpw, (size_t)0, bw, plane, (size_t)mpw, DG_EPI);
     hipLaunchKernelGGL(k_dgemm<1>, gl, dim3(512), 0, I->stream, Th + 2 * bh, T1, T2, mph, ld, ld, mph, (size_t)0, bh, plane, (size_t)mph * ld, plane, (size_t)mph * ld, DG_EPI);
     hipLaunchKernelGGL(k_dgemm<0>, gr, dim3(512), 0, I->stream, T2, Tw + 2 * bw, T1, ld, mpw, ld, mpw, plane, (size_t)mpw, (size_t)0, bw, plane, (size_t)mpw, DG_EPI);

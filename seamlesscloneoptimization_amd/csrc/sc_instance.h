@@ -155,6 +155,7 @@ void lowmode_bands_written(Instance *I, const float *field);       // the launch
 int lowmode_count(int n);
 int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST
 bool wants_float_tables(const Instance *I);
+int effective_method(const Instance *I);                              // sc_solver.cpp: what SC_METHOD_AUTO resolves to for the fields bound to I
 int output_nodes(Instance *I, LmNodes &lm);  // sc_solver.cpp: the float-table correction the post-process of result(I) has to add (none: lm.CN == nullptr)
 int run_sweeps(Instance *I, int method, int sweeps, float omega, int sweeps_per_launch);
 int fused_depth(int method, int sweeps_per_launch); // 0 = plain kernels

@@ -437,16 +437,19 @@ float4 *lowmode_bands_buffer(Instance *I, int sweeps)
 void lowmode_bands_written(Instance *I, const float *field) { I->lm.bands_of = field; }
 
 // Can the correction of the NEXT cycle's result be taken from the current iterate?  The correction is linear in the field:
-// corr(u_next) - corr(u_now) = corr(u_next - u_now), at most max_ratio x the low-mode content of the next cycle's update,
-// which the stop rule bounds by update_tol when it accepts that cycle.  0: no correction is applied at all (exact tables,
-// singular float tables, no unknowns); 1: yes, the difference stays below 0.01 grey levels (0.012 x 0.25 at 2048^2,
-// 0.029 x 0.25 at 4096^2); 2: no (ROIs beyond ~5000^2, where the float tables approach their singularity).
+// corr(u_next) - corr(u_now) = corr(u_next - u_now), at most max_ratio x the low-mode content of the next cycle's update m.
+// The stop rule accepts that cycle when m rho / (1 - rho) <= 0.1 update_tol with rho floored at 0.02, i.e. for m up to
+// 4.9 update_tol (1.2 grey levels at the default 0.25; measured third-cycle updates are 0.06-0.09).  Worst case of the
+// difference therefore: max_ratio x 4.9 x update_tol = 0.015 grey levels at 2048^2 (max_ratio 0.012), 0.036 at 4096^2
+// (0.029); typical 0.001-0.003.  0: no correction is applied at all (exact tables, singular float tables, no unknowns);
+// 1: yes, that worst case stays below 0.05 grey levels; 2: no (ROIs beyond ~5000^2, where the float tables approach their
+// singularity and max_ratio exceeds 0.04): those take the field-keeping path.
 int lowmode_early_kind(Instance *I, float update_tol)
 {
     if (!wants_float_tables(I)) return 0;
     if (lm_prepare(I) != SC_OK) return 2;
     if (I->lm.singular) return 0;
-    return I->lm.max_ratio * (double)update_tol <= 0.01 ? 1 : 2;
+    return I->lm.max_ratio * 4.9 * (double)update_tol <= 0.049 ? 1 : 2;
 }
 
 // Node corrections of the field U (the instance's current shape): what the post-process adds (lm.CN == nullptr: nothing).

@@ -423,7 +423,7 @@ bool mg_reads_half_rhs(const Instance *I)
 {
     const sc_solver_opts &o = I->opts;
     // at least two levels: min(W, H) - 2 > 3 (build_levels)
-    return !(o.flags & SC_FLAG_FLOAT_RHS) && o.method == SC_METHOD_MULTIGRID && o.tol <= 0.f && fused_level0(o) && std::min(I->F.W, I->F.H) - 2 > 3;
+    return !(o.flags & SC_FLAG_FLOAT_RHS) && effective_method(I) == SC_METHOD_MULTIGRID && o.tol <= 0.f && fused_level0(o) && std::min(I->F.W, I->F.H) - 2 > 3;
 }
 
 int mg_solve(Instance *I)
@@ -466,7 +466,7 @@ int mg_solve(Instance *I)
         // (planar, in the memory of the partner field; a small kernel interleaves them into the destination) -- 3 bytes less
         // written and 9 less read per pixel and channel than field + post-process.  The node correction it adds is the one of
         // the iterate BEFORE that cycle, whose cell shares the previous launch leaves behind (lowmode_early_kind: the two
-        // differ by less than 0.01 grey levels).  If the rule rejects the cycle, the same cycle is launched again in the form
+        // differ by 0.001-0.003 grey levels, 0.05 in the worst case the stop rule admits).  If the rule rejects the cycle, the same cycle is launched again in the form
         // that writes the field (its input is untouched) and the solve continues as without this.
         const bool out_wanted = I->spec_post.armed && o.tol <= 0.f && !(o.flags & SC_FLAG_KEEP_FIELD) && pre == 2 && post == 2;
         auto stop_rule = [utol](float m, float m_prev) {

@@ -15,9 +15,20 @@ static Field &other(Instance *I) { return I->result_in_U1 ? I->U0 : I->U1; }
 // correction (sc_lowmode.hip: result + correction = the answer OpenCV and the reference compute); the solution itself
 // stays untouched (the solve may continue if the stop rule rejects the cycle, and the diagnostic hooks read it).
 // SC_FLAG_EXACT_TABLES, the sweep solvers (fixed counts, not converged fields) and ROIs without unknowns: nothing.
+// SC_METHOD_AUTO: the direct solve where it costs no more than the cycles (small ROIs: a handful of launches either way, and
+// the direct form has no iteration error), multigrid above; a residual-based stop (tol > 0) is an iterative notion.
+int effective_method(const Instance *I)
+{
+    const sc_solver_opts &o = I->opts;
+    if (o.method != SC_METHOD_AUTO) return o.method;
+    const int w = I->F.W - 2, h = I->F.H - 2;
+    if (o.tol <= 0.f && w >= 1 && h >= 1 && w <= SC_AUTO_DIRECT_MAX && h <= SC_AUTO_DIRECT_MAX) return SC_METHOD_DST;
+    return SC_METHOD_MULTIGRID;
+}
+
 bool wants_float_tables(const Instance *I)
 {
-    return I->opts.method == SC_METHOD_MULTIGRID && !(I->opts.flags & SC_FLAG_EXACT_TABLES) && I->F.W >= 3 && I->F.H >= 3;
+    return effective_method(I) == SC_METHOD_MULTIGRID && !(I->opts.flags & SC_FLAG_EXACT_TABLES) && I->F.W >= 3 && I->F.H >= 3;
 }
 
 int output_nodes(Instance *I, LmNodes &lm)
@@ -115,9 +126,12 @@ int solve(Instance *I)
     I->info.sweeps = 0;
     I->info.converged = 0;
     I->info.rel_residual = NAN;
+    I->info.method = o.method;
     if (I->F.W < 3 || I->F.H < 3) { I->info.converged = 1; return SC_OK; } // no unknowns
-    if (o.method == SC_METHOD_MULTIGRID) return mg_solve(I);
-    if (o.method == SC_METHOD_DST) return dst_solve(I);
+    const int method = effective_method(I);
+    I->info.method = method;
+    if (method == SC_METHOD_MULTIGRID) return mg_solve(I);
+    if (method == SC_METHOD_DST) return dst_solve(I);
     if (o.tol <= 0.f) {
         int rc = run_sweeps(I, o.method, o.max_sweeps, o.omega, o.sweeps_per_launch);
         if (rc) return rc;

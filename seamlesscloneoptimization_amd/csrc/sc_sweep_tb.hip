@@ -292,7 +292,7 @@ int tb_blocks_level0(int W, int H, int C, int sweeps)
 // Side above which a coarse level would use 8-row bands (fewer, larger workgroups).  Measured on
 // MI355X (bench.py, 2048^2 and 4096^2 ROIs): 4-row bands win at every coarse-level size -- they
 // stay under 128 VGPRs (2 workgroups per CU) and halve the serial work per lane -- so the default
-// never selects the 8-row form; SC_BIG_SIDE overrides for tuning runs.
+// never selects the 8-row form.
 long tb_big_side()
 {
     return 1000000L;
@@ -304,7 +304,7 @@ long tb_big_side()
 // These launches are latency bound (a workgroup's life is a chain of barriers, not bandwidth), and at
 // ~100 VGPRs two workgroups fit a CU, so what matters is the number of rounds the grid needs over the
 // chip's 512 slots: take the smallest R whose grid fits one round; if none does (large levels) the
-// short 4-row bands won every measurement (tools/bench_configs.py c3/c4).  SC_GEN_R overrides for tuning.
+// short 4-row bands won every measurement (tools/bench_configs.py c3/c4).
 int tb_gen_rows(int W, int H, int C, int hx, int hy)
 {
     if ((long)W * H >= tb_big_side() * tb_big_side()) return 8;

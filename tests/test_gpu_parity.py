@@ -22,6 +22,15 @@ def oracles():
     return o, oc
 
 
+def _mg_instance(gpu=0):
+    """A fresh instance pinned to the multigrid path (the default, SC_METHOD_AUTO, would take the direct solve at the
+    small ROI sizes most of these tests use)."""
+    from seamlesscloneoptimization_amd import capi
+    inst = capi.Instance(gpu)
+    inst.set_solver(method=capi.SC_METHOD_MULTIGRID)
+    return inst
+
+
 SIZES = [(16, 12, False), (33, 17, False), (298, 192, False), (300, 260, True), (513, 129, False), (5, 4, False)]
 
 
@@ -121,7 +130,7 @@ def test_sor_to_tolerance_and_auto_omega(hip, oracles):
     hip.set_solver(method=capi.SC_METHOD_RBGS, tol=1e-12, max_sweeps=20, check_every=10)
     hip.field_load(B, lap)
     assert hip.field_solve(allow_not_converged=True) == capi.SC_ERR_NOT_CONVERGED
-    hip.set_solver(**{k: getattr(hip.default_opts(), k) for k in ("method", "tol", "max_sweeps", "check_every", "omega")})
+    hip.set_solver(method=capi.SC_METHOD_MULTIGRID, **{k: getattr(hip.default_opts(), k) for k in ("tol", "max_sweeps", "check_every", "omega")})
 
 
 @pytest.mark.parametrize("W,H", [(77, 53), (130, 41), (64, 64), (298, 192), (300, 9), (400, 12), (517, 400), (260, 203), (1030, 1000), (126, 90), (255, 141), (254, 127), (510, 254)])
@@ -157,7 +166,7 @@ def test_multigrid_cycles_follow_the_spec(hip, W, H):
             want = mg_np.solve(U[c], F[c], cycles=cycles, fused=False)
             assert np.abs(got1[c] - want).max() < 2e-3 * (10.0 if cycles == 1 else 1.0), ("unfused", cycles, c)
     d = hip.default_opts()
-    hip.set_solver(method=d.method, max_sweeps=d.max_sweeps, update_tol=d.update_tol, tol=d.tol)
+    hip.set_solver(method=capi.SC_METHOD_MULTIGRID, max_sweeps=d.max_sweeps, update_tol=d.update_tol, tol=d.tol)
 
 
 def test_c1_clone_matches_oracle_within_one(hip, oracles, c1_inputs):
@@ -178,7 +187,7 @@ def test_c1_clone_matches_oracle_within_one(hip, oracles, c1_inputs):
         # the Dirichlet ring itself is untouched
         assert np.array_equal(body[54, 651:949], c["dst"][54, 651:949])
     d = hip.default_opts()
-    hip.set_solver(method=d.method, tol=d.tol, max_sweeps=d.max_sweeps, check_every=d.check_every)
+    hip.set_solver(method=capi.SC_METHOD_MULTIGRID, tol=d.tol, max_sweeps=d.max_sweeps, check_every=d.check_every)
 
 
 def test_c1_reference_golden_jpeg_through_the_c_abi(hip, c1_inputs, golden_blend_rgb):
@@ -297,7 +306,7 @@ def test_instance_reuse_across_roi_sizes_is_stateless(hip, oracles):
     small = o.synth_inputs(130, 41, margin=32)
     b = big[0].copy(); hip.run(big[1], b, big[2], big[3], big[4])
     got = small[0].copy(); hip.run(small[1], got, small[2], small[3], small[4])
-    fresh = capi.Instance(0)
+    fresh = _mg_instance()
     try:
         want = small[0].copy(); fresh.run(small[1], want, small[2], small[3], small[4])
     finally:
@@ -347,7 +356,7 @@ def test_wrong_bounding_box_guess_is_repeated_not_written(oracles):
     repeated on the true box; an empty mask after a full one must still be EMPTY_MASK with the image intact."""
     from seamlesscloneoptimization_amd import capi
     o, _ = oracles
-    inst = capi.Instance(0)
+    inst = _mg_instance()
     rng = np.random.default_rng(4)
     H, W = 150, 210
     dst = rng.integers(0, 256, (H + 80, W + 80, 3), dtype=np.uint8)
@@ -507,12 +516,12 @@ def test_stream_pool_matches_sequential(oracles):
     from seamlesscloneoptimization_amd.batch import StreamPool
     o, _ = oracles
     items = [o.synth_inputs(180 + 16 * k, 120 + 8 * k, seed_dst=10 + k, seed_patch=20 + k, margin=32) for k in range(8)]
-    seq = capi.Instance(0)
+    seq = _mg_instance()
     want = []
     for dst, patch, mask, cx, cy in items:
         b = dst.copy(); seq.run(patch, b, mask, cx, cy); want.append(b)
     seq.destroy()
-    pool = StreamPool(0, 4)
+    pool = StreamPool(0, 4, method=capi.SC_METHOD_MULTIGRID)
     def one(inst, it):
         dst, patch, mask, cx, cy = it
         b = dst.copy(); inst.run(patch, b, mask, cx, cy); return b
@@ -528,12 +537,12 @@ def test_native_pool_matches_sequential(oracles):
     from seamlesscloneoptimization_amd import capi
     o, _ = oracles
     items = [o.synth_inputs(150 + 24 * k, 100 + 10 * k, seed_dst=40 + k, seed_patch=60 + k, margin=32) for k in range(7)]
-    seq = capi.Instance(0)
+    seq = _mg_instance()
     want = []
     for dst, patch, mask, cx, cy in items:
         b = dst.copy(); seq.run(patch, b, mask, cx, cy); want.append(b)
     seq.destroy()
-    pool = capi.Pool(0, 3)
+    pool = capi.Pool(0, 3, method=capi.SC_METHOD_MULTIGRID)
     assert len(pool.instances) == 3
     for _ in range(2):
         bodies = [it[0].copy() for it in items]
@@ -580,11 +589,11 @@ def test_grouped_clones_share_one_set_of_launches(oracles):
         if k == 2:                                           # same size, holes in the mask
             mask = mask.copy(); mask[40:60, 100:180] = 0
         items.append((dst, patch, mask, cx + 3 * k - 6, cy + 2 * k - 4))
-    seq = capi.Instance(0)
+    seq = _mg_instance()
     alone, cycles = [], []
     for dst, patch, mask, cx, cy in items:
         b = dst.copy(); seq.run(patch, b, mask, cx, cy); alone.append(b); cycles.append(seq.info().sweeps)
-    pool = capi.Pool(0, 2, group=3)
+    pool = capi.Pool(0, 2, group=3, method=capi.SC_METHOD_MULTIGRID)
     inst = pool.instances[0]
 
     def device_jobs(its):
@@ -656,7 +665,7 @@ def test_grouped_clones_large_roi(oracles):
     o, oc = oracles
     W, H = 1100, 900
     items = [o.synth_inputs(W, H, seed_dst=910 + k, seed_patch=920 + k, margin=40) for k in range(3)]
-    inst = capi.Instance(0)
+    inst = _mg_instance()
     alone, cycles = [], []
     for dst, patch, mask, cx, cy in items:
         b = dst.copy(); inst.run(patch, b, mask, cx, cy); alone.append(b); cycles.append(inst.info().sweeps)

@@ -16,6 +16,15 @@ def oracles():
     return oracle_np, oracle_c
 
 
+def _mg_instance(gpu=0):
+    """A fresh instance pinned to the multigrid path (the default, SC_METHOD_AUTO, would take the direct solve at the
+    small ROI sizes most of these tests use)."""
+    from seamlesscloneoptimization_amd import capi
+    inst = capi.Instance(gpu)
+    inst.set_solver(method=capi.SC_METHOD_MULTIGRID)
+    return inst
+
+
 def _solution_field(oc, W, H, seed=0, margin=32):
     from oracle import oracle_np as o
     dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=1001 + seed, seed_patch=2002 + seed, margin=margin)
@@ -201,7 +210,7 @@ def test_config5_batch_of_64_clones_of_1024(oracles):
     from seamlesscloneoptimization_amd import capi
     o, oc = oracles
     N, W, H = 64, 1024, 1024
-    pool = capi.Pool(0, 4, group=8)
+    pool = capi.Pool(0, 4, group=8, method=capi.SC_METHOD_MULTIGRID)
     inst = pool.instances[0]
     jobs = pool.make_jobs(N)
     keep = []
@@ -217,7 +226,7 @@ def test_config5_batch_of_64_clones_of_1024(oracles):
         pool.run(jobs, device_resident=True)
     assert all(j.rc == 0 for j in jobs)
     group_cycles = {i.info().sweeps for i in pool.instances}
-    solo = capi.Instance(0)
+    solo = _mg_instance()
     checked = 0
     for k, (f, b0, b, m, shape, host) in enumerate(keep):
         if host is None:
@@ -373,7 +382,7 @@ def test_config3_literal_rule_red_black_to_1e_4(hip, oracles):
         assert compare.image_diff_stats(want, body)["max"] > 5           # converged by the residual rule, far from the solution
     finally:
         d = hip.default_opts()
-        hip.set_solver(method=d.method, tol=d.tol, max_sweeps=d.max_sweeps, check_every=d.check_every, omega=d.omega)
+        hip.set_solver(method=capi.SC_METHOD_MULTIGRID, tol=d.tol, max_sweeps=d.max_sweeps, check_every=d.check_every, omega=d.omega)
 
 
 def test_frozen_float_table_case_on_the_gpu(hip, golden_dir):
@@ -531,7 +540,7 @@ def test_groups_stop_by_the_same_rule_as_single_clones(oracles):
     o, oc = oracles
     W, H, N = 2048, 2048, 16                                  # 48 channels at 2048^2: 20 304 workgroups per launch, above the host fold's 16 384
     dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=64)
-    pool = capi.Pool(0, 1, group=N, update_tol=0.004)
+    pool = capi.Pool(0, 1, group=N, update_tol=0.004, method=capi.SC_METHOD_MULTIGRID)
     inst = pool.instances[0]
     jobs = pool.make_jobs(N)
     keep = []
@@ -545,7 +554,7 @@ def test_groups_stop_by_the_same_rule_as_single_clones(oracles):
     pool.run(jobs, device_resident=True)
     assert all(j.rc == 0 for j in jobs)
     group_cycles = inst.info().sweeps
-    solo = capi.Instance(0)
+    solo = _mg_instance()
     solo.set_solver(update_tol=0.004)
     alone = dst.copy()
     assert solo.run(patch, alone, mask, cx, cy) == 0

@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert ctypes.sizeof(capi.SolverOpts) == 15 * 4
     o = capi.SolverOpts()
     capi.load().sc_hip_default_opts(ctypes.byref(o))
-    assert o.method == capi.SC_METHOD_MULTIGRID and o.mg_pre == 2 and o.update_tol == pytest.approx(0.25)
+    assert o.method == capi.SC_METHOD_AUTO and o.mg_pre == 2 and o.update_tol == pytest.approx(0.25)
 
 
 def test_host_selftest_row_copier_and_eigen_solver():

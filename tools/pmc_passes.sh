@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: SQ counter passes over the isolated hot-kernel launches (tools/pmc_probe.py), folded per kernel.
 # usage: tools/pmc_passes.sh [kernel-name filter]      (one rocprofv3 --pmc run per counter group)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \

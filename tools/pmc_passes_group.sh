@@ -2,7 +2,7 @@
 # GPU box: SQ counter passes over the dominant kernel AS THE BENCH TIMES IT (48-channel fields of a group of 16 clones; the
 # tagged symbol only the roofline micro-region of bench.py launches), folded per kernel by tools/pmc_fold.py.
 # usage: tools/pmc_passes_group.sh [kernel-name filter]      (one rocprofv3 --pmc run per counter group)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: fabric traffic per launch of the isolated hot kernels (two separate counter passes)
 set -o pipefail
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/qt_f $R/gpurun_out/qt_w
 timeout -k 10 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/qt_f -- python3 $R/tools/pmc_probe.py ${1:-2048} > /dev/null 2>&1 || exit 1

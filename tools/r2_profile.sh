@@ -3,7 +3,7 @@
 # (FETCH_SIZE / WRITE_SIZE x 3 steps / 1 step; --pmc never together with --stats' tracing domains beyond --kernel-trace).
 # usage: tools/r2_profile.sh <tag> [extra bench args]      outputs: gpurun_out/<tag>_*
 set -o pipefail
-R=$GRAFT_REPO_ROOT; T=${1:-r2}; shift
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; T=${1:-r2}; [ $# -gt 0 ] && shift
 GIT=${GIT_HASH:-unknown}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${T}_stats $R/gpurun_out/${T}_f3 $R/gpurun_out/${T}_w3 $R/gpurun_out/${T}_f1 $R/gpurun_out/${T}_w1
