@@ -49,6 +49,11 @@ def parse_args(argv=None):
     ap.add_argument("--extra-flags", type=int, default=0, help="further sc_solver_opts.flags bits (A/B runs of a variant, e.g. 64 = SC_FLAG_SEPARATE_RESTRICT)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--kernel-launches", type=int, default=100, help="launches in the roofline micro-region")
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"],
+                    help="c3 (default): the metric's configuration -- 2048^2 ROIs, --batch clones per GPU per step, weak scaling.  "
+                         "c5: BASELINE config 5 as written -- 64 independent 1024^2 clones in total, image i on rank i mod N "
+                         "(8 per GPU at N = 8), strong scaling")
+    ap.add_argument("--no-c4", action="store_true", help="skip the roofline_c4 leg (config 4: single-sweep Jacobi kernels at a 4096^2 ROI, HBM bound)")
     ap.add_argument("--reference-table", action="store_true",
                     help="instead of the flagship line: the reference's own published table (PDF p3) -- end-to-end latency of the drop-in "
                          "call at source patches 154x100, 300x194, 592x592, 2400x1552, its protocol (1 warm-up + 50 rounds), the CPU port beside it")
@@ -229,6 +234,18 @@ def main():
     if comm.world != args.gpus:
         args.gpus = comm.world
     import numpy as np
+    from seamlesscloneoptimization_amd.batch import shard_indices
+    image_ids = None
+    if args.config == "c5":
+        # BASELINE config 5 as written: 64 independent 1024 x 1024 clones, image i on rank i mod N (8 per GPU at N = 8), no
+        # collective; one step = every rank clones its shard once; value = 64 x 1024^2 x steps / max-over-ranks time (STRONG scaling)
+        args.roi = 1024
+        image_ids = shard_indices(64, comm.rank, comm.world)
+        args.batch = len(image_ids)
+        if args.batch == 0:
+            sys.exit("bench.py --config c5: more ranks than images")
+        args.streams = max(1, min(args.streams, args.batch))
+        args.group = max(1, min(args.group, -(-args.batch // args.streams)))
 
     ndev = capi.device_count()
     if ndev < 1:
@@ -249,7 +266,7 @@ def main():
     jobs = []
     cjobs = pool.make_jobs(args.batch)          # one C job per image: D2D restore + device-resident clone
     for b in range(args.batch):
-        dst, patch, mask, cx, cy = synth(args.roi, comm.rank * args.batch + b)
+        dst, patch, mask, cx, cy = synth(args.roi, (3000 - 1001 + image_ids[b]) if image_ids is not None else comm.rank * args.batch + b)   # c5: seeds 3000 + i
         j = dict(host=(dst, patch, mask, cx, cy) if b in (0, args.batch - 1) else None, f=inst.to_device(patch), fs=patch.shape[:2],
                  b0=inst.to_device(dst), b=inst.to_device(dst), n=dst.nbytes, bs=dst.shape[:2],
                  m=inst.to_device(mask), ms=mask.shape[:2], cx=cx, cy=cy)
@@ -355,22 +372,41 @@ def main():
     ms_rb = inst.field_time_sweeps(capi.SC_METHOD_RBGS, args.kernel_launches, spl, 1.0)
     ms_j = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, args.kernel_launches, spl, 1.0)
     ms_j1 = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, args.kernel_launches, 1, 1.0)
+    src_fp = capi.source_fingerprint()
     rb_bytes = 12.0 * unknowns * (0.5 if rb_depth == 0 else rb_depth)   # plain kernel: one colour per launch
     j_bytes = 12.0 * unknowns * max(j_depth, 1)
 
-    profile = None
-    for name in ("r2_pmc_traffic_bench.json",):
+    # Counter figures (fabric bytes per launch, bytes per timed step) come from committed rocprofv3 --pmc passes of THIS command
+    # (tools/r3_profile.sh -> profiles/r3_pmc_traffic_bench.json).  They are only quoted when the capture matches the run:
+    # same ROI / batch / group and the same library sources (capi.source_fingerprint); otherwise `traffic` is null and
+    # `traffic_stale` says why -- a stale number is never passed on silently.
+    profile, traffic_stale = None, None
+    src_now = capi.source_fingerprint()
+    for name in ("r3_pmc_traffic_bench.json", "r2_pmc_traffic_bench.json"):
         try:
             profile = json.load(open(os.path.join(ROOT, "profiles", name)))
             profile["_file"] = "profiles/" + name
             break
         except Exception:
             pass
+    if profile is None:
+        traffic_stale = "no committed counter capture under profiles/ (run tools/r3_profile.sh on the GPU box)"
+    else:
+        why = []
+        for key, have in (("roi", args.roi), ("batch", args.batch), ("group", group)):
+            if profile.get(key) != have:
+                why.append(f"{key} {profile.get(key)} in the capture, {have} in this run")
+        if profile.get("source_fingerprint") != src_now:
+            why.append(f"library sources changed since the capture (fingerprint {profile.get('source_fingerprint', 'not recorded')} then, {src_now} now)")
+        if why:
+            traffic_stale = f"{profile['_file']} @ {profile.get('git', '?')} does not describe this run: " + "; ".join(why) + \
+                            " -- re-capture with tools/r3_profile.sh"
+            profile = None
 
     def pmc_traffic(symbol, channels):
         """Fabric-side bytes per launch from the committed rocprofv3 PMC passes of this command (2 x FETCH_SIZE + WRITE_SIZE,
-        tools/pmc_traffic.py; collected per MI355X_MICROARCH.md's HBM section); None when no pass covers this configuration."""
-        if not profile or profile.get("roi") != args.roi:
+        tools/pmc_traffic_bench.py; collected per MI355X_MICROARCH.md's HBM section); None when no capture describes this run."""
+        if not profile:
             return None
         for k, v in profile.get("kernels", {}).items():
             if symbol in k and v.get("channels", channels) == channels:
@@ -384,6 +420,7 @@ def main():
              "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "frac_effective": round(ach / HBM_PEAK_GBS, 4),
              "traffic": tr, "frac_traffic": round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
              "traffic_source": (f"{profile['_file']} @ {profile.get('git', '?')}" if tr else None),
+             "traffic_stale": (None if tr else (traffic_stale or "the capture holds no entry for this kernel symbol")),
              "us_per_launch": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch), "note": note}
         return r
 
@@ -410,7 +447,10 @@ def main():
                         "residual + restriction, one launch)", "k_cycle0<4, 8, 8, true, false, false, 19>", c0_bytes, ms_c0,
                         "dominant kernel of the timed region, in the form the timed region launches it; algorithmic bytes = sum of the "
                         "SURVEY 8d figures of the fused operations = 66 B/unknown/channel: frac (= frac_effective) > 1 is 'effective' "
-                        "bandwidth from temporal blocking; frac_traffic = counter-measured fabric bytes / time / 8 TB/s; "
+                        "bandwidth from temporal blocking; frac_traffic = counter-measured fabric bytes / time / 8 TB/s.  The isolated "
+                        "launches are the tagged 4-sweep composed form WITHOUT the two epilogues some in-step launches carry (cell "
+                        "shares of the float-table correction: +7 %; byte output instead of the field store: same duration), on the "
+                        "fields the last group left (values are discarded); "
                         + cache_note(grp_ch), channels=grp_ch)
     else:
         roofline = roofline_rb
@@ -419,16 +459,58 @@ def main():
     roofline_j1 = roof("k_jacobi_roll<4> (5-point sweep, rows rolling through registers, 1 sweep per launch)", "k_jacobi_roll<4, 1>",
                        12.0 * unknowns, ms_j1, "single-sweep Jacobi, single clone: algorithmic == actual traffic; " + cache_note(3))
 
+    # ---- BASELINE config 4: the single-sweep Jacobi kernels at a 4096^2 ROI -- the one configuration whose 604 MB working set
+    #      (3 channels x (u, f, u')) exceeds the 256 MB Infinity Cache, i.e. genuinely streams from HBM.  Both forms the library
+    #      has: rows rolling through registers (k_jacobi_roll<4>, the default) and the LDS-staged 256 x 32 tile with a 1-pixel halo
+    #      that the north-star names (k_jacobi<32>, sc_solver_opts.jacobi_tile_rows = 32).  Counter bytes: profiles/r3_c4_pmc.json.
+    roofline_c4 = None
+    if not args.no_c4 and args.config == "c3":
+        n4 = 4096
+        rng4 = np.random.default_rng(44)
+        U4 = rng4.integers(0, 256, (3, n4, n4)).astype(np.float32)
+        F4 = rng4.integers(-300, 301, (3, n4, n4)).astype(np.float32)
+        inst.field_load(U4, F4)
+        del U4, F4
+        bytes4 = 12.0 * (n4 - 2) * (n4 - 2) * 3
+        try:
+            c4prof = json.load(open(os.path.join(ROOT, "profiles", "r3_c4_pmc.json")))
+        except Exception:
+            c4prof = None
+        c4_stale = None if c4prof and c4prof.get("source_fingerprint") == src_now else \
+            ("no profiles/r3_c4_pmc.json" if not c4prof else f"profiles/r3_c4_pmc.json was captured from other library sources "
+             f"({c4prof.get('source_fingerprint')} then, {src_now} now): re-capture with tools/r3_profile.sh")
+        legs = {}
+        for key, rows, sym, label in (("register_rolling", 0, "k_jacobi_roll<4, 1>", "k_jacobi_roll<4>: a wave owns 256 columns x 4 rows, rows y-1..y+4 roll through registers, no LDS, no barrier (default)"),
+                                      ("lds_tile_16", 16, "k_jacobi<16, 0>", "k_jacobi<16>: LDS-staged 256 x 16 tile + 1-pixel halo, one barrier"),
+                                      ("lds_tile_32", 32, "k_jacobi<32, 0>", "k_jacobi<32>: LDS-staged 256 x 32 tile + 1-pixel halo, one barrier (the form the north-star names)")):
+            inst.set_solver(jacobi_tile_rows=rows)
+            ms4 = inst.field_time_sweeps(capi.SC_METHOD_JACOBI, max(20, args.kernel_launches), 1, 1.0)
+            tr4 = None
+            if c4prof and not c4_stale:
+                tr4 = next((v["traffic_bytes_per_launch"] for k, v in c4prof.get("kernels", {}).items() if sym in k), None)
+            legs[key] = {"kernel": label, "profiler_symbol": "sc::" + sym, "us_per_launch": round(ms4 * 1e3, 2),
+                         "achieved": round(bytes4 / (ms4 * 1e-3) / 1e9, 1), "frac": round(bytes4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": tr4, "frac_traffic": round(tr4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr4 else None,
+                         "traffic_stale": None if tr4 else c4_stale}
+        inst.set_solver(jacobi_tile_rows=0)
+        roofline_c4 = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "roi": [n4, n4], "algorithmic_bytes_per_launch": int(bytes4),
+                       "working_set_MB": round(bytes4 / 1e6, 1), **legs,
+                       "note": "one Jacobi sweep per launch, 3 channels, 12 B per unknown and channel (SURVEY 8d): algorithmic == compulsory "
+                               "traffic; HIP events on the library's stream around back-to-back launches; the register-rolling form is the "
+                               "default because it is the faster of the two here (no barrier, no LDS round trip for the rows a wave owns)"}
+
     total_pix = comm.sum(float(W * H * args.batch)) * args.steps
     value = total_pix / elapsed / 1e6
-    step_traffic = profile.get("step_traffic_bytes") if profile and profile.get("roi") == args.roi and \
-        profile.get("batch") == args.batch and profile.get("group") == group else None
+    step_traffic = profile.get("step_traffic_bytes") if profile else None
     line = {
-        "metric": "Mpix/s seamlessClone (ROI 2048^2)" if args.roi == 2048 else f"Mpix/s seamlessClone (ROI {args.roi}^2)",
+        "metric": ("Mpix/s seamlessClone (BASELINE config 5: 64 x ROI 1024^2 sharded i mod N)" if args.config == "c5" else
+                   "Mpix/s seamlessClone (ROI 2048^2)" if args.roi == 2048 else f"Mpix/s seamlessClone (ROI {args.roi}^2)"),
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if args.config == "c5" else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.batch} independent {W}x{H}-ROI NORMAL_CLONEs per GPU per step on {streams} HIP "
+        "config": {"workload": (f"BASELINE config 5: 64 independent {W}x{H}-ROI clones in total, image i on rank i mod {args.gpus} (this rank: {args.batch}); "
+                                if args.config == "c5" else "") +
+                               f"{args.batch} independent {W}x{H}-ROI NORMAL_CLONEs per GPU per step on {streams} HIP "
                                f"streams, {group} clones per set of solver launches, 3-channel u8 images resident in HBM, solver={args.method}, "
                                + ("result = exact 5-point solution (SC_FLAG_EXACT_TABLES), +-1 grey level vs the exact-denominator port"
                                   if args.exact_tables else
@@ -443,10 +525,12 @@ def main():
                                    "note": "one clone alone on the GPU, hipEvent marks; solve includes the float-table correction and, "
                                            "when post = 0, the post-process enqueued directly behind it"},
         "roofline": roofline, "roofline_red_black": roofline_rb, "roofline_jacobi": roofline_j,
-        "roofline_jacobi_single_sweep": roofline_j1, "roofline_direct_dst": roofline_dst,
+        "roofline_jacobi_single_sweep": roofline_j1, "roofline_c4": roofline_c4, "roofline_direct_dst": roofline_dst,
+        "source_fingerprint": src_fp,
         "whole_step_fabric": ({"bytes_per_step": int(step_traffic), "TB_per_s": round(step_traffic / (elapsed / args.steps) / 1e12, 3),
                                "frac_of_peak": round(step_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                               "traffic_source": f"{profile['_file']} @ {profile.get('git', '?')}"} if step_traffic else None),
+                               "traffic_source": f"{profile['_file']} @ {profile.get('git', '?')}"} if step_traffic else
+                              {"bytes_per_step": None, "frac_of_peak": None, "traffic_stale": traffic_stale}),
         "pcie": pcie,
     }
     if comm.rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:

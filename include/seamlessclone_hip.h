@@ -61,10 +61,12 @@ enum sc_method {
     SC_METHOD_AUTO   = 5     /* DEFAULT.  SC_METHOD_DST for ROIs of at most SC_AUTO_DIRECT_MAX unknowns per side (there it
                                 costs what the multigrid path costs and has no iteration error: diff sum against the
                                 float-table CPU port 2 instead of 129 at the reference's 300x194 patch, whose own published
-                                deviation from OpenCV is 44, PDF p3), SC_METHOD_MULTIGRID above and whenever tol > 0
+                                deviation from OpenCV is 44, PDF p3) and for thin ROIs (SC_AUTO_THIN_MAX), SC_METHOD_MULTIGRID above and whenever tol > 0
                                 asks for a residual-based stop.  sc_run_info.method says which one ran.           */
 };
 #define SC_AUTO_DIRECT_MAX 640
+#define SC_AUTO_THIN_MAX 6          /* ... and for thin ROIs (at most this many unknowns across, up to SC_AUTO_THIN_LONG_MAX along) */
+#define SC_AUTO_THIN_LONG_MAX 2048
 
 typedef struct sc_solver_opts {
     int   method;            /* enum sc_method                                              */

@@ -32,6 +32,8 @@ SC_METHOD_MULTIGRID = 3
 SC_METHOD_DST = 4
 SC_METHOD_AUTO = 5      # default: DST up to SC_AUTO_DIRECT_MAX unknowns per side, MULTIGRID above
 SC_AUTO_DIRECT_MAX = 640
+SC_AUTO_THIN_MAX = 6
+SC_AUTO_THIN_LONG_MAX = 2048
 
 SC_FLAG_NO_SPECULATE = 1 << 0
 SC_FLAG_FLOAT_RHS = 1 << 1
@@ -460,6 +462,20 @@ class Pool:
             self.close()
         except Exception:
             pass
+
+
+def source_fingerprint() -> str:
+    """sha256 (16 hex digits) over the library's sources (csrc/*.hip, *.cpp, *.h and the public header).  Profiles under
+    profiles/ record it; bench.py refuses to quote counter figures captured from other sources (traffic_stale)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_PKG, "csrc", "*.hip")) + glob.glob(os.path.join(_PKG, "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(_PKG, "csrc", "*.h")) + [HEADER_PATH])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def device_count() -> int:

@@ -136,13 +136,18 @@ def test_float32_transform_bound_at_the_published_sizes(inst, oracles, pw, ph):
     assert pairs["gpu_vs_f64_port"][1] <= published          # the GPU vs the port it is specified against: not above the reference's own
 
 
-@pytest.mark.parametrize("W,H", [(382, 5), (5, 200), (640, 6), (300, 7), (9, 9), (1200, 4)])
+@pytest.mark.parametrize("W,H", [(382, 5), (5, 200), (640, 6), (300, 7), (9, 9), (1200, 4), (2600, 5)])
 def test_thin_rois_state_of_the_bound(hip, inst, oracles, W, H):
-    """ROIs narrower than 7: the 3x erode empties the mask (every ROI pixel is within 3 of the frame), the right-hand side is
-    the destination's own Laplacian and the exact solution is the destination itself -- INTEGER values.  clamp-then-truncate
-    of an integer that arithmetic returns as 99.99999 or 100.00001 is a coin flip, in the port just as on the GPU, so the
-    two can differ by one on a visible share of the channels; the bound that holds is max 1.  Multigrid (iteration error
-    0.02) flips more often than the direct solve (rounding error 1e-5); both stay within one and the share is recorded."""
+    """ROIs narrower than 9: the 3x erode empties the mask (every ROI pixel is within 3 of the frame), the right-hand side is
+    the destination's own Laplacian and the exact solution is the destination itself -- INTEGER values.  The reference's
+    float32 eigenvalue tables put every mode a relative ~1e-7 below its exact value (seamlessClone_imp.cpp:596-599), so its
+    answer is v - epsilon and clamp-then-truncate returns v - 1 on most channels.  State of the bound, asserted here:
+      * every path stays within ONE of the float-table port and of the integers v;
+      * the default (SC_METHOD_AUTO -> the direct solve: it is that arithmetic) reproduces the port's bytes on all but a few
+        percent of the channels (the remaining coin flips are values within 1e-6 of an integer);
+      * multigrid returns v itself (its start IS the solution; the float-table correction only carries the lowest modes), i.e. it
+        is off by one wherever the port truncated down -- up to ~100 % of the channels, measured and printed, not a defect of
+        the +-1 contract.  Beyond SC_AUTO_THIN_LONG_MAX the default is multigrid too (2600 x 5)."""
     from seamlesscloneoptimization_amd import capi
     o, oc = oracles
     dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=16, seed_dst=31, seed_patch=32)
@@ -154,9 +159,63 @@ def test_thin_rois_state_of_the_bound(hip, inst, oracles, W, H):
         assert rc in (0, capi.SC_ERR_NOT_CONVERGED)
         d = np.abs(body.astype(np.int16) - want.astype(np.int16))
         assert d.max() <= 1, (name, W, H, int(d.max()))
-        # against the integers the exact solution consists of: also at most one
-        dd = np.abs(body.astype(np.int16) - dst.astype(np.int16))
+        dd = np.abs(body.astype(np.int16) - dst.astype(np.int16))      # against the integers the exact solution consists of
         assert dd.max() <= 1
         shares[name] = round(100.0 * float((d > 0).sum()) / (3.0 * max(1, (W - 2) * (H - 2))), 2)
+    direct = max(W, H) - 2 <= capi.SC_AUTO_THIN_LONG_MAX
+    assert inst.info().method == (capi.SC_METHOD_DST if direct else capi.SC_METHOD_MULTIGRID)
     print("thin ROI %dx%d: %% of ROI channels off by one vs the port:" % (W, H), shares)
-    assert shares["default"] <= 25.0 and shares["multigrid"] <= 25.0
+    if direct and min(W, H) <= 8:
+        assert shares["default"] <= 10.0, shares
+
+
+def test_config4_lds_tiled_sweep_at_4096(inst, oracles):
+    """BASELINE config 4 as written: the LDS-tiled 5-point stencil at a 4096^2 ROI (604 MB of fields, beyond the Infinity
+    Cache).  Size-independent properties: (1) k_jacobi<32> and k_jacobi<16> give the register-rolling kernel's field bit
+    for bit after 3 sweeps; (2) a 40-row strip equals the C oracle's sweeps on that strip's dependency cone; (3) the ring
+    never moves."""
+    from seamlesscloneoptimization_amd import capi
+    _, oc = oracles
+    n = 4096
+    rng = np.random.default_rng(404)
+    U = rng.integers(0, 256, (3, n, n)).astype(np.float32)
+    F = rng.integers(-400, 401, (3, n, n)).astype(np.float32)
+    F[:, 0, :] = F[:, -1, :] = 0; F[:, :, 0] = F[:, :, -1] = 0
+    outs = {}
+    for rows in (0, 32, 16):
+        inst.set_solver(jacobi_tile_rows=rows)
+        inst.field_load(U, F)
+        inst.field_sweep(capi.SC_METHOD_JACOBI, 3, 1.0, 1)
+        outs[rows] = inst.field_store()
+    inst.set_solver(jacobi_tile_rows=0)
+    assert np.array_equal(outs[0], outs[32]) and np.array_equal(outs[0], outs[16])
+    got = outs[0]
+    for sl in (np.s_[:, 0, :], np.s_[:, -1, :], np.s_[:, :, 0], np.s_[:, :, -1]):
+        assert np.array_equal(got[sl], U[sl])
+    assert not np.array_equal(got[:, 1:-1, 1:-1], U[:, 1:-1, 1:-1])
+    # rows a .. b of the result depend on rows a-3 .. b+3 of the input: the oracle on that strip (its first / last row play the
+    # ring and are wrong after a sweep, the error travels one row per sweep) must agree on the rows 3 away from its ends
+    for a in (1, 2017, n - 47):
+        lo, hi = max(a - 3, 0), min(a + 40 + 3, n)
+        want = oc.jacobi(U[:, lo:hi, :], F[:, lo:hi, :], 3)
+        top = 0 if lo == 0 else 3
+        bot = (hi - lo) if hi == n else (hi - lo) - 3
+        assert np.array_equal(want[:, top:bot, :], got[:, lo + top:lo + bot, :]), a
+
+
+def test_bench_config5_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 --config c5` started directly: BASELINE config 5 as written -- 64 x 1024^2 clones sharded
+    i mod N (here 32 per rank, both ranks on this box's one GPU), strong scaling, one JSON line from rank 0."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c5", "--steps", "2", "--warmup", "1",
+                        "--cpu-seconds", "0", "--kernel-launches", "4"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 32 and d["config"]["roi"] == [1024, 1024]
+    assert d["value"] > 0 and "config 5" in d["metric"]
+    assert abs(d["value"] - 64 * 1024 * 1024 * 2 / (d["ms_per_step"] * 2e-3) / 1e6) < 0.01 * d["value"]

@@ -267,3 +267,33 @@ def test_reference_tables_singular_threshold():
         assert bool(L.sc_hip_reference_tables_singular(w, h)) == singular(w, h), (w, h)
     assert L.sc_hip_reference_tables_singular(2046, 2046) == 0 and L.sc_hip_reference_tables_singular(16382, 16382) == 1
     assert L.sc_hip_reference_tables_singular(16382, 2046) == 0          # one short side keeps the denominator negative
+
+
+def test_config5_sharding_is_i_mod_n():
+    """bench.py --config c5: BASELINE config 5 as written -- 64 images, image i on rank i mod N, 8 per GPU at N = 8; every image
+    belongs to exactly one rank for every N the driver uses."""
+    from seamlesscloneoptimization_amd.batch import shard_indices
+    for n in (1, 2, 4, 8):
+        shards = [shard_indices(64, r, n) for r in range(n)]
+        assert sorted(i for s in shards for i in s) == list(range(64))
+        assert all(len(s) == 64 // n for s in shards) and all(i % n == r for r, s in enumerate(shards) for i in s)
+    assert len(shard_indices(64, 7, 8)) == 8
+    # the launcher forwards the mode to every rank
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"--config"' in src and "shard_indices(64, comm.rank, comm.world)" in src and '"strong" if args.config == "c5"' in src
+
+
+def test_launcher_survives_a_chatty_rank0(tmp_path):
+    """Rank 0 printing more than a pipe buffer (64 KiB) before the others finish must not dead-lock the launcher: its
+    stdout goes to a file that is read at the end."""
+    from seamlesscloneoptimization_amd.batch import spawn_ranks
+    stub = tmp_path / "chatty.py"
+    stub.write_text("import os, sys, time\n"
+                    "r = int(os.environ['RANK'])\n"
+                    "if r == 0:\n"
+                    "    sys.stdout.write('x' * 300000 + '\\n'); sys.stdout.flush()\n"
+                    "else:\n"
+                    "    time.sleep(0.3)\n"
+                    "print('done', r, flush=True)\n")
+    rc, out = spawn_ranks(2, [sys.executable, str(stub)])
+    assert rc == 0 and len(out) > 300000 and out.strip().endswith("done 0")

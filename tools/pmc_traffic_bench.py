@@ -4,7 +4,9 @@ KiB units -- MI355X_MICROARCH.md, HBM section; FETCH_SIZE and WRITE_SIZE come fr
 timed step (difference of the totals of a 3-step and a 1-step run, divided by 2).
 
 usage: pmc_traffic_bench.py <fetch dir, 3 steps> <write dir, 3 steps> <fetch dir, 1 step> <write dir, 1 step> <out.json> roi batch group git"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from seamlesscloneoptimization_amd.capi import source_fingerprint   # hashes source files only: no library is loaded
 
 
 def load(d, counter):
@@ -33,7 +35,7 @@ for k in sorted(set(pf) | set(pw)):
 step = ((2 * tf3 + tw3) - (2 * tf1 + tw1)) * 1024 / 2.0
 json.dump({"note": "bytes crossing the L2 -> fabric boundary (Infinity-Cache hits included); read side = 2 x FETCH_SIZE (gfx950 "
                    "correction), KiB units; separate rocprofv3 --pmc passes over `python3 bench.py --cpu-seconds 0 --warmup 0 --steps {3,1}`",
-           "roi": roi, "batch": batch, "group": group, "git": git, "step_traffic_bytes": int(step), "kernels": kern}, open(out, "w"), indent=1)
+           "roi": roi, "batch": batch, "group": group, "git": git, "source_fingerprint": source_fingerprint(), "step_traffic_bytes": int(step), "kernels": kern}, open(out, "w"), indent=1)
 print("step traffic %.2f GB" % (step / 1e9))
 for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"])[:14]:
     print(f"{v['traffic_bytes_per_launch']/1e6:10.2f} MB x{v['launches_sampled']:5d}  {k[:100]}")
