@@ -161,7 +161,7 @@ def reference_table(args):
                "destination restored on the host between rounds (restore time reported, not included)", "published": published[f"{pw}x{ph}"]}
         outs = {}
         for name, method in (("default_auto", capi.SC_METHOD_AUTO), ("multigrid_plus_float_table_correction", capi.SC_METHOD_MULTIGRID),
-                             ("direct_dst", capi.SC_METHOD_DST)):
+                             ("direct_dst", capi.SC_METHOD_DST), ("direct_fft", capi.SC_METHOD_FFT)):
             inst.set_solver(method=method, flags=args.extra_flags)
             body = dst.copy()
             inst.run(patch, body, mask, cx, cy)
@@ -175,7 +175,7 @@ def reference_table(args):
             outs[name] = body.copy()
             row[name] = {"ms_per_clone_end_to_end": round(t_run / 50 * 1e3, 4), "h2d_ms": round(i.ms_h2d, 4), "device_ms": round(i.ms_device_total, 4),
                          "d2h_ms": round(i.ms_d2h, 4), "restore_ms_not_included": round(t_restore / 50 * 1e3, 4), "roi": [i.W, i.H],
-                         "device_bytes": int(i.device_bytes), "method_that_ran": {3: "multigrid", 4: "dst"}.get(i.method, i.method)}
+                         "device_bytes": int(i.device_bytes), "method_that_ran": {3: "multigrid", 4: "dst", 6: "fft"}.get(i.method, i.method)}
         inst.set_solver(method=capi.SC_METHOD_AUTO)
         t0 = time.perf_counter(); ref = oc.seamless_clone(dst, patch, mask, cx, cy, 1, False); one = time.perf_counter() - t0
         reps = max(1, min(20, int(args.cpu_seconds / 4 / max(one, 1e-4))))
@@ -335,6 +335,12 @@ def main():
     clone(inst, jobs[0], sync=True)
     di = inst.info()
     out_dst = inst.from_device(jobs[0]["b"], dst.shape)
+    # ---- the reference's DEFAULT back-end: FFT-based direct solve in float32 (SC_METHOD_FFT, sc_fft.hip)
+    inst.set_solver(method=capi.SC_METHOD_FFT)
+    clone(inst, jobs[0], sync=True)                  # builds the chirp / transform tables for this size
+    clone(inst, jobs[0], sync=True)
+    fi = inst.info()
+    out_fft = inst.from_device(jobs[0]["b"], dst.shape)
     inst.set_solver(method=methods[args.method])
     wp = hp = 2 * (-(-((W - 2 + 1) // 2) // 128) * 128)       # two parity halves, each padded to 128
     dst_flop = 3 * (2.0 * hp * wp * wp + 2.0 * hp * hp * wp)      # the even/odd fold halves the plain matrix form's 2 n^3 per product
@@ -348,6 +354,24 @@ def main():
                     "note": "the reference's own algorithm (direct DST, float tables); the DST matrix's mirror symmetry splits every product "
                             "into two of half the size (flop_per_clone counts what is executed: half of the plain matrix form); peak = MI355X "
                             "FP64 matrix spec; solve stage of one clone by hipEvents (includes the fold / unfold kernels)"}
+
+    nfft = 1
+    while nfft < 2 * (W - 2) - 1:
+        nfft *= 2
+    lg = nfft.bit_length() - 1
+    fft_flop = 3.0 * 4 * (W - 2) * 2 * 5.0 * nfft * lg            # 4 DST passes x rows x 2 FFTs x 5 M log2 M, 3 channels
+    fft_bytes = 3.0 * (W - 2) * (H - 2) * 4 * (2 + 2 + 2 + 2 + 2 + 1)   # five launches read + write a float per unknown; the first reads F, the last writes U
+    df = np.abs(out_fft.astype(np.int16) - out_float.astype(np.int16))
+    roofline_fft = {"bound": "hbm", "kernel": "k_fft_dst<0|1|2> (chirp-z DST-I over a power-of-two FFT in LDS, one workgroup per row) + 2 x k_fft_transpose, SC_METHOD_FFT",
+                    "achieved": round(fft_bytes / (fi.ms_solve * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(fft_bytes / (fi.ms_solve * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "ms_solve": round(fi.ms_solve, 4), "ms_device_total": round(fi.ms_device_total, 4), "fft_length": nfft,
+                    "flop_per_clone": int(fft_flop), "TFLOP_per_s_fp32": round(fft_flop / (fi.ms_solve * 1e-3) / 1e12, 2),
+                    "algorithmic_bytes_per_clone": int(fft_bytes),
+                    "vs_default_path": {"maxdiff": int(df.max()), "percent_differing": round(float((df > 0).mean() * 100), 4)},
+                    "note": "the reference's default algorithm (direct DST via FFTs, float32, float tables); solve stage of one clone by "
+                            "hipEvents; the launches are bound by LDS bandwidth and float32 butterflies, not by HBM (frac = algorithmic "
+                            "bytes of the five launches / time / 8 TB/s)"}
 
     # ---- the drop-in call itself: pageable host images in, result in the caller's image (PCIe inclusive)
     body = dst.copy()
@@ -525,7 +549,7 @@ def main():
                                    "note": "one clone alone on the GPU, hipEvent marks; solve includes the float-table correction and, "
                                            "when post = 0, the post-process enqueued directly behind it"},
         "roofline": roofline, "roofline_red_black": roofline_rb, "roofline_jacobi": roofline_j,
-        "roofline_jacobi_single_sweep": roofline_j1, "roofline_c4": roofline_c4, "roofline_direct_dst": roofline_dst,
+        "roofline_jacobi_single_sweep": roofline_j1, "roofline_c4": roofline_c4, "roofline_direct_dst": roofline_dst, "roofline_direct_fft": roofline_fft,
         "source_fingerprint": src_fp,
         "whole_step_fabric": ({"bytes_per_step": int(step_traffic), "TB_per_s": round(step_traffic / (elapsed / args.steps) / 1e12, 3),
                                "frac_of_peak": round(step_traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),

@@ -58,11 +58,17 @@ enum sc_method {
                                 u = S_h ((S_h g S_w) / den) S_w with den = filter_X + filter_Y - 4 from the float
                                 tables of :596-599, four double-precision products on the matrix cores.  O(n^3):
                                 milliseconds at 2048^2; the non-iterative cross-check of the default path          */
-    SC_METHOD_AUTO   = 5     /* DEFAULT.  SC_METHOD_DST for ROIs of at most SC_AUTO_DIRECT_MAX unknowns per side (there it
+    SC_METHOD_AUTO   = 5,    /* DEFAULT.  SC_METHOD_DST for ROIs of at most SC_AUTO_DIRECT_MAX unknowns per side (there it
                                 costs what the multigrid path costs and has no iteration error: diff sum against the
                                 float-table CPU port 2 instead of 129 at the reference's 300x194 patch, whose own published
                                 deviation from OpenCV is 44, PDF p3) and for thin ROIs (SC_AUTO_THIN_MAX), SC_METHOD_MULTIGRID above and whenever tol > 0
                                 asks for a residual-based stop.  sc_run_info.method says which one ran.           */
+    SC_METHOD_FFT    = 6     /* the reference's DEFAULT direct back-end (poissonSolver2D_FFT, seamlessClone_imp.cpp:1694-1918):
+                                the same u = S_h ((S_h g S_w) / den) S_w in float32 with FFT-based transforms, O(n^2 log n).
+                                The DST-I of each row is a chirp-z transform over a power-of-two FFT held in LDS (sc_fft.hip);
+                                at most 8192 unknowns per side (SC_ERR_BAD_SIZE beyond).  float32 like cuFFT / OpenCV's dft:
+                                within +-1 of the float-table port, diff sums of the size the reference publishes for its
+                                own cuFFT path against OpenCV (PDF p3)                                           */
 };
 #define SC_AUTO_DIRECT_MAX 640
 #define SC_AUTO_THIN_MAX 6          /* ... and for thin ROIs (at most this many unknowns across, up to SC_AUTO_THIN_LONG_MAX along) */

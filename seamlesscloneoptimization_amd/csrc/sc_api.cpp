@@ -421,6 +421,8 @@ void my_seamlessclone_api_imp_destroy(void *p)
     for (auto &m : I->lm.maps) if (m.h.p) (void)hipHostFree(m.h.p);
     for (DevBuf *b : { &I->dst.Sw, &I->dst.Sh, &I->dst.fxy, &I->dst.G, &I->dst.T1, &I->dst.T2 }) if (b->p) (void)hipFree(b->p);
     if (I->dst.hfxy.p) (void)hipHostFree(I->dst.hfxy.p);
+    for (DevBuf *b : { &I->fft.dw.chirp, &I->fft.dh.chirp, &I->fft.A, &I->fft.B, &I->fft.fxy }) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : { &I->fft.dw.h, &I->fft.dh.h, &I->fft.hfxy }) if (b->p) (void)hipHostFree(b->p);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
     if (I->h_fd.p) (void)hipHostFree(I->h_fd.p);
     if (I->d_rect) (void)hipFree(I->d_rect);
@@ -458,7 +460,7 @@ int sc_hip_set_solver(void *p, const sc_solver_opts *o)
 {
     Instance *I = get(p);
     if (!I || !o) return SC_ERR_BAD_ARG;
-    if (o->method < SC_METHOD_JACOBI || o->method > SC_METHOD_AUTO || o->max_sweeps < 0) {
+    if (o->method < SC_METHOD_JACOBI || o->method > SC_METHOD_FFT || o->max_sweeps < 0) {
         I->err = "bad solver options";
         return SC_ERR_BAD_ARG;
     }

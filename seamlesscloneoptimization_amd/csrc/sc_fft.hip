@@ -1,0 +1,404 @@
+// sc_fft.hip -- SC_METHOD_FFT: the reference's DEFAULT direct back-end (poissonSolver2D_FFT, seamlessClone_imp.cpp:1694-1918),
+// hand-written for gfx950: O(n^2 log n), float32 like cuFFT and OpenCV's dft.
+//
+// The reference solves the 5-point system with two batched 1-D complex FFTs of the odd extension per direction (length
+// 2n+2, :1337-1456 / :1735-1794), divides by den = filter_X + filter_Y - 4 (float tables, :1642-1669) and transforms back
+// (:1814-1896).  The transform it needs is the DST-I,
+//     X_k = sum_{j=1..n} x_j sin(pi j k / (n+1)),   k = 1..n,
+// and 2n+2 is rarely a friendly FFT length (4094 = 2 x 23 x 89 at the headline size; cuFFT itself goes through Bluestein for
+// such lengths).  This file computes the DST-I directly as a chirp-z transform: with N = 2(n+1), c_m = exp(i pi m^2 / N),
+//     sin(2 pi j k / N) = Im[ c_j c_k conj(c_{k-j}) ]      =>      X_k = Im[ c_k  sum_j (x_j c_j) conj(c_{k-j}) ],
+// a linear convolution of n points with a 2n-1 point kernel, i.e. a circular convolution of any length M >= 2n-1: M is the
+// next power of two (4096 for n = 2046 -- HALF the 8192 the odd-extension route would need), and the convolution is two
+// power-of-two FFTs in LDS around a pointwise product with the precomputed transform of the chirp.
+//
+// One workgroup per row: the row is loaded once, multiplied by the chirp into LDS (M complex floats, padded against bank
+// conflicts), transformed by in-place radix-16 / 8 / 4 / 2 Gentleman-Sande passes (registers hold a 16-point DFT; the
+// result stays in digit-reversed order), multiplied by the chirp's transform (stored in that same order, 1/M folded in),
+// and brought back by the adjoint passes in reverse order -- no reordering pass at all.  Twiddles come from a table computed
+// in double; the chirp phases are reduced exactly in integers (m^2 mod 2N) before the double sincospi.
+//
+// The 2-D solve is three such launches and two tiled transposes:
+//     rows (fold of the Dirichlet ring fused into the load) -> transpose -> columns: DST, divide by den, DST again, all in
+//     one launch (the row never leaves LDS) -> transpose -> rows (scale 4/((w+1)(h+1)) and the store into the field fused).
+// Everything is float32 (the reference's precision); the float tables are the reference's to the letter (:596-599).
+#include "sc_instance.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace sc {
+
+constexpr int FFT_THREADS = 256;
+constexpr int FFT_MAX_LOGM = 14;                       // M = 16384: n <= 8192 unknowns per side (139 KB of LDS)
+__host__ __device__ __forceinline__ int fft_pad(int i) { return i + (i >> 4); }     // 1 pad element per 16: keeps the strided passes off one bank
+
+struct FftPlan {                                       // one direction (by value in the kernel arguments)
+    const float2 *chirp;                               // c_m, m = 0 .. n
+    const float2 *bhat;                                // transform of the chirp kernel, digit-reversed order, scaled by 1/M
+    const float2 *tw;                                  // exp(-2 pi i k / M), k = 0 .. M-1
+    int n, M, logM, npass;
+    int lr[4];                                         // log2 of the radix of each forward pass
+};
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmulcf(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+
+// R-point DFT in registers, natural order in and out; SGN = -1: exp(-2 pi i jk/R), +1: the conjugate.
+// Radix-2 decimation-in-frequency stages with compile-time twiddles, then the bit-reversal as register renaming.
+template <int R, int SGN>
+__device__ __forceinline__ void dft_small(float2 (&v)[R])
+{
+    constexpr float C16[8] = { 1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f, -0.38268343236508977f,
+                               -0.70710678118654752f, -0.92387953251128674f };
+    constexpr float S16[8] = { 0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f, 0.92387953251128674f,
+                               0.70710678118654752f, 0.38268343236508977f };
+#pragma unroll
+    for (int len = R; len >= 2; len >>= 1) {
+        const int half = len >> 1;
+#pragma unroll
+        for (int blk = 0; blk < R; blk += len) {
+#pragma unroll
+            for (int k = 0; k < half; ++k) {
+                const float2 a = v[blk + k], b = v[blk + k + half];
+                v[blk + k] = make_float2(a.x + b.x, a.y + b.y);
+                const float2 d = make_float2(a.x - b.x, a.y - b.y);
+                const int e = k * (16 / len);                   // twiddle exp(SGN 2 pi i e / 16), e in 0..7
+                if (e == 0) v[blk + k + half] = d;
+                else if (e == 4) v[blk + k + half] = (SGN < 0) ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
+                else {
+                    const float c = C16[e], s = (SGN < 0) ? -S16[e] : S16[e];
+                    v[blk + k + half] = make_float2(d.x * c - d.y * s, d.x * s + d.y * c);
+                }
+            }
+        }
+    }
+    if (R > 2) {
+        float2 t[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            int r = 0;
+#pragma unroll
+            for (int bit = 1, rb = R >> 1; bit < R; bit <<= 1, rb >>= 1) if (i & bit) r |= rb;
+            t[r] = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] = t[i];
+    }
+}
+
+// One in-place Gentleman-Sande pass over S[0..M): sub-transforms of length L = 2^lL split by radix R = 2^LR.
+// Butterfly b = (blk, t): elements blk L + t + q (L/R); outputs y_q'[t] = DFT_R(.)[q'] w_L^(t q') stored at the same places.
+template <int LR>
+__device__ __forceinline__ void pass_fwd(float2 *__restrict__ S, int logM, int lL, const float2 *__restrict__ tw, int tid)
+{
+    constexpr int R = 1 << LR;
+    const int M = 1 << logM, ls = lL - LR, s = 1 << ls, twsh = logM - lL;
+    for (int b = tid; b < (M >> LR); b += FFT_THREADS) {
+        const int blk = b >> ls, t = b & (s - 1);
+        const int base = (blk << lL) + t;
+        float2 v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = S[fft_pad(base + (q << ls))];
+        dft_small<R, -1>(v);
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[q] = cmulf(v[q], tw[((t * q) << twsh) & (M - 1)]);
+#pragma unroll
+        for (int q = 0; q < R; ++q) S[fft_pad(base + (q << ls))] = v[q];
+    }
+}
+// its adjoint (the passes of the inverse transform, applied in reverse order)
+template <int LR>
+__device__ __forceinline__ void pass_adj(float2 *__restrict__ S, int logM, int lL, const float2 *__restrict__ tw, int tid)
+{
+    constexpr int R = 1 << LR;
+    const int M = 1 << logM, ls = lL - LR, s = 1 << ls, twsh = logM - lL;
+    for (int b = tid; b < (M >> LR); b += FFT_THREADS) {
+        const int blk = b >> ls, t = b & (s - 1);
+        const int base = (blk << lL) + t;
+        float2 v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = S[fft_pad(base + (q << ls))];
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[q] = cmulcf(v[q], tw[((t * q) << twsh) & (M - 1)]);
+        dft_small<R, +1>(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) S[fft_pad(base + (q << ls))] = v[q];
+    }
+}
+
+// S holds a_j = x_j c_j at j = 1..n and zeros elsewhere (synchronised).  On return S[k] = sum_j a_j conj(c_{k-j}), k = 1..n
+// (synchronised): forward passes, pointwise product with the chirp's transform, adjoint passes.
+__device__ __forceinline__ void chirp_convolve(float2 *__restrict__ S, const FftPlan &P, int tid)
+{
+    int lL = P.logM;
+    for (int p = 0; p < P.npass; ++p) {
+        const int lr = P.lr[p];
+        if (lr == 4) pass_fwd<4>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 3) pass_fwd<3>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 2) pass_fwd<2>(S, P.logM, lL, P.tw, tid);
+        else pass_fwd<1>(S, P.logM, lL, P.tw, tid);
+        lL -= lr;
+        __syncthreads();
+    }
+    for (int i = tid; i < P.M; i += FFT_THREADS) S[fft_pad(i)] = cmulf(S[fft_pad(i)], P.bhat[i]);
+    __syncthreads();
+    for (int p = P.npass - 1; p >= 0; --p) {
+        const int lr = P.lr[p];
+        lL += lr;
+        if (lr == 4) pass_adj<4>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 3) pass_adj<3>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 2) pass_adj<2>(S, P.logM, lL, P.tw, tid);
+        else pass_adj<1>(S, P.logM, lL, P.tw, tid);
+        __syncthreads();
+    }
+}
+
+// folded right-hand side g = lap - ring neighbours (seamlessClone_imp.cpp:1992-2008) at interior point (x, y), 0-based
+__device__ __forceinline__ float fft_g(const Field &U, const Field &F, int c, int x, int y)
+{
+    const int w = U.W - 2, h = U.H - 2;
+    const size_t o = (size_t)(y + 1) * U.pitch + (x + 1);
+    const float *__restrict__ u = U.at(c);
+    float v = F.at(c)[o];
+    if (x == 0) v -= u[o - 1];
+    if (y == 0) v -= u[o - U.pitch];
+    if (x == w - 1) v -= u[o + 1];
+    if (y == h - 1) v -= u[o + U.pitch];
+    return v;
+}
+
+// MODE 0: rows of the folded right-hand side (from the fields) -> T[c][y][x]
+// MODE 1: rows of `in` (the transposed plane: row = x, entries = y) -> DST, / den, DST -> out, same layout
+// MODE 2: rows of `in` [c][y][x] -> DST, scale -> interior of the field U
+template <int MODE>
+__global__ __launch_bounds__(FFT_THREADS) void k_fft_dst(FftPlan P, Field U, Field F, const float *__restrict__ in, float *__restrict__ out,
+                                                         int rows, const float *__restrict__ f_row, const float *__restrict__ f_k, int exact,
+                                                         float scale)
+{
+    extern __shared__ float2 S[];
+    const int tid = threadIdx.x, r = blockIdx.x, c = blockIdx.y, n = P.n;
+    const float *__restrict__ src = (MODE == 0) ? nullptr : in + ((size_t)c * rows + r) * n;
+    for (int i = tid; i < P.M; i += FFT_THREADS) {
+        float2 a = make_float2(0.f, 0.f);
+        if (i >= 1 && i <= n) {
+            const float x = (MODE == 0) ? fft_g(U, F, c, i - 1, r) : src[i - 1];
+            const float2 ch = P.chirp[i];
+            a = make_float2(x * ch.x, x * ch.y);
+        }
+        S[fft_pad(i)] = a;
+    }
+    __syncthreads();
+    chirp_convolve(S, P, tid);
+    if (MODE == 1) {
+        // X_k = Im(c_k y_k); divide by the reference's denominator (seamlessClone_imp.cpp:1651-1653: float tables added in float,
+        // then - 4) and feed the quotient straight into the second transform: the row stays in LDS
+        // (element k is read and rewritten by the same thread, the zeroed elements are read by nobody here: no barrier in between)
+        for (int k = 1 + tid; k <= n; k += FFT_THREADS) {
+            const float2 y = S[fft_pad(k)], ch = P.chirp[k];
+            const float X = ch.x * y.y + ch.y * y.x;
+            float den;
+            if (exact) den = (float)((2.0 * cospi((double)(r + 1) / (double)(rows + 1)) + 2.0 * cospi((double)k / (double)(n + 1))) - 4.0);
+            else den = (f_row[r] + f_k[k - 1]) - 4.0f;
+            const float q = X / den;
+            S[fft_pad(k)] = make_float2(q * ch.x, q * ch.y);
+        }
+        for (int i = tid; i < P.M; i += FFT_THREADS) if (i == 0 || i > n) S[fft_pad(i)] = make_float2(0.f, 0.f);
+        __syncthreads();
+        chirp_convolve(S, P, tid);
+    }
+    for (int k = 1 + tid; k <= n; k += FFT_THREADS) {
+        const float2 y = S[fft_pad(k)], ch = P.chirp[k];
+        const float X = ch.x * y.y + ch.y * y.x;
+        if (MODE == 2) U.at(c)[(size_t)(r + 1) * U.pitch + k] = X * scale;
+        else out[((size_t)c * rows + r) * n + (k - 1)] = X;
+    }
+}
+
+// out[c][x][y] = in[c][y][x]; 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void k_fft_transpose(const float *__restrict__ in, float *__restrict__ out, int rows, int cols)
+{
+    __shared__ float t[64][65];
+    const int c = blockIdx.z, x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const float *__restrict__ src = in + (size_t)c * rows * cols;
+    float *__restrict__ dst = out + (size_t)c * rows * cols;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int y = y0 + ly + 4 * k, x = x0 + lx;
+        t[ly + 4 * k][lx] = (y < rows && x < cols) ? src[(size_t)y * cols + x] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int x = x0 + ly + 4 * k, y = y0 + lx;
+        if (x < cols && y < rows) dst[(size_t)x * rows + y] = t[lx][ly + 4 * k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static int fft_logm(int n)
+{
+    int l = 1;
+    while ((1 << l) < 2 * n - 1) ++l;
+    return l;
+}
+
+bool fft_supported(int w, int h) { return w >= 1 && h >= 1 && fft_logm(w) <= FFT_MAX_LOGM && fft_logm(h) <= FFT_MAX_LOGM; }
+
+static void fft_radices(int logM, int lr[4], int &npass)
+{
+    npass = 0;
+    int rem = logM;
+    while (rem >= 4) { lr[npass++] = 4; rem -= 4; }
+    if (rem > 0) lr[npass++] = rem;
+}
+
+// position of frequency k after the forward passes (radices lr[p..]) of a length-2^lL block
+static int fft_position(int k, int lL, const int *lr, int npass)
+{
+    int pos = 0;
+    for (int p = 0; p < npass; ++p) {
+        const int R = 1 << lr[p];
+        pos += (k & (R - 1)) << (lL - lr[p]);
+        k >>= lr[p];
+        lL -= lr[p];
+    }
+    return pos;
+}
+
+// in-place radix-2 FFT in double (host: the chirp kernel's transform, once per size)
+static void host_fft(std::vector<double> &re, std::vector<double> &im)
+{
+    const size_t M = re.size();
+    for (size_t i = 1, j = 0; i < M; ++i) {
+        size_t bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= M; len <<= 1) {
+        const size_t half = len >> 1;
+        for (size_t k = 0; k < half; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)len, wr = std::cos(a), wi = std::sin(a);
+            for (size_t i = k; i < M; i += len) {
+                const size_t j = i + half;
+                const double tr = re[j] * wr - im[j] * wi, ti = re[j] * wi + im[j] * wr;
+                re[j] = re[i] - tr; im[j] = im[i] - ti;
+                re[i] += tr; im[i] += ti;
+            }
+        }
+    }
+}
+
+static int fft_build_dim(Instance *I, FftDim &D, int n)
+{
+    if (D.n == n && D.chirp.p) return SC_OK;
+    const int logM = fft_logm(n), M = 1 << logM;
+    int rc;
+    SC_HIP(I, hipStreamSynchronize(I->stream));        // the pinned staging below may still feed the previous size's upload (rare: a new ROI size)
+    const size_t bytes = sizeof(float2) * ((size_t)(n + 1) + 2 * (size_t)M);
+    if ((rc = ensure(I, D.chirp, bytes))) return rc;
+    if ((rc = ensure_pinned(I, D.h, bytes))) return rc;
+    float2 *hc = (float2 *)D.h.p, *hb = hc + (n + 1), *ht = hb + M;
+    const long N2 = 4L * (n + 1);                       // 2N: the period of m^2 in exp(i pi m^2 / N)
+    const double invN = 1.0 / (2.0 * (n + 1));
+    std::vector<double> cr(n + 1), ci(n + 1);
+    for (int m = 0; m <= n; ++m) {
+        const long q = ((long)m * m) % N2;
+        const double a = M_PI * (double)q * invN;
+        cr[m] = std::cos(a); ci[m] = std::sin(a);
+        hc[m] = make_float2((float)cr[m], (float)ci[m]);
+    }
+    std::vector<double> br(M, 0.0), bi(M, 0.0);
+    br[0] = 1.0;
+    for (int m = 1; m <= n - 1; ++m) { br[m] = br[M - m] = cr[m]; bi[m] = bi[M - m] = -ci[m]; }
+    host_fft(br, bi);
+    int lr[4], npass;
+    fft_radices(logM, lr, npass);
+    for (int k = 0; k < M; ++k) {
+        const int pos = fft_position(k, logM, lr, npass);
+        hb[pos] = make_float2((float)(br[k] / M), (float)(bi[k] / M));
+    }
+    for (int k = 0; k < M; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)M;
+        ht[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    SC_HIP(I, hipMemcpyAsync(D.chirp.p, D.h.p, bytes, hipMemcpyHostToDevice, I->stream));
+    D.n = n; D.logM = logM;
+    return SC_OK;
+}
+
+static FftPlan fft_plan_of(const FftDim &D)
+{
+    FftPlan P{};
+    P.chirp = (const float2 *)D.chirp.p;
+    P.bhat = P.chirp + (D.n + 1);
+    P.tw = P.bhat + ((size_t)1 << D.logM);
+    P.n = D.n; P.logM = D.logM; P.M = 1 << D.logM;
+    fft_radices(D.logM, P.lr, P.npass);
+    return P;
+}
+
+static hipError_t fft_opt_in_lds()
+{
+    static bool done = false;
+    if (done) return hipSuccess;
+    const int bytes = (int)(sizeof(float2) * (size_t)fft_pad(1 << FFT_MAX_LOGM)) + 64;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done = e == hipSuccess;
+    return e;
+}
+
+// Direct solve of the fields bound to the instance: interior of result(I) <- the reference's answer.  F must be float.
+int fft_solve(Instance *I)
+{
+    if (I->f_half) { I->err = "internal: float16 right-hand side on the direct path"; return SC_ERR_BAD_ARG; }
+    const int w = I->F.W - 2, h = I->F.H - 2, C = I->F.C;
+    if (!fft_supported(w, h)) { I->err = "SC_METHOD_FFT: more than 8192 unknowns per side"; return SC_ERR_BAD_SIZE; }
+    SC_HIP(I, fft_opt_in_lds());
+    FftState &S = I->fft;
+    int rc;
+    if ((rc = fft_build_dim(I, S.dw, w))) return rc;
+    if ((rc = fft_build_dim(I, S.dh, h))) return rc;
+    const size_t plane = (size_t)w * h;
+    if ((rc = ensure(I, S.A, sizeof(float) * plane * C))) return rc;
+    if ((rc = ensure(I, S.B, sizeof(float) * plane * C))) return rc;
+    bool singular = false;
+    if (S.tw != w || S.th != h) {
+        // the reference's float tables (seamlessClone_imp.cpp:596-599; PI is the float literal of seamlessClone_imp.h:17)
+        if ((rc = ensure(I, S.fxy, sizeof(float) * (size_t)(w + h)))) return rc;
+        if ((rc = ensure_pinned(I, S.hfxy, sizeof(float) * (size_t)(w + h)))) return rc;
+        const double PIf = (double)3.14159265358979323846f;
+        float *fx = (float *)S.hfxy.p, *fy = fx + w;
+        for (int i = 0; i < w; ++i) fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
+        for (int j = 0; j < h; ++j) fy[j] = (float)(2.0 * std::cos(PIf / (h + 1.0) * (j + 1.0)));
+        S.singular = !((fx[0] + fy[0]) - 4.0f < 0.0f);
+        SC_HIP(I, hipMemcpyAsync(S.fxy.p, S.hfxy.p, sizeof(float) * (size_t)(w + h), hipMemcpyHostToDevice, I->stream));
+        S.tw = w; S.th = h;
+    }
+    singular = S.singular;
+    const int exact = (singular || (I->opts.flags & SC_FLAG_EXACT_TABLES)) ? 1 : 0;
+    const FftPlan Pw = fft_plan_of(S.dw), Ph = fft_plan_of(S.dh);
+    const size_t ldsw = sizeof(float2) * (size_t)(fft_pad(Pw.M) + 1), ldsh = sizeof(float2) * (size_t)(fft_pad(Ph.M) + 1);
+    Field &U = I->result_in_U1 ? I->U1 : I->U0;
+    float *A = (float *)S.A.p, *B = (float *)S.B.p;
+    const float *fx = (const float *)S.fxy.p, *fy = fx + w;
+    const float scale = (float)(4.0 / ((w + 1.0) * (h + 1.0)));
+    const dim3 tg_hw((w + 63) / 64, (h + 63) / 64, C), tg_wh((h + 63) / 64, (w + 63) / 64, C);
+    hipLaunchKernelGGL(k_fft_dst<0>, dim3(h, C), dim3(FFT_THREADS), ldsw, I->stream, Pw, U, I->F, (const float *)nullptr, A, h, fx, fy, exact, 1.0f);
+    hipLaunchKernelGGL(k_fft_transpose, tg_hw, dim3(256), 0, I->stream, (const float *)A, B, h, w);                 // B[c][x][y]
+    hipLaunchKernelGGL(k_fft_dst<1>, dim3(w, C), dim3(FFT_THREADS), ldsh, I->stream, Ph, U, I->F, (const float *)B, A, w, fx, fy, exact, 1.0f);
+    hipLaunchKernelGGL(k_fft_transpose, tg_wh, dim3(256), 0, I->stream, (const float *)A, B, w, h);                 // B[c][y][x]
+    hipLaunchKernelGGL(k_fft_dst<2>, dim3(h, C), dim3(FFT_THREADS), ldsw, I->stream, Pw, U, I->F, (const float *)B, A, h, fx, fy, exact, scale);
+    SC_HIP(I, hipGetLastError());
+    I->info.sweeps = 1;
+    I->info.converged = 1;
+    I->info.sweep_launches += 3;
+    return SC_OK;
+}
+
+} // namespace sc

@@ -46,6 +46,15 @@ struct DstState {
     DevBuf hfxy;                           // pinned staging of the float tables
 };
 
+// FFT direct solve (sc_fft.hip): per-direction chirp / transform tables and the two work planes
+struct FftDim { int n = 0, logM = 0; DevBuf chirp, h; };                     // chirp: chirp[n+1] | bhat[M] | tw[M] (float2); h: pinned staging
+struct FftState {
+    FftDim dw, dh;
+    DevBuf A, B, fxy, hfxy;                // work planes [C][h][w] float; the reference's float tables fx[w] + fy[h] (device, pinned)
+    int tw = 0, th = 0;                    // size the float tables were built for
+    bool singular = false;
+};
+
 struct MGLevel {
     Field U, F, T;   // correction, RHS, scratch (residual field); level 0 aliases the instance fields
     MGGeom g;        // geometry of this level and of its transfer to the next coarser one
@@ -106,6 +115,7 @@ struct Instance {
     DevBuf mg_fd, h_fd;    // its matrices: device copy and pinned staging
     LowMode lm;
     DstState dst;
+    FftState fft;
     std::vector<FD1> fd_cache;   // recent 1-D decompositions (a geometry seen before costs no eigen-solve)
     size_t fd_cache_next = 0;
     // reductions / mailboxes
@@ -154,6 +164,8 @@ int lowmode_early_kind(Instance *I, float update_tol);                // see sc_
 void lowmode_bands_written(Instance *I, const float *field);       // the launch went in: B describes `field` (nullptr: nothing)
 int lowmode_count(int n);
 int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST
+int fft_solve(Instance *I);                                           // sc_fft.hip: SC_METHOD_FFT
+bool fft_supported(int w, int h);
 bool wants_float_tables(const Instance *I);
 int effective_method(const Instance *I);                              // sc_solver.cpp: what SC_METHOD_AUTO resolves to for the fields bound to I
 int output_nodes(Instance *I, LmNodes &lm);  // sc_solver.cpp: the float-table correction the post-process of result(I) has to add (none: lm.CN == nullptr)

@@ -137,6 +137,7 @@ int solve(Instance *I)
     I->info.method = method;
     if (method == SC_METHOD_MULTIGRID) return mg_solve(I);
     if (method == SC_METHOD_DST) return dst_solve(I);
+    if (method == SC_METHOD_FFT) return fft_solve(I);
     if (o.tol <= 0.f) {
         int rc = run_sweeps(I, o.method, o.max_sweeps, o.omega, o.sweeps_per_launch);
         if (rc) return rc;
