@@ -160,9 +160,12 @@ def reference_table(args):
         row = {"patch": f"{pw}x{ph}", "dst": [dw, dh], "protocol": "1 warm-up + 50 rounds, pageable host images, one application per call, "
                "destination restored on the host between rounds (restore time reported, not included)", "published": published[f"{pw}x{ph}"]}
         outs = {}
-        for name, method in (("default_auto", capi.SC_METHOD_AUTO), ("multigrid_plus_float_table_correction", capi.SC_METHOD_MULTIGRID),
-                             ("direct_dst", capi.SC_METHOD_DST), ("direct_fft", capi.SC_METHOD_FFT)):
-            inst.set_solver(method=method, flags=args.extra_flags)
+        for name, method, mflags in (("default_auto", capi.SC_METHOD_AUTO, 0), ("multigrid_plus_float_table_correction", capi.SC_METHOD_MULTIGRID, 0),
+                                     ("direct_dst", capi.SC_METHOD_DST, 0), ("direct_fft", capi.SC_METHOD_FFT, 0),
+                                     ("direct_fft_fp64", capi.SC_METHOD_FFT, capi.SC_FLAG_FFT_FP64)):
+            if name == "direct_fft_fp64" and max(pw, ph) > 4096:
+                continue
+            inst.set_solver(method=method, flags=args.extra_flags | mflags)
             body = dst.copy()
             inst.run(patch, body, mask, cx, cy)
             t_run = t_restore = 0.0
@@ -176,7 +179,7 @@ def reference_table(args):
             row[name] = {"ms_per_clone_end_to_end": round(t_run / 50 * 1e3, 4), "h2d_ms": round(i.ms_h2d, 4), "device_ms": round(i.ms_device_total, 4),
                          "d2h_ms": round(i.ms_d2h, 4), "restore_ms_not_included": round(t_restore / 50 * 1e3, 4), "roi": [i.W, i.H],
                          "device_bytes": int(i.device_bytes), "method_that_ran": {3: "multigrid", 4: "dst", 6: "fft"}.get(i.method, i.method)}
-        inst.set_solver(method=capi.SC_METHOD_AUTO)
+        inst.set_solver(method=capi.SC_METHOD_AUTO, flags=args.extra_flags)
         t0 = time.perf_counter(); ref = oc.seamless_clone(dst, patch, mask, cx, cy, 1, False); one = time.perf_counter() - t0
         reps = max(1, min(20, int(args.cpu_seconds / 4 / max(one, 1e-4))))
         t0 = time.perf_counter()

@@ -71,7 +71,7 @@ enum sc_method {
                                 own cuFFT path against OpenCV (PDF p3)                                           */
 };
 #define SC_AUTO_DIRECT_MAX 640
-#define SC_AUTO_THIN_MAX 6          /* ... and for thin ROIs (at most this many unknowns across, up to SC_AUTO_THIN_LONG_MAX along) */
+#define SC_AUTO_THIN_MAX 4          /* ... and for thin ROIs (at most this many unknowns across, up to SC_AUTO_THIN_LONG_MAX along) */
 #define SC_AUTO_THIN_LONG_MAX 2048
 
 typedef struct sc_solver_opts {
@@ -142,6 +142,11 @@ typedef struct sc_solver_opts {
                                             iterate one cycle earlier (difference at most 0.05 grey levels in the worst case the stop rule admits,
                                             0.001-0.003 measured; ROIs where
                                             that bound does not hold take this flag's path by themselves)        */
+
+#define SC_FLAG_FFT_FP64       (1 << 8)  /* SC_METHOD_FFT: the transforms in double instead of float32 (tables, LDS and the planes
+                                            between the launches); at most 4096 unknowns per side.  No transform rounding is left:
+                                            the result agrees with SC_METHOD_DST (both are the reference's float-table arithmetic
+                                            with exact transforms)                                                          */
 
 /* ---- statistics of the last run */
 typedef struct sc_run_info {

@@ -33,7 +33,7 @@ SC_METHOD_DST = 4
 SC_METHOD_AUTO = 5      # default: DST up to SC_AUTO_DIRECT_MAX unknowns per side, MULTIGRID above
 SC_METHOD_FFT = 6       # the reference's default back-end: FFT-based direct solve, float32, O(n^2 log n)
 SC_AUTO_DIRECT_MAX = 640
-SC_AUTO_THIN_MAX = 6
+SC_AUTO_THIN_MAX = 4
 SC_AUTO_THIN_LONG_MAX = 2048
 
 SC_FLAG_NO_SPECULATE = 1 << 0
@@ -44,6 +44,7 @@ SC_FLAG_VCYCLE_BOTTOM = 1 << 4
 SC_FLAG_EXACT_TABLES = 1 << 5
 SC_FLAG_SEPARATE_RESTRICT = 1 << 6
 SC_FLAG_KEEP_FIELD = 1 << 7
+SC_FLAG_FFT_FP64 = 1 << 8
 
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",

@@ -34,26 +34,33 @@ constexpr int FFT_THREADS = 256;
 constexpr int FFT_MAX_LOGM = 14;                       // M = 16384: n <= 8192 unknowns per side (139 KB of LDS)
 __host__ __device__ __forceinline__ int fft_pad(int i) { return i + (i >> 4); }     // 1 pad element per 16: keeps the strided passes off one bank
 
+// T = float: the reference's precision (cuFFT, OpenCV's dft).  T = double (SC_FLAG_FFT_FP64): the same transforms in double --
+// twice the LDS traffic, worth it for small ROIs where the launches are latency bound anyway: the result then carries no
+// transform rounding at all (diff sum against the float-table port 2 instead of ~50 at the reference's 300x194 patch).
+template <typename T> struct cx2 { T x, y; };
+template <typename T> __host__ __device__ __forceinline__ cx2<T> mk(T x, T y) { cx2<T> r; r.x = x; r.y = y; return r; }
+
+template <typename T>
 struct FftPlan {                                       // one direction (by value in the kernel arguments)
-    const float2 *chirp;                               // c_m, m = 0 .. n
-    const float2 *bhat;                                // transform of the chirp kernel, digit-reversed order, scaled by 1/M
-    const float2 *tw;                                  // exp(-2 pi i k / M), k = 0 .. M-1
+    const cx2<T> *chirp;                               // c_m, m = 0 .. n
+    const cx2<T> *bhat;                                // transform of the chirp kernel, digit-reversed order, scaled by 1/M
+    const cx2<T> *tw;                                  // exp(-2 pi i k / M), k = 0 .. M-1
     int n, M, logM, npass;
     int lr[4];                                         // log2 of the radix of each forward pass
 };
 
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmulcf(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+template <typename T> __device__ __forceinline__ cx2<T> cmulf(cx2<T> a, cx2<T> b) { return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <typename T> __device__ __forceinline__ cx2<T> cmulcf(cx2<T> a, cx2<T> b) { return mk<T>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
 
 // R-point DFT in registers, natural order in and out; SGN = -1: exp(-2 pi i jk/R), +1: the conjugate.
 // Radix-2 decimation-in-frequency stages with compile-time twiddles, then the bit-reversal as register renaming.
-template <int R, int SGN>
-__device__ __forceinline__ void dft_small(float2 (&v)[R])
+template <int R, int SGN, typename T>
+__device__ __forceinline__ void dft_small(cx2<T> (&v)[R])
 {
-    constexpr float C16[8] = { 1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f, -0.38268343236508977f,
-                               -0.70710678118654752f, -0.92387953251128674f };
-    constexpr float S16[8] = { 0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f, 0.92387953251128674f,
-                               0.70710678118654752f, 0.38268343236508977f };
+    constexpr double C16[8] = { 1.0, 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.0, -0.38268343236508977,
+                                -0.70710678118654752, -0.92387953251128674 };
+    constexpr double S16[8] = { 0.0, 0.38268343236508977, 0.70710678118654752, 0.92387953251128674, 1.0, 0.92387953251128674,
+                                0.70710678118654752, 0.38268343236508977 };
 #pragma unroll
     for (int len = R; len >= 2; len >>= 1) {
         const int half = len >> 1;
@@ -61,21 +68,21 @@ __device__ __forceinline__ void dft_small(float2 (&v)[R])
         for (int blk = 0; blk < R; blk += len) {
 #pragma unroll
             for (int k = 0; k < half; ++k) {
-                const float2 a = v[blk + k], b = v[blk + k + half];
-                v[blk + k] = make_float2(a.x + b.x, a.y + b.y);
-                const float2 d = make_float2(a.x - b.x, a.y - b.y);
+                const cx2<T> a = v[blk + k], b = v[blk + k + half];
+                v[blk + k] = mk<T>(a.x + b.x, a.y + b.y);
+                const cx2<T> d = mk<T>(a.x - b.x, a.y - b.y);
                 const int e = k * (16 / len);                   // twiddle exp(SGN 2 pi i e / 16), e in 0..7
                 if (e == 0) v[blk + k + half] = d;
-                else if (e == 4) v[blk + k + half] = (SGN < 0) ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
+                else if (e == 4) v[blk + k + half] = (SGN < 0) ? mk<T>(d.y, -d.x) : mk<T>(-d.y, d.x);
                 else {
-                    const float c = C16[e], s = (SGN < 0) ? -S16[e] : S16[e];
-                    v[blk + k + half] = make_float2(d.x * c - d.y * s, d.x * s + d.y * c);
+                    const T c = (T)C16[e], s = (T)((SGN < 0) ? -S16[e] : S16[e]);
+                    v[blk + k + half] = mk<T>(d.x * c - d.y * s, d.x * s + d.y * c);
                 }
             }
         }
     }
     if (R > 2) {
-        float2 t[R];
+        cx2<T> t[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             int r = 0;
@@ -90,39 +97,39 @@ __device__ __forceinline__ void dft_small(float2 (&v)[R])
 
 // One in-place Gentleman-Sande pass over S[0..M): sub-transforms of length L = 2^lL split by radix R = 2^LR.
 // Butterfly b = (blk, t): elements blk L + t + q (L/R); outputs y_q'[t] = DFT_R(.)[q'] w_L^(t q') stored at the same places.
-template <int LR>
-__device__ __forceinline__ void pass_fwd(float2 *__restrict__ S, int logM, int lL, const float2 *__restrict__ tw, int tid)
+template <int LR, typename T>
+__device__ __forceinline__ void pass_fwd(cx2<T> *__restrict__ S, int logM, int lL, const cx2<T> *__restrict__ tw, int tid)
 {
     constexpr int R = 1 << LR;
     const int M = 1 << logM, ls = lL - LR, s = 1 << ls, twsh = logM - lL;
     for (int b = tid; b < (M >> LR); b += FFT_THREADS) {
         const int blk = b >> ls, t = b & (s - 1);
         const int base = (blk << lL) + t;
-        float2 v[R];
+        cx2<T> v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = S[fft_pad(base + (q << ls))];
-        dft_small<R, -1>(v);
+        dft_small<R, -1, T>(v);
 #pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulf(v[q], tw[((t * q) << twsh) & (M - 1)]);
+        for (int q = 1; q < R; ++q) v[q] = cmulf<T>(v[q], tw[((t * q) << twsh) & (M - 1)]);
 #pragma unroll
         for (int q = 0; q < R; ++q) S[fft_pad(base + (q << ls))] = v[q];
     }
 }
 // its adjoint (the passes of the inverse transform, applied in reverse order)
-template <int LR>
-__device__ __forceinline__ void pass_adj(float2 *__restrict__ S, int logM, int lL, const float2 *__restrict__ tw, int tid)
+template <int LR, typename T>
+__device__ __forceinline__ void pass_adj(cx2<T> *__restrict__ S, int logM, int lL, const cx2<T> *__restrict__ tw, int tid)
 {
     constexpr int R = 1 << LR;
     const int M = 1 << logM, ls = lL - LR, s = 1 << ls, twsh = logM - lL;
     for (int b = tid; b < (M >> LR); b += FFT_THREADS) {
         const int blk = b >> ls, t = b & (s - 1);
         const int base = (blk << lL) + t;
-        float2 v[R];
+        cx2<T> v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = S[fft_pad(base + (q << ls))];
 #pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulcf(v[q], tw[((t * q) << twsh) & (M - 1)]);
-        dft_small<R, +1>(v);
+        for (int q = 1; q < R; ++q) v[q] = cmulcf<T>(v[q], tw[((t * q) << twsh) & (M - 1)]);
+        dft_small<R, +1, T>(v);
 #pragma unroll
         for (int q = 0; q < R; ++q) S[fft_pad(base + (q << ls))] = v[q];
     }
@@ -130,7 +137,8 @@ __device__ __forceinline__ void pass_adj(float2 *__restrict__ S, int logM, int l
 
 // S holds a_j = x_j c_j at j = 1..n and zeros elsewhere (synchronised).  On return S[k] = sum_j a_j conj(c_{k-j}), k = 1..n
 // (synchronised): forward passes, pointwise product with the chirp's transform, adjoint passes.
-__device__ __forceinline__ void chirp_convolve(float2 *__restrict__ S, const FftPlan &P, int tid)
+template <typename T>
+__device__ __forceinline__ void chirp_convolve(cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid)
 {
     int lL = P.logM;
     for (int p = 0; p < P.npass; ++p) {
@@ -142,7 +150,7 @@ __device__ __forceinline__ void chirp_convolve(float2 *__restrict__ S, const Fft
         lL -= lr;
         __syncthreads();
     }
-    for (int i = tid; i < P.M; i += FFT_THREADS) S[fft_pad(i)] = cmulf(S[fft_pad(i)], P.bhat[i]);
+    for (int i = tid; i < P.M; i += FFT_THREADS) S[fft_pad(i)] = cmulf<T>(S[fft_pad(i)], P.bhat[i]);
     __syncthreads();
     for (int p = P.npass - 1; p >= 0; --p) {
         const int lr = P.lr[p];
@@ -172,62 +180,64 @@ __device__ __forceinline__ float fft_g(const Field &U, const Field &F, int c, in
 // MODE 0: rows of the folded right-hand side (from the fields) -> T[c][y][x]
 // MODE 1: rows of `in` (the transposed plane: row = x, entries = y) -> DST, / den, DST -> out, same layout
 // MODE 2: rows of `in` [c][y][x] -> DST, scale -> interior of the field U
-template <int MODE>
-__global__ __launch_bounds__(FFT_THREADS) void k_fft_dst(FftPlan P, Field U, Field F, const float *__restrict__ in, float *__restrict__ out,
+template <int MODE, typename T>
+__global__ __launch_bounds__(FFT_THREADS) void k_fft_dst(FftPlan<T> P, Field U, Field F, const T *__restrict__ in, T *__restrict__ out,
                                                          int rows, const float *__restrict__ f_row, const float *__restrict__ f_k, int exact,
-                                                         float scale)
+                                                         double scale)
 {
-    extern __shared__ float2 S[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char fft_smem[];
+    cx2<T> *__restrict__ S = reinterpret_cast<cx2<T> *>(fft_smem);
     const int tid = threadIdx.x, r = blockIdx.x, c = blockIdx.y, n = P.n;
-    const float *__restrict__ src = (MODE == 0) ? nullptr : in + ((size_t)c * rows + r) * n;
+    const T *__restrict__ src = (MODE == 0) ? nullptr : in + ((size_t)c * rows + r) * n;
     for (int i = tid; i < P.M; i += FFT_THREADS) {
-        float2 a = make_float2(0.f, 0.f);
+        cx2<T> a = mk<T>((T)0, (T)0);
         if (i >= 1 && i <= n) {
-            const float x = (MODE == 0) ? fft_g(U, F, c, i - 1, r) : src[i - 1];
-            const float2 ch = P.chirp[i];
-            a = make_float2(x * ch.x, x * ch.y);
+            const T x = (MODE == 0) ? (T)fft_g(U, F, c, i - 1, r) : src[i - 1];
+            const cx2<T> ch = P.chirp[i];
+            a = mk<T>(x * ch.x, x * ch.y);
         }
         S[fft_pad(i)] = a;
     }
     __syncthreads();
-    chirp_convolve(S, P, tid);
+    chirp_convolve<T>(S, P, tid);
     if (MODE == 1) {
         // X_k = Im(c_k y_k); divide by the reference's denominator (seamlessClone_imp.cpp:1651-1653: float tables added in float,
         // then - 4) and feed the quotient straight into the second transform: the row stays in LDS
         // (element k is read and rewritten by the same thread, the zeroed elements are read by nobody here: no barrier in between)
         for (int k = 1 + tid; k <= n; k += FFT_THREADS) {
-            const float2 y = S[fft_pad(k)], ch = P.chirp[k];
-            const float X = ch.x * y.y + ch.y * y.x;
-            float den;
-            if (exact) den = (float)((2.0 * cospi((double)(r + 1) / (double)(rows + 1)) + 2.0 * cospi((double)k / (double)(n + 1))) - 4.0);
-            else den = (f_row[r] + f_k[k - 1]) - 4.0f;
-            const float q = X / den;
-            S[fft_pad(k)] = make_float2(q * ch.x, q * ch.y);
+            const cx2<T> y = S[fft_pad(k)], ch = P.chirp[k];
+            const T X = ch.x * y.y + ch.y * y.x;
+            T den;
+            if (exact) den = (T)((2.0 * cospi((double)(r + 1) / (double)(rows + 1)) + 2.0 * cospi((double)k / (double)(n + 1))) - 4.0);
+            else den = (T)((f_row[r] + f_k[k - 1]) - 4.0f);
+            const T q = X / den;
+            S[fft_pad(k)] = mk<T>(q * ch.x, q * ch.y);
         }
-        for (int i = tid; i < P.M; i += FFT_THREADS) if (i == 0 || i > n) S[fft_pad(i)] = make_float2(0.f, 0.f);
+        for (int i = tid; i < P.M; i += FFT_THREADS) if (i == 0 || i > n) S[fft_pad(i)] = mk<T>((T)0, (T)0);
         __syncthreads();
-        chirp_convolve(S, P, tid);
+        chirp_convolve<T>(S, P, tid);
     }
     for (int k = 1 + tid; k <= n; k += FFT_THREADS) {
-        const float2 y = S[fft_pad(k)], ch = P.chirp[k];
-        const float X = ch.x * y.y + ch.y * y.x;
-        if (MODE == 2) U.at(c)[(size_t)(r + 1) * U.pitch + k] = X * scale;
+        const cx2<T> y = S[fft_pad(k)], ch = P.chirp[k];
+        const T X = ch.x * y.y + ch.y * y.x;
+        if (MODE == 2) U.at(c)[(size_t)(r + 1) * U.pitch + k] = (float)(X * (T)scale);
         else out[((size_t)c * rows + r) * n + (k - 1)] = X;
     }
 }
 
 // out[c][x][y] = in[c][y][x]; 64 x 64 tiles through LDS
-__global__ __launch_bounds__(256) void k_fft_transpose(const float *__restrict__ in, float *__restrict__ out, int rows, int cols)
+template <typename T>
+__global__ __launch_bounds__(256) void k_fft_transpose(const T *__restrict__ in, T *__restrict__ out, int rows, int cols)
 {
-    __shared__ float t[64][65];
+    __shared__ T t[64][65];
     const int c = blockIdx.z, x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const float *__restrict__ src = in + (size_t)c * rows * cols;
-    float *__restrict__ dst = out + (size_t)c * rows * cols;
+    const T *__restrict__ src = in + (size_t)c * rows * cols;
+    T *__restrict__ dst = out + (size_t)c * rows * cols;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int y = y0 + ly + 4 * k, x = x0 + lx;
-        t[ly + 4 * k][lx] = (y < rows && x < cols) ? src[(size_t)y * cols + x] : 0.f;
+        t[ly + 4 * k][lx] = (y < rows && x < cols) ? src[(size_t)y * cols + x] : (T)0;
     }
     __syncthreads();
 #pragma unroll
@@ -244,8 +254,6 @@ static int fft_logm(int n)
     while ((1 << l) < 2 * n - 1) ++l;
     return l;
 }
-
-bool fft_supported(int w, int h) { return w >= 1 && h >= 1 && fft_logm(w) <= FFT_MAX_LOGM && fft_logm(h) <= FFT_MAX_LOGM; }
 
 static void fft_radices(int logM, int lr[4], int &npass)
 {
@@ -292,16 +300,18 @@ static void host_fft(std::vector<double> &re, std::vector<double> &im)
     }
 }
 
+template <typename T>
 static int fft_build_dim(Instance *I, FftDim &D, int n)
 {
-    if (D.n == n && D.chirp.p) return SC_OK;
+    const bool dbl = sizeof(T) == sizeof(double);
+    if (D.n == n && D.dbl == dbl && D.chirp.p) return SC_OK;
     const int logM = fft_logm(n), M = 1 << logM;
     int rc;
     SC_HIP(I, hipStreamSynchronize(I->stream));        // the pinned staging below may still feed the previous size's upload (rare: a new ROI size)
-    const size_t bytes = sizeof(float2) * ((size_t)(n + 1) + 2 * (size_t)M);
+    const size_t bytes = sizeof(cx2<T>) * ((size_t)(n + 1) + 2 * (size_t)M);
     if ((rc = ensure(I, D.chirp, bytes))) return rc;
     if ((rc = ensure_pinned(I, D.h, bytes))) return rc;
-    float2 *hc = (float2 *)D.h.p, *hb = hc + (n + 1), *ht = hb + M;
+    cx2<T> *hc = (cx2<T> *)D.h.p, *hb = hc + (n + 1), *ht = hb + M;
     const long N2 = 4L * (n + 1);                       // 2N: the period of m^2 in exp(i pi m^2 / N)
     const double invN = 1.0 / (2.0 * (n + 1));
     std::vector<double> cr(n + 1), ci(n + 1);
@@ -309,7 +319,7 @@ static int fft_build_dim(Instance *I, FftDim &D, int n)
         const long q = ((long)m * m) % N2;
         const double a = M_PI * (double)q * invN;
         cr[m] = std::cos(a); ci[m] = std::sin(a);
-        hc[m] = make_float2((float)cr[m], (float)ci[m]);
+        hc[m] = mk<T>((T)cr[m], (T)ci[m]);
     }
     std::vector<double> br(M, 0.0), bi(M, 0.0);
     br[0] = 1.0;
@@ -319,21 +329,22 @@ static int fft_build_dim(Instance *I, FftDim &D, int n)
     fft_radices(logM, lr, npass);
     for (int k = 0; k < M; ++k) {
         const int pos = fft_position(k, logM, lr, npass);
-        hb[pos] = make_float2((float)(br[k] / M), (float)(bi[k] / M));
+        hb[pos] = mk<T>((T)(br[k] / M), (T)(bi[k] / M));
     }
     for (int k = 0; k < M; ++k) {
         const double a = -2.0 * M_PI * (double)k / (double)M;
-        ht[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        ht[k] = mk<T>((T)std::cos(a), (T)std::sin(a));
     }
     SC_HIP(I, hipMemcpyAsync(D.chirp.p, D.h.p, bytes, hipMemcpyHostToDevice, I->stream));
-    D.n = n; D.logM = logM;
+    D.n = n; D.logM = logM; D.dbl = dbl;
     return SC_OK;
 }
 
-static FftPlan fft_plan_of(const FftDim &D)
+template <typename T>
+static FftPlan<T> fft_plan_of(const FftDim &D)
 {
-    FftPlan P{};
-    P.chirp = (const float2 *)D.chirp.p;
+    FftPlan<T> P{};
+    P.chirp = (const cx2<T> *)D.chirp.p;
     P.bhat = P.chirp + (D.n + 1);
     P.tw = P.bhat + ((size_t)1 << D.logM);
     P.n = D.n; P.logM = D.logM; P.M = 1 << D.logM;
@@ -341,37 +352,43 @@ static FftPlan fft_plan_of(const FftDim &D)
     return P;
 }
 
+template <typename T>
 static hipError_t fft_opt_in_lds()
 {
     static bool done = false;
     if (done) return hipSuccess;
-    const int bytes = (int)(sizeof(float2) * (size_t)fft_pad(1 << FFT_MAX_LOGM)) + 64;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    const int max_log = sizeof(T) == sizeof(double) ? FFT_MAX_LOGM - 1 : FFT_MAX_LOGM;
+    const int bytes = (int)(sizeof(cx2<T>) * (size_t)fft_pad(1 << max_log)) + 64;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<0, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<2, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done = e == hipSuccess;
     return e;
 }
 
-// Direct solve of the fields bound to the instance: interior of result(I) <- the reference's answer.  F must be float.
-int fft_solve(Instance *I)
+bool fft_supported(int w, int h, bool fp64)
 {
-    if (I->f_half) { I->err = "internal: float16 right-hand side on the direct path"; return SC_ERR_BAD_ARG; }
+    const int mx = fp64 ? FFT_MAX_LOGM - 1 : FFT_MAX_LOGM;        // double: 16 bytes per element, n <= 4096 per side
+    return w >= 1 && h >= 1 && fft_logm(w) <= mx && fft_logm(h) <= mx;
+}
+
+template <typename T>
+static int fft_solve_t(Instance *I)
+{
     const int w = I->F.W - 2, h = I->F.H - 2, C = I->F.C;
-    if (!fft_supported(w, h)) { I->err = "SC_METHOD_FFT: more than 8192 unknowns per side"; return SC_ERR_BAD_SIZE; }
-    SC_HIP(I, fft_opt_in_lds());
+    SC_HIP(I, fft_opt_in_lds<T>());
     FftState &S = I->fft;
     int rc;
-    if ((rc = fft_build_dim(I, S.dw, w))) return rc;
-    if ((rc = fft_build_dim(I, S.dh, h))) return rc;
+    if ((rc = fft_build_dim<T>(I, S.dw, w))) return rc;
+    if ((rc = fft_build_dim<T>(I, S.dh, h))) return rc;
     const size_t plane = (size_t)w * h;
-    if ((rc = ensure(I, S.A, sizeof(float) * plane * C))) return rc;
-    if ((rc = ensure(I, S.B, sizeof(float) * plane * C))) return rc;
-    bool singular = false;
+    if ((rc = ensure(I, S.A, sizeof(T) * plane * C))) return rc;
+    if ((rc = ensure(I, S.B, sizeof(T) * plane * C))) return rc;
     if (S.tw != w || S.th != h) {
         // the reference's float tables (seamlessClone_imp.cpp:596-599; PI is the float literal of seamlessClone_imp.h:17)
         if ((rc = ensure(I, S.fxy, sizeof(float) * (size_t)(w + h)))) return rc;
         if ((rc = ensure_pinned(I, S.hfxy, sizeof(float) * (size_t)(w + h)))) return rc;
+        SC_HIP(I, hipStreamSynchronize(I->stream));
         const double PIf = (double)3.14159265358979323846f;
         float *fx = (float *)S.hfxy.p, *fy = fx + w;
         for (int i = 0; i < w; ++i) fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
@@ -380,25 +397,36 @@ int fft_solve(Instance *I)
         SC_HIP(I, hipMemcpyAsync(S.fxy.p, S.hfxy.p, sizeof(float) * (size_t)(w + h), hipMemcpyHostToDevice, I->stream));
         S.tw = w; S.th = h;
     }
-    singular = S.singular;
-    const int exact = (singular || (I->opts.flags & SC_FLAG_EXACT_TABLES)) ? 1 : 0;
-    const FftPlan Pw = fft_plan_of(S.dw), Ph = fft_plan_of(S.dh);
-    const size_t ldsw = sizeof(float2) * (size_t)(fft_pad(Pw.M) + 1), ldsh = sizeof(float2) * (size_t)(fft_pad(Ph.M) + 1);
+    const int exact = (S.singular || (I->opts.flags & SC_FLAG_EXACT_TABLES)) ? 1 : 0;
+    const FftPlan<T> Pw = fft_plan_of<T>(S.dw), Ph = fft_plan_of<T>(S.dh);
+    const size_t ldsw = sizeof(cx2<T>) * (size_t)(fft_pad(Pw.M) + 1), ldsh = sizeof(cx2<T>) * (size_t)(fft_pad(Ph.M) + 1);
     Field &U = I->result_in_U1 ? I->U1 : I->U0;
-    float *A = (float *)S.A.p, *B = (float *)S.B.p;
+    T *A = (T *)S.A.p, *B = (T *)S.B.p;
     const float *fx = (const float *)S.fxy.p, *fy = fx + w;
-    const float scale = (float)(4.0 / ((w + 1.0) * (h + 1.0)));
+    const double scale = 4.0 / ((w + 1.0) * (h + 1.0));
     const dim3 tg_hw((w + 63) / 64, (h + 63) / 64, C), tg_wh((h + 63) / 64, (w + 63) / 64, C);
-    hipLaunchKernelGGL(k_fft_dst<0>, dim3(h, C), dim3(FFT_THREADS), ldsw, I->stream, Pw, U, I->F, (const float *)nullptr, A, h, fx, fy, exact, 1.0f);
-    hipLaunchKernelGGL(k_fft_transpose, tg_hw, dim3(256), 0, I->stream, (const float *)A, B, h, w);                 // B[c][x][y]
-    hipLaunchKernelGGL(k_fft_dst<1>, dim3(w, C), dim3(FFT_THREADS), ldsh, I->stream, Ph, U, I->F, (const float *)B, A, w, fx, fy, exact, 1.0f);
-    hipLaunchKernelGGL(k_fft_transpose, tg_wh, dim3(256), 0, I->stream, (const float *)A, B, w, h);                 // B[c][y][x]
-    hipLaunchKernelGGL(k_fft_dst<2>, dim3(h, C), dim3(FFT_THREADS), ldsw, I->stream, Pw, U, I->F, (const float *)B, A, h, fx, fy, exact, scale);
+    hipLaunchKernelGGL((k_fft_dst<0, T>), dim3(h, C), dim3(FFT_THREADS), ldsw, I->stream, Pw, U, I->F, (const T *)nullptr, A, h, fx, fy, exact, 1.0);
+    hipLaunchKernelGGL((k_fft_transpose<T>), tg_hw, dim3(256), 0, I->stream, (const T *)A, B, h, w);                 // B[c][x][y]
+    hipLaunchKernelGGL((k_fft_dst<1, T>), dim3(w, C), dim3(FFT_THREADS), ldsh, I->stream, Ph, U, I->F, (const T *)B, A, w, fx, fy, exact, 1.0);
+    hipLaunchKernelGGL((k_fft_transpose<T>), tg_wh, dim3(256), 0, I->stream, (const T *)A, B, w, h);                 // B[c][y][x]
+    hipLaunchKernelGGL((k_fft_dst<2, T>), dim3(h, C), dim3(FFT_THREADS), ldsw, I->stream, Pw, U, I->F, (const T *)B, A, h, fx, fy, exact, scale);
     SC_HIP(I, hipGetLastError());
     I->info.sweeps = 1;
     I->info.converged = 1;
     I->info.sweep_launches += 3;
     return SC_OK;
+}
+
+// Direct solve of the fields bound to the instance: interior of result(I) <- the reference's answer.  F must be float.
+int fft_solve(Instance *I, bool fp64)
+{
+    if (I->f_half) { I->err = "internal: float16 right-hand side on the direct path"; return SC_ERR_BAD_ARG; }
+    const int w = I->F.W - 2, h = I->F.H - 2;
+    if (!fft_supported(w, h, fp64)) {
+        I->err = fp64 ? "SC_METHOD_FFT with SC_FLAG_FFT_FP64: more than 4096 unknowns per side" : "SC_METHOD_FFT: more than 8192 unknowns per side";
+        return SC_ERR_BAD_SIZE;
+    }
+    return fp64 ? fft_solve_t<double>(I) : fft_solve_t<float>(I);
 }
 
 } // namespace sc

@@ -47,7 +47,7 @@ struct DstState {
 };
 
 // FFT direct solve (sc_fft.hip): per-direction chirp / transform tables and the two work planes
-struct FftDim { int n = 0, logM = 0; DevBuf chirp, h; };                     // chirp: chirp[n+1] | bhat[M] | tw[M] (float2); h: pinned staging
+struct FftDim { int n = 0, logM = 0; bool dbl = false; DevBuf chirp, h; };   // chirp: chirp[n+1] | bhat[M] | tw[M] (complex float or double); h: pinned staging
 struct FftState {
     FftDim dw, dh;
     DevBuf A, B, fxy, hfxy;                // work planes [C][h][w] float; the reference's float tables fx[w] + fy[h] (device, pinned)
@@ -164,8 +164,8 @@ int lowmode_early_kind(Instance *I, float update_tol);                // see sc_
 void lowmode_bands_written(Instance *I, const float *field);       // the launch went in: B describes `field` (nullptr: nothing)
 int lowmode_count(int n);
 int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST
-int fft_solve(Instance *I);                                           // sc_fft.hip: SC_METHOD_FFT
-bool fft_supported(int w, int h);
+int fft_solve(Instance *I, bool fp64);                                // sc_fft.hip: SC_METHOD_FFT (fp64: SC_FLAG_FFT_FP64)
+bool fft_supported(int w, int h, bool fp64);
 bool wants_float_tables(const Instance *I);
 int effective_method(const Instance *I);                              // sc_solver.cpp: what SC_METHOD_AUTO resolves to for the fields bound to I
 int output_nodes(Instance *I, LmNodes &lm);  // sc_solver.cpp: the float-table correction the post-process of result(I) has to add (none: lm.CN == nullptr)

@@ -24,7 +24,7 @@ int effective_method(const Instance *I)
     const int w = I->F.W - 2, h = I->F.H - 2;
     if (o.tol > 0.f || w < 1 || h < 1) return SC_METHOD_MULTIGRID;
     if (w <= SC_AUTO_DIRECT_MAX && h <= SC_AUTO_DIRECT_MAX) return SC_METHOD_DST;
-    // ROIs narrower than 9 pixels (the three erodes empty the mask: the exact solution is the destination itself, integers):
+    // ROIs narrower than 7 pixels (the three erodes empty the mask: the exact solution is the destination itself, integers):
     // the reference's float tables put every mode ~1e-7 below its exact value, so its answer is v - epsilon and truncates to v - 1
     // almost everywhere.  Only the direct form reproduces that (it IS that arithmetic); it stays cheap while one side is tiny.
     if (std::min(w, h) <= SC_AUTO_THIN_MAX && std::max(w, h) <= SC_AUTO_THIN_LONG_MAX) return SC_METHOD_DST;
@@ -137,7 +137,7 @@ int solve(Instance *I)
     I->info.method = method;
     if (method == SC_METHOD_MULTIGRID) return mg_solve(I);
     if (method == SC_METHOD_DST) return dst_solve(I);
-    if (method == SC_METHOD_FFT) return fft_solve(I);
+    if (method == SC_METHOD_FFT) return fft_solve(I, (o.flags & SC_FLAG_FFT_FP64) != 0);
     if (o.tol <= 0.f) {
         int rc = run_sweeps(I, o.method, o.max_sweeps, o.omega, o.sweeps_per_launch);
         if (rc) return rc;
