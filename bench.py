@@ -178,7 +178,7 @@ def reference_table(args):
             outs[name] = body.copy()
             row[name] = {"ms_per_clone_end_to_end": round(t_run / 50 * 1e3, 4), "h2d_ms": round(i.ms_h2d, 4), "device_ms": round(i.ms_device_total, 4),
                          "d2h_ms": round(i.ms_d2h, 4), "restore_ms_not_included": round(t_restore / 50 * 1e3, 4), "roi": [i.W, i.H],
-                         "device_bytes": int(i.device_bytes), "method_that_ran": {3: "multigrid", 4: "dst", 6: "fft"}.get(i.method, i.method)}
+                         "device_bytes": int(i.device_bytes), "method_that_ran": {3: "multigrid", 4: "dst", 6: "fft"}.get(i.method, i.method) + (" (double transforms)" if name == "default_auto" and i.method == 6 else "")}
         inst.set_solver(method=capi.SC_METHOD_AUTO, flags=args.extra_flags)
         t0 = time.perf_counter(); ref = oc.seamless_clone(dst, patch, mask, cx, cy, 1, False); one = time.perf_counter() - t0
         reps = max(1, min(20, int(args.cpu_seconds / 4 / max(one, 1e-4))))

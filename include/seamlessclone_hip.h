@@ -58,11 +58,12 @@ enum sc_method {
                                 u = S_h ((S_h g S_w) / den) S_w with den = filter_X + filter_Y - 4 from the float
                                 tables of :596-599, four double-precision products on the matrix cores.  O(n^3):
                                 milliseconds at 2048^2; the non-iterative cross-check of the default path          */
-    SC_METHOD_AUTO   = 5,    /* DEFAULT.  SC_METHOD_DST for ROIs of at most SC_AUTO_DIRECT_MAX unknowns per side (there it
-                                costs what the multigrid path costs and has no iteration error: diff sum against the
-                                float-table CPU port 2 instead of 129 at the reference's 300x194 patch, whose own published
-                                deviation from OpenCV is 44, PDF p3) and for thin ROIs (SC_AUTO_THIN_MAX), SC_METHOD_MULTIGRID above and whenever tol > 0
-                                asks for a residual-based stop.  sc_run_info.method says which one ran.           */
+    SC_METHOD_AUTO   = 5,    /* DEFAULT.  A direct solve -- SC_METHOD_FFT with double transforms -- for ROIs of at most
+                                SC_AUTO_DIRECT_MAX unknowns per side (there it is faster than the cycles and has no iteration
+                                error: diff sum against the float-table CPU port 2 instead of 129 at the reference's 300x194
+                                patch, whose own published deviation from OpenCV is 44, PDF p3) and for thin ROIs
+                                (SC_AUTO_THIN_MAX), SC_METHOD_MULTIGRID above and whenever tol > 0 asks for a residual-based
+                                stop.  sc_run_info.method says which one ran.                                      */
     SC_METHOD_FFT    = 6     /* the reference's DEFAULT direct back-end (poissonSolver2D_FFT, seamlessClone_imp.cpp:1694-1918):
                                 the same u = S_h ((S_h g S_w) / den) S_w in float32 with FFT-based transforms, O(n^2 log n).
                                 The DST-I of each row is a chirp-z transform over a power-of-two FFT held in LDS (sc_fft.hip);
@@ -147,6 +148,15 @@ typedef struct sc_solver_opts {
                                             between the launches); at most 4096 unknowns per side.  No transform rounding is left:
                                             the result agrees with SC_METHOD_DST (both are the reference's float-table arithmetic
                                             with exact transforms)                                                          */
+
+#define SC_FLAG_OPENCV_GREY_MASK (1 << 9) /* masks that are not 0 / 255: OpenCV's semantics -- the three erodes are minimum filters (a grey
+                                            eroded mask) and the gradients are blended with the fractional weights M/255 and
+                                            (255 - M)/255 (OpenCV 3.4.5 modules/photo, Cloning::computeDerivatives / normalClone).
+                                            Default: the reference's -- it thresholds (seamlessClone_imp.cpp:917, sum == 255 * 9:
+                                            every value below 255 erodes to 0) and so only ever blends with 0 / 1.  On 0 / 255 masks
+                                            the two are bit-identical.  PARITY UNPINNED: OpenCV's source is not part of the
+                                            reference and none of its fixtures holds a grey mask; checked against a restatement
+                                            of the published algorithm (oracle/).  Groups run one clone at a time with it.   */
 
 /* ---- statistics of the last run */
 typedef struct sc_run_info {

@@ -62,6 +62,12 @@ def lib():
         L.sco_solve_dst3.restype = None
         L.sco_seamless_clone3.argtypes = L.sco_seamless_clone2.argtypes + [C.c_int]
         L.sco_seamless_clone3.restype = C.c_int
+        L.sco_mask_stage2.argtypes = L.sco_mask_stage.argtypes + [C.c_int]
+        L.sco_mask_stage2.restype = C.c_int
+        L.sco_build_rhs2.argtypes = L.sco_build_rhs.argtypes + [C.c_int]
+        L.sco_build_rhs2.restype = C.c_int
+        L.sco_seamless_clone4.argtypes = L.sco_seamless_clone3.argtypes + [C.c_int]
+        L.sco_seamless_clone4.restype = C.c_int
         L.sco_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -75,28 +81,29 @@ def _f32(a):
     return a.ctypes.data_as(f32p)
 
 
-def mask_stage(mask: np.ndarray, cx: int, cy: int):
+def mask_stage(mask: np.ndarray, cx: int, cy: int, opencv_grey: bool = False):
+    """opencv_grey: OpenCV's grey-mask semantics (7x7 minimum filter) instead of the reference's thresholding erodes."""
     mask = np.ascontiguousarray(mask, dtype=np.uint8)
     mh, mw = mask.shape[:2]
     geo = np.zeros(6, np.int32)
     M = np.zeros(mw * mh, np.uint8)
-    rc = lib().sco_mask_stage(_u8(mask), mw, mh, mask.strides[0], cx, cy, geo.ctypes.data_as(i32p), _u8(M))
+    rc = lib().sco_mask_stage2(_u8(mask), mw, mh, mask.strides[0], cx, cy, geo.ctypes.data_as(i32p), _u8(M), int(opencv_grey))
     if rc:
         raise ValueError(f"sco_mask_stage rc={rc}")
     W, H = int(geo[2]), int(geo[3])
     return geo, M[:W * H].reshape(H, W).copy()
 
 
-def build_rhs(dst, patch, geo, M):
+def build_rhs(dst, patch, geo, M, opencv_grey=False):
     dst = np.ascontiguousarray(dst, np.uint8)
     patch = np.ascontiguousarray(patch, np.uint8)
     M = np.ascontiguousarray(M, np.uint8)
     W, H = int(geo[2]), int(geo[3])
     B = np.zeros((3, H, W), np.float32)
     lap = np.zeros((3, H, W), np.float32)
-    rc = lib().sco_build_rhs(_u8(dst), dst.shape[1], dst.shape[0], dst.strides[0],
-                             _u8(patch), patch.shape[1], patch.shape[0], patch.strides[0],
-                             _u8(M), geo.ctypes.data_as(i32p), _f32(B), _f32(lap))
+    rc = lib().sco_build_rhs2(_u8(dst), dst.shape[1], dst.shape[0], dst.strides[0],
+                              _u8(patch), patch.shape[1], patch.shape[0], patch.strides[0],
+                              _u8(M), geo.ctypes.data_as(i32p), _f32(B), _f32(lap), int(opencv_grey))
     if rc:
         raise ValueError(f"sco_build_rhs rc={rc}")
     return B, lap
@@ -157,15 +164,15 @@ def finish(dst, U, geo):
     return dst
 
 
-def seamless_clone(dst, patch, mask, cx, cy, nthreads=1, exact_den=False, internals="f64"):
-    """Returns a new blended image (input dst is not modified).  internals: see solve_dst."""
+def seamless_clone(dst, patch, mask, cx, cy, nthreads=1, exact_den=False, internals="f64", opencv_grey=False):
+    """Returns a new blended image (input dst is not modified).  internals: see solve_dst; opencv_grey: see mask_stage."""
     out = np.array(dst, np.uint8, copy=True, order="C")
     patch = np.ascontiguousarray(patch, np.uint8)
     mask = np.ascontiguousarray(mask, np.uint8)
-    rc = lib().sco_seamless_clone3(_u8(patch), patch.shape[1], patch.shape[0], patch.strides[0],
+    rc = lib().sco_seamless_clone4(_u8(patch), patch.shape[1], patch.shape[0], patch.strides[0],
                                    _u8(out), out.shape[1], out.shape[0], out.strides[0],
                                    _u8(mask), mask.shape[1], mask.shape[0], mask.strides[0], cx, cy, nthreads,
-                                   int(exact_den), INTERNALS[internals])
+                                   int(exact_den), INTERNALS[internals], int(opencv_grey))
     if rc:
         raise ValueError(f"sco_seamless_clone rc={rc}")
     return out

@@ -84,8 +84,30 @@ def erode3x3(m: np.ndarray) -> np.ndarray:
     return out
 
 
-def mask_stage(mask: np.ndarray, cx: int, cy: int):
-    """Returns dict(x0,y0,W,H,ltx,lty,M) -- SURVEY Appendix A.1 steps 1-4."""
+def erode_min7(m: np.ndarray) -> np.ndarray:
+    """OpenCV's erode(mask, 3x3 ones, iterations = 3) on the ROI VIEW of the zero-bordered mask, as cv::seamlessClone (OpenCV
+    3.4.5, modules/photo/src/seamless_cloning_impl.cpp, Cloning::computeDerivatives) calls it: three 3x3 minimum filters = one
+    7x7 minimum filter (cv::erode itself folds the iterations of a full rectangle into one kernel), reading through the
+    view into the parent matrix, where everything outside the bounding box is zero (that is what makes it the bounding box)
+    and the 1-pixel border was zeroed before; pixels outside the parent are ignored (morphologyDefaultBorderValue) but no
+    window reaches them without also covering a zero.  Net: out = min over the 7x7 window with ZERO outside the ROI.
+    For 0/255 masks this equals the reference's three thresholding passes (seamlessClone_imp.cpp:892-925); for grey masks the
+    reference returns 0 wherever any of the 49 values is below 255, OpenCV returns their minimum.
+    PARITY UNPINNED: OpenCV's source is not in /root/reference and no fixture of the reference holds a grey mask; this is a
+    restatement of the published OpenCV 3.4.5 algorithm, used only behind SC_FLAG_OPENCV_GREY_MASK."""
+    h, w = m.shape
+    p = np.zeros((h + 6, w + 6), np.uint8)
+    p[3:-3, 3:-3] = m
+    out = np.full((h, w), 255, np.uint8)
+    for dy in range(7):
+        for dx in range(7):
+            out = np.minimum(out, p[dy:dy + h, dx:dx + w])
+    return out
+
+
+def mask_stage(mask: np.ndarray, cx: int, cy: int, opencv_grey: bool = False):
+    """Returns dict(x0,y0,W,H,ltx,lty,M) -- SURVEY Appendix A.1 steps 1-4.  opencv_grey: OpenCV's semantics for masks that
+    are not 0/255 (erode_min7; build_rhs then blends with fractional weights) instead of the reference's thresholding."""
     m0 = zero_mask_border(mask)
     x0, x1, y0, y1 = bounding_box(m0)
     W = x1 - x0 + 1
@@ -93,11 +115,14 @@ def mask_stage(mask: np.ndarray, cx: int, cy: int):
     if not (x1 - x0 > 0 and y1 - y0 > 0):
         raise ValueError("empty mask (reference asserts at seamlessClone_imp.cpp:1013)")
     M = m0[y0:y0 + H, x0:x0 + W].copy()
-    for _ in range(3):  # :1060-1062
-        M = erode3x3(M)
+    if opencv_grey:
+        M = erode_min7(M)
+    else:
+        for _ in range(3):  # :1060-1062
+            M = erode3x3(M)
     ltx = cx - (W >> 1)  # :1066
     lty = cy - (H >> 1)
-    return dict(x0=x0, y0=y0, W=W, H=H, ltx=ltx, lty=lty, M=M)
+    return dict(x0=x0, y0=y0, W=W, H=H, ltx=ltx, lty=lty, M=M, opencv_grey=bool(opencv_grey))
 
 
 # --------------------------------------------------------------------------------------
@@ -132,8 +157,15 @@ def build_rhs(dst: np.ndarray, patch: np.ndarray, geo: dict, dtype=F32):
     lap = np.zeros((H, W, 3), dtype=dtype)
     gxb, gyb = _fwd_grad_reflect(B)
     gxp, gyp = _fwd_grad_reflect(P)
-    GX = (one - m) * gxb + m * gxp  # :1952
-    GY = (one - m) * gyb + m * gyp  # :1953
+    if geo.get("opencv_grey"):
+        # OpenCV 3.4.5 Cloning::normalClone / evaluate: patchGradient * (M / 255) and destinationGradient * ((255 - M) / 255), each
+        # weight a convertTo(CV_32F, 1.0 / 255.0) of the eroded mask / of its bitwise_not, then laplacianX = dest + patch
+        mi = ((255 - geo["M"].astype(np.int32)).astype(dtype) * dtype(1.0 / 255.0))[:, :, None]
+        GX = gxb * mi + gxp * m
+        GY = gyb * mi + gyp * m
+    else:
+        GX = (one - m) * gxb + m * gxp  # :1952
+        GY = (one - m) * gyb + m * gyp  # :1953
     lap[1:-1, 1:-1] = (GX[1:-1, 1:-1] - GX[1:-1, :-2]) + (GY[1:-1, 1:-1] - GY[:-2, 1:-1])  # :1987-1990
     g = lap[1:-1, 1:-1].copy()
     g[:, 0] -= B[1:-1, 0]      # x==1        :1992-1995
@@ -249,11 +281,11 @@ def splice(dst: np.ndarray, u8: np.ndarray, geo: dict) -> np.ndarray:
     return out
 
 
-def seamless_clone(dst, patch, mask, cx, cy, return_all=False, float_tables=False):
+def seamless_clone(dst, patch, mask, cx, cy, return_all=False, float_tables=False, opencv_grey=False):
     """Full NORMAL_CLONE path with the float64 direct solve.  dst HxWx3 u8 BGR (any channel
     order works, channels are independent), patch hxwx3 u8, mask hxw u8.  float_tables: see solve_dst
-    (True = the reference's arithmetic, which the HIP library reproduces by default)."""
-    geo = mask_stage(mask, cx, cy)
+    (True = the reference's arithmetic, which the HIP library reproduces by default).  opencv_grey: see mask_stage."""
+    geo = mask_stage(mask, cx, cy, opencv_grey)
     B, lap, g = build_rhs(dst, patch, geo, dtype=np.float64)
     u = solve_dst(g, float_tables)
     out = splice(dst, clamp_truncate(u), geo)

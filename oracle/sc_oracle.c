@@ -46,8 +46,19 @@ static void erode_pass(uint8_t *dst, const uint8_t *src, int W, int H)
 
 /* IMP.cpp:978-1071.  M must hold mw*mh bytes; on return its first W*H bytes are the
  * 3x eroded ROI mask.  Returns 0, or -3 for an empty / degenerate mask (:1013). */
+SCO_API int sco_mask_stage2(const uint8_t *mask, int mw, int mh, int mstride, int cx, int cy, int *geo, uint8_t *M, int grey);
 SCO_API int sco_mask_stage(const uint8_t *mask, int mw, int mh, int mstride, int cx, int cy,
                            int *geo, uint8_t *M)
+{
+    return sco_mask_stage2(mask, mw, mh, mstride, cx, cy, geo, M, 0);
+}
+
+/* grey != 0: OpenCV's semantics for masks that are not 0/255 (PARITY UNPINNED: restatement of the published OpenCV 3.4.5
+ * algorithm, modules/photo/src/seamless_cloning_impl.cpp Cloning::computeDerivatives -- erode(mask ROI view, 3x3 ones,
+ * iterations 3) is one 7x7 minimum filter reading zeros outside the bounding box; see oracle_np.erode_min7).  The reference
+ * thresholds instead (IMP.cpp:917: sum == 255 * 9). */
+SCO_API int sco_mask_stage2(const uint8_t *mask, int mw, int mh, int mstride, int cx, int cy,
+                            int *geo, uint8_t *M, int grey)
 {
     int x0 = mw - 1, x1 = 0, y0 = mh - 1, y1 = 0; /* seeds: IMP.cpp:1006 */
     for (int y = 1; y < mh - 1; ++y)             /* border zeroed first: :989 */
@@ -67,9 +78,23 @@ SCO_API int sco_mask_stage(const uint8_t *mask, int mw, int mh, int mstride, int
             int border = (sx == 0 || sy == 0 || sx == mw - 1 || sy == mh - 1);
             a[y * W + x] = border ? 0 : mask[(size_t)sy * mstride + sx];
         }
-    erode_pass(b, a, W, H); /* :1060-1062 */
-    erode_pass(a, b, W, H);
-    erode_pass(b, a, W, H);
+    if (grey) {
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                int mn = 255;
+                for (int dy = -3; dy <= 3; ++dy)
+                    for (int dx = -3; dx <= 3; ++dx) {
+                        const int yy = y + dy, xx = x + dx;
+                        const int v = (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0 : a[yy * W + xx];
+                        if (v < mn) mn = v;
+                    }
+                b[y * W + x] = (uint8_t)mn;
+            }
+    } else {
+        erode_pass(b, a, W, H); /* :1060-1062 */
+        erode_pass(a, b, W, H);
+        erode_pass(b, a, W, H);
+    }
     memcpy(M, b, (size_t)W * H);
     free(a); free(b);
     geo[0] = x0; geo[1] = y0; geo[2] = W; geo[3] = H;
@@ -83,9 +108,21 @@ SCO_API int sco_mask_stage(const uint8_t *mask, int mw, int mh, int mstride, int
 /* IMP.cpp:1920-2018 fused: B = dst ROI as float (planar), lap = un-folded divergence of
  * the mask-blended forward-difference gradient field (interior; ring = 0).
  * Returns -4 when the ROI leaves the destination (unchecked in the reference). */
+SCO_API int sco_build_rhs2(const uint8_t *dst, int dw, int dh, int dstride, const uint8_t *patch, int pw, int ph, int pstride,
+                           const uint8_t *M, const int *geo, float *B, float *lap, int grey);
 SCO_API int sco_build_rhs(const uint8_t *dst, int dw, int dh, int dstride,
                           const uint8_t *patch, int pw, int ph, int pstride,
                           const uint8_t *M, const int *geo, float *B, float *lap)
+{
+    return sco_build_rhs2(dst, dw, dh, dstride, patch, pw, ph, pstride, M, geo, B, lap, 0);
+}
+
+/* grey != 0: OpenCV's blend for a grey eroded mask (Cloning::normalClone / evaluate, OpenCV 3.4.5): patch gradient times
+ * M * (1/255f), destination gradient times (255 - M) * (1/255f) (convertTo of the mask and of its bitwise_not), summed
+ * destination first.  Identical to the reference's formula for M in {0, 255}. */
+SCO_API int sco_build_rhs2(const uint8_t *dst, int dw, int dh, int dstride,
+                           const uint8_t *patch, int pw, int ph, int pstride,
+                           const uint8_t *M, const int *geo, float *B, float *lap, int grey)
 {
     const int x0 = geo[0], y0 = geo[1], W = geo[2], H = geo[3], ltx = geo[4], lty = geo[5];
     if (ltx < 0 || lty < 0 || ltx + W > dw || lty + H > dh) return -4;
@@ -104,8 +141,14 @@ SCO_API int sco_build_rhs(const uint8_t *dst, int dw, int dh, int dstride,
                 float px = (x < W - 1) ? PT(y, x + 1) : PT(y, x - 1); /* :1944 */
                 float py = (y < H - 1) ? PT(y + 1, x) : PT(y - 1, x); /* :1947 */
                 float msk = (float)M[y * W + x] * (1.0f / 255.0f);    /* :1950 */
-                gx[y * W + x] = (1.0f - msk) * (bx - b0) + msk * (px - p0); /* :1952 */
-                gy[y * W + x] = (1.0f - msk) * (by - b0) + msk * (py - p0); /* :1953 */
+                if (grey) {
+                    const float inv = (float)(255 - M[y * W + x]) * (1.0f / 255.0f);
+                    gx[y * W + x] = (bx - b0) * inv + (px - p0) * msk;
+                    gy[y * W + x] = (by - b0) * inv + (py - p0) * msk;
+                } else {
+                    gx[y * W + x] = (1.0f - msk) * (bx - b0) + msk * (px - p0); /* :1952 */
+                    gy[y * W + x] = (1.0f - msk) * (by - b0) + msk * (py - p0); /* :1953 */
+                }
                 B[c * plane + y * W + x] = b0;
                 lap[c * plane + y * W + x] = 0.0f;
             }
@@ -641,21 +684,33 @@ SCO_API void sco_finish(uint8_t *dst, int dstride, const float *U, const int *ge
 
 /* Whole NORMAL_CLONE path with the direct DST solve, in place on dst (reference
  * semantics, IMP.cpp:470).  Returns 0 or a negative error. */
+SCO_API int sco_seamless_clone4(const uint8_t *patch, int pw, int ph, int pstride, uint8_t *dst, int dw, int dh, int dstride,
+                                const uint8_t *mask, int mw, int mh, int mstride, int cx, int cy, int nthreads, int exact_den,
+                                int internals, int grey);
 SCO_API int sco_seamless_clone3(const uint8_t *patch, int pw, int ph, int pstride,
                                 uint8_t *dst, int dw, int dh, int dstride,
                                 const uint8_t *mask, int mw, int mh, int mstride,
                                 int cx, int cy, int nthreads, int exact_den, int internals)
 {
+    return sco_seamless_clone4(patch, pw, ph, pstride, dst, dw, dh, dstride, mask, mw, mh, mstride, cx, cy, nthreads, exact_den,
+                               internals, 0);
+}
+
+SCO_API int sco_seamless_clone4(const uint8_t *patch, int pw, int ph, int pstride,
+                                uint8_t *dst, int dw, int dh, int dstride,
+                                const uint8_t *mask, int mw, int mh, int mstride,
+                                int cx, int cy, int nthreads, int exact_den, int internals, int grey)
+{
     if (pw != mw || ph != mh) return -2;
     int geo[6];
     uint8_t *M = (uint8_t *)malloc((size_t)mw * mh);
-    int rc = sco_mask_stage(mask, mw, mh, mstride, cx, cy, geo, M);
+    int rc = sco_mask_stage2(mask, mw, mh, mstride, cx, cy, geo, M, grey);
     if (rc) { free(M); return rc; }
     const int W = geo[2], H = geo[3], w = W - 2, h = H - 2;
     const size_t plane = (size_t)W * H;
     float *B = (float *)malloc(sizeof(float) * plane * 3);
     float *lap = (float *)malloc(sizeof(float) * plane * 3);
-    rc = sco_build_rhs(dst, dw, dh, dstride, patch, pw, ph, pstride, M, geo, B, lap);
+    rc = sco_build_rhs2(dst, dw, dh, dstride, patch, pw, ph, pstride, M, geo, B, lap, grey);
     if (rc == 0 && w > 0 && h > 0) {
         float *g = (float *)malloc(sizeof(float) * (size_t)w * h * 3);
         sco_fold(B, lap, W, H, g);

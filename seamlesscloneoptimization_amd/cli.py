@@ -21,8 +21,8 @@ def main(argv=None) -> int:
     ap.add_argument("src"); ap.add_argument("dst"); ap.add_argument("mask")
     ap.add_argument("centerX", type=int); ap.add_argument("centerY", type=int); ap.add_argument("gpu", type=int)
     ap.add_argument("--out", help="write the blended image (.bmp or .yml)")
-    ap.add_argument("--method", default="auto", choices=["auto", "mg", "dst", "sor", "rbgs", "jacobi"],
-                    help="auto (default): dst up to 640 unknowns per side, mg above; mg: multigrid + float-table correction (the reference's arithmetic); dst: the reference's direct DST "
+    ap.add_argument("--method", default="auto", choices=["auto", "mg", "dst", "fft", "sor", "rbgs", "jacobi"],
+                    help="auto (default): direct FFT solve (double) up to 640 unknowns per side, mg above; fft: the reference's default back-end (FFT-based direct solve, float32); mg: multigrid + float-table correction (the reference's arithmetic); dst: the reference's direct DST "
                          "solve on the fp64 matrix cores; sor / rbgs / jacobi: sweeps to a 2e-5 residual")
     ap.add_argument("--exact-tables", action="store_true", help="mg: return the exact solution of the 5-point system instead")
     ap.add_argument("--reference-warmup", action="store_true",
@@ -36,9 +36,9 @@ def main(argv=None) -> int:
     print("mat shape: %d, %d, %d" % (mask.shape[1], mask.shape[0], 1))
     inst = capi.Instance(a.gpu)
     try:
-        opts = {"method": {"auto": 5, "mg": 3, "dst": 4, "sor": 2, "rbgs": 1, "jacobi": 0}[a.method],
+        opts = {"method": {"auto": 5, "mg": 3, "dst": 4, "fft": 6, "sor": 2, "rbgs": 1, "jacobi": 0}[a.method],
                 "reference_warmup": int(a.reference_warmup), "flags": capi.SC_FLAG_EXACT_TABLES if a.exact_tables else 0}
-        if a.method not in ("auto", "mg", "dst"):
+        if a.method not in ("auto", "mg", "dst", "fft"):
             opts.update(tol=2e-5, max_sweeps=1000000, check_every=64)
         inst.set_solver(**opts)
         body = np.array(dst, np.uint8, copy=True, order="C")

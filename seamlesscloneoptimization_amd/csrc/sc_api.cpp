@@ -221,7 +221,7 @@ static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int 
     I->h_rect[0] = mc - 1; I->h_rect[1] = 0; I->h_rect[2] = mr - 1; I->h_rect[3] = 0; // seamlessClone_imp.cpp:1006
     SC_HIP(I, hipMemcpyAsync(I->d_rect, I->h_rect, 4 * sizeof(int), hipMemcpyHostToDevice, I->stream));
     I->erode_done = false;
-    if (predicted) {
+    if (predicted && !(I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) {
         I->mpitch = round_up(predicted->W, 64);
         int rc = ensure(I, I->d_M, (size_t)I->mpitch * predicted->H);
         if (rc) return rc;
@@ -297,7 +297,9 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
     if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
     if ((rc = setup_fields(I, g.W, g.H, 3))) return rc;
     const bool eroded = I->erode_done;
-    if (!eroded) launch_mask_erode3(d_mask, ms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    const bool grey = (I->opts.flags & SC_FLAG_OPENCV_GREY_MASK) != 0;
+    if (!eroded && grey) launch_mask_erode_min7(d_mask, ms, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    else if (!eroded) launch_mask_erode3(d_mask, ms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
     I->erode_done = false;
     if ((rc = tmark(I, 4, eroded))) return rc;
     int solve_rc = SC_OK;
@@ -306,7 +308,7 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         I->f_half = mg_reads_half_rhs(I);
         I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
         launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
-                          I->stream, I->f_half, I->u_half);
+                          I->stream, I->f_half, I->u_half, grey);
         if (pass == passes - 1 && (rc = tmark(I, 5))) return rc;
         I->info.sweep_launches = 0;
         I->spec_post.body_org = body_org; I->spec_post.bstep = bstep;
@@ -785,7 +787,7 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
         const sc_batch_job &j = jobs[i];
         if (j.body_restore) SC_HIP(I, hipMemcpyAsync(j.body, j.body_restore, (size_t)j.body_step * j.body_rows, hipMemcpyDeviceToDevice, I->stream));
     }
-    if (n == 1 || I->opts.reference_warmup) return one_by_one();
+    if (n == 1 || I->opts.reference_warmup || (I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) return one_by_one();
     for (int i = 0; i < n; ++i) {
         const sc_batch_job &j = jobs[i];
         if (validate_images(I, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows, j.body_step,
@@ -969,7 +971,8 @@ int sc_hip_mask_stage(void *p, const uint8_t *mask, int mc, int mr, int ms, int 
     geo[0] = g.x0; geo[1] = g.y0; geo[2] = g.W; geo[3] = g.H; geo[4] = g.ltx; geo[5] = g.lty;
     I->mpitch = round_up(g.W, 64);
     if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
-    launch_mask_erode3((const uint8_t *)I->d_mask.p, dms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    if (I->opts.flags & SC_FLAG_OPENCV_GREY_MASK) launch_mask_erode_min7((const uint8_t *)I->d_mask.p, dms, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+    else launch_mask_erode3((const uint8_t *)I->d_mask.p, dms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
     SC_HIP(I, hipGetLastError());
     if (M_out) {
         if (M_capacity < (size_t)g.W * g.H) return SC_ERR_BAD_SIZE;
@@ -1008,7 +1011,7 @@ int sc_hip_build_rhs(void *p, const uint8_t *face, int fc, int fr, int fs, const
     if ((rc = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return rc;
     if ((rc = setup_fields(I, g.W, g.H, 3))) return rc;
     launch_preprocess((const uint8_t *)I->d_body_roi.p, dfs, (const uint8_t *)I->d_face.p, dfs,
-                      (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F, I->stream);
+                      (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F, I->stream, false, false, (I->opts.flags & SC_FLAG_OPENCV_GREY_MASK) != 0);
     SC_HIP(I, hipGetLastError());
     if (B_out && (rc = download_field(I, I->U0, B_out))) return rc;
     if (lap_out && (rc = download_field(I, I->F, lap_out))) return rc;

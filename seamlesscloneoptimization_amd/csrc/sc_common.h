@@ -50,13 +50,14 @@ struct ImageJobs { enum { MAX = 16 }; ImageJob j[MAX]; };
 // ---------------------------------------------------------------- kernel launchers (sc_kernels.hip)
 void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s);
 void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, uint8_t *M, int mpitch, hipStream_t s);
+void launch_mask_erode_min7(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int mpitch, hipStream_t s);   // OpenCV's grey-mask erode (SC_FLAG_OPENCV_GREY_MASK)
 void launch_mask_bbox_group(const MaskJob *jobs, int n, hipStream_t s);
 void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s);
 // bounding box of the whole mask + erode of the (predicted) ROI g in one launch
 void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, Geo g, uint8_t *M, int mpitch, hipStream_t s);
 // body_org: pointer to the pixel that corresponds to ROI (0,0); face_org likewise (patch + offset)
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
-                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false);
+                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false, bool grey = false);
 // bounding box the host assumed when it launched a clone before the device's answer was back (d_rect == nullptr: none)
 struct RectGuard { const int *d_rect = nullptr; int x0 = 0, x1 = 0, y0 = 0, y1 = 0; };
 // float-table correction at the nodes = every 8th field row and column (sc_lowmode.hip): CN[c][Y][X], ny rows of npitch

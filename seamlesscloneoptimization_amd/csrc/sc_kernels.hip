@@ -223,6 +223,44 @@ void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, ui
     hipLaunchKernelGGL(k_mask_erode3, grid, dim3(256), 0, s, mask, mstep, bytes, g, M, mpitch);
 }
 
+// OpenCV's erode for masks that are not 0 / 255 (SC_FLAG_OPENCV_GREY_MASK): cv::seamlessClone erodes the ROI view of the
+// zero-bordered mask with a 3 x 3 rectangle, 3 iterations (OpenCV 3.4.5, seamless_cloning_impl.cpp, computeDerivatives) -- a 7 x 7
+// MINIMUM filter that reads zeros outside the bounding box.  The reference thresholds instead (:917, sum == 255 * 9): the
+// two agree on 0 / 255 masks only.  Separable: 64 x 16 outputs per workgroup, the 70 x 22 source bytes staged in LDS (zero
+// outside the ROI), horizontal minima, then vertical.  Not a hot kernel (one byte per pixel, a non-default path).
+__global__ __launch_bounds__(256) void k_mask_erode_min7(const uint8_t *__restrict__ mask, int mstep, Geo g, uint8_t *__restrict__ M, int mpitch)
+{
+    __shared__ uint8_t in[22][72];
+    __shared__ uint8_t hm[22][64];
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    for (int i = threadIdx.x; i < 22 * 70; i += 256) {
+        const int ry = i / 70, rx = i - ry * 70;
+        const int y = y0 - 3 + ry, x = x0 - 3 + rx;
+        in[ry][rx] = (y >= 0 && y < g.H && x >= 0 && x < g.W) ? mask[(size_t)(y + g.y0) * mstep + (g.x0 + x)] : (uint8_t)0;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int r = ly; r < 22; r += 4) {
+        unsigned m = 255u;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) m = min(m, (unsigned)in[r][lx + d]);
+        hm[r][lx] = (uint8_t)m;
+    }
+    __syncthreads();
+    for (int r = ly; r < 16; r += 4) {
+        unsigned m = 255u;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) m = min(m, (unsigned)hm[r + d][lx]);
+        const int y = y0 + r, x = x0 + lx;
+        if (y < g.H && x < g.W) M[(size_t)y * mpitch + x] = (uint8_t)m;
+    }
+}
+
+void launch_mask_erode_min7(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int mpitch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mask_erode_min7, dim3((g.W + 63) / 64, (g.H + 15) / 16), dim3(256), 0, s, mask, mstep, g, M, mpitch);
+}
+
 // Whole mask stage in one launch, for a clone launched on a PREDICTED bounding box (sc_api.cpp): the erode of the
 // predicted ROI does not wait for the bounding box the same launch computes.  1-D grid; a workgroup does its share
 // of the scan (if it has one) and then its erode strip (if it has one) -- the two are independent.
@@ -365,7 +403,10 @@ __device__ __forceinline__ void p4_window(const unsigned *row, int word0, int sh
 // HF / HU: the right-hand side (an integer in [-1020, 1020]) / the initial field (8-bit values) are stored as float16,
 // exactly, at the same element pitch / plane size inside their buffers; the fused multigrid path reads them that way
 // (sc_cycle0.hip: every launch reads F, the first one U0).
-template <bool HF, bool HU>
+// GREY (SC_FLAG_OPENCV_GREY_MASK): the eroded mask is a grey value and the blend is OpenCV's for such masks -- patch gradient
+// times M (1/255f) plus destination gradient times (255 - M)(1/255f) (Cloning::normalClone / evaluate, OpenCV 3.4.5) -- instead
+// of the select; bit-identical to the select for M in {0, 255}.  Fields are float then (the right-hand side is no integer).
+template <bool HF, bool HU, bool GREY = false>
 __device__ __forceinline__ void preprocess_block(const uint8_t *__restrict__ body, int bstep,
                                                  const uint8_t *__restrict__ face, int fstep,
                                                  const uint8_t *__restrict__ M, int mpitch,
@@ -416,14 +457,26 @@ __device__ __forceinline__ void preprocess_block(const uint8_t *__restrict__ bod
             if (yin && x + j >= 1 && x + j <= W - 2) {
                 const float bl = P4_BYTE(bc, b - 3), br = P4_BYTE(bc, b + 3), bup = P4_BYTE(bu, b), bdn = P4_BYTE(bd, b);
                 const float pcc = P4_BYTE(pc, b), pl = P4_BYTE(pc, b - 3), pr = P4_BYTE(pc, b + 3), pup = P4_BYTE(pu, b), pdn = P4_BYTE(pd, b);
-                const bool m = ((mw >> (8 * j)) & 0xffu) != 0u;
-                const bool ml = (j == 0 ? mlb : ((mw >> (8 * (j - 1))) & 0xffu)) != 0u;
-                const bool mu = ((muw >> (8 * j)) & 0xffu) != 0u;
+                const unsigned mb = (mw >> (8 * j)) & 0xffu, mlbyte = (j == 0 ? mlb : ((mw >> (8 * (j - 1))) & 0xffu)), mub = (muw >> (8 * j)) & 0xffu;
+                if (GREY) {
+                    const float k = 1.0f / 255.0f;
+                    const float wm = (float)mb * k, wi = (float)(255u - mb) * k, wlm = (float)mlbyte * k, wli = (float)(255u - mlbyte) * k;
+                    const float wum = (float)mub * k, wui = (float)(255u - mub) * k;
+                    const float gx = (br - bcc) * wi + (pr - pcc) * wm;
+                    const float gxl = (bcc - bl) * wli + (pcc - pl) * wlm;
+                    const float gy = (bdn - bcc) * wi + (pdn - pcc) * wm;
+                    const float gyu = (bcc - bup) * wui + (pcc - pup) * wum;
+                    lap = (gx - gxl) + (gy - gyu);
+                } else {
+                const bool m = mb != 0u;
+                const bool ml = mlbyte != 0u;
+                const bool mu = mub != 0u;
                 const float gx = m ? (pr - pcc) : (br - bcc);
                 const float gxl = ml ? (pcc - pl) : (bcc - bl);
                 const float gy = m ? (pdn - pcc) : (bdn - bcc);
                 const float gyu = mu ? (pcc - pup) : (bcc - bup);
                 lap = (gx - gxl) + (gy - gyu);
+                }
             }
             lv[j] = lap;
         }
@@ -446,13 +499,13 @@ __device__ __forceinline__ void preprocess_block(const uint8_t *__restrict__ bod
 }
 #undef P4_BYTE
 
-template <bool HF, bool HU>
+template <bool HF, bool HU, bool GREY = false>
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ body, int bstep,
                                                      const uint8_t *__restrict__ face, int fstep,
                                                      const uint8_t *__restrict__ M, int mpitch,
                                                      Field U0, Field U1, Field F)
 {
-    preprocess_block<HF, HU>(body, bstep, face, fstep, M, mpitch, U0, F, 0);
+    preprocess_block<HF, HU, GREY>(body, bstep, face, fstep, M, mpitch, U0, F, 0);
 }
 
 // a group of clones in one launch: blockIdx.z = member, which owns channels 3z..3z+2 of the group's fields
@@ -480,10 +533,11 @@ void launch_preprocess_group(const ImageJob *jobs, int n, int mpitch, Field U0, 
 }
 
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
-                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half, bool u_half)
+                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half, bool u_half, bool grey)
 {
     dim3 g4((U0.W + P4_TW - 1) / P4_TW, (U0.H + P4_TH - 1) / P4_TH);
-    if (f_half && u_half) hipLaunchKernelGGL((k_preprocess<true, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    if (grey) hipLaunchKernelGGL((k_preprocess<false, false, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    else if (f_half && u_half) hipLaunchKernelGGL((k_preprocess<true, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
     else if (f_half) hipLaunchKernelGGL((k_preprocess<true, false>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
     else hipLaunchKernelGGL((k_preprocess<false, false>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
 }

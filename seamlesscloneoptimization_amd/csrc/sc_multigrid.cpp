@@ -423,7 +423,7 @@ bool mg_reads_half_rhs(const Instance *I)
 {
     const sc_solver_opts &o = I->opts;
     // at least two levels: min(W, H) - 2 > 3 (build_levels)
-    return !(o.flags & SC_FLAG_FLOAT_RHS) && effective_method(I) == SC_METHOD_MULTIGRID && o.tol <= 0.f && fused_level0(o) && std::min(I->F.W, I->F.H) - 2 > 3;
+    return !(o.flags & (SC_FLAG_FLOAT_RHS | SC_FLAG_OPENCV_GREY_MASK)) && effective_method(I) == SC_METHOD_MULTIGRID && o.tol <= 0.f && fused_level0(o) && std::min(I->F.W, I->F.H) - 2 > 3;
 }
 
 int mg_solve(Instance *I)

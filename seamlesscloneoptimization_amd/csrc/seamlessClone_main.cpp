@@ -80,11 +80,12 @@ int main(int argc, const char *argv[])
     printf("argc: %d\n", argc);
     for (int i = 0; i < argc; ++i) printf("argv[%d]: %s\n", i, argv[i]);
     if (argc < 7 || argc > 9) {
-        fprintf(stderr, "usage: %s src.yml dst.yml mask.yml centerX centerY gpu [out.bmp [auto|mg|exact|dst]]\n"
-                        "  auto  (default) dst up to 640 unknowns per side, mg above (SC_METHOD_AUTO)\n"
+        fprintf(stderr, "usage: %s src.yml dst.yml mask.yml centerX centerY gpu [out.bmp [auto|mg|exact|dst|fft]]\n"
+                        "  auto  (default) direct FFT solve in double up to 640 unknowns per side, mg above (SC_METHOD_AUTO)\n"
                         "  mg    multigrid + float-table correction: the reference's arithmetic\n"
                         "  exact multigrid, exact solution of the 5-point system (SC_FLAG_EXACT_TABLES)\n"
-                        "  dst   the reference's direct DST solve on the fp64 matrix cores (SC_METHOD_DST)\n", argv[0]);
+                        "  dst   the reference's direct DST solve on the fp64 matrix cores (SC_METHOD_DST)\n"
+                        "  fft   the reference's default back-end: FFT-based direct solve, float32 (SC_METHOD_FFT)\n", argv[0]);
         return EXIT_FAILURE;
     }
     Mat8 patch, dest, mask;
@@ -103,6 +104,7 @@ int main(int argc, const char *argv[])
         if (solver == "mg") o.method = SC_METHOD_MULTIGRID;
         else if (solver == "exact") { o.method = SC_METHOD_MULTIGRID; o.flags |= SC_FLAG_EXACT_TABLES; }
         else if (solver == "dst") o.method = SC_METHOD_DST;
+        else if (solver == "fft") o.method = SC_METHOD_FFT;
         else { fprintf(stderr, "unknown solver '%s'\n", solver.c_str()); my_seamlessclone_api_imp_destroy(inst); return EXIT_FAILURE; }
         sc_hip_set_solver(inst, &o);
     }
@@ -124,7 +126,7 @@ int main(int argc, const char *argv[])
     printf("Compute stage performance time= %.3f msec, patch size=%dx%d\n", info.ms_device_total, info.W, info.H);
     printf("total device memory used: %zu\n", info.device_bytes);
     printf("transfers: H2D %.3f msec, D2H %.3f msec; solver %s%s: %d cycle(s)\n", info.ms_h2d, info.ms_d2h, solver.c_str(),
-           solver == "auto" ? (info.method == SC_METHOD_DST ? " -> dst" : " -> mg") : "", info.sweeps);
+           solver == "auto" ? (info.method == SC_METHOD_FFT ? " -> fft (double)" : " -> mg") : "", info.sweeps);
     if (argc >= 8 && !write_bmp(argv[7], out)) fprintf(stderr, "cannot write %s\n", argv[7]);
     my_seamlessclone_api_imp_destroy(inst);
     return EXIT_SUCCESS;

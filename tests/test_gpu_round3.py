@@ -42,7 +42,7 @@ def _dsum(a, b):
 
 
 def test_default_solver_choice_and_its_deviation_at_the_published_sizes(inst, oracles, c1_inputs, golden_dir):
-    """SC_METHOD_AUTO (the default): the direct solve up to SC_AUTO_DIRECT_MAX unknowns per side, multigrid above.  At the
+    """SC_METHOD_AUTO (the default): the direct solve (FFT form, double transforms) up to SC_AUTO_DIRECT_MAX unknowns per side, multigrid above.  At the
     reference's small published patch sizes the default's diff sum against the float-table port stays at or below the
     reference's own published deviation from OpenCV (44 at 300x194, PDF p3); the frozen c1 fixture likewise."""
     from seamlesscloneoptimization_amd import capi
@@ -53,7 +53,7 @@ def test_default_solver_choice_and_its_deviation_at_the_published_sizes(inst, or
         want = oc.seamless_clone(dst, patch, mask, cx, cy, 4)
         body = dst.copy()
         assert inst.run(patch, body, mask, cx, cy) == 0
-        assert inst.info().method == capi.SC_METHOD_DST and inst.info().converged == 1
+        assert inst.info().method == capi.SC_METHOD_FFT and inst.info().converged == 1
         mx, sm = _dsum(body, want)
         assert mx <= 1 and sm <= bound, (pw, ph, mx, sm)
     # the reference's own images (config 1) against the frozen fixture
@@ -62,7 +62,7 @@ def test_default_solver_choice_and_its_deviation_at_the_published_sizes(inst, or
     assert inst.run(c["patch"], body, c["mask"], c["cx"], c["cy"]) == 0
     f = np.load(os.path.join(golden_dir, "c1_float_tables.npz"))      # config 1 in the reference's arithmetic, frozen (make_golden.py)
     mx, sm = _dsum(body[54:54 + 192, 651:651 + 298], f["roi_bgr"])
-    assert inst.info().method == capi.SC_METHOD_DST and mx <= 1 and sm <= 44, (mx, sm)
+    assert inst.info().method == capi.SC_METHOD_FFT and mx <= 1 and sm <= 44, (mx, sm)
     outside = body.copy(); outside[55:55 + 190, 652:652 + 296] = c["dst"][55:55 + 190, 652:652 + 296]
     assert np.array_equal(outside, c["dst"])
     # one unknown more than the limit per side: multigrid (3 cycles), still within one of the port
@@ -99,7 +99,7 @@ def test_groups_of_small_clones_take_the_direct_solve_too(oracles):
         j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
         j.centerX, j.centerY, j.body_restore = cx, cy, b0
     pool.run(jobs, device_resident=True)
-    assert inst.info().method == capi.SC_METHOD_DST and inst.field_shape()[0] == 3 * N
+    assert inst.info().method == capi.SC_METHOD_FFT and inst.field_shape()[0] == 3 * N
     solo = capi.Instance(0)
     for (dst, patch, mask, cx, cy), (f, b, b0, m) in zip(items, keep):
         got = inst.from_device(b, dst.shape)
@@ -164,7 +164,7 @@ def test_thin_rois_state_of_the_bound(hip, inst, oracles, W, H):
             assert dd.max() <= 1
         shares[name] = round(100.0 * float((d > 0).sum()) / (3.0 * max(1, (W - 2) * (H - 2))), 2)
     direct = max(W, H) - 2 <= capi.SC_AUTO_THIN_LONG_MAX
-    assert inst.info().method == (capi.SC_METHOD_DST if direct else capi.SC_METHOD_MULTIGRID)
+    assert inst.info().method == (capi.SC_METHOD_FFT if direct else capi.SC_METHOD_MULTIGRID)
     print("thin ROI %dx%d: %% of ROI channels off by one vs the port:" % (W, H), shares)
     if direct and min(W, H) <= 6:
         assert shares["default"] <= 35.0, shares
@@ -331,3 +331,63 @@ def test_fft_direct_solver_c1_and_groups(inst, oracles, c1_inputs, golden_dir):
     inst.field_load(big, big)
     with pytest.raises(capi.SeamlessCloneError):
         inst.field_solve()
+
+
+def _grey_mask(shape, kind):
+    h, w = shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "soft_ellipse":
+        r = np.hypot((xx - w / 2) / (w / 2.2), (yy - h / 2) / (h / 2.2))
+        return np.clip((1.15 - r) * 255 * 3, 0, 255).astype(np.uint8)
+    rng = np.random.default_rng(7)
+    m = np.full((h, w), 255, np.uint8)
+    m[rng.random((h, w)) < 0.02] = 77
+    m[h // 3:h // 3 + 9, w // 4:w // 4 + 30] = 180
+    return m
+
+
+@pytest.mark.parametrize("W,H,kind", [(150, 110, "soft_ellipse"), (333, 190, "specks"), (700, 650, "soft_ellipse"), (1100, 300, "specks")])
+def test_opencv_grey_mask_semantics(inst, oracles, W, H, kind):
+    """SC_FLAG_OPENCV_GREY_MASK (second half; parity unpinned, see oracle/): the eroded mask bit for bit against the
+    7x7-minimum restatement, the right-hand side bit for bit against the C restatement of OpenCV's fractional blend, the
+    finished clone within one -- for the default solver choice, multigrid and the direct solves.  Without the flag the same grey
+    mask gives the reference's thresholding semantics (the two differ visibly)."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=24, seed_dst=W, seed_patch=H)
+    gm = _grey_mask(mask.shape, kind)
+    inst.set_solver(flags=capi.SC_FLAG_OPENCV_GREY_MASK)
+    geo, M = inst.mask_stage(gm, cx, cy)
+    gc, Mc = oc.mask_stage(gm, cx, cy, opencv_grey=True)
+    assert np.array_equal(geo, gc) and np.array_equal(M, Mc) and len(np.unique(M)) > 2
+    _, B, lap = inst.build_rhs(patch, dst, gm, cx, cy)
+    Bc, lapc = oc.build_rhs(dst, patch, gc, Mc, opencv_grey=True)
+    assert np.array_equal(B, Bc) and np.array_equal(lap, lapc)
+    want = oc.seamless_clone(dst, patch, gm, cx, cy, 4, opencv_grey=True)
+    outs = {}
+    for name, method in (("auto", capi.SC_METHOD_AUTO), ("mg", capi.SC_METHOD_MULTIGRID), ("fft", capi.SC_METHOD_FFT), ("dst", capi.SC_METHOD_DST)):
+        inst.set_solver(method=method, flags=capi.SC_FLAG_OPENCV_GREY_MASK)
+        body = dst.copy()
+        assert inst.run(patch, body, gm, cx, cy) == 0
+        assert _dsum(body, want)[0] <= 1, name
+        outs[name] = body
+    # device-resident images and a group (which runs one clone at a time with this flag) give the host call's bytes
+    inst.set_solver(method=capi.SC_METHOD_AUTO, flags=capi.SC_FLAG_OPENCV_GREY_MASK)
+    d_f, d_b, d_m = inst.to_device(patch), inst.to_device(dst), inst.to_device(gm)
+    inst.run_device(d_f, patch.shape[:2], d_b, dst.shape[:2], d_m, gm.shape[:2], cx, cy, sync=True)
+    assert np.array_equal(inst.from_device(d_b, dst.shape), outs["auto"])
+    for p in (d_f, d_b, d_m):
+        inst.free(p)
+    # the reference's semantics (flag off) on the same mask: within one of ITS oracle, and not OpenCV's answer
+    inst.set_solver(method=capi.SC_METHOD_AUTO, flags=0)
+    body = dst.copy()
+    assert inst.run(patch, body, gm, cx, cy) == 0
+    assert _dsum(body, oc.seamless_clone(dst, patch, gm, cx, cy, 4))[0] <= 1
+    assert (body != outs["auto"]).mean() > 0.002
+    # 0 / 255 masks: the flag changes nothing, byte for byte
+    for flags in (0, capi.SC_FLAG_OPENCV_GREY_MASK):
+        inst.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags)
+        b2 = dst.copy()
+        inst.run(patch, b2, mask, cx, cy)
+        outs["bin%d" % flags] = b2
+    assert np.array_equal(outs["bin0"], outs["bin%d" % capi.SC_FLAG_OPENCV_GREY_MASK])

@@ -284,3 +284,40 @@ def test_frozen_c1_float_table_fixture(golden_dir, c1_inputs):
     assert d.max() <= 1 and d.sum() <= 4
     e = np.load(os.path.join(golden_dir, "c1_expected.npz"))
     assert int(f["differs_from_exact"]) == int(np.abs(e["roi_bgr"].astype(int) - f["roi_bgr"].astype(int)).sum()) > 50
+
+
+def _grey_mask(shape, kind):
+    h, w = shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "soft_ellipse":
+        r = np.hypot((xx - w / 2) / (w / 2.2), (yy - h / 2) / (h / 2.2))
+        return np.clip((1.15 - r) * 255 * 3, 0, 255).astype(np.uint8)
+    rng = np.random.default_rng(7)
+    m = np.full((h, w), 255, np.uint8)
+    m[rng.random((h, w)) < 0.02] = rng.integers(1, 255, 1)[0]      # grey specks in an all-255 mask
+    m[h // 3:h // 3 + 9, w // 4:w // 4 + 30] = 180
+    return m
+
+
+@pytest.mark.parametrize("kind", ["soft_ellipse", "specks"])
+def test_opencv_grey_mask_semantics_restatement(kind):
+    """OpenCV's semantics for masks that are not 0/255 (second half; PARITY UNPINNED -- restatement of the published
+    OpenCV 3.4.5 algorithm, no fixture of the reference holds a grey mask): the erode is a 7x7 minimum filter and the blend uses
+    the fractional weights M/255 and (255 - M)/255.  The numpy and the C restatement agree (mask bit for bit, image within one:
+    float64 against float32 products); on a 0/255 mask they are the reference's semantics bit for bit; on a grey mask they are
+    not (the reference thresholds, seamlessClone_imp.cpp:917)."""
+    dst, patch, mask, cx, cy = o.synth_inputs(150, 110, margin=24)
+    gm = _grey_mask(mask.shape, kind)
+    geo = o.mask_stage(gm, cx, cy, opencv_grey=True)
+    gc, Mc = oc.mask_stage(gm, cx, cy, opencv_grey=True)
+    assert np.array_equal(geo["M"], Mc) and len(np.unique(Mc)) > 2
+    ref = o.mask_stage(gm, cx, cy)["M"]
+    assert set(np.unique(ref)) <= {0, 255} and np.all(ref <= geo["M"])            # thresholding never exceeds the minimum filter
+    assert np.array_equal(ref == 255, geo["M"] == 255)                               # and agrees where the window is all 255
+    a = o.seamless_clone(dst, patch, gm, cx, cy, float_tables=True, opencv_grey=True)
+    b = oc.seamless_clone(dst, patch, gm, cx, cy, 2, opencv_grey=True)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    assert (o.seamless_clone(dst, patch, gm, cx, cy, float_tables=True) != a).mean() > 0.01     # the two semantics differ on a grey mask
+    for m2 in (mask, o.synth_inputs(150, 110, margin=24, ellipse=True)[2]):                       # ... and not on 0 / 255 masks
+        assert np.array_equal(o.seamless_clone(dst, patch, m2, cx, cy, opencv_grey=True), o.seamless_clone(dst, patch, m2, cx, cy))
+        assert np.array_equal(oc.seamless_clone(dst, patch, m2, cx, cy, 2, opencv_grey=True), oc.seamless_clone(dst, patch, m2, cx, cy, 2))
