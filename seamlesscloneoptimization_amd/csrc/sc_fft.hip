@@ -95,6 +95,24 @@ __device__ __forceinline__ void dft_small(cx2<T> (&v)[R])
     }
 }
 
+// Twiddles w^q, q = 1 .. R-1, of one butterfly (w = w_L^t): the powers of two come from the table (1, 2, 4, 8: at most four
+// gathers), the others are products of two of them (at most three multiplications deep).  Fifteen gathers per 16-point
+// butterfly made the passes wait for the L1, not for the LDS.
+template <int R, typename T>
+__device__ __forceinline__ void twiddle_powers(cx2<T> (&w)[R], const cx2<T> *__restrict__ tw, int t, int twsh, int M)
+{
+#pragma unroll
+    for (int q = 1; q < R; ++q) {
+        if ((q & (q - 1)) == 0) w[q] = tw[((t * q) << twsh) & (M - 1)];
+        else {
+            int hb = 1;
+#pragma unroll
+            for (int b = 1; b < R; b <<= 1) if (b <= q) hb = b;
+            w[q] = cmulf<T>(w[hb], w[q - hb]);
+        }
+    }
+}
+
 // One in-place Gentleman-Sande pass over S[0..M): sub-transforms of length L = 2^lL split by radix R = 2^LR.
 // Butterfly b = (blk, t): elements blk L + t + q (L/R); outputs y_q'[t] = DFT_R(.)[q'] w_L^(t q') stored at the same places.
 template <int LR, typename T>
@@ -109,8 +127,10 @@ __device__ __forceinline__ void pass_fwd(cx2<T> *__restrict__ S, int logM, int l
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = S[fft_pad(base + (q << ls))];
         dft_small<R, -1, T>(v);
+        cx2<T> w[R];
+        twiddle_powers<R, T>(w, tw, t, twsh, M);
 #pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulf<T>(v[q], tw[((t * q) << twsh) & (M - 1)]);
+        for (int q = 1; q < R; ++q) v[q] = cmulf<T>(v[q], w[q]);
 #pragma unroll
         for (int q = 0; q < R; ++q) S[fft_pad(base + (q << ls))] = v[q];
     }
@@ -127,8 +147,10 @@ __device__ __forceinline__ void pass_adj(cx2<T> *__restrict__ S, int logM, int l
         cx2<T> v[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = S[fft_pad(base + (q << ls))];
+        cx2<T> w[R];
+        twiddle_powers<R, T>(w, tw, t, twsh, M);
 #pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulcf<T>(v[q], tw[((t * q) << twsh) & (M - 1)]);
+        for (int q = 1; q < R; ++q) v[q] = cmulcf<T>(v[q], w[q]);
         dft_small<R, +1, T>(v);
 #pragma unroll
         for (int q = 0; q < R; ++q) S[fft_pad(base + (q << ls))] = v[q];
