@@ -12,11 +12,15 @@
 // next power of two (4096 for n = 2046 -- HALF the 8192 the odd-extension route would need), and the convolution is two
 // power-of-two FFTs in LDS around a pointwise product with the precomputed transform of the chirp.
 //
-// One workgroup per row, the transform held in LDS (M complex values, padded against bank conflicts): in-place radix-16 / 8 / 4 /
-// 2 Gentleman-Sande passes (registers hold a 16-point DFT; the result stays in digit-reversed order), the pointwise product
-// with the chirp's transform (stored in that same order, 1/M folded in), and the adjoint passes in reverse order -- no
-// reordering pass at all; the passes at both ends work between global memory and registers (first_fwd / last_adj below).
-// Twiddles come from a table computed in double; the chirp phases are reduced exactly in integers (m^2 mod 2N) first.
+// (Measured and not kept: pass 0 of the forward / adjoint transform working straight between global memory and registers, and
+// the last forward pass fused with the pointwise product and the first adjoint pass -- half the LDS round trips and barriers,
+// but 146-315 VGPRs instead of 87-136 and only M/16 threads busy in the end passes: 5-20 % faster from 2048^2 up, 15-40 % SLOWER
+// below 1024^2, which is where this path is the default.)
+// One workgroup per row: the row is loaded once, multiplied by the chirp into LDS (M complex floats, padded against bank
+// conflicts), transformed by in-place radix-16 / 8 / 4 / 2 Gentleman-Sande passes (registers hold a 16-point DFT; the
+// result stays in digit-reversed order), multiplied by the chirp's transform (stored in that same order, 1/M folded in),
+// and brought back by the adjoint passes in reverse order -- no reordering pass at all.  Twiddles come from a table computed
+// in double; the chirp phases are reduced exactly in integers (m^2 mod 2N) before the double sincospi.
 //
 // The 2-D solve is three such launches and two tiled transposes:
 //     rows (fold of the Dirichlet ring fused into the load) -> transpose -> columns: DST, divide by den, DST again, all in
@@ -157,121 +161,30 @@ __device__ __forceinline__ void pass_adj(cx2<T> *__restrict__ S, int logM, int l
     }
 }
 
-// ---- one chirp-z transform, with the passes at its ends fused into what surrounds them
-// Pass 0 works on L = M: butterfly b owns the elements b + q s (s = M / R0) -- a set it reads AND writes alone, and whose members
-// lie s apart, so consecutive lanes touch consecutive addresses.  That makes pass 0 the place to meet global memory: the forward
-// transform's pass 0 takes its inputs straight from the source row (times the chirp) instead of from a staged copy, and the
-// adjoint pass 0 hands its outputs to the consumer in registers (the output row, or -- in the two-transform launch -- the next
-// transform's pass 0, with no barrier in between: same butterfly, same elements).  The LAST forward pass has s = 1, t = 0: no
-// twiddles, 2^lr contiguous elements per butterfly -- exactly the elements the FIRST adjoint pass needs, so the two and the
-// pointwise product with the chirp's transform between them are one visit.  LDS round trips per transform: npass instead of
-// 2 npass + 2, barriers 2 npass - 2 instead of 2 npass + 1.
-template <int LR, typename T, typename Load>
-__device__ __forceinline__ void first_fwd(cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid, Load load)
-{
-    constexpr int R = 1 << LR;
-    const int ls = P.logM - LR, s = 1 << ls;
-    for (int b = tid; b < s; b += FFT_THREADS) {
-        cx2<T> v[R], w[R];
-#pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = load(b + (q << ls));
-        twiddle_powers<R, T>(w, P.tw, b, 0, P.M);
-        dft_small<R, -1, T>(v);
-#pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulf<T>(v[q], w[q]);
-#pragma unroll
-        for (int q = 0; q < R; ++q) S[fft_pad(b + (q << ls))] = v[q];
-    }
-}
-template <int LR, typename T, typename Sink>
-__device__ __forceinline__ void last_adj(const cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid, Sink sink)
-{
-    constexpr int R = 1 << LR;
-    const int ls = P.logM - LR, s = 1 << ls;
-    for (int b = tid; b < s; b += FFT_THREADS) {
-        cx2<T> v[R], w[R];
-#pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = S[fft_pad(b + (q << ls))];
-        twiddle_powers<R, T>(w, P.tw, b, 0, P.M);
-#pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulcf<T>(v[q], w[q]);
-        dft_small<R, +1, T>(v);
-#pragma unroll
-        for (int q = 0; q < R; ++q) sink(b + (q << ls), v[q]);
-    }
-}
-// adjoint pass 0 of one transform and forward pass 0 of the next on the same butterfly: y -> f(position, y) -> next input
-template <int LR, typename T, typename Map>
-__device__ __forceinline__ void adj_then_fwd(cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid, Map map)
-{
-    constexpr int R = 1 << LR;
-    const int ls = P.logM - LR, s = 1 << ls;
-    for (int b = tid; b < s; b += FFT_THREADS) {
-        cx2<T> v[R], w[R];
-#pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = S[fft_pad(b + (q << ls))];
-        twiddle_powers<R, T>(w, P.tw, b, 0, P.M);
-#pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulcf<T>(v[q], w[q]);
-        dft_small<R, +1, T>(v);
-#pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = map(b + (q << ls), v[q]);
-        dft_small<R, -1, T>(v);
-#pragma unroll
-        for (int q = 1; q < R; ++q) v[q] = cmulf<T>(v[q], w[q]);
-#pragma unroll
-        for (int q = 0; q < R; ++q) S[fft_pad(b + (q << ls))] = v[q];
-    }
-}
-// last forward pass + pointwise product + first adjoint pass: 2^LR contiguous elements per butterfly, no twiddles
-template <int LR, typename T>
-__device__ __forceinline__ void pass_mid(cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid)
-{
-    constexpr int R = 1 << LR;
-    for (int b = tid; b < (P.M >> LR); b += FFT_THREADS) {
-        const int base = b << LR;
-        cx2<T> v[R];
-#pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = S[fft_pad(base + q)];
-        dft_small<R, -1, T>(v);
-#pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = cmulf<T>(v[q], P.bhat[base + q]);
-        dft_small<R, +1, T>(v);
-#pragma unroll
-        for (int q = 0; q < R; ++q) S[fft_pad(base + q)] = v[q];
-    }
-}
-
-// everything between the two pass-0 visits of one transform (at least two passes: M >= 32)
+// S holds a_j = x_j c_j at j = 1..n and zeros elsewhere (synchronised).  On return S[k] = sum_j a_j conj(c_{k-j}), k = 1..n
+// (synchronised): forward passes, pointwise product with the chirp's transform, adjoint passes.
 template <typename T>
-__device__ __forceinline__ void chirp_inner(cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid)
+__device__ __forceinline__ void chirp_convolve(cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid)
 {
-    __syncthreads();
-    int lL = P.logM - P.lr[0];
-    for (int p = 1; p < P.npass - 1; ++p) {
+    int lL = P.logM;
+    for (int p = 0; p < P.npass; ++p) {
         const int lr = P.lr[p];
-        if (lr == 4) pass_fwd<4, T>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 3) pass_fwd<3, T>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 2) pass_fwd<2, T>(S, P.logM, lL, P.tw, tid);
-        else pass_fwd<1, T>(S, P.logM, lL, P.tw, tid);
+        if (lr == 4) pass_fwd<4>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 3) pass_fwd<3>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 2) pass_fwd<2>(S, P.logM, lL, P.tw, tid);
+        else pass_fwd<1>(S, P.logM, lL, P.tw, tid);
         lL -= lr;
         __syncthreads();
     }
-    {
-        const int lr = P.lr[P.npass - 1];
-        if (lr == 4) pass_mid<4, T>(S, P, tid);
-        else if (lr == 3) pass_mid<3, T>(S, P, tid);
-        else if (lr == 2) pass_mid<2, T>(S, P, tid);
-        else pass_mid<1, T>(S, P, tid);
-        __syncthreads();
-    }
-    for (int p = P.npass - 2; p >= 1; --p) {
+    for (int i = tid; i < P.M; i += FFT_THREADS) S[fft_pad(i)] = cmulf<T>(S[fft_pad(i)], P.bhat[i]);
+    __syncthreads();
+    for (int p = P.npass - 1; p >= 0; --p) {
         const int lr = P.lr[p];
         lL += lr;
-        if (lr == 4) pass_adj<4, T>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 3) pass_adj<3, T>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 2) pass_adj<2, T>(S, P.logM, lL, P.tw, tid);
-        else pass_adj<1, T>(S, P.logM, lL, P.tw, tid);
+        if (lr == 4) pass_adj<4>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 3) pass_adj<3>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 2) pass_adj<2>(S, P.logM, lL, P.tw, tid);
+        else pass_adj<1>(S, P.logM, lL, P.tw, tid);
         __syncthreads();
     }
 }
@@ -293,47 +206,6 @@ __device__ __forceinline__ float fft_g(const Field &U, const Field &F, int c, in
 // MODE 0: rows of the folded right-hand side (from the fields) -> T[c][y][x]
 // MODE 1: rows of `in` (the transposed plane: row = x, entries = y) -> DST, / den, DST -> out, same layout
 // MODE 2: rows of `in` [c][y][x] -> DST, scale -> interior of the field U
-// The first pass has radix 2^LR0 (P.lr[0]); X_k = Im(c_k y_k).
-template <int MODE, typename T, int LR0>
-__device__ __forceinline__ void fft_dst_row(const FftPlan<T> &P, const Field &U, const Field &F, const T *__restrict__ in, T *__restrict__ out,
-                                            int rows, const float *__restrict__ f_row, const float *__restrict__ f_k, int exact, double scale,
-                                            cx2<T> *__restrict__ S)
-{
-    const int tid = threadIdx.x, r = blockIdx.x, c = blockIdx.y, n = P.n;
-    const T *__restrict__ src = (MODE == 0) ? nullptr : in + ((size_t)c * rows + r) * n;
-    first_fwd<LR0, T>(S, P, tid, [&](int p) {
-        if (p < 1 || p > n) return mk<T>((T)0, (T)0);
-        const T x = (MODE == 0) ? (T)fft_g(U, F, c, p - 1, r) : src[p - 1];
-        const cx2<T> ch = P.chirp[p];
-        return mk<T>(x * ch.x, x * ch.y);
-    });
-    chirp_inner<T>(S, P, tid);
-    if (MODE == 1) {
-        // divide by the reference's denominator (seamlessClone_imp.cpp:1651-1653: float tables added in float, then - 4) and feed the
-        // quotient straight into the second transform -- in registers, between the two pass-0 visits of the same butterfly
-        const float fr = f_row[r];
-        const double cr = exact ? 2.0 * cospi((double)(r + 1) / (double)(rows + 1)) : 0.0;
-        adj_then_fwd<LR0, T>(S, P, tid, [&](int k, cx2<T> y) {
-            if (k < 1 || k > n) return mk<T>((T)0, (T)0);
-            const cx2<T> ch = P.chirp[k];
-            const T X = ch.x * y.y + ch.y * y.x;
-            T den;
-            if (exact) den = (T)((cr + 2.0 * cospi((double)k / (double)(n + 1))) - 4.0);
-            else den = (T)((fr + f_k[k - 1]) - 4.0f);
-            const T q = X / den;
-            return mk<T>(q * ch.x, q * ch.y);
-        });
-        chirp_inner<T>(S, P, tid);
-    }
-    last_adj<LR0, T>(S, P, tid, [&](int k, cx2<T> y) {
-        if (k < 1 || k > n) return;
-        const cx2<T> ch = P.chirp[k];
-        const T X = ch.x * y.y + ch.y * y.x;
-        if (MODE == 2) U.at(c)[(size_t)(r + 1) * U.pitch + k] = (float)(X * (T)scale);
-        else out[((size_t)c * rows + r) * n + (k - 1)] = X;
-    });
-}
-
 template <int MODE, typename T>
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_dst(FftPlan<T> P, Field U, Field F, const T *__restrict__ in, T *__restrict__ out,
                                                          int rows, const float *__restrict__ f_row, const float *__restrict__ f_k, int exact,
@@ -341,8 +213,42 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_dst(FftPlan<T> P, Field U, 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_smem[];
     cx2<T> *__restrict__ S = reinterpret_cast<cx2<T> *>(fft_smem);
-    // M >= 32 and the radix plan (fft_radices) make the first pass radix 16
-    fft_dst_row<MODE, T, 4>(P, U, F, in, out, rows, f_row, f_k, exact, scale, S);
+    const int tid = threadIdx.x, r = blockIdx.x, c = blockIdx.y, n = P.n;
+    const T *__restrict__ src = (MODE == 0) ? nullptr : in + ((size_t)c * rows + r) * n;
+    for (int i = tid; i < P.M; i += FFT_THREADS) {
+        cx2<T> a = mk<T>((T)0, (T)0);
+        if (i >= 1 && i <= n) {
+            const T x = (MODE == 0) ? (T)fft_g(U, F, c, i - 1, r) : src[i - 1];
+            const cx2<T> ch = P.chirp[i];
+            a = mk<T>(x * ch.x, x * ch.y);
+        }
+        S[fft_pad(i)] = a;
+    }
+    __syncthreads();
+    chirp_convolve<T>(S, P, tid);
+    if (MODE == 1) {
+        // X_k = Im(c_k y_k); divide by the reference's denominator (seamlessClone_imp.cpp:1651-1653: float tables added in float,
+        // then - 4) and feed the quotient straight into the second transform: the row stays in LDS
+        // (element k is read and rewritten by the same thread, the zeroed elements are read by nobody here: no barrier in between)
+        for (int k = 1 + tid; k <= n; k += FFT_THREADS) {
+            const cx2<T> y = S[fft_pad(k)], ch = P.chirp[k];
+            const T X = ch.x * y.y + ch.y * y.x;
+            T den;
+            if (exact) den = (T)((2.0 * cospi((double)(r + 1) / (double)(rows + 1)) + 2.0 * cospi((double)k / (double)(n + 1))) - 4.0);
+            else den = (T)((f_row[r] + f_k[k - 1]) - 4.0f);
+            const T q = X / den;
+            S[fft_pad(k)] = mk<T>(q * ch.x, q * ch.y);
+        }
+        for (int i = tid; i < P.M; i += FFT_THREADS) if (i == 0 || i > n) S[fft_pad(i)] = mk<T>((T)0, (T)0);
+        __syncthreads();
+        chirp_convolve<T>(S, P, tid);
+    }
+    for (int k = 1 + tid; k <= n; k += FFT_THREADS) {
+        const cx2<T> y = S[fft_pad(k)], ch = P.chirp[k];
+        const T X = ch.x * y.y + ch.y * y.x;
+        if (MODE == 2) U.at(c)[(size_t)(r + 1) * U.pitch + k] = (float)(X * (T)scale);
+        else out[((size_t)c * rows + r) * n + (k - 1)] = X;
+    }
 }
 
 // out[c][x][y] = in[c][y][x]; 64 x 64 tiles through LDS
@@ -370,7 +276,7 @@ __global__ __launch_bounds__(256) void k_fft_transpose(const T *__restrict__ in,
 // ---------------------------------------------------------------------------------------------- host side
 static int fft_logm(int n)
 {
-    int l = 5;                                          // at least 32: two passes, the first of radix 16 (k_fft_dst)
+    int l = 1;
     while ((1 << l) < 2 * n - 1) ++l;
     return l;
 }
