@@ -117,7 +117,10 @@ typedef struct sc_solver_opts {
                                             reference's order, seamlessClone_imp.cpp:1012) instead of launching on
                                             a predicted box                                                      */
 #define SC_FLAG_FLOAT_RHS      (1 << 1)  /* multigrid: keep the right-hand side as float32 (default: float16,
-                                            exact -- it is an integer in [-1020, 1020])                         */
+                                            exact -- it is an integer in [-1020, 1020]) AND level 1's right-hand side and
+                                            correction as float32 (default: float16 -- a correction scheme tolerates it, the
+                                            fixed point is level 0's).  Same fixed point, iterates a relative 5e-4 of a
+                                            correction apart: results within one grey level of the default's, not bit-identical */
 #define SC_FLAG_FLOAT_U0       (1 << 2)  /* multigrid: initial field as float32 (default: float16, exact -- 8-bit
                                             values)                                                             */
 #define SC_FLAG_NO_COMPOSE_L1  (1 << 3)  /* multigrid: level 1 gets its own post-smoothing launch (textbook V(2,2));

@@ -194,7 +194,14 @@ def no_post_levels(levels):
     return (1,) if composes_level1(levels) else ()
 
 
-def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post=()):
+def _f16(a):
+    return a.astype(np.float16).astype(F32)
+
+
+def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post=(), level1_half=False):
+    """level1_half: the library's fast path stores level 1's right-hand side (written by level 0's restriction) and level 1's
+    smoothed correction (read by level 0's prolongation) as float16 (sc_cycle0.hip, TAG bit 7); level 1's own residual and
+    restriction use the unrounded registers."""
     dx, dy = levels[l]
     if direct is not None and l == direct:
         return solve_exact(F, dx, dy)
@@ -205,15 +212,19 @@ def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post=()):
     # a level without post-smoothing does all its sweeps before the restriction
     U = rb_gen(U, F, dx, dy, pre + post if (l > 0 and l in no_post) else pre)
     Fc = restrict(residual_field(U, F, dx, dy), dx, dy)
-    E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post, direct, no_post)
+    if level1_half and l == 0:
+        Fc = _f16(Fc)
+    E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post, direct, no_post, level1_half)
     U = U.copy()
+    if level1_half and l == 1 and l in no_post:
+        U = _f16(U)
     U += prolong(E, dx, dy)
     if l > 0 and l in no_post:
         return U
     return rb_gen(U, F, dx, dy, post)
 
 
-def solve(U0, F, cycles=6, direct="auto", fused=True):
+def solve(U0, F, cycles=6, direct="auto", fused=True, level1_half=False):
     """Multigrid solve of one plane: U0 carries the Dirichlet ring (level 0 is regular).
     direct: "auto" = the level the library solves directly, None = V-cycle down to the coarsest level.
     fused: the library's default (fused) schedule, in which level 1 has no post-smoothing where composes_level1();
@@ -224,5 +235,5 @@ def solve(U0, F, cycles=6, direct="auto", fused=True):
     npl = no_post_levels(levels) if fused else ()
     U = U0.astype(F32).copy()
     for _ in range(cycles):
-        U = vcycle(levels, 0, U, F, direct=d, no_post=npl)
+        U = vcycle(levels, 0, U, F, direct=d, no_post=npl, level1_half=level1_half and 1 in npl)
     return U

@@ -151,6 +151,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     static_assert(!(TAG & 64) || !GEN, "cell shares exist on level 0 only");
     constexpr bool HF = (TAG & 2) != 0, HU = (TAG & 4) != 0;   // HU: the first launch of a clone reads the 8-bit destination values the pre-process stored as float16
     static_assert(!(HF && GEN), "float16 right-hand sides exist on level 0 only");
+    // TAG bit 7: LEVEL 1's right-hand side and correction are stored as float16 (same element pitch / plane size inside their
+    // float buffers).  On level 0 (!GEN) that is the restriction this launch writes and the correction it interpolates from; on
+    // the level-1 launch itself (GEN, ZEROIN) its own F and the correction it writes.  A correction scheme does not care: the
+    // coarse problem is solved to a factor 0.05 per cycle anyway, a relative 5e-4 on its data moves the iterates by that much
+    // of a correction and not the fixed point (level 0's residual is exact).  Halves the traffic of the level-1 launch and takes
+    // 1 byte per unknown off every level-0 launch (oracle/mg_np.py rounds the same two fields).
+    constexpr bool L1H = (TAG & 128) != 0;
+    static_assert(!L1H || !GEN || ZEROIN, "float16 level-1 fields: the level-1 launch starts from a zero correction");
     static_assert(!(PRO && GEN), "the in-kernel prolongation relies on level 0's regular last interval");
     static_assert(2 * T + 2 <= C0_HX, "column halo too small");
     static_assert(R % 2 == 0, "bands must hold whole coarse-row pairs");
@@ -185,13 +193,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     float2 e2r[COMP ? NQ : 1];
     float e2l[COMP ? NQ : 1];          // level-2 column x/4 - 1: source of the ghost value when x/4 itself is the ghost column
     if (PRO) {
-        const float *__restrict__ e = E.at(c);
         const int cx = min(max(x >> 1, 0), E.pitch - 4), J = (y0 >> 1) - 1;
+        if constexpr (L1H) {
+            const __half *__restrict__ e = reinterpret_cast<const __half *>(E.p) + (size_t)c * E.plane;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const __half *er = e + (size_t)min(max(J + j, 0), E.H - 1) * E.pitch + cx;      // cx is even: a 4-byte aligned pair
+                eab[j] = __half22float2(*reinterpret_cast<const __half2 *>(er));
+                ecc[j] = __half2float(er[2]);
+            }
+        } else {
+        const float *__restrict__ e = E.at(c);
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const float *er = e + (size_t)min(max(J + j, 0), E.H - 1) * E.pitch + cx;
             eab[j] = *reinterpret_cast<const float2 *>(er);
             ecc[j] = er[2];
+        }
         }
     }
     if (COMP) {
@@ -206,6 +224,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
     if (!PRO) {   // with PRO the RHS is fetched after the prolongation
         if constexpr (HF) c0_load_half_raw<R>(reinterpret_cast<const __half *>(F.p) + (size_t)c * F.plane, P, H, x, y0, fh);
+        else if constexpr (GEN && L1H) c0_load_half<R>(reinterpret_cast<const __half *>(F.p) + (size_t)c * F.plane, P, H, x, y0, f);
         else c0_load<R>(F.at(c), P, H, x, y0, f);
     }
     const bool x0ok = (x + 0 >= 1) && (x + 0 <= W - 2), x1ok = (x + 1 >= 1) && (x + 1 <= W - 2);
@@ -550,9 +569,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
                 v1 = __builtin_fmaf(h1[r + 1], 0.5f, __builtin_fmaf(m1, 0.5f, h1[r]));
             }
             const float fy = (J == g.y.nc) ? 2.0f * g.y.inv_last : 1.0f;
+            if constexpr (L1H && !GEN) {
+                __half *o = reinterpret_cast<__half *>(Fc.p) + (size_t)c * Fc.plane + (size_t)J * Fc.pitch + I;
+                if (I >= 1 && I <= g.x.nc) o[0] = __float2half_rn(v0 * (fx0 * fy));
+                if (I + 1 >= 1 && I + 1 <= g.x.nc) o[1] = __float2half_rn(v1 * (fx1 * fy));
+            } else {
             float *o = fc + (size_t)J * Fc.pitch + I;
             if (I >= 1 && I <= g.x.nc) o[0] = v0 * (fx0 * fy);
             if (I + 1 >= 1 && I + 1 <= g.x.nc) o[1] = v1 * (fx1 * fy);
+            }
         }
     }
 
@@ -569,6 +594,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             float4 v = u[r];
             if (lm.CN && x <= W - 2) lm_add4(lm, c, x, y, v);   // the lane that holds only the ring column x = W - 1 would read node (x >> 3) + 1 == nx, one past the row (its byte is never spliced)
             *reinterpret_cast<unsigned *>(q + (size_t)y * P + x) = lm_byte(v.x) | (lm_byte(v.y) << 8) | (lm_byte(v.z) << 16) | (lm_byte(v.w) << 24);
+        }
+        return;
+    }
+    if constexpr (GEN && L1H) {      // the level-1 correction leaves as float16: level 0's prolongation reads it that way
+        __half *__restrict__ outh = reinterpret_cast<__half *>(Uout.p) + (size_t)c * Uout.plane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int yr = wv * R + r, y = y0 + r;
+            if (!(yr >= HY && yr < RH - HY && y >= 0 && y < H)) continue;
+            const __half2 a = __floats2half2_rn(u[r].x, u[r].y), b2 = __floats2half2_rn(u[r].z, u[r].w);
+            uint2 pk; pk.x = *reinterpret_cast<const unsigned *>(&a); pk.y = *reinterpret_cast<const unsigned *>(&b2);
+            *reinterpret_cast<uint2 *>(outh + (size_t)y * P + x) = pk;
         }
         return;
     }
@@ -596,27 +633,42 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
 // Level-0 launch whose prolongation source is composed on the fly: U1 = level-1 correction after its pre-smoothing (level 1
 // has no post-smoothing and no prolongation launch of its own), E2 = finished level-2 correction, g1 = level-1 geometry.
 // sweeps = post + pre (4) or, final_cycle, post (2).  Returns the number of partial maxima, -1 if not instantiated.
+// With a float16 right-hand side (f_half: the fast path) level 1's fields are float16 as well (TAG bit 7; sc_multigrid.cpp decides
+// with the same rule: mg_level1_half).
 int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
-                           hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands)
+                           hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands, bool l1_half)
 {
     ComposeArgs ca;
     ca.E2 = E2; ca.g1 = g1;
+    if (l1_half != f_half) {           // instantiated pairs: float16 RHS with float16 level 1, float RHS with float level 1 -- and, for
+        if (l1_half) return -1;        // a level 1 that does fewer than four sweeps (mg_level1_sweeps), float16 RHS with float level 1
+        if (final_cycle) return sweeps == 2 ? launch_c0<2, true, 26>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : -1;
+        if (sweeps != 4) return -1;
+        if (bands && !tag) return launch_c0<4, true, 82>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
+        return tag ? launch_c0<4, true, 19>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 18>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
+    }
     if (final_cycle) {
         if (sweeps != 2) return -1;
-        return f_half ? launch_c0<2, true, 26>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : launch_c0<2, true, 24>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
+        return f_half ? launch_c0<2, true, 154>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : launch_c0<2, true, 24>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
     }
     if (sweeps != 4) return -1;
-    if (bands && !tag) return f_half ? launch_c0<4, true, 82>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : launch_c0<4, true, 80>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
-    if (tag) return f_half ? launch_c0<4, true, 19>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 17>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
-    return f_half ? launch_c0<4, true, 18>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 16>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
+    if (bands && !tag) return f_half ? launch_c0<4, true, 210>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : launch_c0<4, true, 80>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
+    if (tag) return f_half ? launch_c0<4, true, 147>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 17>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
+    return f_half ? launch_c0<4, true, 146>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 16>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
 }
 
 // sweeps = T red-black GS sweeps; prolong: add P*E first and write per-block max|P*E| to `partial`; f_half / u_half: F /
 // Uin hold float16 values (same element layout).  Returns the number of partial maxima written (0 without prolong), or -1
 // for an unsupported depth.
 int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle, float4 *bands)
+                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle, float4 *bands, bool l1_half)
 {
+    if (l1_half) {     // level 1 keeps float16 fields (the composed schedule): the launches without a prolongation write its right-hand side
+        if (prolong || final_cycle || !f_half || tag || sweeps != 2) return -1;
+        if (u_half) launch_c0<2, false, 134>(Uin, Uout, F, Fc, E, g, partial, s);
+        else launch_c0<2, false, 130>(Uin, Uout, F, Fc, E, g, partial, s);
+        return 0;
+    }
     if (final_cycle) {   // prolongation + `sweeps` post-smoothing sweeps, nothing restricted
         if (!prolong || u_half) return -1;
         const ComposeArgs nc = ComposeArgs();
@@ -660,12 +712,17 @@ int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeo
 // E = the finished level-1 correction) + two post-smoothing sweeps; Q (a field's memory: plane c at Q.p + c Q.plane BYTES,
 // rows of Q.pitch bytes) receives the output values, lm the node correction to add (CN == nullptr: none).
 int launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
-                      bool composed, Field E2, const MGGeom &g1, const LmNodes &lm)
+                      bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half)
 {
     ComposeArgs ca;
+    if (l1_half && !(composed && f_half)) return -1;
+    if (composed && f_half && !l1_half) {
+        ca.E2 = E2; ca.g1 = g1;
+        return launch_c0<2, true, 58>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
+    }
     if (composed) {
         ca.E2 = E2; ca.g1 = g1;
-        return f_half ? launch_c0<2, true, 58>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm) : launch_c0<2, true, 56>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
+        return f_half ? launch_c0<2, true, 186>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm) : launch_c0<2, true, 56>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
     }
     return f_half ? launch_c0<2, true, 42>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm) : launch_c0<2, true, 40>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
 }
@@ -686,18 +743,25 @@ int cycle0_blocks(int W, int H, int C, int sweeps)
 
 // Coarse levels (l >= 1): pre-smoothing from a zero correction + residual + restriction in one
 // launch.  Uout receives the smoothed correction, Fc the next level's RHS.
-template <int T, int R>
+template <int T, int R, int TAG = 0>
 static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_t s)
 {
     constexpr int RH = C0_NW * R, HY = 2 * T + 2;
     Field none{};
     const int blocks = ((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * F.C;
-    hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true>), dim3(blocks), dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
+    hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true, TAG>), dim3(blocks), dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
                        Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs(), (float4 *)nullptr, LmNodes());
 }
 
-bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s)
+// half_io: the level's own right-hand side and the correction it writes are float16 (level 1 of the composed schedule, 4 sweeps)
+bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s, bool half_io)
 {
+    if (half_io) {
+        if (sweeps != 4) return false;
+        const int R4 = tb_gen_rows_deep(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
+        R4 == 6 ? launch_cn<4, 6, 128>(Uout, F, Fc, g, s) : launch_cn<4, 4, 128>(Uout, F, Fc, g, s);
+        return true;
+    }
     if (sweeps < 1 || sweeps > 4) return false;
     const int R = sweeps >= 3 ? tb_gen_rows_deep(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2) : tb_gen_rows(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
     if (sweeps == 1) { R == 8 ? launch_cn<1, 8>(Uout, F, Fc, g, s) : R == 6 ? launch_cn<1, 6>(Uout, F, Fc, g, s) : launch_cn<1, 4>(Uout, F, Fc, g, s); }

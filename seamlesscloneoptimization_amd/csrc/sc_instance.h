@@ -110,6 +110,7 @@ struct Instance {
     DevBuf h_partial;     // pinned copy of the same (small grids are folded on the host: no reduction launch)
     std::vector<MGLevel> mg;
     size_t mg_bottom = 0;  // first level run by the fused bottom kernel (== mg.size(): none)
+    bool mg_l1_half = false;   // level 1's planes currently hold float16 values (sc_multigrid.cpp: mg_level1_half; re-zeroed when the mode flips)
     // direct (fast-diagonalisation) solve inside the bottom kernel: level index relative to mg_bottom, or -1
     int fd_level = -1, fd_nxp = 0, fd_nyp = 0;
     DevBuf mg_fd, h_fd;    // its matrices: device copy and pinned staging
@@ -154,6 +155,7 @@ int setup_fields(Instance *I, int W, int H, int C);
 // solver drivers (sc_solver.cpp) -- operate on I->U0/U1/F, leave the answer in result(I)
 int solve(Instance *I);
 bool mg_reads_half_rhs(const Instance *I);
+bool mg_level1_half(const Instance *I);      // sc_multigrid.cpp: level 1's right-hand side and correction are stored as float16 in the solve configured in I
 bool mg_composes_level1(const Instance *I);   // sc_multigrid.cpp   // sc_multigrid.cpp: would the solve configured in I->opts read a float16 F?
 int lowmode_correct(Instance *I, const Field &U, const Field &Out);   // sc_lowmode.hip: Out = U + float-table correction
 int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on = nullptr);      // on: another stream than the instance's          // the correction of U at the node rows (what the post-process adds)

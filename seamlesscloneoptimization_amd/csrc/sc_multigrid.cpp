@@ -306,6 +306,7 @@ static int build_levels(Instance *I)
     }
     I->mg[0].F = I->F;
     I->mg_bottom = bottom_start(I);
+    I->mg_l1_half = false;        // fresh planes: all zero in either format
     return build_fd(I);
 }
 
@@ -363,7 +364,7 @@ static int vcycle(Instance *I, size_t l, int pre, int post, unsigned no_post = 0
     if (l == 0) {
         if ((rc = run_sweeps(I, SC_METHOD_RBGS, pre_here, 1.0f, I->opts.sweeps_per_launch))) return rc;
     } else if (pre_here > 0 && I->opts.sweeps_per_launch != 1 &&
-               launch_cycle_coarse(L.T, L.F, Lc.F, L.g, pre_here, I->stream)) {
+               launch_cycle_coarse(L.T, L.F, Lc.F, L.g, pre_here, I->stream, l == 1 && skip_post && mg_level1_half(I))) {
         std::swap(L.U, L.T);      // one launch did all three
         restricted = true;
     } else if (pre_here > 0) {
@@ -419,6 +420,14 @@ bool mg_composes_level1(const Instance *I)
     return !(o.flags & SC_FLAG_NO_COMPOSE_L1) && I->mg.size() >= 3 && I->mg_bottom >= 2 && pre == 2 && post == 2;
 }
 
+// Level 1 with float16 fields (sc_cycle0.hip, TAG bit 7): the composed schedule on the float16 right-hand side -- the default
+// fast path -- with level 1's standard four sweeps (the only depth the float16 level-1 launch is instantiated for).
+bool mg_level1_half(const Instance *I)
+{
+    const sc_solver_opts &o = I->opts;
+    return mg_composes_level1(I) && I->f_half && fused_level0(o) && o.tol <= 0.f && (o.mg_level1_sweeps == 0 || o.mg_level1_sweeps == 4);
+}
+
 bool mg_reads_half_rhs(const Instance *I)
 {
     const sc_solver_opts &o = I->opts;
@@ -439,6 +448,15 @@ int mg_solve(Instance *I)
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
     const float utol = o.update_tol > 0.f ? o.update_tol : 0.25f;
     const int budget = o.max_sweeps > 0 ? o.max_sweeps : 30;
+    // level 1 in float16 or float: the two formats put a plane's ring and pads at different bytes, so a switch re-zeroes the planes
+    const bool l1h = I->mg.size() >= 2 && mg_level1_half(I);
+    if (I->mg.size() >= 2 && l1h != I->mg_l1_half) {
+        MGLevel &L1 = I->mg[1];
+        SC_HIP(I, hipMemsetAsync(L1.U.p, 0, L1.U.bytes(), I->stream));
+        SC_HIP(I, hipMemsetAsync(L1.F.p, 0, L1.F.bytes(), I->stream));
+        SC_HIP(I, hipMemsetAsync(L1.T.p, 0, L1.T.bytes(), I->stream));
+        I->mg_l1_half = l1h;
+    }
     // the level-0 scratch is the ping-pong partner of the solution; the residual field only
     // writes its interior, and both buffers carry the same ring, so it stays a valid partner
     int cyc = 0;
@@ -456,7 +474,7 @@ int mg_solve(Instance *I)
         Field none{};
         // on the float16 path the pre-process stored the initial field as float16 as well (first launch only)
         if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
-                          I->stream, false, I->f_half, I->u_half) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
+                          I->stream, false, I->f_half, I->u_half, false, nullptr, l1h) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
         I->result_in_U1 = !I->result_in_U1;
         I->u_half = false;             // consumed: both U buffers hold float from here on
         I->info.sweep_launches += 1;
@@ -533,7 +551,7 @@ int mg_solve(Instance *I)
                     I->aux_pending = false;
                 }
                 const int nbo = launch_cycle0_out(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, part_now,
-                                                  I->stream, I->f_half, comp1, comp1 ? I->mg[2].U : Field(), comp1 ? I->mg[1].g : MGGeom(), early_lm);
+                                                  I->stream, I->f_half, comp1, comp1 ? I->mg[2].U : Field(), comp1 ? I->mg[1].g : MGGeom(), early_lm, l1h);
                 early_ready = false;
                 if (nbo > 0) {
                     I->info.sweep_launches += 1;
@@ -556,7 +574,7 @@ int mg_solve(Instance *I)
             const int nb = comp1
                 ? launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
                                          judged ? post : post + pre, part_now, I->stream, false, I->f_half, judged,
-                                         I->mg[2].U, I->mg[1].g, bands)
+                                         I->mg[2].U, I->mg[1].g, bands, l1h)
                 : launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
                                 I->mg[0].g, judged ? post : post + pre, true, part_now, I->stream,
                                 false, I->f_half, false, judged, bands);
@@ -614,7 +632,7 @@ int mg_solve(Instance *I)
             I->spec_post.done = false;     // not converged: the field moves on, the output is written again later
             if (cyc < budget) {            // catch up: pre-smoothing + residual + restriction for the next cycle
                 if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false,
-                                  nullptr, I->stream, false, I->f_half, false) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
+                                  nullptr, I->stream, false, I->f_half, false, false, nullptr, l1h) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
                 I->result_in_U1 = !I->result_in_U1;
                 lowmode_bands_written(I, nullptr);
                 I->info.sweep_launches += 1;

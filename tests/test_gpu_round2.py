@@ -98,15 +98,16 @@ def test_variant_flags(hip, oracles, W, H):
     cycles = hip.info().sweeps
     assert compare.image_diff_stats(want, base)["max"] <= 1
     try:
-        for flags in (capi.SC_FLAG_NO_SPECULATE, capi.SC_FLAG_FLOAT_RHS, capi.SC_FLAG_FLOAT_U0,
-                      capi.SC_FLAG_FLOAT_RHS | capi.SC_FLAG_NO_SPECULATE):
+        for flags in (capi.SC_FLAG_NO_SPECULATE, capi.SC_FLAG_FLOAT_U0, capi.SC_FLAG_FLOAT_U0 | capi.SC_FLAG_NO_SPECULATE):
             hip.set_solver(flags=flags)
             for _ in range(2):                                   # twice: the second call reuses the instance state
                 body = dst.copy()
                 assert hip.run(patch, body, mask, cx, cy) == 0
                 assert hip.info().sweeps == cycles
                 assert np.array_equal(body, base), flags
-        for flags in (capi.SC_FLAG_NO_COMPOSE_L1, capi.SC_FLAG_VCYCLE_BOTTOM,
+        # (SC_FLAG_FLOAT_RHS: since round 3 a float right-hand side also means float level-1 fields, where the default stores level 1's
+        # right-hand side and correction as float16 -- same fixed point, iterates a relative 5e-4 of a correction apart)
+        for flags in (capi.SC_FLAG_FLOAT_RHS, capi.SC_FLAG_FLOAT_RHS | capi.SC_FLAG_NO_SPECULATE, capi.SC_FLAG_NO_COMPOSE_L1, capi.SC_FLAG_VCYCLE_BOTTOM,
                       capi.SC_FLAG_NO_COMPOSE_L1 | capi.SC_FLAG_VCYCLE_BOTTOM | capi.SC_FLAG_FLOAT_RHS):
             hip.set_solver(flags=flags)
             body = dst.copy()

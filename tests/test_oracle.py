@@ -321,3 +321,28 @@ def test_opencv_grey_mask_semantics_restatement(kind):
     for m2 in (mask, o.synth_inputs(150, 110, margin=24, ellipse=True)[2]):                       # ... and not on 0 / 255 masks
         assert np.array_equal(o.seamless_clone(dst, patch, m2, cx, cy, opencv_grey=True), o.seamless_clone(dst, patch, m2, cx, cy))
         assert np.array_equal(oc.seamless_clone(dst, patch, m2, cx, cy, 2, opencv_grey=True), oc.seamless_clone(dst, patch, m2, cx, cy, 2))
+
+
+def test_float16_level1_fields_do_not_change_the_convergence():
+    """The library's fast multigrid path stores level 1's right-hand side and correction as float16 (round 3).  In the numpy
+    spec (oracle/mg_np.py, level1_half) the error after every cycle is the float32 schedule's to three digits, and the fixed
+    point is the direct solution: a correction scheme solves the coarse problem to a factor ~0.05 anyway."""
+    from oracle import mg_np
+    W, H = 300, 260
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=16, seed_dst=5, seed_patch=6)
+    geo, M = oc.mask_stage(mask, cx, cy)
+    B, lap = oc.build_rhs(dst, patch, geo, M)
+    ue = oc.solve_dst(oc.fold(B, lap), 4, exact_den=True)
+    errs = {}
+    for half in (False, True):
+        U = B[1].copy()
+        levels = mg_np.build_levels(W, H)
+        assert mg_np.composes_level1(levels)
+        hist = []
+        for _ in range(4):
+            U = mg_np.solve(U, lap[1], cycles=1, level1_half=half)
+            hist.append(float(np.abs(U[1:-1, 1:-1] - ue[1]).max()))
+        errs[half] = hist
+    for a, b in zip(errs[False], errs[True]):
+        assert abs(a - b) <= 0.05 * a + 2e-4, (errs)
+    assert errs[True][-1] < 0.01
