@@ -161,6 +161,9 @@ typedef struct sc_solver_opts {
                                             reference and none of its fixtures holds a grey mask; checked against a restatement
                                             of the published algorithm (oracle/).  Groups run one clone at a time with it.   */
 
+#define SC_FLAG_FLOAT_L1       (1 << 10) /* multigrid: level 1's right-hand side and correction as float32 (default on the fast path:
+                                            float16, see SC_FLAG_FLOAT_RHS).  Same fixed point, slightly different iterates   */
+
 /* ---- statistics of the last run */
 typedef struct sc_run_info {
     int    x0, y0, W, H, ltx, lty;  /* patch offset, ROI size (ring included), ROI origin in body */

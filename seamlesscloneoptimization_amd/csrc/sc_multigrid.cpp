@@ -425,7 +425,8 @@ bool mg_composes_level1(const Instance *I)
 bool mg_level1_half(const Instance *I)
 {
     const sc_solver_opts &o = I->opts;
-    return mg_composes_level1(I) && I->f_half && fused_level0(o) && o.tol <= 0.f && (o.mg_level1_sweeps == 0 || o.mg_level1_sweeps == 4);
+    return !(o.flags & SC_FLAG_FLOAT_L1) && mg_composes_level1(I) && I->f_half && fused_level0(o) && o.tol <= 0.f &&
+           (o.mg_level1_sweeps == 0 || o.mg_level1_sweeps == 4);
 }
 
 bool mg_reads_half_rhs(const Instance *I)

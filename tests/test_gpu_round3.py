@@ -386,10 +386,39 @@ def test_opencv_grey_mask_semantics(inst, oracles, W, H, kind):
     assert inst.run(patch, body, gm, cx, cy) == 0
     assert _dsum(body, oc.seamless_clone(dst, patch, gm, cx, cy, 4))[0] <= 1
     assert (body != outs["auto"]).mean() > 0.002
-    # 0 / 255 masks: the flag changes nothing, byte for byte
-    for flags in (0, capi.SC_FLAG_OPENCV_GREY_MASK):
+    # 0 / 255 masks: the flag changes nothing, byte for byte (against the float right-hand side the flag implies)
+    for flags in (capi.SC_FLAG_FLOAT_RHS, capi.SC_FLAG_OPENCV_GREY_MASK):
         inst.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags)
         b2 = dst.copy()
         inst.run(patch, b2, mask, cx, cy)
         outs["bin%d" % flags] = b2
-    assert np.array_equal(outs["bin0"], outs["bin%d" % capi.SC_FLAG_OPENCV_GREY_MASK])
+    assert np.array_equal(outs["bin%d" % capi.SC_FLAG_FLOAT_RHS], outs["bin%d" % capi.SC_FLAG_OPENCV_GREY_MASK])
+
+
+def test_float16_level1_fields_against_float_ones(hip, oracles):
+    """Round 3: on the fast multigrid path level 1's right-hand side and correction are float16 (k_cycle0 TAG bit 7);
+    SC_FLAG_FLOAT_L1 keeps them float.  Same fixed point: both within one of the port, the same number of cycles, and
+    nearly every byte equal; alternating between the two on one instance (the planes are re-zeroed at every switch: the
+    formats put the rings at different bytes) reproduces each one's bytes exactly."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    for W, H in ((1030, 1000), (2048, 1100)):
+        dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=32, seed_dst=W, seed_patch=H)
+        want = oc.seamless_clone(dst, patch, mask, cx, cy, min(16, oc.max_threads()))
+        outs = {}
+        try:
+            for rep in range(2):
+                for flags in (0, capi.SC_FLAG_FLOAT_L1):
+                    hip.set_solver(flags=flags)
+                    body = dst.copy()
+                    assert hip.run(patch, body, mask, cx, cy) == 0
+                    assert _dsum(body, want)[0] <= 1
+                    key = (flags, hip.info().sweeps)
+                    if rep == 0:
+                        outs[flags] = (body, hip.info().sweeps)
+                    else:
+                        assert np.array_equal(body, outs[flags][0]) and hip.info().sweeps == outs[flags][1], key
+        finally:
+            hip.set_solver(flags=0)
+        assert outs[0][1] == outs[capi.SC_FLAG_FLOAT_L1][1]
+        assert (outs[0][0] != outs[capi.SC_FLAG_FLOAT_L1][0]).mean() < 0.002

@@ -24,7 +24,7 @@ for name, sym in (("k_jacobi_roll<4>", "k_jacobi_roll<4, 1>"), ("k_jacobi<16>", 
     tr = next((v["traffic_bytes_per_launch"] for k, v in kern.items() if sym in k), None)
     t = timings.get(name, {})
     us = t.get("us_per_launch")
-    sweeps[name] = {"profiler_symbol": "sc::" + sym, "us_per_launch_hip_events_under_the_profiler": us,
+    sweeps[name] = {"profiler_symbol": "sc::" + sym, "us_per_launch_hip_events_unprofiled": us,
                     "algorithmic_bytes_per_launch": alg, "traffic_bytes_per_launch": tr,
                     "traffic_over_algorithmic": round(tr / alg, 3) if tr else None,
                     "algorithmic_TBps": round(alg / (us * 1e-6) / 1e12, 3) if us else None,
@@ -32,8 +32,9 @@ for name, sym in (("k_jacobi_roll<4>", "k_jacobi_roll<4, 1>"), ("k_jacobi<16>", 
                     "frac_of_8TBps_counter_traffic": round(tr / (us * 1e-6) / 8e12, 4) if us and tr else None}
 json.dump({"note": "BASELINE config 4: 4096^2 ROI, 3 channels, one Jacobi sweep per launch; bytes crossing the L2 -> fabric boundary per "
                    "launch = 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE, KiB units, separate rocprofv3 --pmc passes over "
-                   "tools/c4_probe.py (MI355X_MICROARCH.md, HBM section); timings are the HIP-event means the probe printed in the "
-                   "FETCH_SIZE pass (counter collection serialises launches but does not change a launch's duration much)",
+                   "tools/c4_probe.py (MI355X_MICROARCH.md, HBM section); timings are HIP-event means of an UNPROFILED run of the same probe "
+                   "on the same box (under counter collection a launch takes 2.5x as long: never price bytes from one run with time "
+                   "from the other kind)",
            "roi": 4096, "git": git, "source_fingerprint": source_fingerprint(), "probe": timings, "single_sweep_kernels": sweeps,
            "kernels": kern}, open(out, "w"), indent=1)
 for n, v in sweeps.items():

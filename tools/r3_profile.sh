@@ -1,7 +1,9 @@
 #!/bin/bash
 # GPU box: the rocprofv3 evidence of round 3.  (1) kernel statistics of `python3 bench.py`; (2) four counter passes over the same
 # command (FETCH_SIZE / WRITE_SIZE x 3 steps / 1 step) -> <tag>_pmc_traffic_bench.json (copy to profiles/r3_pmc_traffic_bench.json);
-# (3) two counter passes over tools/c4_probe.py (BASELINE config 4, 4096^2) -> <tag>_c4_pmc.json (copy to profiles/r3_c4_pmc.json).
+# (3) tools/c4_probe.py (BASELINE config 4, 4096^2) once without the profiler for the timings (counter collection serialises the
+#     launches and more than doubles their duration) and twice under it for FETCH_SIZE / WRITE_SIZE -> <tag>_c4_pmc.json (copy to
+#     profiles/r3_c4_pmc.json).
 # --pmc is never combined with tracing domains beyond --kernel-trace; the program comes directly after `--`; every run is under
 # its own `timeout -k 10` (a GPU abort under rocprofv3 otherwise hangs until the lease is killed: round 2, s1d.err).
 # usage: tools/r3_profile.sh <tag> [extra bench args]      outputs: gpurun_out/<tag>_*
@@ -23,7 +25,8 @@ for pass in "f3 FETCH_SIZE 3" "w3 WRITE_SIZE 3" "f1 FETCH_SIZE 1" "w1 WRITE_SIZE
   echo "pass $1 done"
 done
 (cd $R && python3 tools/pmc_traffic_bench.py gpurun_out/${T}_f3 gpurun_out/${T}_w3 gpurun_out/${T}_f1 gpurun_out/${T}_w1 gpurun_out/${T}_pmc_traffic_bench.json 2048 32 16 $GIT)
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${T}_c4f -- python3 $R/tools/c4_probe.py 10 > $O/${T}_c4_probe.json 2> $O/${T}_c4f.err || { echo "c4 fetch pass failed"; tail -5 $O/${T}_c4f.err; exit 1; }
+timeout -k 10 200 python3 $R/tools/c4_probe.py 50 > $O/${T}_c4_probe.json 2> $O/${T}_c4_probe.err || { echo "c4 probe (unprofiled timings) failed"; tail -5 $O/${T}_c4_probe.err; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${T}_c4f -- python3 $R/tools/c4_probe.py 10 > $O/${T}_c4_probe_under_pmc.json 2> $O/${T}_c4f.err || { echo "c4 fetch pass failed"; tail -5 $O/${T}_c4f.err; exit 1; }
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${T}_c4w -- python3 $R/tools/c4_probe.py 10 > /dev/null 2> $O/${T}_c4w.err || { echo "c4 write pass failed"; tail -5 $O/${T}_c4w.err; exit 1; }
 (cd $R && python3 tools/c4_fold.py gpurun_out/${T}_c4f gpurun_out/${T}_c4w gpurun_out/${T}_c4_probe.json gpurun_out/${T}_c4_pmc.json $GIT)
 cd $R
