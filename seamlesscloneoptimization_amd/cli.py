@@ -22,7 +22,7 @@ def main(argv=None) -> int:
     ap.add_argument("centerX", type=int); ap.add_argument("centerY", type=int); ap.add_argument("gpu", type=int)
     ap.add_argument("--out", help="write the blended image (.bmp or .yml)")
     ap.add_argument("--method", default="auto", choices=["auto", "mg", "dst", "fft", "sor", "rbgs", "jacobi"],
-                    help="auto (default): direct FFT solve (double) up to 640 unknowns per side, mg above; fft: the reference's default back-end (FFT-based direct solve, float32); mg: multigrid + float-table correction (the reference's arithmetic); dst: the reference's direct DST "
+                    help="auto (default): direct FFT solve (double) up to 900 unknowns per side, mg above; fft: the reference's default back-end (FFT-based direct solve, float32); mg: multigrid + float-table correction (the reference's arithmetic); dst: the reference's direct DST "
                          "solve on the fp64 matrix cores; sor / rbgs / jacobi: sweeps to a 2e-5 residual")
     ap.add_argument("--exact-tables", action="store_true", help="mg: return the exact solution of the 5-point system instead")
     ap.add_argument("--reference-warmup", action="store_true",
