@@ -219,32 +219,15 @@ static int tmark(Instance *I, int k, bool empty_stage = false)
 static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int ms, const Geo *predicted = nullptr)
 {
     I->h_rect[0] = mc - 1; I->h_rect[1] = 0; I->h_rect[2] = mr - 1; I->h_rect[3] = 0; // seamlessClone_imp.cpp:1006
+    SC_HIP(I, hipMemcpyAsync(I->d_rect, I->h_rect, 4 * sizeof(int), hipMemcpyHostToDevice, I->stream));
     I->erode_done = false;
-    I->bbox_pending = false;
-    if (predicted) {
-        // The clone runs on a predicted box: the scan only has to confirm the guess before anything is written, so it goes to the
-        // instance's second stream (behind everything already enqueued on the first: the mask may just have been uploaded) and
-        // the first stream starts with the erode of the predicted ROI.  device_clone makes `stream` wait for ev_bbox behind the
-        // pre-process, long after the scan has finished: the scan and its two small copies leave the critical path (~20 us).
-        SC_HIP(I, hipEventRecord(I->ev_bbox_fork, I->stream));
-        SC_HIP(I, hipStreamWaitEvent(I->aux, I->ev_bbox_fork, 0));
-        SC_HIP(I, hipMemcpyAsync(I->d_rect, I->h_rect, 4 * sizeof(int), hipMemcpyHostToDevice, I->aux));
-        launch_mask_bbox(d_mask, mc, mr, ms, I->d_rect, I->aux);
-        SC_HIP(I, hipGetLastError());
-        SC_HIP(I, hipMemcpyAsync(I->h_rect + 4, I->d_rect, 4 * sizeof(int), hipMemcpyDeviceToHost, I->aux));
-        SC_HIP(I, hipEventRecord(I->ev_bbox, I->aux));
-        I->bbox_pending = true;
+    if (predicted && !(I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) {
         I->mpitch = round_up(predicted->W, 64);
         int rc = ensure(I, I->d_M, (size_t)I->mpitch * predicted->H);
         if (rc) return rc;
-        if (!(I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) {
-            launch_mask_erode3(d_mask, ms, mr, *predicted, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
-            SC_HIP(I, hipGetLastError());
-            I->erode_done = true;
-        }
-        return tmark(I, 2);
-    }
-    SC_HIP(I, hipMemcpyAsync(I->d_rect, I->h_rect, 4 * sizeof(int), hipMemcpyHostToDevice, I->stream));
+        launch_mask_stage(d_mask, mc, mr, ms, I->d_rect, *predicted, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+        I->erode_done = true;
+    } else
     launch_mask_bbox(d_mask, mc, mr, ms, I->d_rect, I->stream);
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipMemcpyAsync(I->h_rect + 4, I->d_rect, 4 * sizeof(int), hipMemcpyDeviceToHost, I->stream));
@@ -326,10 +309,6 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
         launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
                           I->stream, I->f_half, I->u_half, grey);
-        if (I->bbox_pending) {         // the device's rectangle must be there before the guarded output launches read it
-            SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_bbox, 0));
-            I->bbox_pending = false;
-        }
         if (pass == passes - 1 && (rc = tmark(I, 5))) return rc;
         I->info.sweep_launches = 0;
         I->spec_post.body_org = body_org; I->spec_post.bstep = bstep;
@@ -407,8 +386,6 @@ void *my_seamlessclone_api_imp_create_instance(int gpu_id)
     ok = ok && hipStreamCreateWithFlags(&I->aux, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&I->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&I->ev_join, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&I->ev_bbox_fork, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&I->ev_bbox, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_rect, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_red, 2 * sizeof(double), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_rect, 4 * sizeof(int)) == hipSuccess;
@@ -467,8 +444,6 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->ev_rects) (void)hipEventDestroy(I->ev_rects);
     if (I->ev_fork) (void)hipEventDestroy(I->ev_fork);
     if (I->ev_join) (void)hipEventDestroy(I->ev_join);
-    if (I->ev_bbox_fork) (void)hipEventDestroy(I->ev_bbox_fork);
-    if (I->ev_bbox) (void)hipEventDestroy(I->ev_bbox);
     if (I->aux) (void)hipStreamDestroy(I->aux);
     if (I->stream) (void)hipStreamDestroy(I->stream);
     I->magic = 0;
@@ -642,8 +617,8 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p, dfs,
                          (uint8_t *)I->d_body_roi.p, dfs, g, passes);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
-        if (guess) {      // the rectangle's read-back (second stream, ev_bbox) finished long ago: this wait is free
-            SC_HIP(I, hipEventSynchronize(I->ev_bbox));
+        if (guess) {      // the rectangle's read-back (recorded as ev[2]) finished long ago: this wait is free
+            SC_HIP(I, hipEventSynchronize(I->ev[2]));
             if (memcmp(guess, I->h_rect + 4, 4 * sizeof(int)) != 0) return SC_GUESS_WRONG;
         }
         // Interior back into the caller's image: linear D2H pieces of the compact ROI buffer into pinned staging
@@ -831,12 +806,18 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     for (int i = 0; i < n; ++i) {
         h_in[RS * i + 0] = jobs[i].mask_cols - 1; h_in[RS * i + 1] = 0; h_in[RS * i + 2] = jobs[i].mask_rows - 1; h_in[RS * i + 3] = 0;
     }
+    SC_HIP(I, hipMemcpyAsync(d_r, h_in, (size_t)n * RS * sizeof(int), hipMemcpyHostToDevice, I->stream));
     std::vector<MaskJob> mj(n);
     for (int i = 0; i < n; ++i) {
         mj[i] = MaskJob{};
         mj[i].mask = jobs[i].mask; mj[i].mw = jobs[i].mask_cols; mj[i].mh = jobs[i].mask_rows; mj[i].mstep = jobs[i].mask_step;
         mj[i].rect = d_r + RS * i;
     }
+    launch_mask_bbox_group(mj.data(), n, I->stream);
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * RS * sizeof(int), hipMemcpyDeviceToHost, I->stream));
+    if (!I->ev_rects) SC_HIP(I, hipEventCreateWithFlags(&I->ev_rects, hipEventDisableTiming));
+    SC_HIP(I, hipEventRecord(I->ev_rects, I->stream));
     // Like a single clone (predict_rect), the group is launched on PREDICTED bounding boxes -- the interior of every mask,
     // which is what a mask that touches its four inner borders gives -- while the scans' answers are in flight: no host
     // wait in front of the erodes.  Every member's splice carries its guess and writes nothing unless the device found
@@ -853,20 +834,6 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
             check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) != SC_OK || geo[i].W != geo[0].W || geo[i].H != geo[0].H)
             speculative = false;
     }
-    // The scans only validate the guesses of a speculative group, so they run on the instance's second stream (behind what
-    // is already enqueued on the first) beside the erodes, the pre-process and the first cycles; the first stream waits for
-    // them (ev_rects) behind the pre-process, before any guarded splice can read a rectangle.
-    hipStream_t const scan_stream = speculative ? I->aux : I->stream;
-    if (!I->ev_rects) SC_HIP(I, hipEventCreateWithFlags(&I->ev_rects, hipEventDisableTiming));
-    if (speculative) {
-        SC_HIP(I, hipEventRecord(I->ev_bbox_fork, I->stream));
-        SC_HIP(I, hipStreamWaitEvent(I->aux, I->ev_bbox_fork, 0));
-    }
-    SC_HIP(I, hipMemcpyAsync(d_r, h_in, (size_t)n * RS * sizeof(int), hipMemcpyHostToDevice, scan_stream));
-    launch_mask_bbox_group(mj.data(), n, scan_stream);
-    SC_HIP(I, hipGetLastError());
-    SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * RS * sizeof(int), hipMemcpyDeviceToHost, scan_stream));
-    SC_HIP(I, hipEventRecord(I->ev_rects, scan_stream));
     I->err.clear();
     if (!speculative) {
         SC_HIP(I, hipStreamSynchronize(I->stream));
@@ -903,7 +870,6 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     }
     launch_preprocess_group(ij.data(), n, I->mpitch, I->U0, I->F, I->stream, I->f_half, I->u_half);
     SC_HIP(I, hipGetLastError());
-    if (speculative) SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_rects, 0));      // the scans ran on the second stream
     // --- one solve for the group, results spliced per clone
     I->info.sweep_launches = 0;
     I->guard = RectGuard();

@@ -69,10 +69,6 @@ struct Instance {
     // runs here beside the coarse levels of the last cycle; forked and joined with events, see mg_solve
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // bounding-box scan of a clone launched on a PREDICTED box: it only validates the guess, so it runs on `aux` beside the
-    // erode / pre-process / first cycles; `stream` waits for ev_bbox before anything reads the rectangle on the device
-    hipEvent_t ev_bbox_fork = nullptr, ev_bbox = nullptr;
-    bool bbox_pending = false;
     bool aux_pending = false;              // work on aux that `stream` has not waited for yet
     sc_solver_opts opts{};
     sc_run_info info{};
