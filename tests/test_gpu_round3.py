@@ -422,3 +422,30 @@ def test_float16_level1_fields_against_float_ones(hip, oracles):
             hip.set_solver(flags=0)
         assert outs[0][1] == outs[capi.SC_FLAG_FLOAT_L1][1]
         assert (outs[0][0] != outs[capi.SC_FLAG_FLOAT_L1][0]).mean() < 0.002
+
+
+def test_default_path_fuzz_over_small_and_medium_shapes(inst, oracles):
+    """The default solver choice over 36 random ROI shapes up to ~1000 pixels a side (direct solve up to 900 unknowns, multigrid
+    above; rectangular and elliptical masks; every FFT length from 32 to 2048): within one of the float-table port, and the
+    direct solve's deviation stays at rounding level (a handful of channel values per clone)."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    rng = np.random.default_rng(20261004)
+    worst_direct = 0.0
+    for k in range(36):
+        W = int(rng.integers(3, 1010)) if k % 3 else int(rng.integers(3, 140))
+        H = int(rng.integers(3, 1010)) if k % 4 else int(rng.integers(3, 90))
+        dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=8 + int(rng.integers(0, 40)), seed_dst=7000 + k, seed_patch=8000 + k,
+                                                  ellipse=bool(k % 5 == 0 and min(W, H) > 16))
+        want = oc.seamless_clone(dst, patch, mask, cx, cy, 4)
+        body = dst.copy()
+        rc = inst.run(patch, body, mask, cx, cy, allow_not_converged=True)
+        assert rc in (0, capi.SC_ERR_NOT_CONVERGED), (W, H, rc)
+        i = inst.info()
+        d = np.abs(body.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1, (W, H, i.method, int(d.max()))
+        direct = max(i.W, i.H) - 2 <= capi.SC_AUTO_DIRECT_MAX
+        assert i.method == (capi.SC_METHOD_FFT if direct else capi.SC_METHOD_MULTIGRID), (W, H, i.method)
+        if direct and min(i.W, i.H) > 8:
+            worst_direct = max(worst_direct, float((d > 0).sum()) / max(1.0, 3.0 * (i.W - 2) * (i.H - 2)))
+    assert worst_direct < 2e-3, worst_direct
