@@ -429,6 +429,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->h_fd.p) (void)hipHostFree(I->h_fd.p);
     if (I->d_rect) (void)hipFree(I->d_rect);
     if (I->d_rects.p) (void)hipFree(I->d_rects.p);
+    if (I->d_bbox_parts.p) (void)hipFree(I->d_bbox_parts.p);
     if (I->h_rects.p) (void)hipHostFree(I->h_rects.p);
     if (I->d_partials) (void)hipFree(I->d_partials);
     if (I->d_red) (void)hipFree(I->d_red);
@@ -813,7 +814,8 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
         mj[i].mask = jobs[i].mask; mj[i].mw = jobs[i].mask_cols; mj[i].mh = jobs[i].mask_rows; mj[i].mstep = jobs[i].mask_step;
         mj[i].rect = d_r + RS * i;
     }
-    launch_mask_bbox_group(mj.data(), n, I->stream);
+    if ((rc = ensure(I, I->d_bbox_parts, sizeof(int) * mask_bbox_group_parts(mj.data(), n)))) return rc;
+    launch_mask_bbox_group(mj.data(), n, I->stream, (int *)I->d_bbox_parts.p);
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * RS * sizeof(int), hipMemcpyDeviceToHost, I->stream));
     if (!I->ev_rects) SC_HIP(I, hipEventCreateWithFlags(&I->ev_rects, hipEventDisableTiming));

@@ -51,7 +51,8 @@ struct ImageJobs { enum { MAX = 16 }; ImageJob j[MAX]; };
 void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s);
 void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, uint8_t *M, int mpitch, hipStream_t s);
 void launch_mask_erode_min7(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int mpitch, hipStream_t s);   // OpenCV's grey-mask erode (SC_FLAG_OPENCV_GREY_MASK)
-void launch_mask_bbox_group(const MaskJob *jobs, int n, hipStream_t s);
+size_t mask_bbox_group_parts(const MaskJob *jobs, int n);            // ints of scratch the group scan needs (one set of extrema per workgroup)
+void launch_mask_bbox_group(const MaskJob *jobs, int n, hipStream_t s, int *parts);
 void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s);
 // bounding box of the whole mask + erode of the (predicted) ROI g in one launch
 void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, Geo g, uint8_t *M, int mpitch, hipStream_t s);

@@ -121,6 +121,7 @@ struct Instance {
     size_t fd_cache_next = 0;
     // reductions / mailboxes
     DevBuf d_rects, h_rects;     // bounding boxes of a group of clones (sc_hip_run_device_batch): device, pinned
+    DevBuf d_bbox_parts;         // per-workgroup extrema of the group's scans (folded by a second launch instead of atomics)
     hipEvent_t ev_rects = nullptr;   // behind the read-back of a group's bounding boxes
     int group_spec_cooldown = 0;     // calls left without a predicted bounding box after a wrong guess in a group
     int *d_rect = nullptr;
