@@ -784,9 +784,23 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
         }
         return worst;
     };
-    for (int i = 0; i < n; ++i) {
-        const sc_batch_job &j = jobs[i];
-        if (j.body_restore) SC_HIP(I, hipMemcpyAsync(j.body, j.body_restore, (size_t)j.body_step * j.body_rows, hipMemcpyDeviceToDevice, I->stream));
+    {   // refresh the destinations that ask for it: one launch per 16 (k_copy_group); odd alignments take the runtime's copy
+        CopyJobs cj{};
+        int cn = 0;
+        auto flush = [&]() { if (cn) { launch_copy_group(cj, cn, I->stream); cn = 0; } };
+        for (int i = 0; i < n; ++i) {
+            const sc_batch_job &j = jobs[i];
+            if (!j.body_restore) continue;
+            const size_t bytes = (size_t)j.body_step * j.body_rows;
+            if ((((uintptr_t)j.body | (uintptr_t)j.body_restore) & 15) != 0) {
+                SC_HIP(I, hipMemcpyAsync(j.body, j.body_restore, bytes, hipMemcpyDeviceToDevice, I->stream));
+                continue;
+            }
+            cj.dst[cn] = j.body; cj.src[cn] = j.body_restore; cj.bytes[cn] = bytes;
+            if (++cn == CopyJobs::MAX) flush();
+        }
+        flush();
+        SC_HIP(I, hipGetLastError());
     }
     if (n == 1 || I->opts.reference_warmup || (I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) return one_by_one();
     for (int i = 0; i < n; ++i) {

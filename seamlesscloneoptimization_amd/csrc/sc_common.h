@@ -102,6 +102,9 @@ void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t 
 void launch_splice_planar(Field Q, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard());
 void launch_splice_planar_group(Field Q, const ImageJob *jobs, int n, hipStream_t s);
 void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_t s);
+// up to 16 device-to-device copies in one launch (16-byte aligned pointers)
+struct CopyJobs { enum { MAX = 16 }; void *dst[MAX]; const void *src[MAX]; size_t bytes[MAX]; };
+void launch_copy_group(const CopyJobs &t, int n, hipStream_t s);
 
 void launch_jacobi(Field Uin, Field Uout, Field F, hipStream_t s, bool tag = false, int lds_tile_rows = 0);
 void launch_rb_half(Field U, Field F, int color, float omega, hipStream_t s, bool tag = false);

@@ -597,6 +597,38 @@ void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_o
     else hipLaunchKernelGGL((k_preprocess<false, false>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
 }
 
+// Device-to-device refresh of the destinations of a group of clones (sc_batch_job.body_restore) in ONE launch: sixteen separate
+// 16 MB copies run at 2.7 TB/s (each too short to fill the chip, 3 % of a bench step); one launch over all of them streams.
+// 16-byte aligned pointers, sizes in bytes (a tail below 16 bytes is copied bytewise).
+__global__ __launch_bounds__(256) void k_copy_group(CopyJobs t)
+{
+    const int m = blockIdx.y;
+    const uint4 *__restrict__ s4 = reinterpret_cast<const uint4 *>(t.src[m]);
+    uint4 *__restrict__ d4 = reinterpret_cast<uint4 *>(t.dst[m]);
+    const size_t n16 = t.bytes[m] >> 4;
+    const size_t T = (size_t)gridDim.x * 256;              // four fully coalesced 16-byte loads in flight per lane
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * T) {
+        const size_t i1 = i + T, i2 = i + 2 * T, i3 = i + 3 * T;
+        const uint4 a = s4[i], b = s4[i1 < n16 ? i1 : i], c = s4[i2 < n16 ? i2 : i], d = s4[i3 < n16 ? i3 : i];
+        d4[i] = a;
+        if (i1 < n16) d4[i1] = b;
+        if (i2 < n16) d4[i2] = c;
+        if (i3 < n16) d4[i3] = d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (t.bytes[m] & 15)) {
+        const size_t o = (n16 << 4) + threadIdx.x;
+        reinterpret_cast<uint8_t *>(t.dst[m])[o] = reinterpret_cast<const uint8_t *>(t.src[m])[o];
+    }
+}
+
+void launch_copy_group(const CopyJobs &t, int n, hipStream_t s)
+{
+    size_t mx = 0;
+    for (int i = 0; i < n; ++i) mx = std::max(mx, t.bytes[i]);
+    const unsigned gx = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (mx / 16 + 1023) / 1024));
+    hipLaunchKernelGGL(k_copy_group, dim3(gx, n), dim3(256), 0, s, t);
+}
+
 // float16 right-hand side (left by a multigrid clone) -> float, into another buffer; used only when a
 // diagnostic hook wants to read F after such a clone
 __global__ __launch_bounds__(256) void k_half_to_float(const __half *__restrict__ src, float *__restrict__ dst, size_t n)
