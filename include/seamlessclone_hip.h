@@ -73,7 +73,7 @@ enum sc_method {
 };
 #define SC_AUTO_DIRECT_MAX 900
 #define SC_AUTO_THIN_MAX 4          /* ... and for thin ROIs (at most this many unknowns across, up to SC_AUTO_THIN_LONG_MAX along) */
-#define SC_AUTO_THIN_LONG_MAX 2048
+#define SC_AUTO_THIN_LONG_MAX 4096
 
 typedef struct sc_solver_opts {
     int   method;            /* enum sc_method                                              */

@@ -34,7 +34,7 @@ SC_METHOD_AUTO = 5      # default: DST up to SC_AUTO_DIRECT_MAX unknowns per sid
 SC_METHOD_FFT = 6       # the reference's default back-end: FFT-based direct solve, float32, O(n^2 log n)
 SC_AUTO_DIRECT_MAX = 900
 SC_AUTO_THIN_MAX = 4
-SC_AUTO_THIN_LONG_MAX = 2048
+SC_AUTO_THIN_LONG_MAX = 4096
 
 SC_FLAG_NO_SPECULATE = 1 << 0
 SC_FLAG_FLOAT_RHS = 1 << 1

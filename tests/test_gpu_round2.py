@@ -411,7 +411,7 @@ def test_frozen_float_table_case_on_the_gpu(hip, golden_dir):
         assert d.max() <= 1 and (d > 0).mean() < 0.01, (solver, int(d.max()), float((d > 0).mean()))
 
 
-@pytest.mark.parametrize("W,H", [(9, 9), (64, 71), (233, 59), (240, 53), (517, 400), (1030, 1000), (1856, 1700), (2048, 2048)])
+@pytest.mark.parametrize("W,H", [(9, 9), (64, 71), (233, 59), (240, 53), (57, 40), (249, 60), (505, 118), (517, 400), (1030, 1000), (1856, 1700), (2048, 2048)])   # W = 32 j + 25: the lane that holds only the ring column sits on a node column
 def test_output_and_restriction_variants_agree(hip, oracles, W, H):
     """Default: the last multigrid cycle writes output bytes itself (node correction of the iterate one cycle earlier, whose
     cell shares the launch before it leaves behind: k_cycle0 `bands` + k_lm_bands_to_cells).  SC_FLAG_KEEP_FIELD: that cycle
