@@ -422,6 +422,15 @@ def test_float16_level1_fields_against_float_ones(hip, oracles):
             hip.set_solver(flags=0)
         assert outs[0][1] == outs[capi.SC_FLAG_FLOAT_L1][1]
         assert (outs[0][0] != outs[capi.SC_FLAG_FLOAT_L1][0]).mean() < 0.002
+        # fewer level-1 sweeps keep float level-1 fields (the float16 launch exists for the standard four): same contract
+        try:
+            for l1 in (2, 3):
+                hip.set_solver(mg_level1_sweeps=l1)
+                body = dst.copy()
+                assert hip.run(patch, body, mask, cx, cy, allow_not_converged=True) in (0, capi.SC_ERR_NOT_CONVERGED)
+                assert _dsum(body, want)[0] <= 1, l1
+        finally:
+            hip.set_solver(mg_level1_sweeps=0)
 
 
 def test_default_path_fuzz_over_small_and_medium_shapes(inst, oracles):
