@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512) void k_sgemm(const float *__restrict__ A, cons
     float4 ra, rb;
     auto load = [&](int k0) {
         const int kc = k0 + ak;                                   // 4 consecutive k of one row of A
-        ra = *reinterpret_cast<const float4 *>(ap + min(kc, max(a_cols - 4, 0) & ~3));
+        ra = *reinterpret_cast<const float4 *>(ap + (kc < a_cols ? kc : 0));      // (a group that starts inside the row may run up to 3 floats past a_cols: inside the row pitch)
         if (!arow_ok || kc >= a_cols) ra = make_float4(0.f, 0.f, 0.f, 0.f);
         else if (kc + 3 >= a_cols) {                              // the row ends inside this group (a_cols is not a multiple of 4)
             if (kc + 1 >= a_cols) ra.y = 0.f;
