@@ -164,12 +164,6 @@ typedef struct sc_solver_opts {
 #define SC_FLAG_FLOAT_L1       (1 << 10) /* multigrid: level 1's right-hand side and correction as float32 (default on the fast path:
                                             float16, see SC_FLAG_FLOAT_RHS).  Same fixed point, slightly different iterates   */
 
-#define SC_FLAG_NO_DIRECT_MID   (1 << 11) /* multigrid, single clones: cycle through every level down to the LDS-resident bottom.  Default:
-                                            from the second solve of a geometry on, the first level of at most 384 points per
-                                            side below level 1 is solved exactly by four dense products on the fp32 matrix cores
-                                            (sc_fdmid.hip) -- fewer dependent launches per cycle.  Same fixed point, slightly
-                                            different iterates                                                           */
-
 /* ---- statistics of the last run */
 typedef struct sc_run_info {
     int    x0, y0, W, H, ltx, lty;  /* patch offset, ROI size (ring included), ROI origin in body */
@@ -324,10 +318,6 @@ SC_API int sc_hip_reference_tables_singular(int w, int h);
  * eigen-solver behind the direct bottom solve (residual of T V = V L for level operators with an irregular
  * last interval).  Returns 0, or the number of the check that failed. */
 SC_API int sc_hip_selftest_host(void);
-/* GPU self test of the fp32 matrix-core product behind the mid-level direct solve (sc_fdmid.hip) against a host triple loop:
- * ragged operands, shared and per-channel strides, the three epilogues.  Returns the largest error relative to the largest
- * |C| (float rounding, < 1e-5), or a negative value on a HIP error. */
-SC_API double sc_hip_selftest_gpu(void *instance);
 
 #ifdef __cplusplus
 }

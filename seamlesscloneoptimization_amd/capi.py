@@ -47,7 +47,6 @@ SC_FLAG_KEEP_FIELD = 1 << 7
 SC_FLAG_FFT_FP64 = 1 << 8
 SC_FLAG_OPENCV_GREY_MASK = 1 << 9
 SC_FLAG_FLOAT_L1 = 1 << 10
-SC_FLAG_NO_DIRECT_MID = 1 << 11
 
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",
@@ -192,8 +191,6 @@ def load():
     L.sc_hip_time_cycle0.restype = C.c_int
     L.sc_hip_reference_tables_singular.argtypes = [C.c_int, C.c_int]
     L.sc_hip_reference_tables_singular.restype = C.c_int
-    L.sc_hip_selftest_gpu.argtypes = [C.c_void_p]
-    L.sc_hip_selftest_gpu.restype = C.c_double
     L.sc_hip_selftest_host.argtypes = []
     L.sc_hip_selftest_host.restype = C.c_int
     _lib = L

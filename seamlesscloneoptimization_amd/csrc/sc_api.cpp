@@ -426,8 +426,6 @@ void my_seamlessclone_api_imp_destroy(void *p)
     for (DevBuf *b : { &I->fft.dw.chirp, &I->fft.dh.chirp, &I->fft.A, &I->fft.B, &I->fft.fxy }) if (b->p) (void)hipFree(b->p);
     for (DevBuf *b : { &I->fft.dw.h, &I->fft.dh.h, &I->fft.hfxy }) if (b->p) (void)hipHostFree(b->p);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
-    for (DevBuf *b : { &I->fdm.mats, &I->fdm.G1, &I->fdm.G2 }) if (b->p) (void)hipFree(b->p);
-    if (I->fdm.hmats.p) (void)hipHostFree(I->fdm.hmats.p);
     if (I->h_fd.p) (void)hipHostFree(I->h_fd.p);
     if (I->d_rect) (void)hipFree(I->d_rect);
     if (I->d_rects.p) (void)hipFree(I->d_rects.p);
@@ -964,17 +962,9 @@ int sc_hip_selftest_host(void)
     }
     // 2: eigen-decomposition of the 1-D level operators
     if (!(sc::fd_selftest_error() < 1e-11)) return 2;
-    if (!(sc::fd_selftest_error(true) < 1e-8)) return 4;         // the O(n^2) decomposition behind the mid-level direct solve
     // 3: which parts of a level-0 launch make up each cell row of the float-table correction (sc_lowmode.hip)
     if (sc::lowmode_part_map_selftest() != 0) return 3;
     return 0;
-}
-
-double sc_hip_selftest_gpu(void *p)
-{
-    Instance *I = get(p);
-    if (!I || hipSetDevice(I->gpu) != hipSuccess) return -1.0;
-    return sc::fdmid_selftest(I);
 }
 
 // ---------------------------------------------------------------- stage-level hooks

@@ -55,13 +55,6 @@ struct FftState {
     bool singular = false;
 };
 
-// direct solve of one mid level of the hierarchy on the fp32 matrix cores (sc_fdmid.hip): level index (-1: none), its size, the
-// padded sizes, the five matrices (device / pinned staging) and two scratch planes
-struct FdMid {
-    int level = -1, nx = 0, ny = 0, Px = 0, Py = 0, Pk = 0;
-    DevBuf mats, hmats, G1, G2;
-};
-
 struct MGLevel {
     Field U, F, T;   // correction, RHS, scratch (residual field); level 0 aliases the instance fields
     MGGeom g;        // geometry of this level and of its transfer to the next coarser one
@@ -121,8 +114,6 @@ struct Instance {
     // direct (fast-diagonalisation) solve inside the bottom kernel: level index relative to mg_bottom, or -1
     int fd_level = -1, fd_nxp = 0, fd_nyp = 0;
     DevBuf mg_fd, h_fd;    // its matrices: device copy and pinned staging
-    FdMid fdm;
-    int mg_solves = 0;      // multigrid solves on the current hierarchy (the mid-level direct solve is set up on the second)
     LowMode lm;
     DstState dst;
     FftState fft;
@@ -159,7 +150,7 @@ int hip_fail(Instance *I, hipError_t e, const char *what);
 
 int ensure(Instance *I, DevBuf &b, size_t bytes);
 int ensure_pinned(Instance *I, DevBuf &b, size_t bytes);
-double fd_selftest_error(bool fast = false);   // sc_multigrid.cpp
+double fd_selftest_error();   // sc_multigrid.cpp
 int setup_fields(Instance *I, int W, int H, int C);
 
 // solver drivers (sc_solver.cpp) -- operate on I->U0/U1/F, leave the answer in result(I)
@@ -175,8 +166,6 @@ int lowmode_part_map_selftest();                                     // host-onl
 int lowmode_early_kind(Instance *I, float update_tol);                // see sc_lowmode.hip
 void lowmode_bands_written(Instance *I, const float *field);       // the launch went in: B describes `field` (nullptr: nothing)
 int lowmode_count(int n);
-int fdmid_solve(Instance *I, const Field &F, const Field &U);         // sc_fdmid.hip
-double fdmid_selftest(Instance *I);
 int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST
 int fft_solve(Instance *I, bool fp64);                                // sc_fft.hip: SC_METHOD_FFT (fp64: SC_FLAG_FFT_FP64)
 bool fft_supported(int w, int h, bool fp64);

@@ -73,12 +73,10 @@ static size_t bottom_start(Instance *I)
 // Eigen-decomposition of a symmetric tridiagonal matrix by implicit QL with Wilkinson shifts.
 // d: diagonal (n) -> eigenvalues; e: sub-diagonal, e[i] couples i and i+1 (n-1 used, e[n-1] = 0);
 // zt: n x n, row k = eigenvector k on return (kept transposed so the rotation loop is contiguous).
-static bool tridiag_ql(int n, std::vector<double> &d, std::vector<double> &e, std::vector<double> &zt, bool vectors = true)
+static bool tridiag_ql(int n, std::vector<double> &d, std::vector<double> &e, std::vector<double> &zt)
 {
-    if (vectors) {
-        zt.assign((size_t)n * n, 0.0);
-        for (int i = 0; i < n; ++i) zt[(size_t)i * n + i] = 1.0;
-    }
+    zt.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) zt[(size_t)i * n + i] = 1.0;
     for (int l = 0; l < n; ++l) {
         int iter = 0, m;
         do {
@@ -105,13 +103,11 @@ static bool tridiag_ql(int n, std::vector<double> &d, std::vector<double> &e, st
                     p = s * r;
                     d[i + 1] = g + p;
                     g = c * r - b;
-                    if (vectors) {
-                        double *zi = &zt[(size_t)i * n], *zi1 = &zt[(size_t)(i + 1) * n];
-                        for (int k = 0; k < n; ++k) {
-                            f = zi1[k];
-                            zi1[k] = s * zi[k] + c * f;
-                            zi[k] = c * zi[k] - s * f;
-                        }
+                    double *zi = &zt[(size_t)i * n], *zi1 = &zt[(size_t)(i + 1) * n];
+                    for (int k = 0; k < n; ++k) {
+                        f = zi1[k];
+                        zi1[k] = s * zi[k] + c * f;
+                        zi[k] = c * zi[k] - s * f;
                     }
                 }
                 if (r == 0.0 && i >= l) continue;
@@ -139,48 +135,6 @@ static bool fd_decompose(const MGDim &g, FD1 &o)
     return true;
 }
 
-// The same decomposition in O(n^2): eigenvalues by the QL iteration WITHOUT accumulating vectors, eigenvectors from the
-// three-term recurrence the first n-1 rows of T spell out (v_0 = 0, v_1 = 1, v_{i+1} = (lambda + 2) v_i - v_{i-1}: the row of the
-// irregular last interval only selects the eigenvalues).  Every eigenvalue of an unreduced tridiagonal matrix is simple, so the
-// recurrence determines the vector; it is oscillatory (|lambda + 2| <= 2) or grows by at most ~1.6 per step (an eigenvalue below
-// -4 exists for alpha < 1): fine in double for the level sizes used here.  0.1 ms at n = 255 where the full QL takes 6.6 ms:
-// what makes a direct solve of a 255^2 level affordable to set up (sc_fdmid.hip).  Checked against T v = l v in fd_selftest_error.
-static bool fd_decompose_fast(const MGDim &g, FD1 &o)
-{
-    const int n = g.n;
-    o.n = n; o.cw_last = g.cw_last; o.d_last = g.d_last;
-    o.ee.assign(n, 1.0);
-    std::vector<double> d(n, -2.0), e(n, 0.0), none;
-    for (int i = 0; i + 1 < n; ++i) e[i] = 1.0;
-    d[n - 1] = -(double)g.d_last;
-    if (n >= 2) {
-        e[n - 2] = std::sqrt((double)g.cw_last);
-        o.ee[n - 1] = 1.0 / std::sqrt((double)g.cw_last);
-    }
-    if (!tridiag_ql(n, d, e, none, false)) return false;
-    o.lam = d;
-    o.q.assign((size_t)n * n, 0.0);
-    for (int k = 0; k < n; ++k) {
-        double *q = &o.q[(size_t)k * n];
-        const double t = o.lam[k] + 2.0;
-        double vm = 0.0, v = 1.0, nrm = 0.0;
-        for (int i = 0; i < n; ++i) {                 // v = component i of the eigenvector of T (unsymmetrised)
-            const double s = v * o.ee[i];             // symmetrised: q = E v
-            q[i] = s; nrm += s * s;
-            const double vn = t * v - vm;
-            vm = v; v = vn;
-            if (std::fabs(v) > 1e200) {               // rescale a growing (hyperbolic) vector
-                const double f = 1e-200;
-                for (int j = 0; j <= i; ++j) q[j] *= f;
-                nrm *= f * f; v *= f; vm *= f;
-            }
-        }
-        const double inv = 1.0 / std::sqrt(nrm);
-        for (int i = 0; i < n; ++i) q[i] *= inv;
-    }
-    return true;
-}
-
 // 1-D decompositions are kept in a small per-instance cache: alternating between a few ROI sizes (or a
 // square ROI, whose two directions are the same operator) then costs no eigen-solve.
 static const FD1 *fd_cached(Instance *I, const MGDim &g)
@@ -198,17 +152,16 @@ static const FD1 *fd_cached(Instance *I, const MGDim &g)
 
 // host-only check of the decomposition (sc_hip_selftest_host): max |T v_k - l_k v_k| and max |V^-1 V - I| over a few
 // level operators, regular and with an irregular last interval
-double fd_selftest_error(bool fast)
+double fd_selftest_error()
 {
     double worst = 0.0;
-    const int ns[] = { 1, 2, 3, 7, 31, 63, 74, 128, 255, 299, 384 };
+    const int ns[] = { 1, 2, 3, 7, 31, 63, 74, 128 };
     const double alphas[] = { 1.0, 0.5, 0.75, 1.5, 0.96875 };
     for (int n : ns)
         for (double a : alphas) {
-            if (!fast && n > 128) continue;                 // the full QL iteration is only used (and only affordable) for the bottom levels
             MGDim g = make_dim(n, a, 0);
             FD1 f;
-            if (!(fast ? fd_decompose_fast(g, f) : fd_decompose(g, f))) return 1e30;
+            if (!fd_decompose(g, f)) return 1e30;
             auto T = [&](int i, int j) -> double {          // the level operator itself
                 if (i == j) return i == n - 1 ? -(double)g.d_last : -2.0;
                 if (j == i + 1) return 1.0;
@@ -273,57 +226,6 @@ static int build_fd(Instance *I)
         SC_HIP(I, hipMemcpyAsync(I->mg_fd.p, m, sizeof(float) * (size_t)nf, hipMemcpyHostToDevice, I->stream));
         I->fd_level = (int)(l - I->mg_bottom);
         I->fd_nxp = nxp; I->fd_nyp = nyp;
-        return SC_OK;
-    }
-    return SC_OK;
-}
-
-// Mid-level direct solve (sc_fdmid.hip): the first launched level below level 1 of at most 384 points per side is solved exactly
-// by four dense products on the matrix cores instead of being cycled through (single clones only: few channels).  Set up on the
-// second solve of a geometry, so a one-off ROI size never pays for the decomposition (0.1-0.3 ms of host time).
-static int build_fd_mid(Instance *I)
-{
-    FdMid &M = I->fdm;
-    M.level = -1;
-    if ((I->opts.flags & SC_FLAG_NO_DIRECT_MID) || I->F.C > 6) return SC_OK;
-    const size_t lim = std::min(I->mg_bottom, I->mg.size());
-    for (size_t l = 2; l < lim; ++l) {
-        const MGLevel &L = I->mg[l];
-        const int nx = L.g.x.n, ny = L.g.y.n;
-        if (std::max(nx, ny) > 384) continue;
-        if (std::min(nx, ny) < 48) return SC_OK;            // thin: the launches it would replace are cheap
-        FD1 fx, fy;
-        if (!fd_decompose_fast(L.g.x, fx)) return SC_OK;
-        const bool same = nx == ny && L.g.x.cw_last == L.g.y.cw_last && L.g.x.d_last == L.g.y.d_last;
-        if (!same && !fd_decompose_fast(L.g.y, fy)) return SC_OK;
-        const FD1 &gy = same ? fx : fy;
-        const int Px = round_up(nx, 128), Py = round_up(ny, 128), Pk = round_up(nx + 2, 16);
-        const size_t nf = (size_t)Pk * Px + 2 * (size_t)Py * Py + (size_t)Px * Px + (size_t)Py * Px;
-        int rc;
-        if ((rc = ensure_pinned(I, M.hmats, sizeof(float) * nf))) return rc;
-        if ((rc = ensure(I, M.mats, sizeof(float) * nf))) return rc;
-        if ((rc = ensure(I, M.G1, sizeof(float) * (size_t)Py * Px * I->F.C))) return rc;
-        if ((rc = ensure(I, M.G2, sizeof(float) * (size_t)Py * Px * I->F.C))) return rc;
-        SC_HIP(I, hipStreamSynchronize(I->stream));         // the staging may still feed an earlier geometry's upload
-        float *m = (float *)M.hmats.p;
-        memset(m, 0, sizeof(float) * nf);
-        float *R1 = m, *L1 = R1 + (size_t)Pk * Px, *R2 = L1 + (size_t)Py * Py, *L2 = R2 + (size_t)Px * Px, *Dinv = L2 + (size_t)Py * Py;
-        for (int x = 0; x < nx; ++x)
-            for (int i = 0; i < nx; ++i) {
-                const double q = fx.q[(size_t)i * nx + x];
-                R1[(size_t)(x + 1) * Px + i] = (float)(q * fx.ee[x]);      // Vx^-1[i][x], row x + 1: row 0 meets the ring column of F
-                R2[(size_t)i * Px + x] = (float)(q / fx.ee[x]);            // Vx[x][i]
-            }
-        for (int y = 0; y < ny; ++y)
-            for (int j = 0; j < ny; ++j) {
-                const double q = gy.q[(size_t)j * ny + y];
-                L1[(size_t)j * Py + y] = (float)(q * gy.ee[y]);            // Vy^-1[j][y]
-                L2[(size_t)y * Py + j] = (float)(q / gy.ee[y]);            // Vy[y][j]
-            }
-        for (int j = 0; j < ny; ++j)
-            for (int i = 0; i < nx; ++i) Dinv[(size_t)j * Px + i] = (float)(1.0 / (gy.lam[j] + fx.lam[i]));
-        SC_HIP(I, hipMemcpyAsync(M.mats.p, m, sizeof(float) * nf, hipMemcpyHostToDevice, I->stream));
-        M.level = (int)l; M.nx = nx; M.ny = ny; M.Px = Px; M.Py = Py; M.Pk = Pk;
         return SC_OK;
     }
     return SC_OK;
@@ -405,8 +307,6 @@ static int build_levels(Instance *I)
     I->mg[0].F = I->F;
     I->mg_bottom = bottom_start(I);
     I->mg_l1_half = false;        // fresh planes: all zero in either format
-    I->fdm.level = -1;
-    I->mg_solves = 0;
     return build_fd(I);
 }
 
@@ -441,7 +341,6 @@ static int vcycle(Instance *I, size_t l, int pre, int post, unsigned no_post = 0
     const bool skip_post = l > 0 && l < 32 && ((no_post >> l) & 1u);
     MGLevel &L = I->mg[l];
     int rc;
-    if (l > 0 && (int)l == I->fdm.level) return fdmid_solve(I, L.F, L.U);      // this level is solved exactly (sc_fdmid.hip)
     if (l > 0 && l == I->mg_bottom) return run_bottom(I, l, pre, post);
     if (l + 1 == I->mg.size()) { // coarsest level outside the bottom kernel: SOR with its optimal factor
         const int n = std::max(8, std::min(64, 2 * std::max(L.g.x.n, L.g.y.n)));
@@ -550,7 +449,6 @@ int mg_solve(Instance *I)
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
     const float utol = o.update_tol > 0.f ? o.update_tol : 0.25f;
     const int budget = o.max_sweeps > 0 ? o.max_sweeps : 30;
-    if (++I->mg_solves == 2 && I->fdm.level < 0 && (rc = build_fd_mid(I))) return rc;     // a geometry that comes back: direct mid level
     // level 1 in float16 or float: the two formats put a plane's ring and pads at different bytes, so a switch re-zeroes the planes
     const bool l1h = I->mg.size() >= 2 && mg_level1_half(I);
     if (I->mg.size() >= 2 && l1h != I->mg_l1_half) {

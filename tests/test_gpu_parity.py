@@ -145,9 +145,7 @@ def test_multigrid_cycles_follow_the_spec(hip, W, H):
     F = np.zeros((3, H, W), np.float32)
     F[:, 1:-1, 1:-1] = rng.normal(0, 30, (3, H - 2, W - 2)).astype(np.float32)
     for cycles in (1, 3):
-        # (SC_FLAG_NO_DIRECT_MID: the numpy spec cycles through every level; the mid-level direct solve a repeated geometry gets
-        # has its own test, tests/test_gpu_round3.py)
-        hip.set_solver(method=capi.SC_METHOD_MULTIGRID, max_sweeps=cycles, update_tol=1e-30, tol=0.0, flags=capi.SC_FLAG_NO_DIRECT_MID)
+        hip.set_solver(method=capi.SC_METHOD_MULTIGRID, max_sweeps=cycles, update_tol=1e-30, tol=0.0)
         hip.field_load(U, F)
         hip.field_solve(allow_not_converged=True)
         got = hip.field_store()
@@ -168,7 +166,7 @@ def test_multigrid_cycles_follow_the_spec(hip, W, H):
             want = mg_np.solve(U[c], F[c], cycles=cycles, fused=False)
             assert np.abs(got1[c] - want).max() < 2e-3 * (10.0 if cycles == 1 else 1.0), ("unfused", cycles, c)
     d = hip.default_opts()
-    hip.set_solver(method=capi.SC_METHOD_MULTIGRID, max_sweeps=d.max_sweeps, update_tol=d.update_tol, tol=d.tol, flags=0)
+    hip.set_solver(method=capi.SC_METHOD_MULTIGRID, max_sweeps=d.max_sweeps, update_tol=d.update_tol, tol=d.tol)
 
 
 def test_c1_clone_matches_oracle_within_one(hip, oracles, c1_inputs):

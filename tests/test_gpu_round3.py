@@ -458,35 +458,3 @@ def test_default_path_fuzz_over_small_and_medium_shapes(inst, oracles):
         if direct and min(i.W, i.H) > 8:
             worst_direct = max(worst_direct, float((d > 0).sum()) / max(1.0, 3.0 * (i.W - 2) * (i.H - 2)))
     assert worst_direct < 2e-3, worst_direct
-
-
-def test_mid_level_direct_solve(hip, oracles):
-    """Round 3: from the second multigrid solve of a geometry on, a single clone's first level of <= 384 points per side below
-    level 1 is solved exactly by four dense products on the fp32 matrix cores (sc_fdmid.hip) instead of being cycled through.
-    The product kernel against a host triple loop; the clone within one of the port, with the same number of cycles as the
-    plain schedule (SC_FLAG_NO_DIRECT_MID), stable from the second call on, and not slower."""
-    from seamlesscloneoptimization_amd import capi
-    o, oc = oracles
-    err = capi.load().sc_hip_selftest_gpu(hip.h)
-    assert 0.0 <= err < 1e-5, err
-    for W, H in ((2048, 2048), (1300, 1100), (1030, 1000), (1200, 300)):
-        dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=32, seed_dst=W + 1, seed_patch=H + 1)
-        want = oc.seamless_clone(dst, patch, mask, cx, cy, min(16, oc.max_threads()))
-        res = {}
-        try:
-            for flags in (capi.SC_FLAG_NO_DIRECT_MID, 0):
-                hip.set_solver(flags=flags)
-                outs, times = [], []
-                for rep in range(4):
-                    body = dst.copy()
-                    assert hip.run(patch, body, mask, cx, cy) == 0
-                    assert _dsum(body, want)[0] <= 1, (W, H, flags, rep)
-                    outs.append(body); times.append(hip.info().ms_solve)
-                assert np.array_equal(outs[2], outs[3])                       # steady state
-                res[flags] = (hip.info().sweeps, min(times[2:]), outs[3])
-        finally:
-            hip.set_solver(flags=0)
-        print("mid-level direct solve %dx%d: cycles %d / %d, solve %.3f -> %.3f ms" % (W, H, res[capi.SC_FLAG_NO_DIRECT_MID][0], res[0][0],
-                                                                                      res[capi.SC_FLAG_NO_DIRECT_MID][1], res[0][1]))
-        assert res[0][0] <= res[capi.SC_FLAG_NO_DIRECT_MID][0]
-        assert (res[0][2] != res[capi.SC_FLAG_NO_DIRECT_MID][2]).mean() < 0.003
