@@ -62,8 +62,9 @@ enum sc_method {
                                 SC_AUTO_DIRECT_MAX unknowns per side (there it is faster than the cycles and has no iteration
                                 error: diff sum against the float-table CPU port 2 instead of 129 at the reference's 300x194
                                 patch, whose own published deviation from OpenCV is 44, PDF p3) and for thin ROIs
-                                (SC_AUTO_THIN_MAX), SC_METHOD_MULTIGRID above and whenever tol > 0 asks for a residual-based
-                                stop.  sc_run_info.method says which one ran.                                      */
+                                (SC_AUTO_THIN_MAX) -- single clones only: a group of clones (sc_hip_run_device_batch) is about
+                                throughput, where the cycles win at every size --, SC_METHOD_MULTIGRID above and whenever
+                                tol > 0 asks for a residual-based stop.  sc_run_info.method says which one ran.                                      */
     SC_METHOD_FFT    = 6     /* the reference's DEFAULT direct back-end (poissonSolver2D_FFT, seamlessClone_imp.cpp:1694-1918):
                                 the same u = S_h ((S_h g S_w) / den) S_w in float32 with FFT-based transforms, O(n^2 log n).
                                 The DST-I of each row is a chirp-z transform over a power-of-two FFT held in LDS (sc_fft.hip);

@@ -23,6 +23,9 @@ int effective_method(const Instance *I)
     if (o.method != SC_METHOD_AUTO) return o.method;
     const int w = I->F.W - 2, h = I->F.H - 2;
     if (o.tol > 0.f || w < 1 || h < 1) return SC_METHOD_MULTIGRID;
+    // a GROUP of clones (3n channels through one set of launches) is about throughput, and there the cycles win at every size:
+    // 7.5 / 12.1 / 15.1 Gpix/s against 2.1 / 3.3 / 3.5 for the double-precision direct solve at 300^2 / 512^2 / 768^2 ROIs in groups of 16
+    if (I->F.C > 3) return SC_METHOD_MULTIGRID;
     // the direct solve = the FFT form with double transforms (fft_in_double): the answer of the matrix form SC_METHOD_DST (both
     // are the reference's float-table arithmetic with exact transforms; measured diff sums against the port are identical) in
     // 0.09-0.29 ms of device time where the matrix form takes 0.17-0.37 and the cycles 0.18-0.35 (298x192 ... 896^2 ROIs; at 1024^2 the

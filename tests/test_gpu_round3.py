@@ -80,9 +80,11 @@ def test_default_solver_choice_and_its_deviation_at_the_published_sizes(inst, or
     assert inst.info().method == capi.SC_METHOD_MULTIGRID
 
 
-def test_groups_of_small_clones_take_the_direct_solve_too(oracles):
-    """sc_hip_run_device_batch with the default options on small ROIs: one direct solve of 3n channels; every member equals
-    the clone run alone, byte for byte."""
+def test_groups_of_small_clones_keep_the_cycles(oracles):
+    """sc_hip_run_device_batch with the default options on small ROIs: a group is about throughput, so SC_METHOD_AUTO keeps the
+    multigrid cycles for it (3.5x the clone rate of the direct solve at 512^2 in groups of 16) while the same clone alone takes
+    the direct solve.  Every member within one of the port and of the clone run alone; SC_METHOD_FFT asked for explicitly runs
+    the group as one direct solve of 3n channels."""
     from seamlesscloneoptimization_amd import capi
     o, oc = oracles
     N = 5
@@ -99,13 +101,14 @@ def test_groups_of_small_clones_take_the_direct_solve_too(oracles):
         j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
         j.centerX, j.centerY, j.body_restore = cx, cy, b0
     pool.run(jobs, device_resident=True)
-    assert inst.info().method == capi.SC_METHOD_FFT and inst.field_shape()[0] == 3 * N
+    assert inst.info().method == capi.SC_METHOD_MULTIGRID and inst.field_shape()[0] == 3 * N
     solo = capi.Instance(0)
     for (dst, patch, mask, cx, cy), (f, b, b0, m) in zip(items, keep):
         got = inst.from_device(b, dst.shape)
         alone = dst.copy()
         solo.run(patch, alone, mask, cx, cy)
-        assert np.array_equal(got, alone)
+        assert solo.info().method == capi.SC_METHOD_FFT
+        assert _dsum(got, alone)[0] <= 1
         assert _dsum(got, oc.seamless_clone(dst, patch, mask, cx, cy, 2))[0] <= 1
     solo.destroy()
     for t in keep:
