@@ -435,7 +435,7 @@ static int fft_solve_t(Instance *I)
     // Small planes (cache resident: the scattered 4- or 8-byte stores of a transposed write cost nothing there) skip the two
     // transpose launches: each transform launch writes the plane the next one reads row-wise.  Three launches instead of five:
     // 0.057 -> ~0.04 ms of a 298 x 192 clone's solve, where every launch is at its latency floor.
-    const bool tiny = plane * sizeof(T) <= ((size_t)1 << 20);
+    const bool tiny = plane * sizeof(T) <= ((size_t)4 << 20);
     if (tiny) {
         hipLaunchKernelGGL((k_fft_dst<0, T>), dim3(h, C), dim3(FFT_THREADS), ldsw, I->stream, Pw, U, I->F, (const T *)nullptr, B, h, fx, fy, exact, 1.0, 1);   // B[c][x][y]
         hipLaunchKernelGGL((k_fft_dst<1, T>), dim3(w, C), dim3(FFT_THREADS), ldsh, I->stream, Ph, U, I->F, (const T *)B, A, w, fx, fy, exact, 1.0, 1);        // A[c][y][x]
