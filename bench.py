@@ -472,7 +472,7 @@ def main():
     if args.method == "mg":
         c0_bytes = (4 * 12.0 + 8.0 + 1.0 + 9.0) * (W - 2) * (H - 2) * grp_ch
         roofline = roof(f"k_cycle0<4,8,8,PRO> on a group of {grp_ch // 3} clones = {grp_ch} channels (prolongation + 4 red-black sweeps + "
-                        "residual + restriction, one launch)", "k_cycle0<4, 8, 8, true, false, false, 19>" if (opts["flags"] & capi.SC_FLAG_FLOAT_L1) else "k_cycle0<4, 8, 8, true, false, false, 147>", c0_bytes, ms_c0,
+                        "residual + restriction, one launch)", "k_cycle0<4, 8, 8, true, false, false, %d>" % (19 if (opts["flags"] & capi.SC_FLAG_FLOAT_L1) else 147 if (opts["flags"] & capi.SC_FLAG_FLOAT_FIELD) else 915), c0_bytes, ms_c0,
                         "dominant kernel of the timed region, in the form the timed region launches it; algorithmic bytes = sum of the "
                         "SURVEY 8d figures of the fused operations = 66 B/unknown/channel: frac (= frac_effective) > 1 is 'effective' "
                         "bandwidth from temporal blocking; frac_traffic = counter-measured fabric bytes / time / 8 TB/s.  The isolated "

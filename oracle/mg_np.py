@@ -198,8 +198,17 @@ def _f16(a):
     return a.astype(np.float16).astype(F32)
 
 
-def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post=(), level1_half=False):
-    """level1_half: the library's fast path stores level 1's right-hand side (written by level 0's restriction) and level 1's
+def _q16(a):
+    """16-bit fixed point of the level-0 field between two launches (sc_cycle0.hip, TAG bits 8, 9):
+    code = trunc(64 u + 16384.5) clamped to [0, 65535]; u = code / 64 - 256."""
+    t = (a.astype(F32) * F32(64.0) + F32(16384.5)).astype(F32)
+    code = np.clip(np.trunc(np.clip(t, 0.0, 65535.0)), 0, 65535).astype(F32)
+    return (code * F32(0.015625) - F32(256.0)).astype(F32)
+
+
+def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post=(), level1_half=False, field_q16=False):
+    """field_q16: the fast path stores level 0's field between its launches (after the pre-smoothing; the residual uses the
+    registers) as 16-bit fixed point.  level1_half: the library's fast path stores level 1's right-hand side (written by level 0's restriction) and level 1's
     smoothed correction (read by level 0's prolongation) as float16 (sc_cycle0.hip, TAG bit 7); level 1's own residual and
     restriction use the unrounded registers."""
     dx, dy = levels[l]
@@ -215,7 +224,7 @@ def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post=(), level1_half=
     if level1_half and l == 0:
         Fc = _f16(Fc)
     E = vcycle(levels, l + 1, np.zeros_like(Fc), Fc, pre, post, direct, no_post, level1_half)
-    U = U.copy()
+    U = _q16(U) if (field_q16 and l == 0) else U.copy()
     if level1_half and l == 1 and l in no_post:
         U = _f16(U)
     U += prolong(E, dx, dy)
@@ -224,7 +233,7 @@ def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post=(), level1_half=
     return rb_gen(U, F, dx, dy, post)
 
 
-def solve(U0, F, cycles=6, direct="auto", fused=True, level1_half=False):
+def solve(U0, F, cycles=6, direct="auto", fused=True, level1_half=False, field_q16=False):
     """Multigrid solve of one plane: U0 carries the Dirichlet ring (level 0 is regular).
     direct: "auto" = the level the library solves directly, None = V-cycle down to the coarsest level.
     fused: the library's default (fused) schedule, in which level 1 has no post-smoothing where composes_level1();
@@ -235,5 +244,6 @@ def solve(U0, F, cycles=6, direct="auto", fused=True, level1_half=False):
     npl = no_post_levels(levels) if fused else ()
     U = U0.astype(F32).copy()
     for _ in range(cycles):
-        U = vcycle(levels, 0, U, F, direct=d, no_post=npl, level1_half=level1_half and 1 in npl)
+        U = vcycle(levels, 0, U, F, direct=d, no_post=npl, level1_half=level1_half and 1 in npl,
+                   field_q16=field_q16 and level1_half and 1 in npl)
     return U

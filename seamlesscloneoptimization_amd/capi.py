@@ -47,6 +47,7 @@ SC_FLAG_KEEP_FIELD = 1 << 7
 SC_FLAG_FFT_FP64 = 1 << 8
 SC_FLAG_OPENCV_GREY_MASK = 1 << 9
 SC_FLAG_FLOAT_L1 = 1 << 10
+SC_FLAG_FLOAT_FIELD = 1 << 11
 
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",

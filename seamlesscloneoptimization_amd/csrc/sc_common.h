@@ -128,7 +128,7 @@ void launch_max_final2(const float *d_a, int na, const float *d_b, int nb, unsig
 // residual + restriction into Fc.  Returns #partials written, 0 without prolong, -1 if unsupported.
 int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
                    float *partial, hipStream_t s, bool tag = false, bool f_half = false, bool u_half = false,
-                   bool final_cycle = false, float4 *bands = nullptr, bool l1_half = false);
+                   bool final_cycle = false, float4 *bands = nullptr, bool l1_half = false, bool q16_out = false);
 // bands (final form, or 4 sweeps with prolongation): receives the cell shares of the float-table correction of the field the
 // launch writes, two float4 per (channel, tile row, wave, 8-column cell) -- see k_cycle0 and sc_lowmode.hip
 void cycle0_row_geometry(int H, int sweeps, int &nby, int &step, int &hy);
@@ -136,10 +136,11 @@ int  cycle0_blocks(int W, int H, int C, int sweeps);
 // the same launch with its prolongation source composed on the fly from level 1 (before post-smoothing) and level 2
 // (sc_cycle0.hip, ComposeArgs); -1: combination not instantiated
 int  launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
-                            hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands = nullptr, bool l1_half = false);
+                            hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands = nullptr, bool l1_half = false,
+                            bool u_q16 = false);
 // the last cycle with its result leaving as output bytes (planar, in Q's memory) instead of as a field; see sc_cycle0.hip
 int  launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
-                       bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half = false);
+                       bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half = false, bool u_q16 = false);
 // coarse level: zero-guess pre-smoothing + residual + restriction fused (Uout = smoothed correction, Fc = next RHS)
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s, bool half_io = false);
 

@@ -90,6 +90,35 @@ __device__ __forceinline__ void c0_load_half_raw(const __half *__restrict__ p, i
         v[r] = *reinterpret_cast<const uint2 *>(p + (size_t)yc * P + xc);
     }
 }
+// The field BETWEEN the level-0 launches of the fast path as 16-bit fixed point (TAG bits 8, 9): code = trunc(64 u + 16384.5)
+// clamped to [0, 65535], u = code / 64 - 256: the range [-256, 768) in steps of 1/64.  The solution of a clone lies in
+// [-255, 510] (it is the source patch plus a discrete harmonic function whose boundary values are differences of 8-bit
+// values), 8-bit boundary values are exact, and a rounding of at most 1/128 per stored value is to a multigrid iterate what
+// one more high-frequency error component is: the next launch's sweeps damp it, and the last launch's output never passes
+// through it.  Same element pitch / plane size as the float field, 2 bytes per unknown instead of 4, read AND written.
+template <int R>
+__device__ __forceinline__ void c0_load_q16(const uint16_t *__restrict__ p, int P, int H, int x, int y0, float4 (&v)[R])
+{
+    const int xc = min(max(x, 0), P - 4);
+    uint2 raw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int yc = min(max(y0 + r, 0), H - 1);
+        raw[r] = *reinterpret_cast<const uint2 *>(p + (size_t)yc * P + xc);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        v[r].x = __builtin_fmaf((float)(raw[r].x & 0xffffu), 0.015625f, -256.0f);
+        v[r].y = __builtin_fmaf((float)(raw[r].x >> 16), 0.015625f, -256.0f);
+        v[r].z = __builtin_fmaf((float)(raw[r].y & 0xffffu), 0.015625f, -256.0f);
+        v[r].w = __builtin_fmaf((float)(raw[r].y >> 16), 0.015625f, -256.0f);
+    }
+}
+__device__ __forceinline__ unsigned c0_q16(float u)
+{
+    return (unsigned)__builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, 16384.5f), 0.0f, 65535.0f);
+}
+
 // Level 0 (regular stencil) holds q = -f/4 instead of f (exact in either format: a power-of-two scaling): the Gauss-Seidel
 // update 0.25 (S - f) is then ONE fused multiply-add, fma(S, 0.25, q) -- S/4 and q are exact, so the single rounding of the
 // fma is the rounding of 0.25 (S - f), bit for bit what the subtract-then-scale form gives -- and the residual's f - X is
@@ -158,6 +187,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     // of a correction and not the fixed point (level 0's residual is exact).  Halves the traffic of the level-1 launch and takes
     // 1 byte per unknown off every level-0 launch (oracle/mg_np.py rounds the same two fields).
     constexpr bool L1H = (TAG & 128) != 0;
+    // TAG bits 8 / 9: the incoming / outgoing field is 16-bit fixed point (c0_load_q16)
+    constexpr bool UQI = (TAG & 256) != 0, UQO = (TAG & 512) != 0;
+    static_assert(!((UQI || UQO) && (GEN || (HU && UQI) || (OUT && UQO))), "16-bit fields: level 0, between its launches");
     static_assert(!L1H || !GEN || ZEROIN, "float16 level-1 fields: the level-1 launch starts from a zero correction");
     static_assert(!(PRO && GEN), "the in-kernel prolongation relies on level 0's regular last interval");
     static_assert(2 * T + 2 <= C0_HX, "column halo too small");
@@ -180,6 +212,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         for (int r = 0; r < R; ++r) u[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else if (HU) {
         c0_load_half<R>(reinterpret_cast<const __half *>(Uin.p) + (size_t)c * Uin.plane, P, H, x, y0, u);
+    } else if (UQI) {
+        c0_load_q16<R>(reinterpret_cast<const uint16_t *>(Uin.p) + (size_t)c * Uin.plane, P, H, x, y0, u);
     } else {
         c0_load<R>(Uin.at(c), P, H, x, y0, u);
     }
@@ -609,6 +643,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         }
         return;
     }
+    if constexpr (UQO) {
+        uint16_t *__restrict__ outq = reinterpret_cast<uint16_t *>(Uout.p) + (size_t)c * Uout.plane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int yr = wv * R + r, y = y0 + r;
+            if (!(yr >= HY && yr < RH - HY && y >= 0 && y < H)) continue;
+            uint2 pk;
+            pk.x = c0_q16(u[r].x) | (c0_q16(u[r].y) << 16);
+            pk.y = c0_q16(u[r].z) | (c0_q16(u[r].w) << 16);
+            *reinterpret_cast<uint2 *>(outq + (size_t)y * P + x) = pk;
+        }
+        return;
+    }
     float *__restrict__ out = Uout.at(c);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -634,12 +681,21 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
 // has no post-smoothing and no prolongation launch of its own), E2 = finished level-2 correction, g1 = level-1 geometry.
 // sweeps = post + pre (4) or, final_cycle, post (2).  Returns the number of partial maxima, -1 if not instantiated.
 // With a float16 right-hand side (f_half: the fast path) level 1's fields are float16 as well (TAG bit 7; sc_multigrid.cpp decides
-// with the same rule: mg_level1_half).
+// with the same rule: mg_level1_half).  u_q16 (float16 level 1 only): Uin holds 16-bit fixed point (c0_load_q16) and so will
+// Uout, except after the final cycle, which leaves a float field.
 int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
-                           hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands, bool l1_half)
+                           hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands, bool l1_half,
+                           bool u_q16)
 {
     ComposeArgs ca;
     ca.E2 = E2; ca.g1 = g1;
+    if (u_q16) {
+        if (!l1_half || !f_half) return -1;
+        if (final_cycle) return sweeps == 2 ? launch_c0<2, true, 154 | 256>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : -1;
+        if (sweeps != 4) return -1;
+        if (bands && !tag) return launch_c0<4, true, 210 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
+        return tag ? launch_c0<4, true, 147 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 146 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
+    }
     if (l1_half != f_half) {           // instantiated pairs: float16 RHS with float16 level 1, float RHS with float level 1 -- and, for
         if (l1_half) return -1;        // a level 1 that does fewer than four sweeps (mg_level1_sweeps), float16 RHS with float level 1
         if (final_cycle) return sweeps == 2 ? launch_c0<2, true, 26>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : -1;
@@ -661,11 +717,13 @@ int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, c
 // Uin hold float16 values (same element layout).  Returns the number of partial maxima written (0 without prolong), or -1
 // for an unsupported depth.
 int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle, float4 *bands, bool l1_half)
+                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle, float4 *bands, bool l1_half, bool q16_out)
 {
+    if (q16_out && !(l1_half && u_half)) return -1;      // the first launch of a clone on the fast path only
     if (l1_half) {     // level 1 keeps float16 fields (the composed schedule): the launches without a prolongation write its right-hand side
         if (prolong || final_cycle || !f_half || tag || sweeps != 2) return -1;
-        if (u_half) launch_c0<2, false, 134>(Uin, Uout, F, Fc, E, g, partial, s);
+        if (q16_out) launch_c0<2, false, 134 | 512>(Uin, Uout, F, Fc, E, g, partial, s);
+        else if (u_half) launch_c0<2, false, 134>(Uin, Uout, F, Fc, E, g, partial, s);
         else launch_c0<2, false, 130>(Uin, Uout, F, Fc, E, g, partial, s);
         return 0;
     }
@@ -712,10 +770,15 @@ int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeo
 // E = the finished level-1 correction) + two post-smoothing sweeps; Q (a field's memory: plane c at Q.p + c Q.plane BYTES,
 // rows of Q.pitch bytes) receives the output values, lm the node correction to add (CN == nullptr: none).
 int launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
-                      bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half)
+                      bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half, bool u_q16)
 {
     ComposeArgs ca;
     if (l1_half && !(composed && f_half)) return -1;
+    if (u_q16) {
+        if (!l1_half) return -1;
+        ca.E2 = E2; ca.g1 = g1;
+        return launch_c0<2, true, 186 | 256>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
+    }
     if (composed && f_half && !l1_half) {
         ca.E2 = E2; ca.g1 = g1;
         return launch_c0<2, true, 58>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);

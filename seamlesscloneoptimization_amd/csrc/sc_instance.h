@@ -91,6 +91,8 @@ struct Instance {
     bool out_direct = false;               // the last solve wrote output bytes from its last cycle: result(I) is the iterate before it, not the solution
     bool f_half = false;      // F currently holds float16 values (written by the pre-process for the fused multigrid path)
     bool u_half = false;      // ... and so does the initial field U0 until the first cycle has consumed it
+    bool u_q16 = false;       // multigrid fast path, during a solve: the current field is 16-bit fixed point (sc_cycle0.hip, TAG bits 8, 9)
+    bool mg_q16_last = false; // ... the last solve kept its field so (sc_hip_time_cycle0 times the same form)
     // Speculative epilogue: the multigrid driver enqueues the post-process right behind the cycle whose
     // convergence check it is about to wait for, so the host round trip of the check overlaps useful work.
     // If the check then fails the solve simply continues and the post-process runs again at the end.

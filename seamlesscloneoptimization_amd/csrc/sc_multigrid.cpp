@@ -429,6 +429,15 @@ bool mg_level1_half(const Instance *I)
            (o.mg_level1_sweeps == 0 || o.mg_level1_sweeps == 4);
 }
 
+// The field between the level-0 launches as 16-bit fixed point (sc_cycle0.hip, TAG bits 8, 9): the fast path with float16
+// level-1 fields whose last cycle leaves output bytes (`out_wanted` in mg_solve).  The judged cycle always reads the 16-bit
+// field and leaves bytes or a float field; a solve that goes on after it continues on float fields.
+static bool mg_field_q16(const Instance *I, bool out_wanted)
+{
+    // (SEPARATE_RESTRICT: the float-table correction would read the field itself between two launches)
+    return out_wanted && I->u_half && !(I->opts.flags & (SC_FLAG_FLOAT_FIELD | SC_FLAG_SEPARATE_RESTRICT)) && mg_level1_half(I);
+}
+
 bool mg_reads_half_rhs(const Instance *I)
 {
     const sc_solver_opts &o = I->opts;
@@ -473,11 +482,14 @@ int mg_solve(Instance *I)
     if (I->f_half && !(fused0 && o.tol <= 0.f)) { I->err = "internal: float16 right-hand side on a path that needs float"; return SC_ERR_BAD_ARG; }
     if (fused0) {
         Field none{};
+        const bool out_wanted = I->spec_post.armed && o.tol <= 0.f && !(o.flags & SC_FLAG_KEEP_FIELD) && pre == 2 && post == 2;
+        const bool q16 = l1h && mg_field_q16(I, out_wanted);
         // on the float16 path the pre-process stored the initial field as float16 as well (first launch only)
         if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
-                          I->stream, false, I->f_half, I->u_half, false, nullptr, l1h) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
+                          I->stream, false, I->f_half, I->u_half, false, nullptr, l1h, q16) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
         I->result_in_U1 = !I->result_in_U1;
-        I->u_half = false;             // consumed: both U buffers hold float from here on
+        I->u_half = false;             // consumed: both U buffers hold float (or 16-bit fixed point: u_q16) from here on
+        I->u_q16 = I->mg_q16_last = q16;
         I->info.sweep_launches += 1;
         int nb_last = 0;                   // workgroups (= partial maxima) of the previous cycle's level-0 launch
         // Output straight from the last cycle.  When the caller armed the splice (spec_post) the cycle the stop rule is about to
@@ -487,7 +499,6 @@ int mg_solve(Instance *I)
         // the iterate BEFORE that cycle, whose cell shares the previous launch leaves behind (lowmode_early_kind: the two
         // differ by 0.001-0.003 grey levels, 0.05 in the worst case the stop rule admits).  If the rule rejects the cycle, the same cycle is launched again in the form
         // that writes the field (its input is untouched) and the solve continues as without this.
-        const bool out_wanted = I->spec_post.armed && o.tol <= 0.f && !(o.flags & SC_FLAG_KEEP_FIELD) && pre == 2 && post == 2;
         auto stop_rule = [utol](float m, float m_prev) {
             if (m_prev > 0.f) {
                 const float rho = std::min(0.5f, std::max(0.02f, m / m_prev));
@@ -552,7 +563,7 @@ int mg_solve(Instance *I)
                     I->aux_pending = false;
                 }
                 const int nbo = launch_cycle0_out(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, part_now,
-                                                  I->stream, I->f_half, comp1, comp1 ? I->mg[2].U : Field(), comp1 ? I->mg[1].g : MGGeom(), early_lm, l1h);
+                                                  I->stream, I->f_half, comp1, comp1 ? I->mg[2].U : Field(), comp1 ? I->mg[1].g : MGGeom(), early_lm, l1h, I->u_q16);
                 early_ready = false;
                 if (nbo > 0) {
                     I->info.sweep_launches += 1;
@@ -575,14 +586,16 @@ int mg_solve(Instance *I)
             const int nb = comp1
                 ? launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
                                          judged ? post : post + pre, part_now, I->stream, false, I->f_half, judged,
-                                         I->mg[2].U, I->mg[1].g, bands, l1h)
+                                         I->mg[2].U, I->mg[1].g, bands, l1h, I->u_q16)
                 : launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
                                 I->mg[0].g, judged ? post : post + pre, true, part_now, I->stream,
                                 false, I->f_half, false, judged, bands);
             if (nb <= 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
             I->result_in_U1 = !I->result_in_U1;
+            if (judged) I->u_q16 = false;      // the final form leaves a float field
             lowmode_bands_written(I, bands ? result(I).p : nullptr);
-            if (!judged && early != 2) {       // the node correction the next cycle's output will carry, from this launch's field
+            // (a 16-bit field cannot be read by the correction itself: without the cell shares the judged cycle leaves a float field instead)
+            if (!judged && early != 2 && !(early == 1 && !bands && I->u_q16)) {       // the node correction the next cycle's output will carry, from this launch's field
                 early_lm = LmNodes();
                 // a group of clones: its coarse levels fill the chip, nothing to overlap (measured: -2 %); a small clone: the two
                 // cross-stream waits cost more than the 15-us chain they hide (154x100 ... 300x194 patches: +20 us)

@@ -98,13 +98,21 @@ def test_variant_flags(hip, oracles, W, H):
     cycles = hip.info().sweeps
     assert compare.image_diff_stats(want, base)["max"] <= 1
     try:
-        for flags in (capi.SC_FLAG_NO_SPECULATE, capi.SC_FLAG_FLOAT_U0, capi.SC_FLAG_FLOAT_U0 | capi.SC_FLAG_NO_SPECULATE):
+        # (SC_FLAG_FLOAT_U0: a float initial field also means float fields between the level-0 launches, where the default keeps
+        # 16-bit fixed point -- byte-identical to SC_FLAG_FLOAT_FIELD, within one grey level of the default)
+        hip.set_solver(flags=capi.SC_FLAG_FLOAT_FIELD)
+        base_float = dst.copy()
+        assert hip.run(patch, base_float, mask, cx, cy) == 0
+        assert compare.image_diff_stats(want, base_float)["max"] <= 1 and compare.image_diff_stats(base, base_float)["max"] <= 1
+        for flags, same_as in ((capi.SC_FLAG_NO_SPECULATE, base), (capi.SC_FLAG_FLOAT_U0, base_float),
+                               (capi.SC_FLAG_FLOAT_U0 | capi.SC_FLAG_NO_SPECULATE, base_float),
+                               (capi.SC_FLAG_FLOAT_FIELD | capi.SC_FLAG_NO_SPECULATE, base_float)):
             hip.set_solver(flags=flags)
             for _ in range(2):                                   # twice: the second call reuses the instance state
                 body = dst.copy()
                 assert hip.run(patch, body, mask, cx, cy) == 0
                 assert hip.info().sweeps == cycles
-                assert np.array_equal(body, base), flags
+                assert np.array_equal(body, same_as), flags
         # (SC_FLAG_FLOAT_RHS: since round 3 a float right-hand side also means float level-1 fields, where the default stores level 1's
         # right-hand side and correction as float16 -- same fixed point, iterates a relative 5e-4 of a correction apart)
         for flags in (capi.SC_FLAG_FLOAT_RHS, capi.SC_FLAG_FLOAT_RHS | capi.SC_FLAG_NO_SPECULATE, capi.SC_FLAG_NO_COMPOSE_L1, capi.SC_FLAG_VCYCLE_BOTTOM,
@@ -427,10 +435,12 @@ def test_output_and_restriction_variants_agree(hip, oracles, W, H):
     geo, M = oc.mask_stage(mask, cx, cy)
     B, lap = oc.build_rhs(dst, patch, geo, M)
     want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
-    KEEP, SEP, NOSPEC = capi.SC_FLAG_KEEP_FIELD, capi.SC_FLAG_SEPARATE_RESTRICT, capi.SC_FLAG_NO_SPECULATE
+    KEEP, SEP, NOSPEC, FF = capi.SC_FLAG_KEEP_FIELD, capi.SC_FLAG_SEPARATE_RESTRICT, capi.SC_FLAG_NO_SPECULATE, capi.SC_FLAG_FLOAT_FIELD
     out, fields = {}, {}
     try:
-        for flags in (0, SEP, NOSPEC, KEEP, KEEP | SEP, KEEP | NOSPEC):
+        # (KEEP and SEP run on float fields; FF = the byte-output path on float fields as well; 0 = the default, whose field between
+        # the level-0 launches is 16-bit fixed point: different roundings of the same iterates)
+        for flags in (0, FF, SEP, NOSPEC, FF | NOSPEC, KEEP, KEEP | SEP, KEEP | NOSPEC):
             hip.set_solver(flags=flags)
             for rep in range(2):                                     # the second call reuses buffers and the part maps
                 body = dst.copy()
@@ -448,14 +458,16 @@ def test_output_and_restriction_variants_agree(hip, oracles, W, H):
             fields[flags] = hip.field_store()
     finally:
         hip.set_solver(flags=0)
-    assert np.array_equal(out[0], out[NOSPEC]) and np.array_equal(out[KEEP], out[KEEP | NOSPEC])
+    assert np.array_equal(out[0], out[NOSPEC]) and np.array_equal(out[KEEP], out[KEEP | NOSPEC]) and np.array_equal(out[FF], out[FF | NOSPEC])
     scale = max(1.0, float(np.abs(fields[0]).max()))
     for flags in (SEP, KEEP | SEP):
         assert np.abs(fields[0] - fields[flags]).max() <= 2e-5 * scale
     assert np.array_equal(fields[0], fields[KEEP])
     for flags in (SEP, KEEP, KEEP | SEP):
-        s = compare.image_diff_stats(out[0], out[flags])
+        s = compare.image_diff_stats(out[FF], out[flags])
         assert s["max"] <= 1 and s["percent"] < 0.02, (flags, compare.format_stats(s))
+    s = compare.image_diff_stats(out[0], out[FF])           # the 16-bit field's roundings: values within ~0.003 of an integer flip
+    assert s["max"] <= 1 and s["percent"] < 0.25, compare.format_stats(s)
     for flags, body in out.items():
         s = compare.image_diff_stats(want, body)
         assert s["max"] <= 1 and s["percent"] < 0.5, (flags, compare.format_stats(s))
@@ -505,15 +517,19 @@ def test_rejected_last_cycle_is_relaunched_with_its_field(hip, oracles, W, H):
     want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
     out, cycles = {}, {}
     try:
-        for flags in (0, capi.SC_FLAG_KEEP_FIELD):
+        for flags in (0, capi.SC_FLAG_FLOAT_FIELD, capi.SC_FLAG_KEEP_FIELD):
             hip.set_solver(flags=flags, update_tol=0.002)
             body = dst.copy()
             assert hip.run(patch, body, mask, cx, cy) == 0
             out[flags], cycles[flags] = body, hip.info().sweeps
     finally:
         hip.set_solver(flags=0, update_tol=0.0)
-    assert cycles[0] == cycles[capi.SC_FLAG_KEEP_FIELD] >= 4, cycles
-    assert np.array_equal(out[0], out[capi.SC_FLAG_KEEP_FIELD])
+    assert cycles[0] == cycles[capi.SC_FLAG_FLOAT_FIELD] == cycles[capi.SC_FLAG_KEEP_FIELD] >= 4, cycles
+    assert np.array_equal(out[capi.SC_FLAG_FLOAT_FIELD], out[capi.SC_FLAG_KEEP_FIELD])
+    # the default's first three cycles ran on the 16-bit field, the rejected one was relaunched from it into a float field and the
+    # solve went on in float: the same fixed point, approached from a point <= 1/128 away
+    s = compare.image_diff_stats(out[0], out[capi.SC_FLAG_KEEP_FIELD])
+    assert s["max"] <= 1 and s["percent"] < 0.05, compare.format_stats(s)
     s = compare.image_diff_stats(want, out[0])
     assert s["max"] <= 1 and s["percent"] < 0.5, compare.format_stats(s)
 

@@ -436,6 +436,45 @@ def test_float16_level1_fields_against_float_ones(hip, oracles):
             hip.set_solver(mg_level1_sweeps=0)
 
 
+def test_fixed16_field_between_the_level0_launches(hip, oracles):
+    """The fast multigrid path keeps level 0's field BETWEEN its launches as 16-bit fixed point (steps of 1/64 over
+    [-256, 768): k_cycle0 TAG bits 8, 9); SC_FLAG_FLOAT_FIELD keeps float.  A clone's solution lies in [-255, 510] (source patch
+    plus a harmonic function of boundary differences): the extremes are driven here (black destination, white-rimmed black patch
+    and the opposite; full-range noise), beside an ordinary clone.  Each within one of the float-table port, the same cycle
+    count with either format, the share of channels that differ between the two stays at the roundings' level."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    W, H = 700, 560
+    rng = np.random.default_rng(16)
+    cases = {}
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=32, seed_dst=3, seed_patch=4)
+    cases["ordinary"] = (dst, patch)
+    lo_d, lo_p = np.zeros_like(dst), np.zeros_like(patch)
+    lo_p[:12] = lo_p[-12:] = 255; lo_p[:, :12] = lo_p[:, -12:] = 255            # u = patch - 255 inside: down to -255
+    lo_p[200:300, 250:450] = rng.integers(0, 256, (100, 200, 3), dtype=np.uint8)
+    cases["down to -255"] = (lo_d, lo_p)
+    hi_d, hi_p = np.full_like(dst, 255), np.full_like(patch, 255)
+    hi_p[:12] = hi_p[-12:] = 0; hi_p[:, :12] = hi_p[:, -12:] = 0                # u = patch + 255 inside: up to 510
+    hi_p[200:300, 250:450] = rng.integers(0, 256, (100, 200, 3), dtype=np.uint8)
+    cases["up to 510"] = (hi_d, hi_p)
+    cases["noise"] = (rng.integers(0, 256, dst.shape, dtype=np.uint8), rng.integers(0, 256, patch.shape, dtype=np.uint8))
+    try:
+        for name, (d, p) in cases.items():
+            want = oc.seamless_clone(d, p, mask, cx, cy, min(16, oc.max_threads()))
+            outs = {}
+            for flags in (0, capi.SC_FLAG_FLOAT_FIELD):
+                hip.set_solver(flags=flags)
+                body = d.copy()
+                assert hip.run(p, body, mask, cx, cy) == 0
+                assert _dsum(body, want)[0] <= 1, (name, flags)
+                outs[flags] = (body, hip.info().sweeps, (body != want).mean())
+            assert outs[0][1] == outs[capi.SC_FLAG_FLOAT_FIELD][1], name
+            assert (outs[0][0] != outs[capi.SC_FLAG_FLOAT_FIELD][0]).mean() < 0.003, name
+            assert outs[0][2] <= outs[capi.SC_FLAG_FLOAT_FIELD][2] + 0.002, (name, outs[0][2], outs[capi.SC_FLAG_FLOAT_FIELD][2])
+    finally:
+        hip.set_solver(flags=0)
+
+
 def test_default_path_fuzz_over_small_and_medium_shapes(inst, oracles):
     """The default solver choice over 36 random ROI shapes up to ~1000 pixels a side (direct solve up to 900 unknowns, multigrid
     above; rectangular and elliptical masks; every FFT length from 32 to 2048): within one of the float-table port, and the
