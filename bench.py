@@ -457,8 +457,8 @@ def main():
     j_name = "k_jacobi_roll (register-rolling 5-point, 1 sweep)" if j_depth == 0 else \
         f"k_jacobi_tb<{j_depth},8,8> ({j_depth} fused Jacobi sweeps per launch, register blocked)"
 
-    def cache_note(ch):
-        ws = (W - 2) * (H - 2) * ch * 12
+    def cache_note(ch, bytes_per_unknown=12):
+        ws = (W - 2) * (H - 2) * ch * bytes_per_unknown
         return "working set %.0f MB %s the 256 MB Infinity Cache" % (ws / 1e6, "fits" if ws < 256e6 else "exceeds")
     rb_sym = "k_rb_half<false, 1>" if rb_depth == 0 else f"k_rb_tb<{rb_depth}, 8, 8, false, false, 8, {1 if rb_depth <= 2 else 2}>"
     j_sym = "k_jacobi_roll<4, 1>" if j_depth == 0 else f"k_jacobi_tb<{j_depth}, 8, 8, 1, {1 if j_depth <= 4 else 2}>"
@@ -479,7 +479,10 @@ def main():
                         "launches are the tagged 4-sweep composed form WITHOUT the two epilogues some in-step launches carry (cell "
                         "shares of the float-table correction: +7 %; byte output instead of the field store: same duration), on the "
                         "fields the last group left (values are discarded); "
-                        + cache_note(grp_ch), channels=grp_ch)
+                        + "fields as the launch stores them ("
+                        + ("float32 U in / out, " if (opts["flags"] & (capi.SC_FLAG_FLOAT_FIELD | capi.SC_FLAG_FLOAT_L1)) else "16-bit fixed-point U in / out, ")
+                        + "float16 right-hand side): "
+                        + cache_note(grp_ch, 10 if (opts["flags"] & (capi.SC_FLAG_FLOAT_FIELD | capi.SC_FLAG_FLOAT_L1)) else 6), channels=grp_ch)
     else:
         roofline = roofline_rb
     roofline_j = roof(j_name, j_sym, j_bytes, ms_j, "the Jacobi stencil named by the north-star, same field, single clone; effective "
