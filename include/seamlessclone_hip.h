@@ -165,13 +165,14 @@ typedef struct sc_solver_opts {
 #define SC_FLAG_FLOAT_L1       (1 << 10) /* multigrid: level 1's right-hand side and correction as float32 (default on the fast path:
                                             float16, see SC_FLAG_FLOAT_RHS).  Same fixed point, slightly different iterates.
                                             Implies SC_FLAG_FLOAT_FIELD                                                        */
-#define SC_FLAG_FLOAT_FIELD    (1 << 11) /* multigrid: the field between the level-0 launches as float32.  Default on the fast
-                                            path (float16 right-hand side and level 1, output bytes from the last cycle):
-                                            16-bit fixed point, code = trunc(64 u + 16384.5) in [0, 65535], i.e. [-256, 768) in
-                                            steps of 1/64 -- a clone's solution lies in [-255, 510], its 8-bit boundary values
-                                            are exact, and a rounding of <= 1/128 per stored value is damped by the next
-                                            launch's sweeps; the last cycle's output never passes through it.  Halves the field
-                                            traffic of every level-0 launch                                                   */
+#define SC_FLAG_FLOAT_FIELD    (1 << 11) /* multigrid: the field between the level-0 launches always as float32.  Default on the fast
+                                            path (float16 right-hand side and level 1, output bytes from the last cycle): the first
+                                            stores of a solve -- all but the one the judged cycle reads -- are 16-bit fixed point,
+                                            code = trunc(64 u + 16384.5) in [0, 65535], i.e. [-256, 768) in steps of 1/64.  A clone's
+                                            solution lies in [-255, 510], its 8-bit boundary values are exact, and a rounding of
+                                            <= 1/128 two cycles before the output is gone by then (each cycle removes 90 % of any
+                                            error).  Takes 2 bytes per unknown off four of the six field transfers between a
+                                            solve's level-0 launches                                                           */
 
 /* ---- statistics of the last run */
 typedef struct sc_run_info {

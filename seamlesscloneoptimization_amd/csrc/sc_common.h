@@ -137,10 +137,10 @@ int  cycle0_blocks(int W, int H, int C, int sweeps);
 // (sc_cycle0.hip, ComposeArgs); -1: combination not instantiated
 int  launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
                             hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands = nullptr, bool l1_half = false,
-                            bool u_q16 = false);
+                            int u_q16 = 0);
 // the last cycle with its result leaving as output bytes (planar, in Q's memory) instead of as a field; see sc_cycle0.hip
 int  launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
-                       bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half = false, bool u_q16 = false);
+                       bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half = false);
 // coarse level: zero-guess pre-smoothing + residual + restriction fused (Uout = smoothed correction, Fc = next RHS)
 bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s, bool half_io = false);
 

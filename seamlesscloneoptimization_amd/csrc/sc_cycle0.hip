@@ -94,8 +94,9 @@ __device__ __forceinline__ void c0_load_half_raw(const __half *__restrict__ p, i
 // clamped to [0, 65535], u = code / 64 - 256: the range [-256, 768) in steps of 1/64.  The solution of a clone lies in
 // [-255, 510] (it is the source patch plus a discrete harmonic function whose boundary values are differences of 8-bit
 // values), 8-bit boundary values are exact, and a rounding of at most 1/128 per stored value is to a multigrid iterate what
-// one more high-frequency error component is: the next launch's sweeps damp it, and the last launch's output never passes
-// through it.  Same element pitch / plane size as the float field, 2 bytes per unknown instead of 4, read AND written.
+// one more high-frequency error component is: the cycles that follow remove it like any other error.  Only the first stores of a
+// solve use it (sc_multigrid.cpp: the launch before the judged cycle writes float again, so two cycles lie between the last
+// rounding and the output).  Same element pitch / plane size as the float field, 2 bytes per unknown instead of 4.
 template <int R>
 __device__ __forceinline__ void c0_load_q16(const uint16_t *__restrict__ p, int P, int H, int x, int y0, float4 (&v)[R])
 {
@@ -681,18 +682,20 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
 // has no post-smoothing and no prolongation launch of its own), E2 = finished level-2 correction, g1 = level-1 geometry.
 // sweeps = post + pre (4) or, final_cycle, post (2).  Returns the number of partial maxima, -1 if not instantiated.
 // With a float16 right-hand side (f_half: the fast path) level 1's fields are float16 as well (TAG bit 7; sc_multigrid.cpp decides
-// with the same rule: mg_level1_half).  u_q16 (float16 level 1 only): Uin holds 16-bit fixed point (c0_load_q16) and so will
-// Uout, except after the final cycle, which leaves a float field.
+// with the same rule: mg_level1_half).  u_q16 (float16 level 1, full cycles only): Uin holds 16-bit fixed point (c0_load_q16);
+// bit 1 (value 2) set: so will Uout, clear: Uout leaves as float (the launch before the judged cycle).
 int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
                            hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands, bool l1_half,
-                           bool u_q16)
+                           int u_q16)
 {
     ComposeArgs ca;
     ca.E2 = E2; ca.g1 = g1;
     if (u_q16) {
-        if (!l1_half || !f_half) return -1;
-        if (final_cycle) return sweeps == 2 ? launch_c0<2, true, 154 | 256>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : -1;
-        if (sweeps != 4) return -1;
+        if (!l1_half || !f_half || final_cycle || sweeps != 4) return -1;
+        if (!(u_q16 & 2)) {
+            if (tag) return -1;
+            return bands ? launch_c0<4, true, 210 | 256>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : launch_c0<4, true, 146 | 256>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
+        }
         if (bands && !tag) return launch_c0<4, true, 210 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
         return tag ? launch_c0<4, true, 147 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 146 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
     }
@@ -770,15 +773,10 @@ int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeo
 // E = the finished level-1 correction) + two post-smoothing sweeps; Q (a field's memory: plane c at Q.p + c Q.plane BYTES,
 // rows of Q.pitch bytes) receives the output values, lm the node correction to add (CN == nullptr: none).
 int launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
-                      bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half, bool u_q16)
+                      bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half)
 {
     ComposeArgs ca;
     if (l1_half && !(composed && f_half)) return -1;
-    if (u_q16) {
-        if (!l1_half) return -1;
-        ca.E2 = E2; ca.g1 = g1;
-        return launch_c0<2, true, 186 | 256>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
-    }
     if (composed && f_half && !l1_half) {
         ca.E2 = E2; ca.g1 = g1;
         return launch_c0<2, true, 58>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);

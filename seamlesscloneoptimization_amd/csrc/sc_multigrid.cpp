@@ -429,13 +429,13 @@ bool mg_level1_half(const Instance *I)
            (o.mg_level1_sweeps == 0 || o.mg_level1_sweeps == 4);
 }
 
-// The field between the level-0 launches as 16-bit fixed point (sc_cycle0.hip, TAG bits 8, 9): the fast path with float16
-// level-1 fields whose last cycle leaves output bytes (`out_wanted` in mg_solve).  The judged cycle always reads the 16-bit
-// field and leaves bytes or a float field; a solve that goes on after it continues on float fields.
+// The field between the FIRST level-0 launches of a solve as 16-bit fixed point (sc_cycle0.hip, TAG bits 8, 9): the fast path
+// with float16 level-1 fields whose last cycle leaves output bytes (`out_wanted` in mg_solve).  The launch before the judged
+// cycle reads the 16-bit field and writes float: the judged cycle, and a solve that goes on after it, run on float fields, and
+// two cycles lie between the last rounding (<= 1/128) and the output.
 static bool mg_field_q16(const Instance *I, bool out_wanted)
 {
-    // (SEPARATE_RESTRICT: the float-table correction would read the field itself between two launches)
-    return out_wanted && I->u_half && !(I->opts.flags & (SC_FLAG_FLOAT_FIELD | SC_FLAG_SEPARATE_RESTRICT)) && mg_level1_half(I);
+    return out_wanted && I->u_half && !(I->opts.flags & SC_FLAG_FLOAT_FIELD) && mg_level1_half(I);
 }
 
 bool mg_reads_half_rhs(const Instance *I)
@@ -483,7 +483,7 @@ int mg_solve(Instance *I)
     if (fused0) {
         Field none{};
         const bool out_wanted = I->spec_post.armed && o.tol <= 0.f && !(o.flags & SC_FLAG_KEEP_FIELD) && pre == 2 && post == 2;
-        const bool q16 = l1h && mg_field_q16(I, out_wanted);
+        const bool q16 = l1h && mg_field_q16(I, out_wanted) && budget > 1;      // (max_sweeps = 1: the first cycle is the judged one)
         // on the float16 path the pre-process stored the initial field as float16 as well (first launch only)
         if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
                           I->stream, false, I->f_half, I->u_half, false, nullptr, l1h, q16) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
@@ -563,7 +563,7 @@ int mg_solve(Instance *I)
                     I->aux_pending = false;
                 }
                 const int nbo = launch_cycle0_out(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, part_now,
-                                                  I->stream, I->f_half, comp1, comp1 ? I->mg[2].U : Field(), comp1 ? I->mg[1].g : MGGeom(), early_lm, l1h, I->u_q16);
+                                                  I->stream, I->f_half, comp1, comp1 ? I->mg[2].U : Field(), comp1 ? I->mg[1].g : MGGeom(), early_lm, l1h);
                 early_ready = false;
                 if (nbo > 0) {
                     I->info.sweep_launches += 1;
@@ -586,16 +586,15 @@ int mg_solve(Instance *I)
             const int nb = comp1
                 ? launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
                                          judged ? post : post + pre, part_now, I->stream, false, I->f_half, judged,
-                                         I->mg[2].U, I->mg[1].g, bands, l1h, I->u_q16)
+                                         I->mg[2].U, I->mg[1].g, bands, l1h, I->u_q16 ? (next_judged ? 1 : 3) : 0)
                 : launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
                                 I->mg[0].g, judged ? post : post + pre, true, part_now, I->stream,
                                 false, I->f_half, false, judged, bands);
             if (nb <= 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
             I->result_in_U1 = !I->result_in_U1;
-            if (judged) I->u_q16 = false;      // the final form leaves a float field
+            if (next_judged) I->u_q16 = false;      // the launch before the judged cycle left a float field
             lowmode_bands_written(I, bands ? result(I).p : nullptr);
-            // (a 16-bit field cannot be read by the correction itself: without the cell shares the judged cycle leaves a float field instead)
-            if (!judged && early != 2 && !(early == 1 && !bands && I->u_q16)) {       // the node correction the next cycle's output will carry, from this launch's field
+            if (!judged && early != 2) {       // the node correction the next cycle's output will carry, from this launch's field
                 early_lm = LmNodes();
                 // a group of clones: its coarse levels fill the chip, nothing to overlap (measured: -2 %); a small clone: the two
                 // cross-stream waits cost more than the 15-us chain they hide (154x100 ... 300x194 patches: +20 us)

@@ -348,10 +348,11 @@ def test_float16_level1_fields_do_not_change_the_convergence():
     assert errs[True][-1] < 0.01
 
 
-def test_fixed16_field_between_launches_costs_a_rounding_floor_only():
-    """The fast path keeps level 0's field between its launches as 16-bit fixed point (steps of 1/64 over [-256, 768);
-    oracle/mg_np.py, field_q16).  In the numpy spec the error per cycle is the float schedule's until it meets the floor the
-    last stored rounding leaves after the last launch's two sweeps: about 0.0013 grey levels rms, 0.006 at most."""
+def test_fixed16_field_in_the_first_stores_leaves_no_trace():
+    """The fast path keeps level 0's field between its FIRST launches as 16-bit fixed point (steps of 1/64 over [-256, 768);
+    oracle/mg_np.py, field_q16); the launch before the judged cycle writes float again.  In the numpy spec the error after
+    2, 3 and 4 cycles is the float schedule's to three digits: a rounding of at most 1/128 is one more error component, and
+    every cycle removes 90 % of those."""
     from oracle import mg_np
     W, H = 300, 260
     dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=16, seed_dst=5, seed_patch=6)
@@ -365,5 +366,5 @@ def test_fixed16_field_between_launches_costs_a_rounding_floor_only():
         for fq in (False, True):
             U = mg_np.solve(B[1].copy(), lap[1], cycles=cycles, level1_half=True, field_q16=fq)
             e[fq] = U[1:-1, 1:-1] - ue[1]
-        assert np.abs(e[True]).max() <= np.abs(e[False]).max() + 0.006
-        assert e[True].std() <= np.hypot(e[False].std(), 0.0016)
+        assert np.abs(e[True]).max() <= 1.01 * np.abs(e[False]).max() + 2e-4, cycles
+        assert e[True].std() <= 1.01 * e[False].std() + 2e-5, cycles
