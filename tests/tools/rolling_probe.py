@@ -1,0 +1,39 @@
+"""The barrier-free rolling red-black sweeps (k_rb_roll, SC_FLAG_ROLLING_SWEEPS) against the blocked ones (k_rb_tb): bit-exactness
+against the CPU sweeps over awkward shapes, then the time of a 4-sweep launch on a single clone's field (3 channels) and on a
+group's (48 channels).  Needs tools/experiments/rolling_sweeps.patch applied (the kernel was not kept: its header has the numbers).
+Run on the GPU box: python tests/tools/rolling_probe.py"""
+import sys, os, json
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+from seamlesscloneoptimization_amd import capi
+from oracle import oracle_c as oc
+if not hasattr(capi, "SC_FLAG_ROLLING_SWEEPS"):
+    sys.exit("rolling_probe.py: apply tools/experiments/rolling_sweeps.patch and rebuild first")
+inst = capi.Instance(0)
+bad = 0
+for (W, H) in [(33, 17), (298, 192), (513, 129), (250, 300), (241, 257), (1030, 70), (700, 523), (481, 40), (3, 3), (5, 9), (255, 1031)]:
+    rng = np.random.default_rng(W * 7 + H)
+    U = rng.normal(100, 50, (3, H, W)).astype(np.float32)
+    F = rng.normal(0, 30, (3, H, W)).astype(np.float32)
+    for n in (2, 4, 6, 9):
+        want = oc.rbgs(U, F, n, 1.0)
+        inst.set_solver(flags=capi.SC_FLAG_ROLLING_SWEEPS)
+        inst.field_load(U, F); inst.field_sweep(capi.SC_METHOD_RBGS, n, 1.0, 0)
+        got = inst.field_store()
+        if not np.array_equal(got, want):
+            bad += 1
+            d = np.argwhere(got != want)
+            print("MISMATCH", W, H, n, len(d), d[:4].tolist(), flush=True)
+print("bit-exact cases failed:", bad, flush=True)
+for C, side in ((3, 2048), (48, 2048), (3, 4096)):
+    rng = np.random.default_rng(C)
+    U = rng.normal(100, 50, (C, side, side)).astype(np.float32)
+    F = rng.normal(0, 30, (C, side, side)).astype(np.float32)
+    row = {"channels": C, "side": side}
+    for name, fl in (("blocked_k_rb_tb", 0), ("rolling_k_rb_roll", capi.SC_FLAG_ROLLING_SWEEPS)):
+        inst.set_solver(flags=fl)
+        inst.field_load(U, F)
+        ms = min(inst.field_time_sweeps(capi.SC_METHOD_RBGS, 20, 4, 1.0) for _ in range(3))
+        row[name + "_us_per_4_sweeps"] = round(ms * 1e3, 1)
+        row[name + "_TBps_algorithmic"] = round(4 * 12.0 * (side - 2) ** 2 * C / (ms * 1e-3) / 1e12, 2)
+    print(json.dumps(row), flush=True)
