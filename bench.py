@@ -54,6 +54,11 @@ def parse_args(argv=None):
                     help="c3 (default): the metric's configuration -- 2048^2 ROIs, --batch clones per GPU per step, weak scaling.  "
                          "c5: BASELINE config 5 as written -- 64 independent 1024^2 clones in total, image i on rank i mod N "
                          "(8 per GPU at N = 8), strong scaling")
+    ap.add_argument("--affinity", default="auto", choices=["auto", "none"],
+                    help="N > 1: pin each rank (and the library threads it starts) to its share of the host cores (auto) or leave the mask alone")
+    ap.add_argument("--host-calls", type=int, default=24, help="timed drop-in host-image calls of the `pcie` leg (median / p95 / min are reported)")
+    ap.add_argument("--no-float32-leg", action="store_true", help="skip value_float32_storage (the same timed step with float32 fields and right-hand side)")
+    ap.add_argument("--no-new-size", action="store_true", help="skip the new_size leg (first call at a ROI size the instance has not seen)")
     ap.add_argument("--no-c4", action="store_true", help="skip the roofline_c4 leg (config 4: single-sweep Jacobi kernels at a 4096^2 ROI, HBM bound)")
     ap.add_argument("--reference-table", action="store_true",
                     help="instead of the flagship line: the reference's own published table (PDF p3) -- end-to-end latency of the drop-in "
@@ -79,6 +84,59 @@ def synth(roi, rank):
     patch = np.clip(base[:, :, None] + rng.normal(0.0, 20.0, (Hp, Wp, 3)), 0, 255).astype(np.uint8)
     mask = np.full((Hp, Wp), 255, np.uint8)
     return dst, patch, mask, Wd // 2, Hd // 2
+
+
+class BatchSynth:
+    """The same images for a whole batch without 25 s of numpy in front of 0.13 s of GPU work: the smooth parts and ONE pair of
+    unit-variance noise fields are built once per rank (float32); image k is smooth + sigma x (the noise shifted by a k-dependent
+    offset), clipped to 8 bits -- the SURVEY 8d statistics (same smooth parts, N(0, 12) / N(0, 20) pixel noise), every image
+    different from every other, ~0.1 s each instead of ~0.8.  Image 0 of rank 0 is synth(roi, 0) itself, bit for bit: the CPU
+    baseline and the parity figures of the JSON line are computed on it."""
+
+    def __init__(self, roi, seed):
+        import numpy as np
+        self.np = np
+        self.roi = roi
+        W = H = roi
+        Hd, Wd = H + 256, W + 256
+        Hp, Wp = H + 2, W + 2
+        yy, xx = np.mgrid[0:Hd, 0:Wd].astype(np.float32)
+        self.base_d = (128.0 + 60.0 * np.sin(2 * np.pi * xx / Wd) * np.cos(2 * np.pi * yy / Hd)).astype(np.float32)[:, :, None]
+        xx = np.arange(Wp, dtype=np.float32)[None, :, None]
+        self.base_p = (110.0 + 50.0 * np.cos(3 * np.pi * xx / max(W, 1))).astype(np.float32)
+        rng = np.random.default_rng(seed)
+        self.nd = rng.standard_normal((Hd, Wd, 3), dtype=np.float32)
+        self.npatch = rng.standard_normal((Hp, Wp, 3), dtype=np.float32)
+        self.mask = np.full((Hp, Wp), 255, np.uint8)
+        self.centre = (Wd // 2, Hd // 2)
+
+    def image(self, k):
+        np = self.np
+        sd = (37 * k + 11, 101 * k + 5)
+        dst = np.clip(self.base_d + 12.0 * np.roll(self.nd, sd, axis=(0, 1)), 0, 255).astype(np.uint8)
+        patch = np.clip(self.base_p + 20.0 * np.roll(self.npatch, (53 * k + 3, 71 * k + 29), axis=(0, 1)), 0, 255).astype(np.uint8)
+        return dst, patch, self.mask, self.centre[0], self.centre[1]
+
+
+def pin_rank_to_its_cores(local_rank, world, mode="auto", gpu_pci_bus_id=None):
+    """One rank per GPU shares a host with world - 1 others, each with pool workers and copy helpers (sc_pool.cpp,
+    sc_hostcopy.cpp): pin this process -- and so every thread it creates later -- to its share of the cores BEFORE the library
+    starts its threads.  auto: the cores the kernel lists as local to the GPU's PCI device (/sys/bus/pci/devices/<bdf>/
+    local_cpulist) split evenly among the ranks that share them, else an even split of the current affinity mask; none: leave
+    the mask alone.  Returns the list of cores (what the JSON line reports)."""
+    from seamlesscloneoptimization_amd.batch import rank_cores
+    if mode == "none" or world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    local = None
+    if gpu_pci_bus_id:
+        try:
+            local = open(f"/sys/bus/pci/devices/{gpu_pci_bus_id.lower()}/local_cpulist").read().strip()
+        except OSError:
+            local = None
+    cores = rank_cores(local_rank, world, sorted(os.sched_getaffinity(0)), local)
+    if cores:
+        os.sched_setaffinity(0, cores)
+    return cores
 
 
 def cpu_baseline(dst, patch, mask, cx, cy, gpu_out, gpu_out_exact, budget_s):
@@ -209,6 +267,87 @@ def reference_table(args):
     inst.destroy()
 
 
+def new_size_leg(capi, seed=4):
+    """What a ROI size the instance has not seen costs.  The reference rebuilds its per-size state inside EVERY run()
+    (SeamlessClone::init_resize, seamlessClone_imp.cpp:1073-1116: DST matrix / eigenvalue tables on the device, cuBLAS pointer
+    arrays), so its published times include it; here per-size state (multigrid hierarchy + bottom solver matrices, chirp /
+    transform tables of the direct solve, float-table correction tables) is cached, and a caller whose mask changes every
+    frame meets a new size on most calls.  Device-resident images, synchronous calls, host wall time per call:
+      * fresh: the very first call of a fresh instance at the reference's four published patch sizes (arena allocation,
+        per-size state, code-object load of the kernels it touches: everything);
+      * stream: 64 clones with pseudo-random ROI sizes drawn from [100, 900]^2 and from [1000, 2400]^2 on one instance whose
+        arena has been grown by one call at the largest size -- every call is a size the instance has never seen; right
+        after each, the same call again (the size is cached now: steady state).  median / p95 of both and of the ratio."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    big = 2402
+    dstw = big + 64
+    noise_p = rng.integers(0, 256, (big, big, 3), dtype=np.uint8)
+    noise_d = np.clip(128.0 + rng.normal(0.0, 14.0, (dstw, dstw, 3)), 0, 255).astype(np.uint8)
+    mask = np.full((big, big), 255, np.uint8)
+    out = {}
+
+    def call(inst, dev, pw, ph):
+        d_face, d_body, d_keep, d_mask = dev
+        # a pw x ph patch / mask and a (pw + 64) x (ph + 64) destination as views of the big device images (row steps of the big ones)
+        inst.copy_d2d_async(d_body, d_keep, noise_d.nbytes)
+        inst.sync()
+        t0 = time.perf_counter()
+        rc = inst.L.sc_hip_run_device(inst.h, d_face, pw, ph, 3 * big, d_body, pw + 64, ph + 64, 3 * dstw, d_mask, pw, ph, big,
+                                      (pw + 64) // 2, (ph + 64) // 2, True)
+        dt = (time.perf_counter() - t0) * 1e3
+        if rc not in (capi.SC_OK, capi.SC_ERR_NOT_CONVERGED):
+            raise capi.SeamlessCloneError(rc, f"new_size leg, {pw}x{ph}")
+        return dt
+
+    def upload(inst):
+        return inst.to_device(noise_p), inst.to_device(noise_d), inst.to_device(noise_d), inst.to_device(mask)
+
+    fresh = {}
+    for pw, ph in ((154, 100), (300, 194), (592, 592), (2400, 1552)):
+        inst = capi.Instance(0)
+        try:
+            dev = upload(inst)
+            first = call(inst, dev, pw, ph)
+            again = sorted(call(inst, dev, pw, ph) for _ in range(5))[2]
+            fresh[f"{pw}x{ph}"] = {"first_call_ms": round(first, 3), "steady_ms": round(again, 3), "method": int(inst.info().method)}
+            for d in dev:
+                inst.free(d)
+        finally:
+            inst.destroy()
+    out["fresh_instance"] = fresh
+
+    inst = capi.Instance(0)
+    try:
+        dev = upload(inst)
+        call(inst, dev, 2402, 2402)                 # grow the arena once: from here on a new size costs its per-size state only
+        call(inst, dev, 902, 902)
+        for name, lo, hi in (("roi_100_900", 100, 900), ("roi_1000_2400", 1000, 2400)):
+            first, steady, seen = [], [], set()
+            while len(first) < 64:
+                pw, ph = int(rng.integers(lo, hi + 1)) + 2, int(rng.integers(lo, hi + 1)) + 2
+                if (pw, ph) in seen:
+                    continue
+                seen.add((pw, ph))
+                first.append(call(inst, dev, pw, ph))
+                assert inst.info().new_size == 1
+                steady.append(min(call(inst, dev, pw, ph), call(inst, dev, pw, ph)))
+                assert inst.info().new_size == 0
+            ratio = sorted(f / s for f, s in zip(first, steady))
+            fs, ss = sorted(first), sorted(steady)
+            out[name] = {"clones": len(first), "first_call_ms": {"median": round(fs[32], 3), "p95": round(fs[60], 3), "max": round(fs[-1], 3)},
+                         "steady_ms": {"median": round(ss[32], 3), "p95": round(ss[60], 3)},
+                         "first_over_steady": {"median": round(ratio[32], 3), "p95": round(ratio[60], 3), "max": round(ratio[-1], 3)}}
+        for d in dev:
+            inst.free(d)
+    finally:
+        inst.destroy()
+    out["note"] = ("device-resident images, synchronous sc_hip_run_device, host wall time per call; first = a ROI size the instance has "
+                   "never seen, steady = the same call repeated (best of 2); the reference rebuilds its per-size state in every call "
+                   "(seamlessClone_imp.cpp:1073-1116), here it is built on the device once per size and cached")
+    return out
+
+
 def launch_ranks(args):
     """--gpus N > 1 without a launcher: one fresh child process per rank, started BEFORE this process touches HIP
     (it never does: the library is only loaded by the children).  Rank 0's JSON line is forwarded."""
@@ -237,6 +376,9 @@ def main():
     comm = Comm()
     if comm.world != args.gpus:
         args.gpus = comm.world
+    # CPU placement before the library starts any thread (pool workers, copy helpers inherit the mask)
+    ndev0 = max(1, capi.device_count())
+    cores = pin_rank_to_its_cores(comm.local_rank, comm.world, args.affinity, capi.device_pci_bus_id(comm.local_rank % ndev0))
     import numpy as np
     from seamlesscloneoptimization_amd.batch import shard_indices
     image_ids = None
@@ -269,8 +411,12 @@ def main():
     W = H = args.roi
     jobs = []
     cjobs = pool.make_jobs(args.batch)          # one C job per image: D2D restore + device-resident clone
+    gen = BatchSynth(args.roi, 3000 + comm.rank if image_ids is not None else 1001 + 7919 * comm.rank)
     for b in range(args.batch):
-        dst, patch, mask, cx, cy = synth(args.roi, (3000 - 1001 + image_ids[b]) if image_ids is not None else comm.rank * args.batch + b)   # c5: seeds 3000 + i
+        if b == 0 and comm.rank == 0 and image_ids is None:
+            dst, patch, mask, cx, cy = synth(args.roi, 0)      # SURVEY 8d's image itself: the CPU baseline and the parity figures use it
+        else:
+            dst, patch, mask, cx, cy = gen.image(image_ids[b] if image_ids is not None else b)
         j = dict(host=(dst, patch, mask, cx, cy) if b in (0, args.batch - 1) else None, f=inst.to_device(patch), fs=patch.shape[:2],
                  b0=inst.to_device(dst), b=inst.to_device(dst), n=dst.nbytes, bs=dst.shape[:2],
                  m=inst.to_device(mask), ms=mask.shape[:2], cx=cx, cy=cy)
@@ -295,8 +441,22 @@ def main():
     step()                                   # set-up, not a warm-up step: sizes every instance's device arena for this ROI (hipMalloc)
     for _ in range(args.warmup):
         step()
-    elapsed = timed_region(comm, sync_all, lambda: [step() for _ in range(args.steps)])
+    t_rank = []
+    elapsed = timed_region(comm, sync_all, lambda: [step() for _ in range(args.steps)], t_rank)
+    per_rank_ms = [round(t * 1e3, 3) for t in comm.gather(t_rank[0])]          # this rank's own elapsed time, every rank's on rank 0
     group_cycles = max(i.info().sweeps for i in pool.instances)
+    devices = comm.gather(float(inst.info().device))
+    # the same timed step with float32 storage throughout (field between the level-0 launches, right-hand side, level 1): what the
+    # 16-bit / float16 storage formats of the default are worth, timed by the same clock
+    value_f32 = None
+    if args.method == "mg" and not args.no_float32_leg:
+        pool.set_solver(flags=opts["flags"] | capi.SC_FLAG_FLOAT_FIELD | capi.SC_FLAG_FLOAT_RHS)
+        for _ in range(max(1, min(args.warmup, 2))):
+            step()
+        el32 = timed_region(comm, sync_all, lambda: [step() for _ in range(args.steps)])
+        value_f32 = (el32, max(i.info().sweeps for i in pool.instances))
+        pool.set_solver(flags=opts["flags"])
+        step()                                # back on the default's fields (level 1 re-zeroed) before anything else is measured
     dst, patch, mask, cx, cy = jobs[0]["host"]
     out = inst.from_device(jobs[0]["b"], dst.shape)
     if not all(i.info().converged for i in pool.instances) or np.array_equal(out, dst):
@@ -322,6 +482,24 @@ def main():
     clone(inst, jobs[0], sync=True)
     clone(inst, jobs[0], sync=True)
     info = inst.info()
+    # ... and the same clone without the stage marks (each is an event in the stream with a ~5 us bubble behind it): the
+    # un-instrumented device time of ONE 2048^2 clone -- BASELINE config 3 as written -- by hipEvents, and the wall time of the call
+    inst.set_solver(flags=opts["flags"] | capi.SC_FLAG_NO_STAGE_MARKS)
+    solo_dev, solo_wall = [], []
+    for _ in range(12):
+        inst.copy_d2d_async(jobs[0]["b"], jobs[0]["b0"], jobs[0]["n"])
+        inst.sync()
+        t0 = time.perf_counter()
+        inst.run_device(jobs[0]["f"], jobs[0]["fs"], jobs[0]["b"], jobs[0]["bs"], jobs[0]["m"], jobs[0]["ms"], jobs[0]["cx"], jobs[0]["cy"], sync=True)
+        solo_wall.append((time.perf_counter() - t0) * 1e3)
+        solo_dev.append(inst.info().ms_device_total)
+    inst.set_solver(flags=opts["flags"])
+    solo_dev.sort(); solo_wall.sort()
+    single_clone = {"ms": round(solo_dev[len(solo_dev) // 2], 4), "Mpix_per_s": round(W * H / (solo_dev[len(solo_dev) // 2] * 1e-3) / 1e6, 1),
+                    "ms_min": round(solo_dev[0], 4), "wall_ms_median": round(solo_wall[len(solo_wall) // 2], 4), "cycles": int(inst.info().sweeps),
+                    "note": "ONE clone alone on the GPU (BASELINE config 3 as written), images resident in HBM: median of 12 of the hipEvent "
+                            "time from the first to the last kernel of the clone, no stage marks in between (SC_FLAG_NO_STAGE_MARKS); "
+                            "wall = host time of the synchronous call"}
     # the same clone with the exact tables (parity pair of the CPU baseline leg)
     if args.method == "mg":
         inst.set_solver(flags=opts["flags"] ^ capi.SC_FLAG_EXACT_TABLES)
@@ -377,20 +555,36 @@ def main():
                             "hipEvents; the launches are bound by LDS bandwidth and float32 butterflies, not by HBM (frac = algorithmic "
                             "bytes of the five launches / time / 8 TB/s)"}
 
-    # ---- the drop-in call itself: pageable host images in, result in the caller's image (PCIe inclusive)
+    # ---- the drop-in call itself: pageable host images in, result in the caller's image (PCIe inclusive).  --host-calls timed
+    #      calls after two untimed ones (the first sizes the pinned staging: hipHostMalloc of ~40 MB), the destination restored on
+    #      the host between calls; median / p95 / min of the call and of its stages
     body = dst.copy()
-    inst.run(patch, body, mask, cx, cy)
-    t0 = time.perf_counter()
-    body[...] = dst
-    t_restore = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    inst.run(patch, body, mask, cx, cy)
-    t_host = time.perf_counter() - t0
-    hi = inst.info()
-    pcie = {"h2d_ms": round(hi.ms_h2d, 4), "d2h_ms": round(hi.ms_d2h, 4), "device_ms": round(hi.ms_device_total, 4),
-            "call_ms": round(t_host * 1e3, 4), "Mpix_per_s_inclusive": round(W * H / t_host / 1e6, 1),
-            "note": "my_seamlessclone_api_imp_run on pageable numpy images, one clone, one stream: pack into pinned staging + H2D of "
-                    "the ROI of face/body and the mask, clone, D2H + splice of the interior (never `value`)"}
+    first_ms = []
+    for _ in range(2):
+        body[...] = dst
+        t0 = time.perf_counter()
+        inst.run(patch, body, mask, cx, cy)
+        first_ms.append(round((time.perf_counter() - t0) * 1e3, 4))
+    calls = []
+    for _ in range(max(3, args.host_calls)):
+        body[...] = dst
+        t0 = time.perf_counter()
+        inst.run(patch, body, mask, cx, cy)
+        t_host = (time.perf_counter() - t0) * 1e3
+        hi = inst.info()
+        calls.append((t_host, hi.ms_h2d, hi.ms_device_total, hi.ms_d2h, hi.ms_call))
+
+    def stat(k):
+        v = sorted(c[k] for c in calls)
+        return {"median": round(v[len(v) // 2], 4), "p95": round(v[min(len(v) - 1, int(round(0.95 * (len(v) - 1))))], 4), "min": round(v[0], 4)}
+    st_call = stat(0)
+    pcie = {"call_ms": st_call["median"], "call_ms_p95": st_call["p95"], "call_ms_min": st_call["min"], "calls_timed": len(calls),
+            "first_two_calls_ms": first_ms,
+            "h2d_ms": stat(1), "device_ms": stat(2), "d2h_ms": stat(3), "stream_ms": stat(4),
+            "Mpix_per_s_inclusive": round(W * H / (st_call["median"] * 1e-3) / 1e6, 1),
+            "note": "my_seamlessclone_api_imp_run on pageable numpy images, one clone, one instance: pack into pinned staging + H2D of "
+                    "the mask and of the ROI of face/body, clone, D2H + splice of the interior (never `value`); call_ms = host wall time of "
+                    "the call (median), stream_ms = hipEvent time from the first upload to the last download"}
 
     # ---- sweep kernels named by the north-star, on freshly built float fields of the same images (single clone, 3 channels)
     spl = args.sweeps_per_launch            # 0: library default = fused kernels at their deepest depth
@@ -530,6 +724,9 @@ def main():
                                "traffic; HIP events on the library's stream around back-to-back launches; the register-rolling form is the "
                                "default because it is the faster of the two here (no barrier, no LDS round trip for the rows a wave owns)"}
 
+    new_size = None
+    if comm.rank == 0 and args.gpus == 1 and not args.no_new_size and args.config == "c3":
+        new_size = new_size_leg(capi)
     total_pix = comm.sum(float(W * H * args.batch)) * args.steps
     value = total_pix / elapsed / 1e6
     step_traffic = profile.get("step_traffic_bytes") if profile else None
@@ -538,7 +735,10 @@ def main():
                    "Mpix/s seamlessClone (ROI 2048^2)" if args.roi == 2048 else f"Mpix/s seamlessClone (ROI {args.roi}^2)"),
         "value": round(value, 2), "unit": "Mpix/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if args.config == "c5" else "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": ("f32" if (opts["flags"] & capi.SC_FLAG_FLOAT_FIELD and opts["flags"] & capi.SC_FLAG_FLOAT_RHS) or args.method != "mg" else
+                  "f32 (arithmetic); storage: 16-bit fixed-point field on the first two level-0 stores of a solve, float16 right-hand side and level 1"),
+        "data": "synthetic",
         "config": {"workload": (f"BASELINE config 5: 64 independent {W}x{H}-ROI clones in total, image i on rank i mod {args.gpus} (this rank: {args.batch}); "
                                 if args.config == "c5" else "") +
                                f"{args.batch} independent {W}x{H}-ROI NORMAL_CLONEs per GPU per step on {streams} HIP "
@@ -551,6 +751,12 @@ def main():
                    "clones_per_launch_group": group,
                    "parallelism": f"{args.gpus} GPU(s) x {args.batch} independent images, no collective",
                    "cycles_or_sweeps": int(group_cycles)},
+        "single_clone": single_clone,
+        "value_float32_storage": ({"value": round(total_pix / value_f32[0] / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(value_f32[0] / args.steps * 1e3, 4),
+                                   "cycles": int(value_f32[1]), "flags": "SC_FLAG_FLOAT_FIELD | SC_FLAG_FLOAT_RHS",
+                                   "note": "the same timed step (same steps, same clock) with float32 storage throughout: field between the "
+                                           "level-0 launches, right-hand side, level 1"} if value_f32 else None),
+        "per_rank": {"elapsed_ms": per_rank_ms, "device": [int(d) for d in devices], "cores_of_rank0": len(cores), "affinity": args.affinity},
         "single_clone_stages_ms": {"mask": round(info.ms_mask, 4), "pre": round(info.ms_pre, 4), "solve": round(info.ms_solve, 4),
                                    "post": round(info.ms_post, 4), "device_total": round(info.ms_device_total, 4),
                                    "note": "one clone alone on the GPU, hipEvent marks; solve includes the float-table correction and, "
@@ -563,6 +769,7 @@ def main():
                                "traffic_source": f"{profile['_file']} @ {profile.get('git', '?')}"} if step_traffic else
                               {"bytes_per_step": None, "frac_of_peak": None, "traffic_stale": traffic_stale}),
         "pcie": pcie,
+        "new_size": new_size,
     }
     if comm.rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(dst, patch, mask, cx, cy, out_float, out_exact, args.cpu_seconds)

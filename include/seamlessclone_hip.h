@@ -174,6 +174,12 @@ typedef struct sc_solver_opts {
                                             error).  Takes 2 bytes per unknown off four of the six field transfers between a
                                             solve's level-0 launches                                                           */
 
+#define SC_FLAG_NO_STAGE_MARKS  (1 << 12) /* sc_hip_run_device(..., bSync = true): record only the first and the last stage mark.  Every
+                                            mark is an event in the stream with a ~5 us bubble behind it, so the per-stage timeline
+                                            (ms_mask, ms_pre, ms_solve) costs a 2048^2 clone ~15 us; with this flag ms_device_total is the
+                                            un-instrumented device time of the clone and the per-stage figures read 0 (all of it is booked
+                                            under ms_post).  Results are unaffected                                              */
+
 /* ---- statistics of the last run */
 typedef struct sc_run_info {
     int    x0, y0, W, H, ltx, lty;  /* patch offset, ROI size (ring included), ROI origin in body */
@@ -189,6 +195,13 @@ typedef struct sc_run_info {
     float  last_update;             /* MULTIGRID: max |coarse-grid correction| of the last checked cycle (grey levels) */
     size_t device_bytes;            /* arena bytes owned by the instance                    */
     int    method;                  /* enum sc_method that ran (what SC_METHOD_AUTO resolved to) */
+    int    device;                  /* HIP device the instance runs on (create_instance's gpu_id)  */
+    float  ms_call;                 /* my_seamlessclone_api_imp_run: hipEvent time of the whole call's stream work, first upload
+                                       to last download (what the reference's bSync timing brackets, seamlessClone_imp.cu:310-344) */
+    int    field_retry;             /* 1: the 16-bit fixed-point field of the multigrid fast path saturated during this clone (an
+                                       iterate left [-256, 768): possible when the mask mixes patch and destination gradients into a
+                                       non-conservative field) -- nothing was written, the clone was repeated on float32 fields */
+    int    new_size;                /* 1: this run built per-size state (multigrid hierarchy, transform or correction tables) */
 } sc_run_info;
 
 /* ---- the reference's four entry points ------------------------------------------------- */
@@ -202,8 +215,12 @@ SC_API void *my_seamlessclone_api_imp_create_instance(int gpu_id);
  * face = patch (CV_8UC3), body = destination (CV_8UC3, modified in place), mask (CV_8UC1,
  * same size as face).  Host pointers (pageable or page-locked).  The call completes before it
  * returns whatever bSync says, because the result has to land in caller memory (the reference
- * is synchronous here as well: D2H + host splice, seamlessClone_imp.cpp:471-483); bSync is kept
- * for signature compatibility.  Returns SC_OK or a negative SC_ERR_*. */
+ * is synchronous here as well: D2H + host splice, seamlessClone_imp.cpp:471-483).  bSync = true
+ * does what the reference's does (seamlessClone_imp.cu:310-349): the call is timed with events on
+ * the instance's stream and prints the reference's two lines on stdout,
+ *     "Compute stage performance time= %.3f msec, patch size=%dx%d" and "total device memory used: %d";
+ * the reference's Python binding passes false (SeamlessClone.cpp:63), its CLI true (seamlessClone_main.cu:91).
+ * The same time is in sc_run_info.ms_call either way.  Returns SC_OK or a negative SC_ERR_*. */
 SC_API int my_seamlessclone_api_imp_run(void *instance,
                                  const uint8_t *face, int face_cols, int face_rows, int face_step,
                                  uint8_t *body, int body_cols, int body_rows, int body_step,
@@ -240,6 +257,9 @@ SC_API int   sc_hip_memcpy_h2d(void *instance, void *dptr, const void *hptr, siz
 SC_API int   sc_hip_memcpy_d2h(void *instance, void *hptr, const void *dptr, size_t bytes);
 SC_API int   sc_hip_memcpy_d2d_async(void *instance, void *dst, const void *src, size_t bytes); /* on the instance stream */
 SC_API int   sc_hip_device_count(void);
+/* PCI address of HIP device `gpu_id` as "dddd:bb:dd.f" (what /sys/bus/pci/devices/ is keyed by: a host that pins its threads to
+ * the cores local to a GPU reads <that directory>/local_cpulist).  Returns SC_OK, or SC_ERR_BAD_ARG / SC_ERR_HIP with buf[0] = 0. */
+SC_API int   sc_hip_device_pci_bus_id(int gpu_id, char *buf, int len);
 /* page-locked host memory for callers that want their images DMA-able in place (run() copies a page-locked image
  * whose row step equals the library's device pitch without staging; every other host image is packed first) */
 SC_API void *sc_hip_host_alloc(void *instance, size_t bytes);

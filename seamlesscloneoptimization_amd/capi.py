@@ -30,7 +30,7 @@ SC_METHOD_RBGS = 1
 SC_METHOD_SOR = 2
 SC_METHOD_MULTIGRID = 3
 SC_METHOD_DST = 4
-SC_METHOD_AUTO = 5      # default: DST up to SC_AUTO_DIRECT_MAX unknowns per side, MULTIGRID above
+SC_METHOD_AUTO = 5      # default: the FFT-form direct solve (double transforms) up to SC_AUTO_DIRECT_MAX unknowns per side, MULTIGRID above
 SC_METHOD_FFT = 6       # the reference's default back-end: FFT-based direct solve, float32, O(n^2 log n)
 SC_AUTO_DIRECT_MAX = 900
 SC_AUTO_THIN_MAX = 4
@@ -48,6 +48,7 @@ SC_FLAG_FFT_FP64 = 1 << 8
 SC_FLAG_OPENCV_GREY_MASK = 1 << 9
 SC_FLAG_FLOAT_L1 = 1 << 10
 SC_FLAG_FLOAT_FIELD = 1 << 11
+SC_FLAG_NO_STAGE_MARKS = 1 << 12
 
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",
@@ -66,7 +67,8 @@ class RunInfo(C.Structure):
                 ("sweeps", C.c_int), ("converged", C.c_int), ("rel_residual", C.c_double),
                 ("ms_h2d", C.c_float), ("ms_mask", C.c_float), ("ms_pre", C.c_float), ("ms_solve", C.c_float),
                 ("ms_post", C.c_float), ("ms_d2h", C.c_float), ("ms_device_total", C.c_float),
-                ("sweep_launches", C.c_int), ("last_update", C.c_float), ("device_bytes", C.c_size_t), ("method", C.c_int)]
+                ("sweep_launches", C.c_int), ("last_update", C.c_float), ("device_bytes", C.c_size_t), ("method", C.c_int),
+                ("device", C.c_int), ("ms_call", C.c_float), ("field_retry", C.c_int), ("new_size", C.c_int)]
 
 
 class BatchJob(C.Structure):
@@ -150,6 +152,8 @@ def load():
     L.sc_hip_memcpy_d2d_async.restype = C.c_int
     L.sc_hip_device_count.argtypes = []
     L.sc_hip_device_count.restype = C.c_int
+    L.sc_hip_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    L.sc_hip_device_pci_bus_id.restype = C.c_int
     L.sc_hip_mask_stage.argtypes = [C.c_void_p] + _IMG + [C.c_int, C.c_int, i32p, u8p, C.c_size_t]
     L.sc_hip_mask_stage.restype = C.c_int
     L.sc_hip_build_rhs.argtypes = [C.c_void_p] + _IMG * 3 + [C.c_int, C.c_int, i32p, f32p, f32p, C.c_size_t]
@@ -267,8 +271,10 @@ class Instance:
         return i
 
     # ---- the clone
-    def run(self, face, body, mask, cx, cy, sync=True, allow_not_converged=False):
-        """In place on `body` (reference semantics).  Returns the C return code."""
+    def run(self, face, body, mask, cx, cy, sync=False, allow_not_converged=False):
+        """In place on `body` (reference semantics).  Returns the C return code.  The call is complete when it returns
+        either way; sync = the reference's bSync: True also prints its two timing lines on stdout (the reference's
+        Python binding passes False, SeamlessClone.cpp:63)."""
         if not body.flags.writeable:
             raise ValueError("body must be writeable: the clone is in place")
         f, b, m = _img(face), _img(body), _img(mask)
@@ -440,6 +446,17 @@ class Pool:
     def make_jobs(n: int):
         return (BatchJob * n)()
 
+    def set_solver(self, **solver):
+        """The same options on every instance of the pool (between batches)."""
+        o = self.instances[0].get_solver()
+        for k, v in solver.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        rc = self.L.sc_hip_pool_set_solver(self.h, C.byref(o))
+        if rc != SC_OK:
+            raise SeamlessCloneError(rc, "bad solver options")
+
     def run(self, jobs, device_resident: bool):
         rc = self.L.sc_hip_pool_run(self.h, jobs, len(jobs), 1 if device_resident else 0)
         if rc != SC_OK:
@@ -485,3 +502,11 @@ def source_fingerprint() -> str:
 
 def device_count() -> int:
     return int(load().sc_hip_device_count())
+
+
+def device_pci_bus_id(gpu_id: int) -> str | None:
+    """'0000:c1:00.0' of HIP device gpu_id, or None (no such device)."""
+    buf = C.create_string_buffer(64)
+    if load().sc_hip_device_pci_bus_id(int(gpu_id), buf, 64) != SC_OK:
+        return None
+    return buf.value.decode() or None

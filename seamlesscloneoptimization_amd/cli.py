@@ -42,14 +42,13 @@ def main(argv=None) -> int:
             opts.update(tol=2e-5, max_sweeps=1000000, check_every=64)
         inst.set_solver(**opts)
         body = np.array(dst, np.uint8, copy=True, order="C")
-        inst.run(np.ascontiguousarray(src), body, np.ascontiguousarray(mask), a.centerX, a.centerY, sync=True)
+        inst.run(np.ascontiguousarray(src), body, np.ascontiguousarray(mask), a.centerX, a.centerY, sync=False)
         body2 = np.array(dst, np.uint8, copy=True, order="C")      # timed run after the warm-up, as the reference does
+        sys.stdout.flush()       # the timed call (bSync = true) prints the reference's two lines from inside the library (C stdio)
         inst.run(np.ascontiguousarray(src), body2, np.ascontiguousarray(mask), a.centerX, a.centerY, sync=True)
         i = inst.info()
-        print("Compute stage performance time= %.3f msec, patch size=%dx%d" % (i.ms_device_total, i.W, i.H))
-        print("total device memory used: %d" % i.device_bytes)
-        print("transfers: H2D %.3f msec, D2H %.3f msec; solver %s: %d cycles/sweeps"
-              % (i.ms_h2d, i.ms_d2h, a.method, i.sweeps))
+        print("device stages: %.3f msec (ROI %dx%d); transfers: H2D %.3f msec, D2H %.3f msec; solver %s: %d cycles/sweeps"
+              % (i.ms_device_total, i.W, i.H, i.ms_h2d, i.ms_d2h, a.method, i.sweeps))
     finally:
         inst.destroy()
     if a.out:

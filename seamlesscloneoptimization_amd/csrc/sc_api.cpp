@@ -208,6 +208,7 @@ static int validate_images(Instance *I, const void *face, int fc, int fr, int fs
 static int tmark(Instance *I, int k, bool empty_stage = false)
 {
     if (!I->stage_marks) { I->tm[k] = nullptr; return SC_OK; }    // asynchronous device call: nobody reads the timeline
+    if (I->marks_ends_only && k != 0 && k != 7) empty_stage = true;   // SC_FLAG_NO_STAGE_MARKS: first and last mark only
     if (empty_stage && k > 0) { I->tm[k] = I->tm[k - 1]; return SC_OK; }
     I->tm[k] = I->ev[k];
     SC_HIP(I, hipEventRecord(I->ev[k], I->stream));
@@ -304,6 +305,10 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
     if ((rc = tmark(I, 4, eroded))) return rc;
     int solve_rc = SC_OK;
     for (int pass = 0; pass < passes; ++pass) {
+        if (solve_rc == SC_RETRY_FLOAT_FIELD) {      // the 16-bit field of the pass before saturated: nothing was written, the
+            I->force_float_field = true;             // same pass again on float fields (sc_cycle0.hip, c0_q16_checked)
+            I->info.field_retry = 1;
+        }
         I->result_in_U1 = false;
         I->f_half = mg_reads_half_rhs(I);
         I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
@@ -316,12 +321,14 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         I->spec_post.armed = true; I->spec_post.done = false;
         solve_rc = solve(I);
         I->spec_post.armed = false;
+        I->force_float_field = false;
+        if (solve_rc == SC_RETRY_FLOAT_FIELD) { --pass; continue; }
         if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
         if (!I->spec_post.done) {          // otherwise the solver already enqueued it behind its last cycle
             if (pass == passes - 1 && (rc = tmark(I, 6))) return rc;
             LmNodes lm;
             if ((rc = output_nodes(I, lm))) return rc;
-            launch_postprocess(result(I), body_org, bstep, I->stream, I->guard, lm);
+            launch_postprocess(result(I), body_org, bstep, I->stream, I->guard, lm);      // (a solve that got here stored no 16-bit field or kept it in range)
         } else if (pass == passes - 1) {
             I->tm[6] = nullptr;            // no mark between the last cycle and the post-process (an event there costs a
         }                                  // ~5 us bubble): ms_post is reported as 0 and ms_solve includes it
@@ -336,6 +343,7 @@ static void fill_info_geo(Instance *I, const Geo &g)
 {
     I->info.x0 = g.x0; I->info.y0 = g.y0; I->info.W = g.W; I->info.H = g.H; I->info.ltx = g.ltx; I->info.lty = g.lty;
     I->info.device_bytes = I->arena_bytes;
+    I->info.device = I->gpu;
 }
 
 static float ev_ms(hipEvent_t a, hipEvent_t b)
@@ -370,6 +378,16 @@ int sc_hip_device_count(void)
     return n;
 }
 
+int sc_hip_device_pci_bus_id(int gpu_id, char *buf, int len)
+{
+    if (!buf || len < 16) return SC_ERR_BAD_ARG;
+    buf[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || gpu_id < 0 || gpu_id >= n) { (void)hipGetLastError(); return SC_ERR_BAD_ARG; }
+    if (hipDeviceGetPCIBusId(buf, len, gpu_id) != hipSuccess) { (void)hipGetLastError(); buf[0] = 0; return SC_ERR_HIP; }
+    return SC_OK;
+}
+
 void *my_seamlessclone_api_imp_create_instance(int gpu_id)
 {
     int n = 0;
@@ -386,13 +404,15 @@ void *my_seamlessclone_api_imp_create_instance(int gpu_id)
     ok = ok && hipStreamCreateWithFlags(&I->aux, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&I->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&I->ev_join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&I->ev_fd_fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&I->ev_fd, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_rect, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_red, 2 * sizeof(double), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_rect, 4 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_partials, 2 * sizeof(double) * residual_max_blocks()) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_red, 2 * sizeof(double)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&I->d_maxcorr, 2 * sizeof(unsigned)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&I->h_maxcorr, 2 * sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void **)&I->d_maxcorr, 4 * sizeof(unsigned)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&I->h_maxcorr, 4 * sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
     ok = ok && mg_bottom_prepare() == hipSuccess;   // opt in to >64 KiB dynamic LDS for the bottom kernel
     for (int i = 0; ok && i < 8; ++i) ok = hipEventCreate(&I->ev[i]) == hipSuccess;
     ok = ok && hipEventCreate(&I->ev_k0) == hipSuccess && hipEventCreate(&I->ev_k1) == hipSuccess;
@@ -418,15 +438,27 @@ void my_seamlessclone_api_imp_destroy(void *p)
     for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
     if (I->mg_partial.p) (void)hipFree(I->mg_partial.p);
     if (I->h_partial.p) (void)hipHostFree(I->h_partial.p);
-    for (DevBuf *b : { &I->lm.Sx, &I->lm.Sy, &I->lm.R, &I->lm.P, &I->lm.E, &I->lm.CN, &I->lm.B, &I->lm.maps[0].d, &I->lm.maps[1].d }) if (b->p) (void)hipFree(b->p);
-    if (I->lm.hR.p) (void)hipHostFree(I->lm.hR.p);
+    for (DevBuf *b : { &I->lm.P, &I->lm.E, &I->lm.CN, &I->lm.B, &I->lm.maps[0].d, &I->lm.maps[1].d }) if (b->p) (void)hipFree(b->p);
+    for (LowMode::Tables &t : I->lm.tables) {          // (lm.Sx / Sy / R are views of one of these)
+        for (DevBuf *b : { &t.Sx, &t.Sy, &t.R }) if (b->p) (void)hipFree(b->p);
+        if (t.hR.p) (void)hipHostFree(t.hR.p);
+        if (t.ev) (void)hipEventDestroy(t.ev);
+    }
     for (auto &m : I->lm.maps) if (m.h.p) (void)hipHostFree(m.h.p);
     for (DevBuf *b : { &I->dst.Sw, &I->dst.Sh, &I->dst.fxy, &I->dst.G, &I->dst.T1, &I->dst.T2 }) if (b->p) (void)hipFree(b->p);
     if (I->dst.hfxy.p) (void)hipHostFree(I->dst.hfxy.p);
-    for (DevBuf *b : { &I->fft.dw.chirp, &I->fft.dh.chirp, &I->fft.A, &I->fft.B, &I->fft.fxy }) if (b->p) (void)hipFree(b->p);
-    for (DevBuf *b : { &I->fft.dw.h, &I->fft.dh.h, &I->fft.hfxy }) if (b->p) (void)hipHostFree(b->p);
+    for (DevBuf *b : { &I->fft.A, &I->fft.B, &I->fft.tw64 }) if (b->p) (void)hipFree(b->p);
+    for (FftDim &d : I->fft.dims) if (d.chirp.p) (void)hipFree(d.chirp.p);
+    for (FftFxy &f : I->fft.fxy) {
+        if (f.d.p) (void)hipFree(f.d.p);
+        if (f.hst.p) (void)hipHostFree(f.hst.p);
+        if (f.ev) (void)hipEventDestroy(f.ev);
+    }
+    if (I->fft.ev_fork) (void)hipEventDestroy(I->fft.ev_fork);
+    if (I->fft.ev_built) (void)hipEventDestroy(I->fft.ev_built);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
-    if (I->h_fd.p) (void)hipHostFree(I->h_fd.p);
+    if (I->ev_fd_fork) (void)hipEventDestroy(I->ev_fd_fork);
+    if (I->ev_fd) (void)hipEventDestroy(I->ev_fd);
     if (I->d_rect) (void)hipFree(I->d_rect);
     if (I->d_rects.p) (void)hipFree(I->d_rects.p);
     if (I->d_bbox_parts.p) (void)hipFree(I->d_bbox_parts.p);
@@ -475,7 +507,7 @@ int sc_hip_set_solver(void *p, const sc_solver_opts *o)
         I->err = "mg_level1_sweeps must be 0 or 2..4";
         return SC_ERR_BAD_ARG;
     }
-    if (o->flags != I->opts.flags) I->mg.clear();   // the hierarchy (direct bottom solve or not) depends on the flags
+    if ((o->flags ^ I->opts.flags) & SC_FLAG_VCYCLE_BOTTOM) I->mg.clear();   // the hierarchy (direct bottom solve or not) depends on this flag only
     I->opts = *o;
     return SC_OK;
 }
@@ -493,6 +525,7 @@ int sc_hip_get_info(void *p, sc_run_info *info)
     Instance *I = get(p);
     if (!I || !info) return SC_ERR_BAD_ARG;
     I->info.device_bytes = I->arena_bytes;
+    I->info.device = I->gpu;
     *info = I->info;
     return SC_OK;
 }
@@ -592,6 +625,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     Instance *I = get(p);
     if (!I) return SC_ERR_BAD_ARG;
     I->err.clear();
+    I->info.field_retry = 0; I->info.new_size = 0;
     SC_HIP(I, hipSetDevice(I->gpu));
     int rc = validate_images(I, face, fc, fr, fs, body, bc, br, bs, mask, mc, mr, ms);
     if (rc) return rc;
@@ -599,6 +633,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     const int dms = round_up(mc, 256);
     if ((rc = ensure(I, I->d_mask, (size_t)dms * mr))) return rc;
     I->stage_marks = true;         // a host-image call is synchronous whatever bSync says: its timeline is always read
+    I->marks_ends_only = false;
     if ((rc = tmark(I, 0))) return rc;
     if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
     if ((rc = tmark(I, 1))) return rc;
@@ -689,8 +724,13 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     }
     fill_info_geo(I, g);
     remember_rect(I, mc, mr, I->h_rect + 4);
-    (void)bSync;
     finish_timing(I, true);
+    I->info.ms_call = ev_ms(I->tm[0], I->ev_k1);
+    if (bSync) {      // the reference's bSync: time the call on the stream and say so (seamlessClone_imp.cu:336-349)
+        printf("Compute stage performance time= %.3f msec, patch size=%dx%d\n", I->info.ms_call, g.W, g.H);      // the reference's ucMask has the ROI's size by then (seamlessClone_imp.cpp:1024)
+        printf("total device memory used: %zu\n", I->arena_bytes);
+        fflush(stdout);
+    }
     return rc;
 }
 
@@ -700,11 +740,13 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     Instance *I = get(p);
     if (!I) return SC_ERR_BAD_ARG;
     I->err.clear();
+    I->info.field_retry = 0; I->info.new_size = 0;
     SC_HIP(I, hipSetDevice(I->gpu));
     int rc = validate_images(I, d_face, fc, fr, fs, d_body, bc, br, bs, d_mask, mc, mr, ms);
     if (rc) return rc;
     I->stage_marks = bSync;        // the stage timeline (sc_run_info::ms_*) is filled for synchronous calls only, like the
                                    // reference's bSync timing: each mark is an event in the stream and a ~5 us bubble behind it
+    I->marks_ends_only = bSync && (I->opts.flags & SC_FLAG_NO_STAGE_MARKS);
     if ((rc = tmark(I, 0))) return rc;
     if ((rc = tmark(I, 1, true))) return rc;       // nothing to upload: images are device resident
     const int passes = I->opts.reference_warmup ? 2 : 1;
@@ -773,6 +815,7 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     Instance *I = get(p);
     if (!I || !jobs || n <= 0) return SC_ERR_BAD_ARG;
     I->err.clear();
+    I->info.field_retry = 0; I->info.new_size = 0;
     SC_HIP(I, hipSetDevice(I->gpu));
     auto one_by_one = [&]() -> int {
         int worst = SC_OK;
@@ -872,9 +915,6 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     for (int i = 0; i < n; ++i) { mj[i].g = geo[i]; mj[i].M = (uint8_t *)I->d_M.p + mplane * i; mj[i].mpitch = I->mpitch; }
     launch_mask_erode3_group(mj.data(), n, I->stream);
     I->erode_done = false;
-    I->result_in_U1 = false;
-    I->f_half = mg_reads_half_rhs(I);
-    I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
     std::vector<ImageJob> ij(n);
     for (int i = 0; i < n; ++i) {
         const sc_batch_job &j = jobs[i];
@@ -884,16 +924,26 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
         ij[i].d_rect = speculative ? d_r + RS * i : nullptr;
         ij[i].rx0 = guess[4 * i]; ij[i].rx1 = guess[4 * i + 1]; ij[i].ry0 = guess[4 * i + 2]; ij[i].ry1 = guess[4 * i + 3];
     }
-    launch_preprocess_group(ij.data(), n, I->mpitch, I->U0, I->F, I->stream, I->f_half, I->u_half);
-    SC_HIP(I, hipGetLastError());
-    // --- one solve for the group, results spliced per clone
-    I->info.sweep_launches = 0;
-    I->guard = RectGuard();
-    I->spec_post.group = ij;
-    I->spec_post.ev_solved = nullptr;
-    I->spec_post.armed = true; I->spec_post.done = false;     // the solver enqueues the splices behind the cycle it expects to accept
-    const int solve_rc = solve(I);
-    I->spec_post.armed = false;
+    int solve_rc = SC_OK;
+    for (;;) {
+        I->result_in_U1 = false;
+        I->f_half = mg_reads_half_rhs(I);
+        I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
+        launch_preprocess_group(ij.data(), n, I->mpitch, I->U0, I->F, I->stream, I->f_half, I->u_half);
+        SC_HIP(I, hipGetLastError());
+        // --- one solve for the group, results spliced per clone
+        I->info.sweep_launches = 0;
+        I->guard = RectGuard();
+        I->spec_post.group = ij;
+        I->spec_post.ev_solved = nullptr;
+        I->spec_post.armed = true; I->spec_post.done = false;     // the solver enqueues the splices behind the cycle it expects to accept
+        solve_rc = solve(I);
+        I->spec_post.armed = false;
+        I->force_float_field = false;
+        if (solve_rc != SC_RETRY_FLOAT_FIELD) break;
+        I->force_float_field = true;       // a member's 16-bit field saturated: no member was written, the group again on float fields
+        I->info.field_retry = 1;
+    }
     const bool spliced = I->spec_post.done;
     I->spec_post.group.clear();
     if (solve_rc != SC_OK && solve_rc != SC_ERR_NOT_CONVERGED) return solve_rc;
@@ -960,8 +1010,9 @@ int sc_hip_selftest_host(void)
         rc.parallel(0, [&](int) { ++hits; });
         if (hits != 1) return 1;
     }
-    // 2: eigen-decomposition of the 1-D level operators
+    // 2: eigen-decomposition of the 1-D level operators (the QL reference), 4: the closed form the device builds from against it
     if (!(sc::fd_selftest_error() < 1e-11)) return 2;
+    if (!(sc::fd_closed_selftest_error() < 1e-10)) return 4;
     // 3: which parts of a level-0 launch make up each cell row of the float-table correction (sc_lowmode.hip)
     if (sc::lowmode_part_map_selftest() != 0) return 3;
     return 0;

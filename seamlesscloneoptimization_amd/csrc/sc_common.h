@@ -61,6 +61,13 @@ void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_o
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false, bool grey = false);
 // bounding box the host assumed when it launched a clone before the device's answer was back (d_rect == nullptr: none)
 struct RectGuard { const int *d_rect = nullptr; int x0 = 0, x1 = 0, y0 = 0, y1 = 0; };
+// "Do not write": a device word the launches of one solve may set to that solve's generation number (a 16-bit fixed-point store
+// of the field saturated, k_cycle0 TAG bit 9); the output launches of the same solve then write nothing and the host repeats
+// the clone on float fields.  A generation instead of a flag: nothing has to be reset between solves.  p == nullptr: none.
+struct AbortFlag { unsigned *p = nullptr; unsigned gen = 0; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool abort_set(const AbortFlag &a) { return a.p && *reinterpret_cast<const volatile unsigned *>(a.p) == a.gen; }
+#endif
 // float-table correction at the nodes = every 8th field row and column (sc_lowmode.hip): CN[c][Y][X], ny rows of npitch
 // floats per channel; the post-process adds the bilinear interpolation between the four nodes around a pixel.
 // CN == nullptr: none.
@@ -94,13 +101,13 @@ __device__ __forceinline__ float lm_bilinear(const LmNodes &lm, int c, int x, in
     return __builtin_fmaf(ty, bot - top, top);
 }
 #endif
-void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard(), LmNodes lm = LmNodes());
+void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard(), LmNodes lm = LmNodes(), AbortFlag ab = AbortFlag());
 // the same for a group (fields of 3n channels), one launch per 16 members
 void launch_preprocess_group(const ImageJob *jobs, int n, int mpitch, Field U0, Field F, hipStream_t s, bool f_half, bool u_half);
-void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s, LmNodes lm = LmNodes());
+void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s, LmNodes lm = LmNodes(), AbortFlag ab = AbortFlag());
 // splice of output bytes a multigrid launch left planar in Q's memory (launch_cycle0_out): interleave into the destination
-void launch_splice_planar(Field Q, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard());
-void launch_splice_planar_group(Field Q, const ImageJob *jobs, int n, hipStream_t s);
+void launch_splice_planar(Field Q, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard = RectGuard(), AbortFlag ab = AbortFlag());
+void launch_splice_planar_group(Field Q, const ImageJob *jobs, int n, hipStream_t s, AbortFlag ab = AbortFlag());
 void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_t s);
 // up to 16 device-to-device copies in one launch (16-byte aligned pointers)
 struct CopyJobs { enum { MAX = 16 }; void *dst[MAX]; const void *src[MAX]; size_t bytes[MAX]; };
@@ -123,12 +130,12 @@ bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &
 int  launch_rb_tb_prolong0(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, Field E, float *partial, hipStream_t s);
 int  tb_blocks_level0(int W, int H, int C, int sweeps);
 void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_t s);
-void launch_max_final2(const float *d_a, int na, const float *d_b, int nb, unsigned *d_out2, hipStream_t s);   // out[0] = max a, out[1] = max b (-1: b empty)
+void launch_max_final2(const float *d_a, int na, const float *d_b, int nb, unsigned *d_out2, hipStream_t s, const unsigned *flag = nullptr);   // out[0] = max a, out[1] = max b (-1: b empty), out[2] = *flag (0 without one)
 // whole level-0 part of a V-cycle in one launch (sc_cycle0.hip): [prolong E] + `sweeps` RBGS sweeps +
 // residual + restriction into Fc.  Returns #partials written, 0 without prolong, -1 if unsupported.
 int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
                    float *partial, hipStream_t s, bool tag = false, bool f_half = false, bool u_half = false,
-                   bool final_cycle = false, float4 *bands = nullptr, bool l1_half = false, bool q16_out = false);
+                   bool final_cycle = false, float4 *bands = nullptr, bool l1_half = false, bool q16_out = false, AbortFlag sat = AbortFlag());
 // bands (final form, or 4 sweeps with prolongation): receives the cell shares of the float-table correction of the field the
 // launch writes, two float4 per (channel, tile row, wave, 8-column cell) -- see k_cycle0 and sc_lowmode.hip
 void cycle0_row_geometry(int H, int sweeps, int &nby, int &step, int &hy);
@@ -137,7 +144,7 @@ int  cycle0_blocks(int W, int H, int C, int sweeps);
 // (sc_cycle0.hip, ComposeArgs); -1: combination not instantiated
 int  launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
                             hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands = nullptr, bool l1_half = false,
-                            int u_q16 = 0);
+                            int u_q16 = 0, AbortFlag sat = AbortFlag());     // sat: where a saturating 16-bit store reports itself
 // the last cycle with its result leaving as output bytes (planar, in Q's memory) instead of as a field; see sc_cycle0.hip
 int  launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
                        bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half = false);
@@ -193,6 +200,11 @@ struct MGBottomArgs {
 __host__ __device__ static inline long fd_mat_floats(int nxp, int nyp) { return 2L * nxp * nxp + 2L * nyp * nyp + (long)nxp * nyp; }
 __host__ __device__ static inline long fd_lds_floats(int nxp, int nyp) { return fd_mat_floats(nxp, nyp) + 2L * nxp * nyp; }
 hipError_t mg_bottom_prepare();
+// per-size state built on the device (sc_mg_kernels.hip): the direct solve's matrices from the closed-form eigenpairs of the
+// level's two 1-D operators (nx, ny <= 128), and the zeroing of every plane of the levels >= 1 in one launch
+void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s);
+struct ZeroJobs { enum { MAX = 48 }; void *p[MAX]; size_t n16[MAX]; int count; };     // n16: 16-byte units
+void launch_zero_multi(const ZeroJobs &z, hipStream_t s);
 void launch_mg_bottom(const MGBottomArgs &a, int C, hipStream_t s);
 
 } // namespace sc

@@ -91,12 +91,17 @@ __device__ __forceinline__ void c0_load_half_raw(const __half *__restrict__ p, i
     }
 }
 // The field BETWEEN the level-0 launches of the fast path as 16-bit fixed point (TAG bits 8, 9): code = trunc(64 u + 16384.5)
-// clamped to [0, 65535], u = code / 64 - 256: the range [-256, 768) in steps of 1/64.  The solution of a clone lies in
-// [-255, 510] (it is the source patch plus a discrete harmonic function whose boundary values are differences of 8-bit
-// values), 8-bit boundary values are exact, and a rounding of at most 1/128 per stored value is to a multigrid iterate what
-// one more high-frequency error component is: the cycles that follow remove it like any other error.  Only the first stores of a
-// solve use it (sc_multigrid.cpp: the launch before the judged cycle writes float again, so two cycles lie between the last
-// rounding and the output).  Same element pitch / plane size as the float field, 2 bytes per unknown instead of 4.
+// clamped to [0, 65535], u = code / 64 - 256: the range [-256, 768) in steps of 1/64.  With a CONSERVATIVE guidance field (the
+// gradient of one image: a mask that is all 255 inside its bounding box) the solution of a clone lies in [-255, 510] -- it is
+// the source patch plus a discrete harmonic function whose boundary values are differences of 8-bit values.  A mask that mixes
+// patch and destination gradients pixel by pixel (holes, stripes, rings) makes the field non-conservative, and then neither the
+// solution nor the iterates are bounded by the images' range (rings of inward ramps pile up 1500 grey levels at 512^2).  So the
+// range is CHECKED: a store that saturates reports itself (c0_q16_checked, AbortFlag), the output launches of that solve then
+// write nothing and the host repeats the clone on float fields (sc_run_info.field_retry).  8-bit boundary values are exact,
+// and a rounding of at most 1/128 per stored value is to a multigrid iterate what one more high-frequency error component is:
+// the cycles that follow remove it like any other error.  Only the first stores of a solve use the format (sc_multigrid.cpp:
+// the launch before the judged cycle writes float again, so two cycles lie between the last rounding and the output).  Same
+// element pitch / plane size as the float field, 2 bytes per unknown instead of 4.
 template <int R>
 __device__ __forceinline__ void c0_load_q16(const uint16_t *__restrict__ p, int P, int H, int x, int y0, float4 (&v)[R])
 {
@@ -115,9 +120,15 @@ __device__ __forceinline__ void c0_load_q16(const uint16_t *__restrict__ p, int 
         v[r].w = __builtin_fmaf((float)(raw[r].y >> 16), 0.015625f, -256.0f);
     }
 }
-__device__ __forceinline__ unsigned c0_q16(float u)
+// code of u, and `seen |= the unclamped integer`: any bit above the 16th in `seen` (a negative value sets the sign bits) says a
+// value left the range.  v_cvt_i32_f32 saturates, so there is no wrap-around for wild values; same codes as
+// trunc(clamp(64 u + 16384.5, 0, 65535)) bit for bit.
+__device__ __forceinline__ unsigned c0_q16_checked(float u, int &seen)
 {
-    return (unsigned)__builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, 16384.5f), 0.0f, 65535.0f);
+    int i;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(__builtin_fmaf(u, 64.0f, 16384.5f)));
+    seen |= i;
+    return (unsigned)min(max(i, 0), 65535);
 }
 
 // Level 0 (regular stencil) holds q = -f/4 instead of f (exact in either format: a power-of-two scaling): the Gauss-Seidel
@@ -170,7 +181,7 @@ __device__ __forceinline__ float c0_comp(const float4 &v, int k) { return k == 0
 // `bands` is not null)
 template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
-                                                    float *__restrict__ partial, ComposeArgs comp, float4 *__restrict__ bands, LmNodes lm)
+                                                    float *__restrict__ partial, ComposeArgs comp, float4 *__restrict__ bands, LmNodes lm, AbortFlag sat)
 {
     constexpr int HY = 2 * T + 2, RH = NW * R;
     constexpr bool COMP = (TAG & 16) != 0;      // E is U1; the interpolated level-2 correction is added on the fly (ComposeArgs)
@@ -646,15 +657,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
     if constexpr (UQO) {
         uint16_t *__restrict__ outq = reinterpret_cast<uint16_t *>(Uout.p) + (size_t)c * Uout.plane;
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;          // per column: pad columns right of the ring hold nothing the solve uses
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int yr = wv * R + r, y = y0 + r;
             if (!(yr >= HY && yr < RH - HY && y >= 0 && y < H)) continue;
             uint2 pk;
-            pk.x = c0_q16(u[r].x) | (c0_q16(u[r].y) << 16);
-            pk.y = c0_q16(u[r].z) | (c0_q16(u[r].w) << 16);
+            pk.x = c0_q16_checked(u[r].x, s0) | (c0_q16_checked(u[r].y, s1) << 16);
+            pk.y = c0_q16_checked(u[r].z, s2) | (c0_q16_checked(u[r].w, s3) << 16);
             *reinterpret_cast<uint2 *>(outq + (size_t)y * P + x) = pk;
         }
+        const int seen = s0 | (x + 1 < W ? s1 : 0) | (x + 2 < W ? s2 : 0) | (x + 3 < W ? s3 : 0);
+        if ((seen & ~0xffff) && sat.p) *sat.p = sat.gen;       // rare; every writer stores the same word
         return;
     }
     float *__restrict__ out = Uout.at(c);
@@ -669,12 +683,12 @@ constexpr int C0_NW = 8, C0_R = 8;
 
 template <int T, bool PRO, int TAG = 0>
 static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s,
-                     const ComposeArgs &comp = ComposeArgs(), float4 *bands = nullptr, const LmNodes &lm = LmNodes())
+                     const ComposeArgs &comp = ComposeArgs(), float4 *bands = nullptr, const LmNodes &lm = LmNodes(), const AbortFlag &sat = AbortFlag())
 {
     constexpr int RH = C0_NW * C0_R, HY = 2 * T + 2;
     const int blocks = ((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
     hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false, TAG>), dim3(blocks), dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E,
-                       g, partial, comp, bands, lm);
+                       g, partial, comp, bands, lm, sat);
     return blocks;
 }
 
@@ -686,7 +700,7 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
 // bit 1 (value 2) set: so will Uout, clear: Uout leaves as float (the launch before the judged cycle).
 int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
                            hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands, bool l1_half,
-                           int u_q16)
+                           int u_q16, AbortFlag sat)
 {
     ComposeArgs ca;
     ca.E2 = E2; ca.g1 = g1;
@@ -696,8 +710,9 @@ int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, c
             if (tag) return -1;
             return bands ? launch_c0<4, true, 210 | 256>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands) : launch_c0<4, true, 146 | 256>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
         }
-        if (bands && !tag) return launch_c0<4, true, 210 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
-        return tag ? launch_c0<4, true, 147 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca) : launch_c0<4, true, 146 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca);
+        if (bands && !tag) return launch_c0<4, true, 210 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands, LmNodes(), sat);
+        return tag ? launch_c0<4, true, 147 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca, nullptr, LmNodes(), sat)
+                   : launch_c0<4, true, 146 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca, nullptr, LmNodes(), sat);
     }
     if (l1_half != f_half) {           // instantiated pairs: float16 RHS with float16 level 1, float RHS with float level 1 -- and, for
         if (l1_half) return -1;        // a level 1 that does fewer than four sweeps (mg_level1_sweeps), float16 RHS with float level 1
@@ -720,12 +735,12 @@ int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, c
 // Uin hold float16 values (same element layout).  Returns the number of partial maxima written (0 without prolong), or -1
 // for an unsupported depth.
 int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle, float4 *bands, bool l1_half, bool q16_out)
+                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle, float4 *bands, bool l1_half, bool q16_out, AbortFlag sat)
 {
     if (q16_out && !(l1_half && u_half)) return -1;      // the first launch of a clone on the fast path only
     if (l1_half) {     // level 1 keeps float16 fields (the composed schedule): the launches without a prolongation write its right-hand side
         if (prolong || final_cycle || !f_half || tag || sweeps != 2) return -1;
-        if (q16_out) launch_c0<2, false, 134 | 512>(Uin, Uout, F, Fc, E, g, partial, s);
+        if (q16_out) launch_c0<2, false, 134 | 512>(Uin, Uout, F, Fc, E, g, partial, s, ComposeArgs(), nullptr, LmNodes(), sat);
         else if (u_half) launch_c0<2, false, 134>(Uin, Uout, F, Fc, E, g, partial, s);
         else launch_c0<2, false, 130>(Uin, Uout, F, Fc, E, g, partial, s);
         return 0;
@@ -811,7 +826,7 @@ static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_
     Field none{};
     const int blocks = ((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * F.C;
     hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true, TAG>), dim3(blocks), dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
-                       Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs(), (float4 *)nullptr, LmNodes());
+                       Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs(), (float4 *)nullptr, LmNodes(), AbortFlag());
 }
 
 // half_io: the level's own right-hand side and the correction it writes are float16 (level 1 of the composed schedule, 4 sweeps)

@@ -213,6 +213,7 @@ static int dst_prepare(Instance *I)
     for (DevBuf *b : { &D.G, &D.T1, &D.T2 })
         if ((rc = ensure(I, *b, plane * C))) return rc;
     if (D.w == w && D.h == h && D.Sw.p && D.Sh.p) return SC_OK;
+    I->info.new_size = 1;
     if ((rc = ensure(I, D.Sw, (size_t)4 * mpw * mpw * sizeof(double)))) return rc;
     if ((rc = ensure(I, D.Sh, (size_t)4 * mph * mph * sizeof(double)))) return rc;
     if ((rc = ensure(I, D.fxy, (size_t)(w + h) * sizeof(float)))) return rc;

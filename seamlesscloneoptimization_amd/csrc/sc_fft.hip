@@ -290,80 +290,165 @@ static void fft_radices(int logM, int lr[4], int &npass)
     if (rem > 0) lr[npass++] = rem;
 }
 
-// position of frequency k after the forward passes (radices lr[p..]) of a length-2^lL block
-static int fft_position(int k, int lL, const int *lr, int npass)
+// ---- the tables of one transform length, built on the device --------------------------------------------------------------
+// (Round 3 built them on the host: a serial radix-2 double FFT with cos / sin in its inner loop plus M sincos for the
+// twiddles, behind a stream synchronisation -- ~0.5 ms per direction at M = 2048, several times the 0.1-0.3 ms clone that
+// needed them.  The reference builds its per-size tables with a kernel inside every call: seamlessClone_imp.cpp:569-603.)
+// k_fft_tables: chirp c_m = exp(i pi m^2 / N), m = 0 .. n (phase reduced exactly: m^2 mod 2N in integers), and the twiddles
+// exp(-2 pi i k / M), in double, stored as T; `tw64` additionally receives the twiddles in double when the transform of the
+// chirp kernel below runs in double while T is float.
+template <typename T>
+__global__ __launch_bounds__(256) void k_fft_tables(cx2<T> *__restrict__ chirp, cx2<T> *__restrict__ tw, cx2<double> *__restrict__ tw64, int n, int M)
 {
-    int pos = 0;
-    for (int p = 0; p < npass; ++p) {
-        const int R = 1 << lr[p];
-        pos += (k & (R - 1)) << (lL - lr[p]);
-        k >>= lr[p];
-        lL -= lr[p];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i <= n) {
+        const long long N2 = 4LL * (n + 1);
+        const long long q = ((long long)i * i) % N2;
+        double sn, cs;
+        sincospi((double)q / (double)(2 * (n + 1)), &sn, &cs);
+        chirp[i] = mk<T>((T)cs, (T)sn);
     }
-    return pos;
+    if (i < M) {
+        double sn, cs;
+        sincospi(-2.0 * (double)i / (double)M, &sn, &cs);
+        tw[i] = mk<T>((T)cs, (T)sn);
+        if (tw64) tw64[i] = mk<double>(cs, sn);
+    }
 }
-
-// in-place radix-2 FFT in double (host: the chirp kernel's transform, once per size)
-static void host_fft(std::vector<double> &re, std::vector<double> &im)
+// k_fft_bhat: the transform of the chirp kernel b (b_0 = 1, b_m = b_{M-m} = conj(c_m), m = 1 .. n-1, zero elsewhere) by the SAME
+// in-LDS forward passes the solve uses -- their output order (digit reversed) is the order the pointwise product wants --
+// computed in TC (double whenever the row fits the LDS: M <= 8192) and stored as T with the 1/M of the inverse folded in.
+template <typename TC, typename T>
+__global__ __launch_bounds__(FFT_THREADS) void k_fft_bhat(FftPlan<TC> P, cx2<T> *__restrict__ bhat)
 {
-    const size_t M = re.size();
-    for (size_t i = 1, j = 0; i < M; ++i) {
-        size_t bit = M >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
-    }
-    for (size_t len = 2; len <= M; len <<= 1) {
-        const size_t half = len >> 1;
-        for (size_t k = 0; k < half; ++k) {
-            const double a = -2.0 * M_PI * (double)k / (double)len, wr = std::cos(a), wi = std::sin(a);
-            for (size_t i = k; i < M; i += len) {
-                const size_t j = i + half;
-                const double tr = re[j] * wr - im[j] * wi, ti = re[j] * wi + im[j] * wr;
-                re[j] = re[i] - tr; im[j] = im[i] - ti;
-                re[i] += tr; im[i] += ti;
-            }
+    extern __shared__ __attribute__((aligned(16))) unsigned char fft_smem[];
+    cx2<TC> *__restrict__ S = reinterpret_cast<cx2<TC> *>(fft_smem);
+    const int tid = threadIdx.x, n = P.n, M = P.M;
+    const long long N2 = 4LL * (n + 1);
+    for (int i = tid; i < M; i += FFT_THREADS) {
+        const int m = i <= M / 2 ? i : M - i;
+        cx2<TC> v = mk<TC>((TC)0, (TC)0);
+        if (m == 0 && i == 0) v = mk<TC>((TC)1, (TC)0);
+        else if (m >= 1 && m <= n - 1) {
+            const long long q = ((long long)m * m) % N2;
+            double sn, cs;
+            sincospi((double)q / (double)(2 * (n + 1)), &sn, &cs);
+            v = mk<TC>((TC)cs, (TC)(-sn));
         }
+        S[fft_pad(i)] = v;
+    }
+    __syncthreads();
+    int lL = P.logM;
+    for (int p = 0; p < P.npass; ++p) {
+        const int lr = P.lr[p];
+        if (lr == 4) pass_fwd<4>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 3) pass_fwd<3>(S, P.logM, lL, P.tw, tid);
+        else if (lr == 2) pass_fwd<2>(S, P.logM, lL, P.tw, tid);
+        else pass_fwd<1>(S, P.logM, lL, P.tw, tid);
+        lL -= lr;
+        __syncthreads();
+    }
+    const TC inv = (TC)1 / (TC)M;
+    for (int i = tid; i < M; i += FFT_THREADS) {
+        const cx2<TC> v = S[fft_pad(i)];
+        bhat[i] = mk<T>((T)(v.x * inv), (T)(v.y * inv));
     }
 }
 
 template <typename T>
-static int fft_build_dim(Instance *I, FftDim &D, int n)
+static FftPlan<T> fft_plan_raw(const cx2<T> *chirp, int n, int logM)
+{
+    FftPlan<T> P{};
+    P.chirp = chirp;
+    P.bhat = chirp + (n + 1);
+    P.tw = P.bhat + ((size_t)1 << logM);
+    P.n = n; P.logM = logM; P.M = 1 << logM;
+    fft_radices(logM, P.lr, P.npass);
+    return P;
+}
+
+// The tables for n unknowns in precision T: from the instance's LRU, or built now on the second stream (the caller makes the
+// main stream wait for I->fft.ev_built before the first transform launch).  `keep`: an entry that must not be evicted (the
+// other direction of the same solve).
+template <typename T>
+static int fft_build_dim(Instance *I, FftDim *&out, int n, const FftDim *keep)
 {
     const bool dbl = sizeof(T) == sizeof(double);
-    if (D.n == n && D.dbl == dbl && D.chirp.p) return SC_OK;
+    FftState &S = I->fft;
+    FftDim *victim = nullptr;
+    for (FftDim &d : S.dims) {
+        if (d.chirp.p && d.n == n && d.dbl == dbl) { d.used = ++S.tick; out = &d; return SC_OK; }
+        if (&d != keep && (!victim || d.used < victim->used)) victim = &d;
+    }
+    FftDim &D = *victim;
+    I->info.new_size = 1;
     const int logM = fft_logm(n), M = 1 << logM;
     int rc;
-    SC_HIP(I, hipStreamSynchronize(I->stream));        // the pinned staging below may still feed the previous size's upload (rare: a new ROI size)
-    const size_t bytes = sizeof(cx2<T>) * ((size_t)(n + 1) + 2 * (size_t)M);
+    const size_t bytes = sizeof(cx2<T>) * (3 * (size_t)M + 1);      // chirp[n + 1 <= M + 1] | bhat[M] | tw[M]: sized by M alone, so an entry is reallocated only when M grows
+    D.n = 0;
     if ((rc = ensure(I, D.chirp, bytes))) return rc;
-    if ((rc = ensure_pinned(I, D.h, bytes))) return rc;
-    cx2<T> *hc = (cx2<T> *)D.h.p, *hb = hc + (n + 1), *ht = hb + M;
-    const long N2 = 4L * (n + 1);                       // 2N: the period of m^2 in exp(i pi m^2 / N)
-    const double invN = 1.0 / (2.0 * (n + 1));
-    std::vector<double> cr(n + 1), ci(n + 1);
-    for (int m = 0; m <= n; ++m) {
-        const long q = ((long)m * m) % N2;
-        const double a = M_PI * (double)q * invN;
-        cr[m] = std::cos(a); ci[m] = std::sin(a);
-        hc[m] = mk<T>((T)cr[m], (T)ci[m]);
+    const bool tc_double = dbl || logM <= FFT_MAX_LOGM - 1;      // the build's own transform in double whenever its row fits the LDS
+    if (tc_double && !dbl && (rc = ensure(I, S.tw64, sizeof(cx2<double>) * (size_t)M))) return rc;
+    if (!S.ev_fork) {
+        SC_HIP(I, hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming));
+        SC_HIP(I, hipEventCreateWithFlags(&S.ev_built, hipEventDisableTiming));
     }
-    std::vector<double> br(M, 0.0), bi(M, 0.0);
-    br[0] = 1.0;
-    for (int m = 1; m <= n - 1; ++m) { br[m] = br[M - m] = cr[m]; bi[m] = bi[M - m] = -ci[m]; }
-    host_fft(br, bi);
-    int lr[4], npass;
-    fft_radices(logM, lr, npass);
-    for (int k = 0; k < M; ++k) {
-        const int pos = fft_position(k, logM, lr, npass);
-        hb[pos] = mk<T>((T)(br[k] / M), (T)(bi[k] / M));
+    // on the second stream, behind everything the main stream has been given so far (launches that still read the evicted tables)
+    SC_HIP(I, hipEventRecord(S.ev_fork, I->stream));
+    SC_HIP(I, hipStreamWaitEvent(I->aux, S.ev_fork, 0));
+    cx2<T> *chirp = (cx2<T> *)D.chirp.p, *bhat = chirp + (n + 1), *tw = bhat + M;
+    hipLaunchKernelGGL((k_fft_tables<T>), dim3((std::max(M, n + 1) + 255) / 256), dim3(256), 0, I->aux, chirp, tw,
+                       (tc_double && !dbl) ? (cx2<double> *)S.tw64.p : (cx2<double> *)nullptr, n, M);
+    if (dbl) {
+        FftPlan<double> P = fft_plan_raw<double>((const cx2<double> *)D.chirp.p, n, logM);
+        hipLaunchKernelGGL((k_fft_bhat<double, double>), dim3(1), dim3(FFT_THREADS), sizeof(cx2<double>) * (size_t)(fft_pad(M) + 1), I->aux, P, (cx2<double> *)bhat);
+    } else if (tc_double) {
+        FftPlan<double> P{};
+        P.tw = (const cx2<double> *)S.tw64.p;
+        P.n = n; P.logM = logM; P.M = M;
+        fft_radices(logM, P.lr, P.npass);
+        hipLaunchKernelGGL((k_fft_bhat<double, float>), dim3(1), dim3(FFT_THREADS), sizeof(cx2<double>) * (size_t)(fft_pad(M) + 1), I->aux, P, (cx2<float> *)bhat);
+    } else {
+        FftPlan<float> P = fft_plan_raw<float>((const cx2<float> *)D.chirp.p, n, logM);
+        hipLaunchKernelGGL((k_fft_bhat<float, float>), dim3(1), dim3(FFT_THREADS), sizeof(cx2<float>) * (size_t)(fft_pad(M) + 1), I->aux, P, (cx2<float> *)bhat);
     }
-    for (int k = 0; k < M; ++k) {
-        const double a = -2.0 * M_PI * (double)k / (double)M;
-        ht[k] = mk<T>((T)std::cos(a), (T)std::sin(a));
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipEventRecord(S.ev_built, I->aux));
+    S.pending = true;
+    D.n = n; D.logM = logM; D.dbl = dbl; D.used = ++S.tick;
+    out = &D;
+    return SC_OK;
+}
+
+// The reference's float tables fx[w] + fy[h] (seamlessClone_imp.cpp:596-599; PI is the float literal of seamlessClone_imp.h:17), computed on the
+// host -- its libm is the one the CPU oracle's tables come from, and an entry that rounds the other way moves the lowest modes by
+// grey levels -- into an LRU entry's OWN pinned staging: no stream synchronisation, the entry's upload event is waited for only
+// when the entry is reused for another size (long complete by then).
+static int fft_fxy(Instance *I, FftFxy *&out, int w, int h)
+{
+    FftState &S = I->fft;
+    FftFxy *victim = nullptr;
+    for (FftFxy &f : S.fxy) {
+        if (f.d.p && f.w == w && f.h == h) { f.used = ++S.tick; out = &f; return SC_OK; }
+        if (!victim || f.used < victim->used) victim = &f;
     }
-    SC_HIP(I, hipMemcpyAsync(D.chirp.p, D.h.p, bytes, hipMemcpyHostToDevice, I->stream));
-    D.n = n; D.logM = logM; D.dbl = dbl;
+    FftFxy &X = *victim;
+    I->info.new_size = 1;
+    int rc;
+    if (X.ev) SC_HIP(I, hipEventSynchronize(X.ev));
+    else SC_HIP(I, hipEventCreateWithFlags(&X.ev, hipEventDisableTiming));
+    X.w = 0;
+    if ((rc = ensure(I, X.d, sizeof(float) * (size_t)(w + h)))) return rc;
+    if ((rc = ensure_pinned(I, X.hst, sizeof(float) * (size_t)(w + h)))) return rc;
+    const double PIf = (double)3.14159265358979323846f;
+    float *fx = (float *)X.hst.p, *fy = fx + w;
+    for (int i = 0; i < w; ++i) fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
+    for (int j = 0; j < h; ++j) fy[j] = (float)(2.0 * std::cos(PIf / (h + 1.0) * (j + 1.0)));
+    X.singular = !((fx[0] + fy[0]) - 4.0f < 0.0f);
+    SC_HIP(I, hipMemcpyAsync(X.d.p, X.hst.p, sizeof(float) * (size_t)(w + h), hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipEventRecord(X.ev, I->stream));
+    X.w = w; X.h = h; X.used = ++S.tick;
+    out = &X;
     return SC_OK;
 }
 
@@ -379,16 +464,23 @@ static FftPlan<T> fft_plan_of(const FftDim &D)
     return P;
 }
 
+// Opt the three transform kernels in to more than 64 KB of dynamic LDS.  The attribute belongs to the (function, DEVICE) pair:
+// once per instance -- an instance lives on one device -- not once per process (a second GPU in the same process would never opt in).
 template <typename T>
-static hipError_t fft_opt_in_lds()
+static hipError_t fft_opt_in_lds(Instance *I)
 {
-    static bool done = false;
+    bool &done = sizeof(T) == sizeof(double) ? I->fft_lds_double : I->fft_lds_float;
     if (done) return hipSuccess;
     const int max_log = sizeof(T) == sizeof(double) ? FFT_MAX_LOGM - 1 : FFT_MAX_LOGM;
     const int bytes = (int)(sizeof(cx2<T>) * (size_t)fft_pad(1 << max_log)) + 64;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<0, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<1, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<2, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    // the table builders: a double row of up to 2^(FFT_MAX_LOGM - 1) points, or a float row of 2^FFT_MAX_LOGM
+    const int bbytes = (int)(sizeof(cx2<double>) * (size_t)fft_pad(1 << (FFT_MAX_LOGM - 1))) + 64;
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_bhat<double, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bbytes);
+    if (e == hipSuccess && sizeof(T) == sizeof(float))
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_bhat<float, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bbytes);
     done = e == hipSuccess;
     return e;
 }
@@ -403,33 +495,27 @@ template <typename T>
 static int fft_solve_t(Instance *I)
 {
     const int w = I->F.W - 2, h = I->F.H - 2, C = I->F.C;
-    SC_HIP(I, fft_opt_in_lds<T>());
+    SC_HIP(I, fft_opt_in_lds<T>(I));
     FftState &S = I->fft;
     int rc;
-    if ((rc = fft_build_dim<T>(I, S.dw, w))) return rc;
-    if ((rc = fft_build_dim<T>(I, S.dh, h))) return rc;
+    FftDim *dw = nullptr, *dh = nullptr;
+    FftFxy *X = nullptr;
+    if ((rc = fft_build_dim<T>(I, dw, w, nullptr))) return rc;
+    if ((rc = fft_build_dim<T>(I, dh, h, dw))) return rc;
     const size_t plane = (size_t)w * h;
     if ((rc = ensure(I, S.A, sizeof(T) * plane * C))) return rc;
     if ((rc = ensure(I, S.B, sizeof(T) * plane * C))) return rc;
-    if (S.tw != w || S.th != h) {
-        // the reference's float tables (seamlessClone_imp.cpp:596-599; PI is the float literal of seamlessClone_imp.h:17)
-        if ((rc = ensure(I, S.fxy, sizeof(float) * (size_t)(w + h)))) return rc;
-        if ((rc = ensure_pinned(I, S.hfxy, sizeof(float) * (size_t)(w + h)))) return rc;
-        SC_HIP(I, hipStreamSynchronize(I->stream));
-        const double PIf = (double)3.14159265358979323846f;
-        float *fx = (float *)S.hfxy.p, *fy = fx + w;
-        for (int i = 0; i < w; ++i) fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
-        for (int j = 0; j < h; ++j) fy[j] = (float)(2.0 * std::cos(PIf / (h + 1.0) * (j + 1.0)));
-        S.singular = !((fx[0] + fy[0]) - 4.0f < 0.0f);
-        SC_HIP(I, hipMemcpyAsync(S.fxy.p, S.hfxy.p, sizeof(float) * (size_t)(w + h), hipMemcpyHostToDevice, I->stream));
-        S.tw = w; S.th = h;
+    if ((rc = fft_fxy(I, X, w, h))) return rc;
+    if (S.pending) {                  // tables of a new length are being built on the second stream
+        SC_HIP(I, hipStreamWaitEvent(I->stream, S.ev_built, 0));
+        S.pending = false;
     }
-    const int exact = (S.singular || (I->opts.flags & SC_FLAG_EXACT_TABLES)) ? 1 : 0;
-    const FftPlan<T> Pw = fft_plan_of<T>(S.dw), Ph = fft_plan_of<T>(S.dh);
+    const int exact = (X->singular || (I->opts.flags & SC_FLAG_EXACT_TABLES)) ? 1 : 0;
+    const FftPlan<T> Pw = fft_plan_of<T>(*dw), Ph = fft_plan_of<T>(*dh);
     const size_t ldsw = sizeof(cx2<T>) * (size_t)(fft_pad(Pw.M) + 1), ldsh = sizeof(cx2<T>) * (size_t)(fft_pad(Ph.M) + 1);
     Field &U = I->result_in_U1 ? I->U1 : I->U0;
     T *A = (T *)S.A.p, *B = (T *)S.B.p;
-    const float *fx = (const float *)S.fxy.p, *fy = fx + w;
+    const float *fx = (const float *)X->d.p, *fy = fx + w;
     const double scale = 4.0 / ((w + 1.0) * (h + 1.0));
     const dim3 tg_hw((w + 63) / 64, (h + 63) / 64, C), tg_wh((h + 63) / 64, (w + 63) / 64, C);
     // Small planes (cache resident: the scattered 4- or 8-byte stores of a transposed write cost nothing there) skip the two

@@ -34,8 +34,14 @@ struct LowMode {
     PartMap *map_used = nullptr;
     int band_rows = 0;
     const float *bands_of = nullptr;       // the field whose parts B holds (nullptr: none); cleared whenever a solve starts or moves on
-    DevBuf Sx, Sy, R, P, E, CN;            // Sx[nx][Kxp], Sy[ny][Kyp] (sines at the nodes), R[Kyp][Kxp], P = cell shares float4[C][cells_y][cells_x], E = partial products of the coarse projection [parts][C][Kyp][Kxp], CN[C][ny][npitch]
-    DevBuf hR;                             // pinned staging of R
+    DevBuf Sx, Sy, R, P, E, CN;            // Sx[nx][Kxp], Sy[ny][Kyp] (sines at the nodes), R[Kyp][Kxp] -- views of the current entry of `tables` --, P = cell shares float4[C][cells_y][cells_x], E = partial products of the coarse projection [parts][C][Kyp][Kxp], CN[C][ny][npitch]
+    // the per-size tables, kept in a small LRU (a caller alternating between a few ROI sizes rebuilds nothing): Sx, Sy built on
+    // the device, R on the host into the entry's own pinned staging (no stream synchronisation; the upload event is waited for
+    // only when the entry is reused for another size)
+    struct Tables { int w = 0, h = 0; bool singular = false; double max_ratio = 0.0; DevBuf Sx, Sy, R, hR; hipEvent_t ev = nullptr; unsigned long long used = 0; };
+    enum { TABLES = 4 };
+    Tables tables[TABLES];
+    unsigned long long tick = 0;
 };
 
 // direct DST solve (sc_dst.hip): DST matrices, the reference's float tables and the double work planes
@@ -46,13 +52,20 @@ struct DstState {
     DevBuf hfxy;                           // pinned staging of the float tables
 };
 
-// FFT direct solve (sc_fft.hip): per-direction chirp / transform tables and the two work planes
-struct FftDim { int n = 0, logM = 0; bool dbl = false; DevBuf chirp, h; };   // chirp: chirp[n+1] | bhat[M] | tw[M] (complex float or double); h: pinned staging
+// FFT direct solve (sc_fft.hip): per-direction chirp / transform tables and the two work planes.  The tables of a transform
+// length are built ON THE DEVICE (k_fft_tables, k_fft_bhat) and kept in a small LRU: a caller whose mask changes with every
+// frame meets new ROI sizes all the time, and alternating between a few sizes costs nothing.
+struct FftDim { int n = 0, logM = 0; bool dbl = false; DevBuf chirp; unsigned long long used = 0; };   // chirp: chirp[n+1] | bhat[M] | tw[M] (complex float or double)
+struct FftFxy { int w = 0, h = 0; bool singular = false; DevBuf d, hst; hipEvent_t ev = nullptr; unsigned long long used = 0; };   // the reference's float tables fx[w] + fy[h]: device, pinned staging of its own, upload event
 struct FftState {
-    FftDim dw, dh;
-    DevBuf A, B, fxy, hfxy;                // work planes [C][h][w] float; the reference's float tables fx[w] + fy[h] (device, pinned)
-    int tw = 0, th = 0;                    // size the float tables were built for
-    bool singular = false;
+    enum { DIMS = 8, FXY = 4 };
+    FftDim dims[DIMS];
+    FftFxy fxy[FXY];
+    unsigned long long tick = 0;
+    DevBuf A, B;                           // work planes [C][h][w]
+    DevBuf tw64;                           // double twiddles of the build's own transform (float tables are built through a double FFT)
+    hipEvent_t ev_fork = nullptr, ev_built = nullptr;   // the build runs on the instance's second stream
+    bool pending = false;                  // ... and `stream` has not waited for ev_built yet
 };
 
 struct MGLevel {
@@ -93,6 +106,12 @@ struct Instance {
     bool u_half = false;      // ... and so does the initial field U0 until the first cycle has consumed it
     bool u_q16 = false;       // multigrid fast path, during a solve: the current field is 16-bit fixed point (sc_cycle0.hip, TAG bits 8, 9)
     bool mg_q16_last = false; // ... the last solve kept its field so (sc_hip_time_cycle0 times the same form)
+    // 16-bit stores check their range: `sat` is the current solve's report word + generation (sc_common.h AbortFlag; p == nullptr:
+    // the solve stores no 16-bit field); a solve whose word was set returns SC_RETRY_FLOAT_FIELD and the caller repeats the
+    // clone with force_float_field set
+    AbortFlag sat;
+    unsigned sat_counter = 0;
+    bool force_float_field = false;
     // Speculative epilogue: the multigrid driver enqueues the post-process right behind the cycle whose
     // convergence check it is about to wait for, so the host round trip of the check overlaps useful work.
     // If the check then fails the solve simply continues and the post-process runs again at the end.
@@ -115,12 +134,13 @@ struct Instance {
     bool mg_l1_half = false;   // level 1's planes currently hold float16 values (sc_multigrid.cpp: mg_level1_half; re-zeroed when the mode flips)
     // direct (fast-diagonalisation) solve inside the bottom kernel: level index relative to mg_bottom, or -1
     int fd_level = -1, fd_nxp = 0, fd_nyp = 0;
-    DevBuf mg_fd, h_fd;    // its matrices: device copy and pinned staging
+    DevBuf mg_fd;          // its matrices (built on the device, k_fd_build)
+    hipEvent_t ev_fd_fork = nullptr, ev_fd = nullptr;   // the build runs on `aux`: started behind ev_fd_fork, finished at ev_fd
+    bool fd_pending = false;                            // ... and `stream` has not waited for ev_fd yet
     LowMode lm;
     DstState dst;
     FftState fft;
-    std::vector<FD1> fd_cache;   // recent 1-D decompositions (a geometry seen before costs no eigen-solve)
-    size_t fd_cache_next = 0;
+    bool fft_lds_float = false, fft_lds_double = false;   // this instance's device has the FFT kernels opted in to > 64 KB of LDS (sc_fft.hip)
     // reductions / mailboxes
     DevBuf d_rects, h_rects;     // bounding boxes of a group of clones (sc_hip_run_device_batch): device, pinned
     DevBuf d_bbox_parts;         // per-workgroup extrema of the group's scans (folded by a second launch instead of atomics)
@@ -131,16 +151,21 @@ struct Instance {
     double *d_partials = nullptr;
     double *d_red = nullptr;
     double *h_red = nullptr;     // pinned
-    unsigned *d_maxcorr = nullptr;     // two words: max correction of the last cycle and of the one before (bits of a float)
-    unsigned *h_maxcorr = nullptr;     // pinned, two words
+    unsigned *d_maxcorr = nullptr;     // max correction of the last cycle and of the one before (bits of a float), the solve's saturation word (four words allocated)
+    unsigned *h_maxcorr = nullptr;     // pinned, the same
     hipEvent_t ev[8]{};
     bool stage_marks = true;   // record the stage marks (synchronous calls); tmark() in sc_api.cpp
+    bool marks_ends_only = false;   // ... but only the first and the last one (SC_FLAG_NO_STAGE_MARKS)
     hipEvent_t tm[8]{};   // stage marks of the current run: ev[k], or the previous mark where a stage is empty (no record call)
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     size_t arena_bytes = 0;
 
     bool ok() const { return magic == 0x5C10E001u; }
 };
+
+// internal return code of a solve (never crosses the C ABI): a 16-bit fixed-point store saturated, no output was written;
+// repeat the pre-process and the solve with Instance::force_float_field set
+constexpr int SC_RETRY_FLOAT_FIELD = 1;
 
 // error helper: records the message, returns SC_ERR_HIP
 int hip_fail(Instance *I, hipError_t e, const char *what);
@@ -153,6 +178,7 @@ int hip_fail(Instance *I, hipError_t e, const char *what);
 int ensure(Instance *I, DevBuf &b, size_t bytes);
 int ensure_pinned(Instance *I, DevBuf &b, size_t bytes);
 double fd_selftest_error();   // sc_multigrid.cpp
+double fd_closed_selftest_error();
 int setup_fields(Instance *I, int W, int H, int C);
 
 // solver drivers (sc_solver.cpp) -- operate on I->U0/U1/F, leave the answer in result(I)

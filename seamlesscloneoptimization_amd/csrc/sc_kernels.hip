@@ -690,8 +690,9 @@ __device__ __forceinline__ void postprocess_block(const Field &U, uint8_t *__res
 }
 
 template <bool LM>
-__global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restrict__ body, int bstep, RectGuard guard, LmNodes lm)
+__global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restrict__ body, int bstep, RectGuard guard, LmNodes lm, AbortFlag ab)
 {
+    if (abort_set(ab)) return;       // a 16-bit store of this solve saturated: the host repeats the clone on float fields
     if (guard.d_rect) {
         const int *__restrict__ r = guard.d_rect;
         if (r[0] != guard.x0 || r[1] != guard.x1 || r[2] != guard.y0 || r[3] != guard.y1) return;
@@ -700,8 +701,9 @@ __global__ __launch_bounds__(256) void k_postprocess(Field U, uint8_t *__restric
 }
 
 template <bool LM>
-__global__ __launch_bounds__(256) void k_postprocess_group(Field U, ImageJobs t, LmNodes lm)
+__global__ __launch_bounds__(256) void k_postprocess_group(Field U, ImageJobs t, LmNodes lm, AbortFlag ab)
 {
+    if (abort_set(ab)) return;
     const ImageJob &j = t.j[blockIdx.z];
     if (j.d_rect && (j.d_rect[0] != j.rx0 || j.d_rect[1] != j.rx1 || j.d_rect[2] != j.ry0 || j.d_rect[3] != j.ry1)) return;
     postprocess_block<LM>(U, j.body_org, j.bstep, 3 * blockIdx.z, lm);
@@ -738,8 +740,9 @@ __device__ __forceinline__ void splice_block(const Field &Q, uint8_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_splice_planar(Field Q, uint8_t *__restrict__ body, int bstep, RectGuard guard)
+__global__ __launch_bounds__(256) void k_splice_planar(Field Q, uint8_t *__restrict__ body, int bstep, RectGuard guard, AbortFlag ab)
 {
+    if (abort_set(ab)) return;
     if (guard.d_rect) {
         const int *__restrict__ r = guard.d_rect;
         if (r[0] != guard.x0 || r[1] != guard.x1 || r[2] != guard.y0 || r[3] != guard.y1) return;
@@ -747,20 +750,21 @@ __global__ __launch_bounds__(256) void k_splice_planar(Field Q, uint8_t *__restr
     splice_block(Q, body, bstep, 0);
 }
 
-__global__ __launch_bounds__(256) void k_splice_planar_group(Field Q, ImageJobs t)
+__global__ __launch_bounds__(256) void k_splice_planar_group(Field Q, ImageJobs t, AbortFlag ab)
 {
+    if (abort_set(ab)) return;
     const ImageJob &j = t.j[blockIdx.z];
     if (j.d_rect && (j.d_rect[0] != j.rx0 || j.d_rect[1] != j.rx1 || j.d_rect[2] != j.ry0 || j.d_rect[3] != j.ry1)) return;
     splice_block(Q, j.body_org, j.bstep, 3 * blockIdx.z);
 }
 
-void launch_splice_planar(Field Q, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard)
+void launch_splice_planar(Field Q, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard, AbortFlag ab)
 {
     dim3 grid(((Q.W + 7) / 8 + 63) / 64, (Q.H + 3) / 4);
-    hipLaunchKernelGGL(k_splice_planar, grid, dim3(256), 0, s, Q, body_org, bstep, guard);
+    hipLaunchKernelGGL(k_splice_planar, grid, dim3(256), 0, s, Q, body_org, bstep, guard, ab);
 }
 
-void launch_splice_planar_group(Field Q, const ImageJob *jobs, int n, hipStream_t s)
+void launch_splice_planar_group(Field Q, const ImageJob *jobs, int n, hipStream_t s, AbortFlag ab)
 {
     for (int i0 = 0; i0 < n; i0 += ImageJobs::MAX) {
         ImageJobs t{};
@@ -769,11 +773,11 @@ void launch_splice_planar_group(Field Q, const ImageJob *jobs, int n, hipStream_
         Field q = Q;
         q.p = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(Q.p) + (size_t)3 * i0 * Q.plane);      // planes are Q.plane BYTES apart here
         dim3 grid(((Q.W + 7) / 8 + 63) / 64, (Q.H + 3) / 4, cnt);
-        hipLaunchKernelGGL(k_splice_planar_group, grid, dim3(256), 0, s, q, t);
+        hipLaunchKernelGGL(k_splice_planar_group, grid, dim3(256), 0, s, q, t, ab);
     }
 }
 
-void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s, LmNodes lm)
+void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t s, LmNodes lm, AbortFlag ab)
 {
     for (int i0 = 0; i0 < n; i0 += ImageJobs::MAX) {
         ImageJobs t{};
@@ -784,16 +788,16 @@ void launch_postprocess_group(Field U, const ImageJob *jobs, int n, hipStream_t 
         LmNodes l = lm;
         if (l.CN) l.CN += (size_t)3 * i0 * l.ny * l.npitch;
         dim3 grid(((U.W + 3) / 4 + 63) / 64, (U.H + 3) / 4, cnt);
-        if (l.CN) hipLaunchKernelGGL(k_postprocess_group<true>, grid, dim3(256), 0, s, u, t, l);
-        else hipLaunchKernelGGL(k_postprocess_group<false>, grid, dim3(256), 0, s, u, t, l);
+        if (l.CN) hipLaunchKernelGGL(k_postprocess_group<true>, grid, dim3(256), 0, s, u, t, l, ab);
+        else hipLaunchKernelGGL(k_postprocess_group<false>, grid, dim3(256), 0, s, u, t, l, ab);
     }
 }
 
-void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard, LmNodes lm)
+void launch_postprocess(Field U, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard, LmNodes lm, AbortFlag ab)
 {
     dim3 grid(((U.W + 3) / 4 + 63) / 64, (U.H + 3) / 4);
-    if (lm.CN) hipLaunchKernelGGL(k_postprocess<true>, grid, dim3(256), 0, s, U, body_org, bstep, guard, lm);
-    else hipLaunchKernelGGL(k_postprocess<false>, grid, dim3(256), 0, s, U, body_org, bstep, guard, lm);
+    if (lm.CN) hipLaunchKernelGGL(k_postprocess<true>, grid, dim3(256), 0, s, U, body_org, bstep, guard, lm, ab);
+    else hipLaunchKernelGGL(k_postprocess<false>, grid, dim3(256), 0, s, U, body_org, bstep, guard, lm, ab);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -301,14 +301,22 @@ static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double 
     max_ratio = 0.0;
     const double PIf = (double)3.14159265358979323846f;
     std::vector<float> fx(Kx), fy(Ky);
-    for (int i = 0; i < Kx; ++i) fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
-    for (int j = 0; j < Ky; ++j) fy[j] = (float)(2.0 * std::cos(PIf / (h + 1.0) * (j + 1.0)));
+    std::vector<double> sa2(Kx), sb2(Ky);          // sin^2 of the half angles: one sine per mode and direction, not per table entry
+    for (int i = 0; i < Kx; ++i) {
+        fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
+        const double sa = std::sin(0.5 * M_PI * (i + 1.0) / (w + 1.0));
+        sa2[i] = sa * sa;
+    }
+    for (int j = 0; j < Ky; ++j) {
+        fy[j] = (float)(2.0 * std::cos(PIf / (h + 1.0) * (j + 1.0)));
+        const double sb = std::sin(0.5 * M_PI * (j + 1.0) / (h + 1.0));
+        sb2[j] = sb * sb;
+    }
     const double scale = 4.0 / ((w + 1.0) * (h + 1.0));
     for (int j = 0; j < Ky; ++j)
         for (int i = 0; i < Kxp; ++i) {
             if (i >= Kx) { R[(size_t)j * Kxp + i] = 0.f; continue; }
-            const double sa = std::sin(0.5 * M_PI * (i + 1.0) / (w + 1.0)), sb = std::sin(0.5 * M_PI * (j + 1.0) / (h + 1.0));
-            const double den_e = -4.0 * (sa * sa + sb * sb);
+            const double den_e = -4.0 * (sa2[i] + sb2[j]);
             const float den_f = (fx[i] + fy[j]) - 4.0f;
             R[(size_t)j * Kxp + i] = (den_f < 0.0f) ? (float)((den_e / (double)den_f - 1.0) * scale) : 0.0f;
             if (den_f < 0.0f) max_ratio = std::max(max_ratio, std::fabs(den_e / (double)den_f - 1.0));
@@ -334,16 +342,34 @@ static int lm_prepare(Instance *I)
     if ((rc = ensure(I, L.CN, sizeof(float) * (size_t)C * ny * npitch))) return rc;
     L.C = C;
     if (L.w == w && L.h == h && L.Sx.p && L.Sy.p && L.R.p) return SC_OK;
-    if ((rc = ensure(I, L.Sx, sizeof(float) * (size_t)nx * Kxp))) return rc;
-    if ((rc = ensure(I, L.Sy, sizeof(float) * (size_t)ny * Kyp))) return rc;
-    if ((rc = ensure(I, L.R, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
-    if ((rc = ensure_pinned(I, L.hR, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
-    std::memset(L.hR.p, 0, sizeof(float) * (size_t)Kyp * Kxp);
-    L.singular = !build_ratio(w, h, Kx, Ky, Kxp, (float *)L.hR.p, L.max_ratio);
-    SC_HIP(I, hipMemcpyAsync(L.R.p, L.hR.p, sizeof(float) * (size_t)Kyp * Kxp, hipMemcpyHostToDevice, I->stream));
-    hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)nx * Kxp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sx.p, w, nx, Kx, Kxp);
-    hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)ny * Kyp + 255) / 256)), dim3(256), 0, I->stream, (float *)L.Sy.p, h, ny, Ky, Kyp);
-    SC_HIP(I, hipGetLastError());
+    L.w = 0;
+    LowMode::Tables *T = nullptr, *victim = nullptr;
+    for (LowMode::Tables &t : L.tables) {
+        if (t.R.p && t.w == w && t.h == h) { T = &t; break; }
+        if (!victim || t.used < victim->used) victim = &t;
+    }
+    if (!T) {                                  // a size not in the cache: build into the least recently used entry
+        T = victim;
+        I->info.new_size = 1;
+        if (T->ev) SC_HIP(I, hipEventSynchronize(T->ev));       // its staging fed an upload once: long complete
+        else SC_HIP(I, hipEventCreateWithFlags(&T->ev, hipEventDisableTiming));
+        T->w = 0;
+        if ((rc = ensure(I, T->Sx, sizeof(float) * (size_t)nx * Kxp))) return rc;
+        if ((rc = ensure(I, T->Sy, sizeof(float) * (size_t)ny * Kyp))) return rc;
+        if ((rc = ensure(I, T->R, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
+        if ((rc = ensure_pinned(I, T->hR, sizeof(float) * (size_t)Kyp * Kxp))) return rc;
+        std::memset(T->hR.p, 0, sizeof(float) * (size_t)Kyp * Kxp);
+        T->singular = !build_ratio(w, h, Kx, Ky, Kxp, (float *)T->hR.p, T->max_ratio);
+        SC_HIP(I, hipMemcpyAsync(T->R.p, T->hR.p, sizeof(float) * (size_t)Kyp * Kxp, hipMemcpyHostToDevice, I->stream));
+        SC_HIP(I, hipEventRecord(T->ev, I->stream));
+        hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)nx * Kxp + 255) / 256)), dim3(256), 0, I->stream, (float *)T->Sx.p, w, nx, Kx, Kxp);
+        hipLaunchKernelGGL(k_lm_table, dim3((unsigned)(((size_t)ny * Kyp + 255) / 256)), dim3(256), 0, I->stream, (float *)T->Sy.p, h, ny, Ky, Kyp);
+        SC_HIP(I, hipGetLastError());
+        T->w = w; T->h = h;
+    }
+    T->used = ++L.tick;
+    L.Sx = T->Sx; L.Sy = T->Sy; L.R = T->R;      // views
+    L.singular = T->singular; L.max_ratio = T->max_ratio;
     L.w = w; L.h = h; L.Kx = Kx; L.Ky = Ky; L.Kxp = Kxp; L.Kyp = Kyp; L.nx = nx; L.ny = ny; L.npitch = npitch;
     return SC_OK;
 }

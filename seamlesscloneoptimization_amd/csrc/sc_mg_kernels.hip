@@ -9,8 +9,65 @@
 #include "sc_common.h"
 #include "sc_wave.h"
 #include "sc_mg_device.h"
+#include "sc_fd_closed.h"
 
 namespace sc {
+
+// ---- per-size state of a new hierarchy, built on the device (the reference does the same with its tables: initDSTMatrix_kernel,
+//      seamlessClone_imp.cpp:569-603) --------------------------------------------------------------------------------------
+// All planes of the levels >= 1 zeroed by ONE launch (their rings and pads must be zero; a buffer reused from another ROI size
+// holds that size's data): blockIdx.y = buffer, grid-stride 16-byte stores.
+__global__ __launch_bounds__(256) void k_zero_multi(ZeroJobs z)
+{
+    float4 *__restrict__ p = reinterpret_cast<float4 *>(z.p[blockIdx.y]);
+    const size_t n = z.n16[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+void launch_zero_multi(const ZeroJobs &z, hipStream_t s)
+{
+    if (z.count <= 0) return;
+    hipLaunchKernelGGL(k_zero_multi, dim3(128, z.count), dim3(256), 0, s, z);
+}
+
+// The five matrices of the bottom kernel's direct solve (MGBottomArgs: Mx1 | My1T | My2T | Mx2 | Dinv, zero padded to nxp / nyp)
+// from the closed-form eigenpairs of the two 1-D level operators (sc_fd_closed.h): one thread per eigenvalue (50 bisection
+// steps), then every thread fills its share of the ~5 n^2 entries with one double sine each.  ~15 us on one CU, once per new
+// ROI size, on the instance's second stream beside the first launches of the clone that needs it.
+__global__ __launch_bounds__(1024) void k_fd_build(float *__restrict__ m, int nx, int ny, int nxp, int nyp, float cwx, float dx, float cwy, float dy)
+{
+    __shared__ FdPair px[128], py[128];
+    const int t = threadIdx.x;
+    if (t < nx) px[t] = fd_pair(t, nx, (double)cwx, (double)dx);
+    if (t >= 128 && t - 128 < ny) py[t - 128] = fd_pair(t - 128, ny, (double)cwy, (double)dy);
+    __syncthreads();
+    const int nxx = nxp * nxp, nyy = nyp * nyp, total = 2 * nxx + 2 * nyy + nxp * nyp;
+    for (int e = t; e < total; e += 1024) {
+        float v = 0.f;
+        if (e < nxx) {                                   // Mx1[x][i] = Vx^-1[i][x] = q_i(x) ee_x
+            const int x = e / nxp, i = e - x * nxp;
+            if (x < nx && i < nx) v = (float)(fd_component(px[i], x + 1, nx) * px[i].inv_norm * (x == nx - 1 ? 1.0 / (double)cwx : 1.0));
+        } else if (e < nxx + nyy) {                      // My1T[y][j] = Vy^-1[j][y]
+            const int r = e - nxx, y = r / nyp, j = r - y * nyp;
+            if (y < ny && j < ny) v = (float)(fd_component(py[j], y + 1, ny) * py[j].inv_norm * (y == ny - 1 ? 1.0 / (double)cwy : 1.0));
+        } else if (e < nxx + 2 * nyy) {                  // My2T[j][y] = Vy[y][j] = q_j(y) / ee_y
+            const int r = e - nxx - nyy, j = r / nyp, y = r - j * nyp;
+            if (y < ny && j < ny) v = (float)(fd_component(py[j], y + 1, ny) * py[j].inv_norm);
+        } else if (e < 2 * nxx + 2 * nyy) {              // Mx2[i][x] = Vx[x][i]
+            const int r = e - nxx - 2 * nyy, i = r / nxp, x = r - i * nxp;
+            if (x < nx && i < nx) v = (float)(fd_component(px[i], x + 1, nx) * px[i].inv_norm);
+        } else {                                         // Dinv[j][i] = 1 / (ly_j + lx_i)
+            const int r = e - 2 * nxx - 2 * nyy, j = r / nxp, i = r - j * nxp;
+            if (j < ny && i < nx) v = (float)(1.0 / (py[j].lam + px[i].lam));
+        }
+        m[e] = v;
+    }
+}
+
+void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fd_build, dim3(1), dim3(1024), 0, s, mats, g.x.n, g.y.n, nxp, nyp, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last);
+}
 
 // ---- general red-black half sweep (levels >= 1; ring = 0) ---------------------------------
 template <bool SOR>
@@ -199,8 +256,9 @@ __global__ __launch_bounds__(256) void k_max_final(const float *__restrict__ par
 // two lists in one launch (this cycle's maxima and the previous cycle's): block b folds list b into out[b]; an empty list
 // gives -1 ("unknown")
 __global__ __launch_bounds__(256) void k_max_final2(const float *__restrict__ pa, int na, const float *__restrict__ pb, int nb,
-                                                    unsigned *__restrict__ out)
+                                                    unsigned *__restrict__ out, const unsigned *__restrict__ flag)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = flag ? *flag : 0u;      // the solve's "a 16-bit store saturated" word rides along (AbortFlag)
     const float *__restrict__ partial = blockIdx.x ? pb : pa;
     const int n = blockIdx.x ? nb : na;
     float m = n > 0 ? 0.f : -1.f;
@@ -213,9 +271,9 @@ __global__ __launch_bounds__(256) void k_max_final2(const float *__restrict__ pa
     if (threadIdx.x == 0) out[blockIdx.x] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
-void launch_max_final2(const float *d_a, int na, const float *d_b, int nb, unsigned *d_out2, hipStream_t s)
+void launch_max_final2(const float *d_a, int na, const float *d_b, int nb, unsigned *d_out2, hipStream_t s, const unsigned *flag)
 {
-    hipLaunchKernelGGL(k_max_final2, dim3(2), dim3(256), 0, s, d_a, na, d_b, nb, d_out2);
+    hipLaunchKernelGGL(k_max_final2, dim3(2), dim3(256), 0, s, d_a, na, d_b, nb, d_out2, flag);
 }
 
 void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_t s)

@@ -5,6 +5,7 @@
 // Level 0 runs the exact 5-point kernels of the sweep solvers; coarser levels the general
 // ones.  Converges ~20x per V(2,2) cycle at every size tried (tools/mg_proto2.py).
 #include "sc_instance.h"
+#include "sc_fd_closed.h"
 #include <algorithm>
 #include <cmath>
 #include <functional>
@@ -135,21 +136,6 @@ static bool fd_decompose(const MGDim &g, FD1 &o)
     return true;
 }
 
-// 1-D decompositions are kept in a small per-instance cache: alternating between a few ROI sizes (or a
-// square ROI, whose two directions are the same operator) then costs no eigen-solve.
-static const FD1 *fd_cached(Instance *I, const MGDim &g)
-{
-    for (const FD1 &f : I->fd_cache)
-        if (f.n == g.n && f.cw_last == g.cw_last && f.d_last == g.d_last) return &f;
-    FD1 f;
-    if (!fd_decompose(g, f)) return nullptr;
-    constexpr size_t CAP = 16;
-    if (I->fd_cache.size() < CAP) { I->fd_cache.reserve(CAP); I->fd_cache.push_back(std::move(f)); return &I->fd_cache.back(); }
-    const size_t slot = I->fd_cache_next++ % CAP;
-    I->fd_cache[slot] = std::move(f);
-    return &I->fd_cache[slot];
-}
-
 // host-only check of the decomposition (sc_hip_selftest_host): max |T v_k - l_k v_k| and max |V^-1 V - I| over a few
 // level operators, regular and with an irregular last interval
 double fd_selftest_error()
@@ -184,7 +170,12 @@ double fd_selftest_error()
     return worst;
 }
 
-// Chooses the bottom level solved directly and uploads its matrices.  I->fd_level = -1 when nothing fits.
+// Chooses the bottom level solved directly and has its matrices built ON THE DEVICE from the closed-form eigenpairs of the
+// level's two 1-D operators (sc_fd_closed.h, k_fd_build) -- no host eigen-solve, no staging copy, no wait.  The build runs on
+// the instance's second stream, beside the first launches of the clone that needs it; run_bottom() makes the main stream
+// wait for it.  (Rounds 1-3 ran the implicit-QL solve above on the host for every new ROI size: 0.1-0.3 ms per direction at
+// n = 63, as long as the clone itself; it now only serves sc_hip_selftest_host as the reference the closed form is checked
+// against.)  I->fd_level = -1 when nothing fits.
 static int build_fd(Instance *I)
 {
     I->fd_level = -1;
@@ -196,39 +187,70 @@ static int build_fd(Instance *I)
         const int nx = L.g.x.n, ny = L.g.y.n, nxp = round_up(nx, 4), nyp = round_up(ny, 4);
         if (nx > 128 || ny > 128) continue;
         if ((planes + fd_lds_floats(nxp, nyp)) * (long)sizeof(float) > (long)MG_BOTTOM_LDS_BYTES) continue;
-        const FD1 *pfx = fd_cached(I, L.g.x), *pfy = fd_cached(I, L.g.y);
-        if (pfx && !(pfx->n == nx && pfx->cw_last == L.g.x.cw_last && pfx->d_last == L.g.x.d_last))
-            pfx = fd_cached(I, L.g.x);          // inserting y evicted x from a full cache: x goes into the next slot
-        if (!pfx || !pfy) return SC_OK;                                           // keep the V-cycle bottom
-        const FD1 &fx = *pfx, &fy = *pfy;
         const long nf = fd_mat_floats(nxp, nyp);
         int rc;
-        if ((rc = ensure_pinned(I, I->h_fd, sizeof(float) * (size_t)nf))) return rc;
         if ((rc = ensure(I, I->mg_fd, sizeof(float) * (size_t)nf))) return rc;
-        float *m = (float *)I->h_fd.p;
-        memset(m, 0, sizeof(float) * (size_t)nf);
-        float *Mx1 = m, *My1T = Mx1 + (size_t)nxp * nxp, *My2T = My1T + (size_t)nyp * nyp, *Mx2 = My2T + (size_t)nyp * nyp,
-              *Dinv = Mx2 + (size_t)nxp * nxp;
-        for (int x = 0; x < nx; ++x)
-            for (int i = 0; i < nx; ++i) {
-                const double q = fx.q[(size_t)i * nx + x];
-                Mx1[(size_t)x * nxp + i] = (float)(q * fx.ee[x]);         // Vx^-1[i][x]
-                Mx2[(size_t)i * nxp + x] = (float)(q / fx.ee[x]);         // Vx[x][i]
-            }
-        for (int y = 0; y < ny; ++y)
-            for (int j = 0; j < ny; ++j) {
-                const double q = fy.q[(size_t)j * ny + y];
-                My1T[(size_t)y * nyp + j] = (float)(q * fy.ee[y]);        // Vy^-1[j][y]
-                My2T[(size_t)j * nyp + y] = (float)(q / fy.ee[y]);        // Vy[y][j]
-            }
-        for (int j = 0; j < ny; ++j)
-            for (int i = 0; i < nx; ++i) Dinv[(size_t)j * nxp + i] = (float)(1.0 / (fy.lam[j] + fx.lam[i]));
-        SC_HIP(I, hipMemcpyAsync(I->mg_fd.p, m, sizeof(float) * (size_t)nf, hipMemcpyHostToDevice, I->stream));
+        // everything that read the previous matrices has been enqueued on the main stream: the build starts behind it
+        SC_HIP(I, hipEventRecord(I->ev_fd_fork, I->stream));
+        SC_HIP(I, hipStreamWaitEvent(I->aux, I->ev_fd_fork, 0));
+        launch_fd_build((float *)I->mg_fd.p, L.g, nxp, nyp, I->aux);
+        SC_HIP(I, hipGetLastError());
+        SC_HIP(I, hipEventRecord(I->ev_fd, I->aux));
+        I->fd_pending = true;
         I->fd_level = (int)(l - I->mg_bottom);
         I->fd_nxp = nxp; I->fd_nyp = nyp;
         return SC_OK;
     }
     return SC_OK;
+}
+
+// host-only check of the closed form (sc_hip_selftest_host): its matrices V, V^-1 and eigenvalues against the QL-based
+// decomposition over level operators of every size the bottom solve can meet, regular and with an irregular last interval
+// on either side of the alpha = 0.7071 threshold (one eigenvalue below -4).  Returns the worst deviation found.
+double fd_closed_selftest_error()
+{
+    double worst = 0.0;
+    const double alphas[] = { 1.0, 0.5, 0.625, 0.70703125, 0.7109375, 0.75, 0.875, 1.125, 1.25, 1.5, 0.96875 };
+    for (int n = 1; n <= 128; n += (n < 20 ? 1 : 9))
+        for (double a : alphas) {
+            MGDim g = make_dim(n, a, 0);
+            FD1 f;
+            if (!fd_decompose(g, f)) return 1e30;
+            std::vector<FdPair> p(n);
+            for (int k = 0; k < n; ++k) p[k] = fd_pair(k, n, (double)g.cw_last, (double)g.d_last);
+            // eigenvalues: the two sets must agree as sets (QL's order is arbitrary)
+            std::vector<double> la(f.lam), lb(n);
+            for (int k = 0; k < n; ++k) lb[k] = p[k].lam;
+            std::sort(la.begin(), la.end()); std::sort(lb.begin(), lb.end());
+            for (int k = 0; k < n; ++k) worst = std::max(worst, std::fabs(la[k] - lb[k]));
+            // T v = lambda v for the closed form's own vectors, and V^-1 V = I
+            auto T = [&](int i, int j) -> double {
+                if (i == j) return i == n - 1 ? -(double)g.d_last : -2.0;
+                if (j == i + 1) return 1.0;
+                if (j == i - 1) return i == n - 1 ? (double)g.cw_last : 1.0;
+                return 0.0;
+            };
+            std::vector<double> V((size_t)n * n), Vi((size_t)n * n);      // V[x][k], Vinv[k][x]
+            for (int k = 0; k < n; ++k)
+                for (int x = 0; x < n; ++x) {
+                    const double v = fd_component(p[k], x + 1, n) * p[k].inv_norm;
+                    V[(size_t)x * n + k] = v;
+                    Vi[(size_t)k * n + x] = v * (x == n - 1 ? 1.0 / (double)g.cw_last : 1.0);
+                }
+            for (int k = 0; k < n; ++k) {
+                for (int i = 0; i < n; ++i) {
+                    double tv = 0.0;
+                    for (int j = std::max(0, i - 1); j <= std::min(n - 1, i + 1); ++j) tv += T(i, j) * V[(size_t)j * n + k];
+                    worst = std::max(worst, std::fabs(tv - p[k].lam * V[(size_t)i * n + k]));
+                }
+                for (int m = 0; m < n; ++m) {
+                    double dot = 0.0;
+                    for (int x = 0; x < n; ++x) dot += Vi[(size_t)k * n + x] * V[(size_t)x * n + m];
+                    worst = std::max(worst, std::fabs(dot - (k == m ? 1.0 : 0.0)));
+                }
+            }
+        }
+    return worst;
 }
 
 static int run_bottom(Instance *I, size_t l0, int pre, int post)
@@ -258,6 +280,10 @@ static int run_bottom(Instance *I, size_t l0, int pre, int post)
     a.lds_floats = off;
     a.Ftop = I->mg[l0].F;
     a.Utop = I->mg[l0].U;
+    if (I->fd_pending) {          // the matrices of a new hierarchy are being built on the second stream (build_fd)
+        SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0));
+        I->fd_pending = false;
+    }
     launch_mg_bottom(a, I->F.C, I->stream);
     return SC_OK;
 }
@@ -267,6 +293,7 @@ static int build_levels(Instance *I)
     const int W = I->F.W, H = I->F.H, C = I->F.C;
     if (!I->mg.empty() && I->mg[0].F.p == I->F.p && I->mg[0].F.W == W && I->mg[0].F.H == H && I->mg[0].F.C == C)
         return SC_OK;
+    I->info.new_size = 1;
     I->mg.clear();
     struct L1 { int nx, ny; double ax, ay; };
     std::vector<L1> ls;
@@ -281,6 +308,7 @@ static int build_levels(Instance *I)
     const size_t nl = ls.size();
     if (I->mg_bufs.size() < 3 * nl) I->mg_bufs.resize(3 * nl);
     I->mg.resize(nl);
+    ZeroJobs zj{};
     for (size_t l = 0; l < nl; ++l) {
         MGLevel &L = I->mg[l];
         const int ncx = (l + 1 < nl) ? ls[l + 1].nx : 0, ncy = (l + 1 < nl) ? ls[l + 1].ny : 0;
@@ -299,11 +327,15 @@ static int build_levels(Instance *I)
         L.F = level_field(I->mg_bufs[3 * l + 1].p, Wl, Hl, C);
         L.T = level_field(I->mg_bufs[3 * l + 2].p, Wl, Hl, C);
         // rings and pads of F/U must be zero; ensure() zero-fills fresh memory, but a reused
-        // larger buffer may hold stale data from another ROI size
-        SC_HIP(I, hipMemsetAsync(L.U.p, 0, L.U.bytes(), I->stream));
-        SC_HIP(I, hipMemsetAsync(L.F.p, 0, L.F.bytes(), I->stream));
-        SC_HIP(I, hipMemsetAsync(L.T.p, 0, L.T.bytes(), I->stream));
+        // larger buffer may hold stale data from another ROI size: every plane of every level in ONE launch below
+        // (24-36 memsets were 70-100 us of launches in front of the first clone at a new size)
+        for (const Field *f : { &L.U, &L.F, &L.T }) {
+            if (zj.count == ZeroJobs::MAX) { launch_zero_multi(zj, I->stream); zj.count = 0; }
+            zj.p[zj.count] = f->p; zj.n16[zj.count] = (f->bytes() + 15) / 16; ++zj.count;       // buffers are 4096 bytes larger than the field
+        }
     }
+    launch_zero_multi(zj, I->stream);
+    SC_HIP(I, hipGetLastError());
     I->mg[0].F = I->F;
     I->mg_bottom = bottom_start(I);
     I->mg_l1_half = false;        // fresh planes: all zero in either format
@@ -435,7 +467,7 @@ bool mg_level1_half(const Instance *I)
 // two cycles lie between the last rounding (<= 1/128) and the output.
 static bool mg_field_q16(const Instance *I, bool out_wanted)
 {
-    return out_wanted && I->u_half && !(I->opts.flags & SC_FLAG_FLOAT_FIELD) && mg_level1_half(I);
+    return out_wanted && I->u_half && !(I->opts.flags & SC_FLAG_FLOAT_FIELD) && !I->force_float_field && mg_level1_half(I);
 }
 
 bool mg_reads_half_rhs(const Instance *I)
@@ -453,7 +485,7 @@ int mg_solve(Instance *I)
     {
         const int nb = std::max(std::max(prolong_blocks(I->F.W - 2, I->F.H - 2, I->F.C), tb_blocks_level0(I->F.W, I->F.H, I->F.C, 2)),
                                 cycle0_blocks(I->F.W, I->F.H, I->F.C, 4));      // the deepest forms have the most workgroups
-        if ((rc = ensure(I, I->mg_partial, 2 * sizeof(float) * (size_t)nb))) return rc;   // two cycles' worth (see the stop rule)
+        if ((rc = ensure(I, I->mg_partial, sizeof(float) * (2 * (size_t)nb + 64)))) return rc;   // two cycles' worth (see the stop rule) + the saturation word behind them
     }
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
     const float utol = o.update_tol > 0.f ? o.update_tol : 0.25f;
@@ -484,9 +516,16 @@ int mg_solve(Instance *I)
         Field none{};
         const bool out_wanted = I->spec_post.armed && o.tol <= 0.f && !(o.flags & SC_FLAG_KEEP_FIELD) && pre == 2 && post == 2;
         const bool q16 = l1h && mg_field_q16(I, out_wanted) && budget > 1;      // (max_sweeps = 1: the first cycle is the judged one)
+        const int nb_cap = cycle0_blocks(I->F.W, I->F.H, I->F.C, 4);   // deepest form = largest halo = most workgroups
+        // The 16-bit stores check their range (sc_cycle0.hip, c0_q16_checked): one that saturates writes this solve's generation
+        // word behind the partial maxima; the output launches then write nothing, the read-back of the maxima brings the word
+        // along, and the clone is repeated on float fields (SC_RETRY_FLOAT_FIELD).  A NaN pattern: no maximum ever has these bits.
+        AbortFlag sat;
+        if (q16) { sat.p = (unsigned *)((float *)I->mg_partial.p + 2 * (size_t)nb_cap); sat.gen = 0x7fc00000u | (++I->sat_counter & 0x3fffffu); }
+        I->sat = sat;
         // on the float16 path the pre-process stored the initial field as float16 as well (first launch only)
         if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
-                          I->stream, false, I->f_half, I->u_half, false, nullptr, l1h, q16) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
+                          I->stream, false, I->f_half, I->u_half, false, nullptr, l1h, q16, sat) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
         I->result_in_U1 = !I->result_in_U1;
         I->u_half = false;             // consumed: both U buffers hold float (or 16-bit fixed point: u_q16) from here on
         I->u_q16 = I->mg_q16_last = q16;
@@ -512,16 +551,21 @@ int mg_solve(Instance *I)
         // small D2H costs ~5 us on the critical path; large grids (groups of clones) reduce both lists on the device first (one
         // launch).  m_prev < 0: unknown.  `output` (the splice or post-process of the result, or nothing) is enqueued between the launch
         // and the read-back: it then starts without a gap while the host waits.
+        bool saturated = false;            // set by correction_maxima: a 16-bit store of this solve left its range
         auto correction_maxima = [&](int nb, int nb_prev, int nb_cap, float *part_now, const std::function<int()> &output, float &m, float &m_prev) -> int {
             m = 0.f; m_prev = -1.f;
             int orc;
             if (nb <= 16384) {
                 const bool have_prev = nb_prev > 0 && nb_prev <= 16384;   // the launch of the previous cycle wrote the other half
-                if ((orc = ensure_pinned(I, I->h_partial, 2 * sizeof(float) * (size_t)nb_cap))) return orc;
+                if ((orc = ensure_pinned(I, I->h_partial, sizeof(float) * (2 * (size_t)nb_cap + 64)))) return orc;
                 if ((orc = output())) return orc;
-                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap : ((cyc & 1) * nb_cap + nb)),
+                // both halves and, when this solve stored 16-bit fields, the saturation word right behind them: ONE copy
+                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap + (sat.p ? 1 : 0) : ((cyc & 1) * nb_cap + nb)),
                                          hipMemcpyDeviceToHost, I->stream));
+                if (sat.p && !have_prev)
+                    SC_HIP(I, hipMemcpyAsync((float *)I->h_partial.p + 2 * (size_t)nb_cap, sat.p, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
                 SC_HIP(I, hipStreamSynchronize(I->stream));
+                if (sat.p) { unsigned w; memcpy(&w, (const float *)I->h_partial.p + 2 * (size_t)nb_cap, sizeof(w)); saturated = w == sat.gen; }
                 const float *hp = (const float *)I->h_partial.p + (size_t)(cyc & 1) * nb_cap;            // this cycle's half
                 const float *hq = (const float *)I->h_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;      // the previous cycle's
                 for (int i = 0; i < nb; ++i) m = hp[i] > m ? hp[i] : m;
@@ -531,12 +575,13 @@ int mg_solve(Instance *I)
                 }
             } else {
                 const float *part_prev = (const float *)I->mg_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;
-                launch_max_final2(part_now, nb, part_prev, nb_prev > 0 ? nb_prev : 0, I->d_maxcorr, I->stream);
+                launch_max_final2(part_now, nb, part_prev, nb_prev > 0 ? nb_prev : 0, I->d_maxcorr, I->stream, sat.p);
                 if ((orc = output())) return orc;
-                SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
+                SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
                 SC_HIP(I, hipStreamSynchronize(I->stream));
                 memcpy(&m, &I->h_maxcorr[0], sizeof(float));
                 memcpy(&m_prev, &I->h_maxcorr[1], sizeof(float));
+                saturated = sat.p && I->h_maxcorr[2] == sat.gen;
             }
             return SC_OK;
         };
@@ -549,7 +594,6 @@ int mg_solve(Instance *I)
             // initial guess was already the answer, and every check costs a host round trip
             // (~25 us), so checking starts with the third cycle.
             const bool judged = !(cyc + 1 < 3 && cyc + 1 < budget && o.tol <= 0.f);
-            const int nb_cap = cycle0_blocks(I->F.W, I->F.H, I->F.C, 4);   // deepest form = largest halo = most workgroups
             float *const part_now = (float *)I->mg_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;    // this cycle's maxima; the previous cycle's sit in the other half
             // the judged cycle runs in its final form; when the float-table correction will follow it leaves the correction's
             // cell shares behind (sc_lowmode.hip), which saves the correction its own pass over the field
@@ -572,11 +616,12 @@ int mg_solve(Instance *I)
                     const Field Q = I->result_in_U1 ? I->U0 : I->U1;
                     float m, m_prev;
                     if ((rc = correction_maxima(nbo, nb_last, nb_cap, part_now, [&]() -> int {
-                            if (I->spec_post.group.empty()) launch_splice_planar(Q, I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard);
-                            else launch_splice_planar_group(Q, I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream);
+                            if (I->spec_post.group.empty()) launch_splice_planar(Q, I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard, sat);
+                            else launch_splice_planar_group(Q, I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream, sat);
                             return SC_OK;
                         }, m, m_prev))) return rc;
                     I->info.last_update = m;
+                    if (saturated) { I->info.sweeps = cyc; return SC_RETRY_FLOAT_FIELD; }      // nothing was written (AbortFlag)
                     if (stop_rule(m, m_prev)) { I->spec_post.done = true; I->out_direct = true; ok = true; break; }
                     // rejected: the same cycle again in the form that keeps the field, then on as usual
                     --cyc;
@@ -586,7 +631,7 @@ int mg_solve(Instance *I)
             const int nb = comp1
                 ? launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
                                          judged ? post : post + pre, part_now, I->stream, false, I->f_half, judged,
-                                         I->mg[2].U, I->mg[1].g, bands, l1h, I->u_q16 ? (next_judged ? 1 : 3) : 0)
+                                         I->mg[2].U, I->mg[1].g, bands, l1h, I->u_q16 ? (next_judged ? 1 : 3) : 0, sat)
                 : launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
                                 I->mg[0].g, judged ? post : post + pre, true, part_now, I->stream,
                                 false, I->f_half, false, judged, bands);
@@ -622,12 +667,13 @@ int mg_solve(Instance *I)
                     LmNodes lm;
                     const int lrc = output_nodes(I, lm);
                     if (lrc) return lrc;
-                    if (I->spec_post.group.empty()) launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard, lm);
-                    else launch_postprocess_group(result(I), I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream, lm);
+                    if (I->spec_post.group.empty()) launch_postprocess(result(I), I->spec_post.body_org, I->spec_post.bstep, I->stream, I->guard, lm, sat);
+                    else launch_postprocess_group(result(I), I->spec_post.group.data(), (int)I->spec_post.group.size(), I->stream, lm, sat);
                     I->spec_post.done = true;
                     return SC_OK;
                 }, m, m_prev))) return rc;
             I->info.last_update = m;
+            if (saturated) { I->spec_post.done = false; I->info.sweeps = cyc; return SC_RETRY_FLOAT_FIELD; }
             if (o.tol > 0.f) {
                 double r[2];
                 if ((rc = eval_residual(I, r))) return rc;

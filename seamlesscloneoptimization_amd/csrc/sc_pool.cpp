@@ -46,7 +46,7 @@ void run_job(void *inst, sc_batch_job &j, int device_resident)
     } else {
         j.rc = my_seamlessclone_api_imp_run(inst, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols,
                                             j.body_rows, j.body_step, j.mask, j.mask_cols, j.mask_rows, j.mask_step,
-                                            j.centerX, j.centerY, 0, true);
+                                            j.centerX, j.centerY, 0, false);     // bSync = false: no timing lines on stdout (the call is synchronous either way)
     }
 }
 

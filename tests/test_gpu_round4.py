@@ -1,0 +1,175 @@
+"""GPU parity tests added in round 4 (through the C ABI, against the CPU oracle): the range check of the 16-bit fixed-point
+field, the first call at a new ROI size (per-size state built on the device), the reference's bSync protocol, the
+one-launch coarse part of a cycle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracles():
+    from oracle import oracle_np, oracle_c
+    oracle_c.build()
+    return oracle_np, oracle_c
+
+
+@pytest.fixture()
+def inst():
+    """A fresh instance with the library's DEFAULT options (the session fixture `hip` is pinned to multigrid)."""
+    from seamlesscloneoptimization_amd import capi
+    i = capi.Instance(0)
+    yield i
+    i.destroy()
+
+
+def _dmax(a, b):
+    return int(np.abs(a.astype(np.int16) - b.astype(np.int16)).max())
+
+
+def ring_ramp_inputs(W, H, period=32, band=2, margin=32, seed=5):
+    """A NON-CONSERVATIVE guidance field: the patch is a radial sawtooth that rises towards the centre inside every ring, and
+    the mask is zero in a thin band around every jump back, so the blended gradients only ever point inwards.  The solution of
+    that Poisson problem is a cone ~ (mean gradient) x (distance to the border) high -- far outside any 8-bit image's range --
+    which is what makes the multigrid fast path's 16-bit fixed-point field (range [-256, 768)) saturate."""
+    Hd, Wd = H + margin, W + margin
+    rng = np.random.default_rng(seed)
+    dst = np.clip(128.0 + rng.normal(0.0, 6.0, (Hd, Wd, 3)), 0, 255).astype(np.uint8)
+    Hp, Wp = H + 2, W + 2
+    yy, xx = np.mgrid[0:Hp, 0:Wp]
+    r = np.hypot(yy - (Hp - 1) / 2.0, xx - (Wp - 1) / 2.0)
+    ph = (r / period) % 1.0
+    patch = np.clip(255.0 * (1.0 - ph)[:, :, None] + rng.normal(0.0, 3.0, (Hp, Wp, 3)), 0, 255).astype(np.uint8)
+    mask = np.where((ph * period < band) | (ph * period > period - band), 0, 255).astype(np.uint8)
+    return dst, patch, mask, Wd // 2, Hd // 2
+
+
+def test_saturating_16bit_field_is_noticed_and_repeated_on_float_fields(hip, oracles):
+    """the 16-bit fixed-point field between the first level-0 launches clamps to [-256, 768), which only bounds
+    the iterates of a conservative guidance field.  Rings of inward ramps drive the solution to ~1500: the stores that saturate
+    report it, the output launches of that solve write nothing, and the clone is repeated on float fields -- the result is the
+    one SC_FLAG_FLOAT_FIELD gives, byte for byte, and within one of the float-table port; an ordinary clone is not repeated."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    dst, patch, mask, cx, cy = ring_ramp_inputs(640, 560)
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, min(16, oc.max_threads()))
+    try:
+        hip.set_solver(flags=0)
+        body = dst.copy()
+        assert hip.run(patch, body, mask, cx, cy, allow_not_converged=True) in (0, capi.SC_ERR_NOT_CONVERGED)
+        i = hip.info()
+        assert i.field_retry == 1, "the rings did not saturate the 16-bit field: the test drives nothing"
+        assert _dmax(body, want) <= 1
+        hip.set_solver(flags=capi.SC_FLAG_FLOAT_FIELD)
+        body_f = dst.copy()
+        assert hip.run(patch, body_f, mask, cx, cy, allow_not_converged=True) in (0, capi.SC_ERR_NOT_CONVERGED)
+        assert hip.info().field_retry == 0
+        assert np.array_equal(body, body_f)
+        # the result is not trivial: the cone leaves the 8-bit range in the middle and comes back to the destination at the ring
+        roi = body[i.lty:i.lty + i.H, i.ltx:i.ltx + i.W]
+        assert (roi == 255).mean() > 0.3 and (roi < 250).mean() > 0.05
+        # an ordinary clone of the same size keeps the 16-bit field
+        hip.set_solver(flags=0)
+        d2, p2, m2, cx2, cy2 = o.synth_inputs(640, 560, margin=32)
+        b2 = d2.copy()
+        assert hip.run(p2, b2, m2, cx2, cy2) == 0 and hip.info().field_retry == 0
+    finally:
+        hip.set_solver(flags=0)
+
+
+def test_saturating_member_of_a_group_repeats_the_group(oracles):
+    """The same through sc_hip_run_device_batch: one member of a group of three saturates -> no member is written by the first
+    solve, the group runs again on float fields, every member within one of the port."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    W, H = 640, 560
+    items = [o.synth_inputs(W, H, margin=32, seed_dst=11, seed_patch=12), ring_ramp_inputs(W, H), o.synth_inputs(W, H, margin=32, seed_dst=13, seed_patch=14)]
+    inst = capi.Instance(0)
+    try:
+        inst.set_solver(method=capi.SC_METHOD_MULTIGRID)
+        jobs = capi.Pool.make_jobs(len(items))
+        dev = []
+        for j, (dst, patch, mask, cx, cy) in zip(jobs, items):
+            f, b, m = inst.to_device(patch), inst.to_device(dst), inst.to_device(mask)
+            dev.append((f, b, m))
+            j.face, j.face_cols, j.face_rows, j.face_step = f, patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+            j.body, j.body_cols, j.body_rows, j.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+            j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
+            j.centerX, j.centerY, j.body_restore = cx, cy, None
+        inst.run_device_batch(jobs)
+        assert inst.info().field_retry == 1
+        for (dst, patch, mask, cx, cy), (f, b, m) in zip(items, dev):
+            got = inst.from_device(b, dst.shape)
+            want = oc.seamless_clone(dst, patch, mask, cx, cy, min(16, oc.max_threads()))
+            assert _dmax(got, want) <= 1
+        for f, b, m in dev:
+            inst.free(f); inst.free(b); inst.free(m)
+    finally:
+        inst.destroy()
+
+
+def test_bsync_prints_the_reference_lines_and_fills_ms_call(inst, oracles, capfd):
+    """seamlessClone_imp.cu:336-349: with bSync the reference times the call on its stream and prints two lines; the binding's
+    default (bSync = false, SeamlessClone.cpp:63) is silent.  Either way the call is complete on return and ms_call is filled."""
+    o, _ = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(96, 64, margin=32)
+    body = dst.copy()
+    inst.run(patch, body, mask, cx, cy, sync=False)
+    assert capfd.readouterr().out == ""
+    quiet = body.copy()
+    body = dst.copy()
+    inst.run(patch, body, mask, cx, cy, sync=True)
+    out = capfd.readouterr().out
+    assert "Compute stage performance time=" in out and "patch size=96x64" in out and "total device memory used:" in out
+    assert np.array_equal(body, quiet)
+    i = inst.info()
+    assert i.ms_call > 0 and i.ms_call >= i.ms_device_total and i.device == 0
+
+
+def test_thirty_new_roi_sizes_back_to_back_on_one_instance(inst, oracles):
+    """in a drop-in use every frame has its own mask, so a ROI size the instance has never seen is the
+    norm.  Per-size state is now built on the device (bottom-solver matrices from closed-form eigenpairs, chirp / transform
+    tables by the solver's own FFT, one zeroing launch for the hierarchy) and cached in small LRUs.  Thirty distinct sizes in a
+    row on one instance with the DEFAULT options -- direct solve below 900 unknowns per side, multigrid above, odd and even
+    sizes, irregular last intervals on every level --: each within one of the float-table port on its FIRST call, byte-identical
+    when repeated (cached state = freshly built state), and a size that has been evicted from every cache in between gives the
+    bytes of its first visit."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    rng = np.random.default_rng(20261005)
+    sizes = [(298, 192), (154, 100), (901, 640), (1203, 777)]
+    while len(sizes) < 30:
+        big = len(sizes) % 3 == 0
+        W = int(rng.integers(903, 1400)) if big else int(rng.integers(20, 900))
+        H = int(rng.integers(300, 1100)) if big else int(rng.integers(20, 900))
+        if (W, H) not in sizes:
+            sizes.append((W, H))
+    first = {}
+    for k, (W, H) in enumerate(sizes):
+        dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=16, seed_dst=100 + k, seed_patch=200 + k, ellipse=(k % 7 == 3))
+        want = oc.seamless_clone(dst, patch, mask, cx, cy, min(16, oc.max_threads()))
+        body = dst.copy()
+        rc = inst.run(patch, body, mask, cx, cy, allow_not_converged=True)
+        i = inst.info()
+        assert rc in (0, capi.SC_ERR_NOT_CONVERGED) and i.new_size == 1, (W, H, rc, i.new_size)
+        assert _dmax(body, want) <= 1, (W, H, i.method)
+        again = dst.copy()
+        inst.run(patch, again, mask, cx, cy, allow_not_converged=True)
+        assert inst.info().new_size == 0 and np.array_equal(again, body), (W, H)
+        first[(W, H)] = (dst, patch, mask, cx, cy, body)
+    for W, H in sizes[:6]:                      # evicted from every LRU (8 transform lengths, 4 table sets) long ago
+        dst, patch, mask, cx, cy, body = first[(W, H)]
+        again = dst.copy()
+        inst.run(patch, again, mask, cx, cy, allow_not_converged=True)
+        assert np.array_equal(again, body), (W, H)
+
+
+def test_pci_bus_id_of_the_device():
+    """sc_hip_device_pci_bus_id: what bench.py keys the rank's CPU affinity on (/sys/bus/pci/devices/<bdf>/local_cpulist)."""
+    import re
+    from seamlesscloneoptimization_amd import capi
+    bdf = capi.device_pci_bus_id(0)
+    assert bdf and re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", bdf), bdf
+    assert capi.device_pci_bus_id(9999) is None

@@ -297,3 +297,82 @@ def test_launcher_survives_a_chatty_rank0(tmp_path):
                     "print('done', r, flush=True)\n")
     rc, out = spawn_ranks(2, [sys.executable, str(stub)])
     assert rc == 0 and len(out) > 300000 and out.strip().endswith("done 0")
+
+
+def test_rank_cores_split_by_gpu_locality():
+    """Round 4: every rank pins itself (and the library threads it starts) to its share of the host cores.  With the kernel's
+    list of cores local to the rank's GPU the split is among the ranks that share that list, else an even contiguous split."""
+    from seamlesscloneoptimization_amd.batch import parse_cpulist, rank_cores
+    assert parse_cpulist("0-3,8-11\n") == [0, 1, 2, 3, 8, 9, 10, 11] and parse_cpulist("5") == [5] and parse_cpulist("") == []
+    allowed = list(range(128))                       # two sockets x 32 cores x 2 threads, socket-major numbering
+    seen = []
+    for r in range(8):
+        c = rank_cores(r, 8, allowed, "0-31,64-95" if r < 4 else "32-63,96-127")
+        assert len(c) == 16 and set(c) <= set(parse_cpulist("0-31,64-95" if r < 4 else "32-63,96-127")), (r, c)
+        seen += c
+    assert sorted(seen) == allowed                   # a partition: no core shared, none left out
+    # no locality information: even contiguous split
+    assert [rank_cores(r, 4, list(range(16))) for r in range(4)] == [list(range(4 * r, 4 * r + 4)) for r in range(4)]
+    # a cpulist that names the whole mask (a one-socket box) carries no information either
+    assert rank_cores(1, 2, list(range(16)), "0-15") == list(range(8, 16))
+    # more ranks than cores: share, never empty
+    assert rank_cores(3, 8, [0, 1, 2]) == [0] and rank_cores(0, 1, [4, 5]) == [4, 5]
+    with pytest.raises(ValueError):
+        rank_cores(2, 2, [0, 1])
+
+
+def test_spawn_ranks_reports_a_real_failure_and_does_not_retry_it(tmp_path, capfd):
+    """a rank that dies for a real reason must not be retried silently.  The launcher reports every rank's
+    exit code and stderr, and launches again only when the ranks' stderr shows a rendezvous error."""
+    from seamlesscloneoptimization_amd import batch
+    count = tmp_path / "count"
+    stub = tmp_path / "die.py"
+    stub.write_text("import os, sys\n"
+                    f"open({str(count)!r}, 'a').write('x')\n"
+                    "if os.environ['RANK'] == '1':\n"
+                    "    sys.stderr.write('HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION: pretend GPU fault\\n'); sys.exit(9)\n"
+                    "import time; time.sleep(30)\n")
+    rc, out = batch.spawn_ranks(2, [sys.executable, str(stub)], retries=3)
+    assert rc == 9 and out == ""
+    assert len(count.read_text()) == 2                                  # two ranks, ONE attempt
+    rep = batch.spawn_ranks.last_report
+    assert rep["first_failed_rank"] == 1 and rep["codes"][1] == 9 and "pretend GPU fault" in rep["stderr"][1]
+    err = capfd.readouterr().err
+    assert "rank 1 failed first" in err and "pretend GPU fault" in err and "launching again" not in err
+    # a rendezvous error IS retried (once here), and the first attempt is still reported
+    count.write_text("")
+    stub.write_text("import os, sys\n"
+                    f"n = len(open({str(count)!r}).read()); open({str(count)!r}, 'a').write('x')\n"
+                    "if n < 2 and os.environ['RANK'] == '0':\n"
+                    "    sys.stderr.write('RuntimeError: The server socket has failed to listen on any local network address. "
+                    "port: 29500, useIpv6: 0, code: -98, name: EADDRINUSE, message: address already in use\\n'); sys.exit(1)\n"
+                    "import time; time.sleep(0.2 if n >= 2 else 30)\n"
+                    "print('rank', os.environ['RANK'], 'up', flush=True)\n")
+    rc, out = batch.spawn_ranks(2, [sys.executable, str(stub)], retries=1)
+    assert rc == 0 and "rank 0 up" in out
+    err = capfd.readouterr().err
+    assert "address already in use" in err and "launching again on a new port" in err
+
+
+_GATHER = r'''
+import os, sys, time
+sys.path.insert(0, os.environ["SC_ROOT"])
+from seamlesscloneoptimization_amd.batch import Comm, timed_region
+comm = Comm()
+own = []
+dt = timed_region(comm, lambda: None, lambda: time.sleep(0.05 * (comm.rank + 1)), own)
+per_rank = comm.gather(own[0])
+assert len(per_rank) == comm.world and abs(max(per_rank) - dt) < 1e-9 and per_rank[0] < per_rank[1], per_rank
+assert comm.gather(float(comm.rank * 3)) == [0.0, 3.0]
+print("rank", comm.rank, "gather ok", flush=True)
+comm.close()
+'''
+
+
+def test_per_rank_elapsed_is_gathered_beside_the_maximum(tmp_path):
+    """bench.py prints every rank's own elapsed time beside the max-over-ranks (a scaling run can then see imbalance)."""
+    from seamlesscloneoptimization_amd.batch import spawn_ranks
+    stub = tmp_path / "gather.py"
+    stub.write_text(_GATHER)
+    rc, out = spawn_ranks(2, [sys.executable, str(stub)], extra_env={"SC_ROOT": ROOT})
+    assert rc == 0 and "rank 0 gather ok" in out
