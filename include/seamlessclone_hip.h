@@ -109,8 +109,12 @@ typedef struct sc_solver_opts {
                                 with a 1-pixel halo (k_jacobi<rows>).  Bit-identical fields.              */
     int   mg_level1_sweeps;  /* multigrid, default schedule (level 1 without post-smoothing, SC_FLAG_NO_COMPOSE_L1 clear): sweeps
                                 level 1 does before its restriction; 0 = default (4), 2..4                        */
-    int   reserved[2];
+    int   mg_direct_max;     /* multigrid bottom kernel: the first level whose sides are both at most this many unknowns is solved
+                                directly (fast diagonalisation); the LDS-resident levels above it cycle.  0 = default
+                                (SC_MG_DIRECT_MAX_DEFAULT); at most 128.  Same fixed point, slightly different iterates        */
+    int   reserved[1];
 } sc_solver_opts;
+#define SC_MG_DIRECT_MAX_DEFAULT 128
 
 /* ---- sc_solver_opts.flags: non-default variants of the same path, selectable per instance so one process (one
  *      test run) can drive every variant.  Unless noted a variant gives the default path's result bit for bit. */

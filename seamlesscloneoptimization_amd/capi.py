@@ -59,7 +59,7 @@ ERR_NAMES = {
 class SolverOpts(C.Structure):
     _fields_ = [("method", C.c_int), ("max_sweeps", C.c_int), ("tol", C.c_float), ("check_every", C.c_int),
                 ("omega", C.c_float), ("sweeps_per_launch", C.c_int), ("reference_warmup", C.c_int),
-                ("mg_pre", C.c_int), ("mg_post", C.c_int), ("update_tol", C.c_float), ("flags", C.c_int), ("jacobi_tile_rows", C.c_int), ("mg_level1_sweeps", C.c_int), ("reserved", C.c_int * 2)]
+                ("mg_pre", C.c_int), ("mg_post", C.c_int), ("update_tol", C.c_float), ("flags", C.c_int), ("jacobi_tile_rows", C.c_int), ("mg_level1_sweeps", C.c_int), ("mg_direct_max", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class RunInfo(C.Structure):

@@ -219,19 +219,26 @@ static int tmark(Instance *I, int k, bool empty_stage = false)
 // does not depend on the box being computed); device_clone then skips its own erode launch.
 static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int ms, const Geo *predicted = nullptr)
 {
-    I->h_rect[0] = mc - 1; I->h_rect[1] = 0; I->h_rect[2] = mr - 1; I->h_rect[3] = 0; // seamlessClone_imp.cpp:1006
-    SC_HIP(I, hipMemcpyAsync(I->d_rect, I->h_rect, 4 * sizeof(int), hipMemcpyHostToDevice, I->stream));
+    // The scan's workgroups leave their extrema as parts, the last one to finish folds them into the rectangle (seeded like the
+    // reference's, seamlessClone_imp.cpp:1006) and stores it in device memory AND in the pinned mailbox h_rect[4..7]: no seed
+    // upload and no read-back copy in the stream (each was a command of its own in front of / behind the launch).
+    int rc = ensure(I, I->d_bbox_parts, sizeof(int) * 4 * (size_t)mask_bbox_blocks(mc, mr));
+    if (rc) return rc;
+    BboxFold fold;
+    fold.parts = (int *)I->d_bbox_parts.p;
+    fold.counter = (unsigned *)(I->d_rect + 32);      // a line of its own; zero between launches (the folding workgroup resets it)
+    fold.rect_dev = I->d_rect;
+    fold.rect_host = I->h_rect + 4;
     I->erode_done = false;
     if (predicted && !(I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) {
         I->mpitch = round_up(predicted->W, 64);
-        int rc = ensure(I, I->d_M, (size_t)I->mpitch * predicted->H);
+        rc = ensure(I, I->d_M, (size_t)I->mpitch * predicted->H);
         if (rc) return rc;
-        launch_mask_stage(d_mask, mc, mr, ms, I->d_rect, *predicted, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+        launch_mask_stage(d_mask, mc, mr, ms, fold, *predicted, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
         I->erode_done = true;
     } else
-    launch_mask_bbox(d_mask, mc, mr, ms, I->d_rect, I->stream);
+    launch_mask_bbox(d_mask, mc, mr, ms, fold, I->stream);
     SC_HIP(I, hipGetLastError());
-    SC_HIP(I, hipMemcpyAsync(I->h_rect + 4, I->d_rect, 4 * sizeof(int), hipMemcpyDeviceToHost, I->stream));
     return tmark(I, 2);
 }
 
@@ -408,7 +415,8 @@ void *my_seamlessclone_api_imp_create_instance(int gpu_id)
     ok = ok && hipEventCreateWithFlags(&I->ev_fd, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_rect, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_red, 2 * sizeof(double), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipMalloc((void **)&I->d_rect, 4 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&I->d_rect, 64 * sizeof(int)) == hipSuccess;       // the rectangle; word 32: the scan's arrival counter
+    ok = ok && hipMemset(I->d_rect, 0, 64 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_partials, 2 * sizeof(double) * residual_max_blocks()) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_red, 2 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_maxcorr, 4 * sizeof(unsigned)) == hipSuccess;
@@ -507,7 +515,8 @@ int sc_hip_set_solver(void *p, const sc_solver_opts *o)
         I->err = "mg_level1_sweeps must be 0 or 2..4";
         return SC_ERR_BAD_ARG;
     }
-    if ((o->flags ^ I->opts.flags) & SC_FLAG_VCYCLE_BOTTOM) I->mg.clear();   // the hierarchy (direct bottom solve or not) depends on this flag only
+    if (((o->flags ^ I->opts.flags) & SC_FLAG_VCYCLE_BOTTOM) || o->mg_direct_max != I->opts.mg_direct_max) I->mg.clear();   // the hierarchy (which bottom level is solved directly) depends on these only
+    if (o->mg_direct_max < 0) { I->err = "mg_direct_max must be >= 0"; return SC_ERR_BAD_ARG; }
     I->opts = *o;
     return SC_OK;
 }

@@ -48,14 +48,18 @@ struct ImageJob { const uint8_t *face_org; int fstep; uint8_t *body_org; int bst
 struct ImageJobs { enum { MAX = 16 }; ImageJob j[MAX]; };
 
 // ---------------------------------------------------------------- kernel launchers (sc_kernels.hip)
-void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s);
+// single-mask bounding box: per-workgroup parts folded by the last workgroup to arrive (sc_kernels.hip, mask_bbox_block);
+// nbx / nblocks are filled in by the launchers
+struct BboxFold { int *parts = nullptr; unsigned *counter = nullptr; int *rect_dev = nullptr; int *rect_host = nullptr; int nbx = 0, nblocks = 0; };
+int  mask_bbox_blocks(int mw, int mh);                               // workgroups of the scan = parts (4 ints each) it needs
+void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, BboxFold fold, hipStream_t s);
 void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, uint8_t *M, int mpitch, hipStream_t s);
 void launch_mask_erode_min7(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int mpitch, hipStream_t s);   // OpenCV's grey-mask erode (SC_FLAG_OPENCV_GREY_MASK)
 size_t mask_bbox_group_parts(const MaskJob *jobs, int n);            // ints of scratch the group scan needs (one set of extrema per workgroup)
 void launch_mask_bbox_group(const MaskJob *jobs, int n, hipStream_t s, int *parts);
 void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s);
 // bounding box of the whole mask + erode of the (predicted) ROI g in one launch
-void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, Geo g, uint8_t *M, int mpitch, hipStream_t s);
+void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, BboxFold fold, Geo g, uint8_t *M, int mpitch, hipStream_t s);
 // body_org: pointer to the pixel that corresponds to ROI (0,0); face_org likewise (patch + offset)
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false, bool grey = false);
@@ -64,7 +68,9 @@ struct RectGuard { const int *d_rect = nullptr; int x0 = 0, x1 = 0, y0 = 0, y1 =
 // "Do not write": a device word the launches of one solve may set to that solve's generation number (a 16-bit fixed-point store
 // of the field saturated, k_cycle0 TAG bit 9); the output launches of the same solve then write nothing and the host repeats
 // the clone on float fields.  A generation instead of a flag: nothing has to be reset between solves.  p == nullptr: none.
-struct AbortFlag { unsigned *p = nullptr; unsigned gen = 0; };
+// `host`: a second copy of the word in pinned host memory, for the host to read without a copy command (the device copy is the
+// one the output launches test: a million threads polling a word across PCIe made the splice 170 times slower).
+struct AbortFlag { unsigned *p = nullptr; unsigned gen = 0; unsigned *host = nullptr; };
 #if defined(__HIPCC__)
 __device__ __forceinline__ bool abort_set(const AbortFlag &a) { return a.p && *reinterpret_cast<const volatile unsigned *>(a.p) == a.gen; }
 #endif

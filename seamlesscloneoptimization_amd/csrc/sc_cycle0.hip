@@ -668,7 +668,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             *reinterpret_cast<uint2 *>(outq + (size_t)y * P + x) = pk;
         }
         const int seen = s0 | (x + 1 < W ? s1 : 0) | (x + 2 < W ? s2 : 0) | (x + 3 < W ? s3 : 0);
-        if ((seen & ~0xffff) && sat.p) *sat.p = sat.gen;       // rare; every writer stores the same word
+        if ((seen & ~0xffff) && sat.p) { *sat.p = sat.gen; if (sat.host) *sat.host = sat.gen; }       // rare; every writer stores the same word
         return;
     }
     float *__restrict__ out = Uout.at(c);
@@ -681,16 +681,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 
 constexpr int C0_NW = 8, C0_R = 8;
 
-template <int T, bool PRO, int TAG = 0>
+template <int T, bool PRO, int TAG = 0, int NW = C0_NW>
 static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s,
                      const ComposeArgs &comp = ComposeArgs(), float4 *bands = nullptr, const LmNodes &lm = LmNodes(), const AbortFlag &sat = AbortFlag())
 {
-    constexpr int RH = C0_NW * C0_R, HY = 2 * T + 2;
+    constexpr int RH = NW * C0_R, HY = 2 * T + 2;
     const int blocks = ((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
-    hipLaunchKernelGGL((k_cycle0<T, C0_NW, C0_R, PRO, false, false, TAG>), dim3(blocks), dim3(C0_NW * 64), 0, s, Uin, Uout, F, Fc, E,
+    hipLaunchKernelGGL((k_cycle0<T, NW, C0_R, PRO, false, false, TAG>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, Fc, E,
                        g, partial, comp, bands, lm, sat);
     return blocks;
 }
+
+// (Round 4, measured and not kept: sixteen-wave workgroups -- 128-row windows, one per CU -- for a single clone's two-sweep level-0
+// launches, 486 workgroups on 256 slots instead of 1080 on 512: 30.6 us against 29.0.  The launch is not paced by rounds of
+// workgroup slots; level 1's launch is, see launch_cycle_coarse.)
 
 // Level-0 launch whose prolongation source is composed on the fly: U1 = level-1 correction after its pre-smoothing (level 1
 // has no post-smoothing and no prolongation launch of its own), E2 = finished level-2 correction, g1 = level-1 geometry.
@@ -819,14 +823,21 @@ int cycle0_blocks(int W, int H, int C, int sweeps)
 
 // Coarse levels (l >= 1): pre-smoothing from a zero correction + residual + restriction in one
 // launch.  Uout receives the smoothed correction, Fc the next level's RHS.
-template <int T, int R, int TAG = 0>
+template <int T, int R, int TAG = 0, int NW = C0_NW>
 static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_t s)
 {
-    constexpr int RH = C0_NW * R, HY = 2 * T + 2;
+    constexpr int RH = NW * R, HY = 2 * T + 2;
     Field none{};
     const int blocks = ((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * F.C;
-    hipLaunchKernelGGL((k_cycle0<T, C0_NW, R, false, true, true, TAG>), dim3(blocks), dim3(C0_NW * 64), 0, s, F /*unused Uin: geometry only*/,
+    hipLaunchKernelGGL((k_cycle0<T, NW, R, false, true, true, TAG>), dim3(blocks), dim3(NW * 64), 0, s, F /*unused Uin: geometry only*/,
                        Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs(), (float4 *)nullptr, LmNodes(), AbortFlag());
+}
+
+// workgroups of a coarse-level launch with NW waves of R rows each at depth T
+static int cn_blocks(const Field &F, int T, int R, int NW)
+{
+    const int RH = NW * R, HY = 2 * T + 2;
+    return ((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * F.C;
 }
 
 // half_io: the level's own right-hand side and the correction it writes are float16 (level 1 of the composed schedule, 4 sweeps)
@@ -835,6 +846,10 @@ bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int swe
     if (half_io) {
         if (sweeps != 4) return false;
         const int R4 = tb_gen_rows_deep(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
+        // Round 4: a single clone's level 1 at 2048^2 is 555 eight-wave workgroups on 512 slots (two per CU): 43 of them make a second
+        // round and the launch takes 18 us for 10 us of work.  Sixteen-wave workgroups (96-row windows, 76 of them exact instead of
+        // 28 of 48; one per CU) need 210: one round.  Taken whenever it turns more than one round of the 8-wave form into one.
+        if (R4 == 6 && cn_blocks(F, 4, 6, 8) > 512 && cn_blocks(F, 4, 6, 16) <= 256) { launch_cn<4, 6, 128, 16>(Uout, F, Fc, g, s); return true; }
         R4 == 6 ? launch_cn<4, 6, 128>(Uout, F, Fc, g, s) : launch_cn<4, 4, 128>(Uout, F, Fc, g, s);
         return true;
     }

@@ -62,9 +62,15 @@ __device__ __forceinline__ unsigned nonzero_bytes(unsigned w)
 // part != nullptr: the workgroup leaves its four extrema there with a plain store (neutral values if it saw nothing) and touches
 // no atomic; a second, tiny launch folds them (k_mask_bbox_fold_group).  Used for groups of masks: thousands of workgroups'
 // atomics on a handful of words cost more than the scan (74 us for sixteen 2050^2 masks, 0.13 of the HBM peak) -- L2 caches
-// of different XCDs do not see one another's updates, so the "look first" test below rarely spares one.
+// of different XCDs do not see one another's updates, so a "look first" test rarely spares one.
+// fold.parts != nullptr (a single mask, round 4): the same parts, and the LAST workgroup to finish folds them -- no second launch
+// and ONE atomic per workgroup (its arrival ticket) instead of four on the same line: ~400 workgroups x 4 atomics x ~12 ns were
+// 18 of the 27 us this launch took at 2050^2.  Parts are written through (agent-scope stores) and drained before the ticket,
+// the last arriver reads them with agent-scope loads after its add has returned (MI355X_MICROARCH.md, valid forms: one lane
+// signals for its workgroup's stores, the workgroup whose add came last reads).  It writes the rectangle to device memory (the
+// output launches' RectGuard reads it there) AND straight into the host's pinned mailbox: no copy command in the stream.
 __device__ __forceinline__ void mask_bbox_block(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
-                                                int *__restrict__ rect, int bx, int by, int *__restrict__ part = nullptr)
+                                                const BboxFold &fold, int bx, int by, int *__restrict__ part = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = bx * 64 + lane;
@@ -120,31 +126,58 @@ __device__ __forceinline__ void mask_bbox_block(const uint8_t *__restrict__ mask
         }
         if (part) {
             part[0] = minx; part[1] = maxx; part[2] = miny; part[3] = maxy;
-        } else if (maxx >= 0) {
-            // Hundreds of workgroups updating the same four words cost ~12 ns per atomic, more than the scan
-            // itself.  Look first: a plain (possibly stale) read of a min word is never below its true value
-            // and of a max word never above it, so "my value would not improve what I see" safely skips the
-            // atomic; for an all-255 mask only the workgroups on the mask's border still issue one.
-            const volatile int *seen = rect;
-            if (minx < seen[0]) atomicMin(&rect[0], minx);
-            if (maxx > seen[1]) atomicMax(&rect[1], maxx);
-            if (miny < seen[2]) atomicMin(&rect[2], miny);
-            if (maxy > seen[3]) atomicMax(&rect[3], maxy);
+        } else {
+            int *mine = fold.parts + 4 * (by * fold.nbx + bx);
+            __hip_atomic_store(&mine[0], minx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&mine[1], maxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&mine[2], miny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&mine[3], maxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(fold.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            red[0][0] = (ticket == (unsigned)fold.nblocks - 1u) ? 1 : 0;       // (the waves' extrema in red[][] have been consumed above)
         }
+    }
+    if (part) return;
+    __syncthreads();
+    if (red[0][0] == 0 || wave != 0) return;
+    // the last workgroup to arrive: every part is in memory
+    minx = INT_MAX; maxx = -1; miny = INT_MAX; maxy = -1;
+    for (int i = lane; i < fold.nblocks; i += 64) {
+        const int *p = fold.parts + 4 * i;
+        minx = min(minx, __hip_atomic_load(&p[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        maxx = max(maxx, __hip_atomic_load(&p[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        miny = min(miny, __hip_atomic_load(&p[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        maxy = max(maxy, __hip_atomic_load(&p[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    minx = wave_min_i(minx); maxx = wave_max_i(maxx);
+    miny = wave_min_i(miny); maxy = wave_max_i(maxy);
+    if (lane == 0) {
+        // the reference seeds its rectangle with {W-1, 0, H-1, 0} (seamlessClone_imp.cpp:1006) and reduces into it
+        int r0 = mw - 1, r1 = 0, r2 = mh - 1, r3 = 0;
+        if (maxx >= 0) { r0 = min(r0, minx); r1 = max(r1, maxx); r2 = min(r2, miny); r3 = max(r3, maxy); }
+        fold.rect_dev[0] = r0; fold.rect_dev[1] = r1; fold.rect_dev[2] = r2; fold.rect_dev[3] = r3;
+        fold.rect_host[0] = r0; fold.rect_host[1] = r1; fold.rect_host[2] = r2; fold.rect_host[3] = r3;
+        *fold.counter = 0u;                        // ready for the next launch (ordered behind this one)
     }
 }
 
-__global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
-                                                   int *__restrict__ rect)
+__global__ __launch_bounds__(256) void k_mask_bbox(const uint8_t *__restrict__ mask, int mw, int mh, int mstep, BboxFold fold)
 {
-    mask_bbox_block(mask, mw, mh, mstep, rect, blockIdx.x, blockIdx.y);
+    mask_bbox_block(mask, mw, mh, mstep, fold, blockIdx.x, blockIdx.y);
 }
 
-void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, hipStream_t s)
+int mask_bbox_blocks(int mw, int mh)
 {
     const int chunks = (mw + 15 + 15) / 16;   // +15: a row may start up to 15 bytes into its first chunk
+    return ((chunks + 63) / 64) * ((mh + 4 * BB_ROWS - 1) / (4 * BB_ROWS));
+}
+
+void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, BboxFold fold, hipStream_t s)
+{
+    const int chunks = (mw + 15 + 15) / 16;
     dim3 grid((chunks + 63) / 64, (mh + 4 * BB_ROWS - 1) / (4 * BB_ROWS));
-    hipLaunchKernelGGL(k_mask_bbox, grid, dim3(256), 0, s, mask, mw, mh, mstep, d_rect);
+    fold.nbx = (int)grid.x; fold.nblocks = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL(k_mask_bbox, grid, dim3(256), 0, s, mask, mw, mh, mstep, fold);
 }
 
 // Crop to the bounding box + three 3x3 erodes (seamlessClone_imp.cpp:1052-1062, kernel
@@ -271,21 +304,22 @@ void launch_mask_erode_min7(const uint8_t *mask, int mstep, Geo g, uint8_t *M, i
 // predicted ROI does not wait for the bounding box the same launch computes.  1-D grid; a workgroup does its share
 // of the scan (if it has one) and then its erode strip (if it has one) -- the two are independent.
 __global__ __launch_bounds__(256) void k_mask_stage(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
-                                                    int *__restrict__ rect, int bb_nx, int bb_n, size_t mask_bytes, Geo g,
+                                                    BboxFold fold, int bb_nx, int bb_n, size_t mask_bytes, Geo g,
                                                     uint8_t *__restrict__ M, int mpitch, int er_nx, int er_n)
 {
     const int b = blockIdx.x;
-    if (b < bb_n) mask_bbox_block(mask, mw, mh, mstep, rect, b % bb_nx, b / bb_nx);     // block-uniform branch (it has a barrier)
+    if (b < bb_n) mask_bbox_block(mask, mw, mh, mstep, fold, b % bb_nx, b / bb_nx);     // block-uniform branch (it has barriers)
     if (b < er_n) mask_erode3_block(mask, mstep, mask_bytes, g, M, mpitch, b % er_nx, b / er_nx);
 }
 
-void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, int *d_rect, Geo g, uint8_t *M, int mpitch, hipStream_t s)
+void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, BboxFold fold, Geo g, uint8_t *M, int mpitch, hipStream_t s)
 {
     const int chunks = (mw + 15 + 15) / 16;
     const int bb_nx = (chunks + 63) / 64, bb_n = bb_nx * ((mh + 4 * BB_ROWS - 1) / (4 * BB_ROWS));
     const int er_nx = ((g.W + 3) / 4 + 63) / 64, er_n = er_nx * ((g.H + 4 * ER_STRIP - 1) / (4 * ER_STRIP));
     const size_t bytes = (size_t)mstep * (mh - 1) + (size_t)(g.x0 + g.W + 1);
-    hipLaunchKernelGGL(k_mask_stage, dim3(std::max(bb_n, er_n)), dim3(256), 0, s, mask, mw, mh, mstep, d_rect, bb_nx, bb_n, bytes, g,
+    fold.nbx = bb_nx; fold.nblocks = bb_n;
+    hipLaunchKernelGGL(k_mask_stage, dim3(std::max(bb_n, er_n)), dim3(256), 0, s, mask, mw, mh, mstep, fold, bb_nx, bb_n, bytes, g,
                        M, mpitch, er_nx, er_n);
 }
 
@@ -301,7 +335,7 @@ __global__ __launch_bounds__(256) void k_mask_bbox_group(MaskJobs t, int *__rest
         if (threadIdx.x == 0) { part[0] = INT_MAX; part[1] = -1; part[2] = INT_MAX; part[3] = -1; }
         return;
     }
-    mask_bbox_block(j.mask, j.mw, j.mh, j.mstep, j.rect, blockIdx.x, blockIdx.y, part);
+    mask_bbox_block(j.mask, j.mw, j.mh, j.mstep, BboxFold(), blockIdx.x, blockIdx.y, part);
 }
 
 // one workgroup per mask: extrema of its `per` workgroup parts, combined with the host's seeds in the rectangle

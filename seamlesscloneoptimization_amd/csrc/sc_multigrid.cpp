@@ -185,7 +185,8 @@ static int build_fd(Instance *I)
         const MGLevel &L = I->mg[l];
         planes += bottom_floats(L);
         const int nx = L.g.x.n, ny = L.g.y.n, nxp = round_up(nx, 4), nyp = round_up(ny, 4);
-        if (nx > 128 || ny > 128) continue;
+        const int dmax = I->opts.mg_direct_max > 0 ? std::min(I->opts.mg_direct_max, 128) : SC_MG_DIRECT_MAX_DEFAULT;
+        if (nx > dmax || ny > dmax) continue;
         if ((planes + fd_lds_floats(nxp, nyp)) * (long)sizeof(float) > (long)MG_BOTTOM_LDS_BYTES) continue;
         const long nf = fd_mat_floats(nxp, nyp);
         int rc;
@@ -520,8 +521,18 @@ int mg_solve(Instance *I)
         // The 16-bit stores check their range (sc_cycle0.hip, c0_q16_checked): one that saturates writes this solve's generation
         // word behind the partial maxima; the output launches then write nothing, the read-back of the maxima brings the word
         // along, and the clone is repeated on float fields (SC_RETRY_FLOAT_FIELD).  A NaN pattern: no maximum ever has these bits.
+        // Up to 16384 workgroups (single clones, small groups) the host folds the per-workgroup maxima itself -- and the launches
+        // store them (and the saturation word) STRAIGHT INTO PINNED HOST MEMORY: no read-back copy behind the judged cycle (a
+        // command of its own on the critical path, ~4 us + its gap).  Larger grids fold on the device first.
+        const bool host_fold = nb_cap <= 16384;
+        if (host_fold && (rc = ensure_pinned(I, I->h_partial, sizeof(float) * (2 * (size_t)nb_cap + 64)))) return rc;
+        float *const part_base = host_fold ? (float *)I->h_partial.p : (float *)I->mg_partial.p;
         AbortFlag sat;
-        if (q16) { sat.p = (unsigned *)((float *)I->mg_partial.p + 2 * (size_t)nb_cap); sat.gen = 0x7fc00000u | (++I->sat_counter & 0x3fffffu); }
+        if (q16) {      // the device word sits behind the device list of maxima (the output launches test it there), its host copy behind the pinned one
+            sat.p = (unsigned *)((float *)I->mg_partial.p + 2 * (size_t)nb_cap);
+            sat.host = host_fold ? (unsigned *)((float *)I->h_partial.p + 2 * (size_t)nb_cap) : nullptr;
+            sat.gen = 0x7fc00000u | (++I->sat_counter & 0x3fffffu);
+        }
         I->sat = sat;
         // on the float16 path the pre-process stored the initial field as float16 as well (first launch only)
         if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
@@ -546,25 +557,18 @@ int mg_solve(Instance *I)
             return m <= utol;
         };
         // max |correction| of the cycle just launched = max over its per-workgroup maxima (at part_now; `cyc` already counts the
-        // cycle), and of the cycle before when its maxima are at hand.  A few thousand maxima are folded here on the host (the
-        // read-back is needed anyway and a reduction launch costs ~5 us of GPU time) -- both cycles' halves in ONE copy, a second
-        // small D2H costs ~5 us on the critical path; large grids (groups of clones) reduce both lists on the device first (one
-        // launch).  m_prev < 0: unknown.  `output` (the splice or post-process of the result, or nothing) is enqueued between the launch
+        // cycle), and of the cycle before when its maxima are at hand.  A few thousand maxima are folded here on the host, out of
+        // the pinned buffer the launches wrote them to (host_fold); large grids (groups of clones) reduce both lists on the device
+        // first (one launch) and copy three words.  m_prev < 0: unknown.  `output` (the splice or post-process of the result, or nothing) is enqueued between the launch
         // and the read-back: it then starts without a gap while the host waits.
         bool saturated = false;            // set by correction_maxima: a 16-bit store of this solve left its range
         auto correction_maxima = [&](int nb, int nb_prev, int nb_cap, float *part_now, const std::function<int()> &output, float &m, float &m_prev) -> int {
             m = 0.f; m_prev = -1.f;
             int orc;
-            if (nb <= 16384) {
-                const bool have_prev = nb_prev > 0 && nb_prev <= 16384;   // the launch of the previous cycle wrote the other half
-                if ((orc = ensure_pinned(I, I->h_partial, sizeof(float) * (2 * (size_t)nb_cap + 64)))) return orc;
+            if (host_fold) {
+                const bool have_prev = nb_prev > 0;                       // the launch of the previous cycle wrote the other half
                 if ((orc = output())) return orc;
-                // both halves and, when this solve stored 16-bit fields, the saturation word right behind them: ONE copy
-                SC_HIP(I, hipMemcpyAsync(I->h_partial.p, I->mg_partial.p, sizeof(float) * (size_t)(have_prev ? 2 * nb_cap + (sat.p ? 1 : 0) : ((cyc & 1) * nb_cap + nb)),
-                                         hipMemcpyDeviceToHost, I->stream));
-                if (sat.p && !have_prev)
-                    SC_HIP(I, hipMemcpyAsync((float *)I->h_partial.p + 2 * (size_t)nb_cap, sat.p, sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
-                SC_HIP(I, hipStreamSynchronize(I->stream));
+                SC_HIP(I, hipStreamSynchronize(I->stream));               // the maxima are in the pinned buffer when the launch has ended
                 if (sat.p) { unsigned w; memcpy(&w, (const float *)I->h_partial.p + 2 * (size_t)nb_cap, sizeof(w)); saturated = w == sat.gen; }
                 const float *hp = (const float *)I->h_partial.p + (size_t)(cyc & 1) * nb_cap;            // this cycle's half
                 const float *hq = (const float *)I->h_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;      // the previous cycle's
@@ -574,7 +578,7 @@ int mg_solve(Instance *I)
                     for (int i = 0; i < nb_prev; ++i) m_prev = hq[i] > m_prev ? hq[i] : m_prev;
                 }
             } else {
-                const float *part_prev = (const float *)I->mg_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;
+                const float *part_prev = part_base + (size_t)((cyc + 1) & 1) * nb_cap;
                 launch_max_final2(part_now, nb, part_prev, nb_prev > 0 ? nb_prev : 0, I->d_maxcorr, I->stream, sat.p);
                 if ((orc = output())) return orc;
                 SC_HIP(I, hipMemcpyAsync(I->h_maxcorr, I->d_maxcorr, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, I->stream));
@@ -594,7 +598,7 @@ int mg_solve(Instance *I)
             // initial guess was already the answer, and every check costs a host round trip
             // (~25 us), so checking starts with the third cycle.
             const bool judged = !(cyc + 1 < 3 && cyc + 1 < budget && o.tol <= 0.f);
-            float *const part_now = (float *)I->mg_partial.p + (size_t)((cyc + 1) & 1) * nb_cap;    // this cycle's maxima; the previous cycle's sit in the other half
+            float *const part_now = part_base + (size_t)((cyc + 1) & 1) * nb_cap;    // this cycle's maxima; the previous cycle's sit in the other half
             // the judged cycle runs in its final form; when the float-table correction will follow it leaves the correction's
             // cell shares behind (sc_lowmode.hip), which saves the correction its own pass over the field
             const bool next_judged = !judged && !(cyc + 2 < 3 && cyc + 2 < budget && o.tol <= 0.f);

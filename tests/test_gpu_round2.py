@@ -467,7 +467,9 @@ def test_output_and_restriction_variants_agree(hip, oracles, W, H):
         s = compare.image_diff_stats(out[a], out[b])
         assert s["max"] <= 1 and s["percent"] < 0.02, (a, b, compare.format_stats(s))
     s = compare.image_diff_stats(out[0], out[FF])           # the 16-bit stores' roundings, two cycles later: ~1e-4 grey levels
-    assert s["max"] <= 1 and s["percent"] < 0.03, compare.format_stats(s)
+    # (a count of channels that sit within ~1e-4 of an integer: 0.029-0.031 % at 2048^2 depending on the last bits of the bottom
+    #  solver's matrices -- host QL in round 3, closed form on the device since round 4)
+    assert s["max"] <= 1 and s["percent"] < 0.05, compare.format_stats(s)
     for flags, body in out.items():
         s = compare.image_diff_stats(want, body)
         assert s["max"] <= 1 and s["percent"] < 0.5, (flags, compare.format_stats(s))
