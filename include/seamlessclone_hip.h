@@ -184,6 +184,12 @@ typedef struct sc_solver_opts {
                                             un-instrumented device time of the clone and the per-stage figures read 0 (all of it is booked
                                             under ms_post).  Results are unaffected                                              */
 
+#define SC_FLAG_BOTTOM_F32     (1 << 13) /* multigrid: the bottom kernel's direct solve as float32 SIMD inner products with every operand
+                                            staged in LDS (k_mg_bottom, rounds 1-3).  Default since round 4 where the bottom's first level
+                                            has at most 96 unknowns per side: four products on the matrix cores in float32
+                                            (v_mfma_f32_32x32x2_f32, operands straight from memory into registers: k_mg_bottom_mm).
+                                            Same arithmetic up to the order of the additions                                       */
+
 /* ---- statistics of the last run */
 typedef struct sc_run_info {
     int    x0, y0, W, H, ltx, lty;  /* patch offset, ROI size (ring included), ROI origin in body */

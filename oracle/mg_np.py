@@ -147,15 +147,20 @@ def bottom_start(levels) -> int:
     return len(levels)
 
 
-def direct_level(levels):
-    """Index of the level solved exactly (fast diagonalisation in LDS), or None."""
+def direct_level(levels, matrix_cores=True):
+    """Index of the level solved exactly (fast diagonalisation), or None.  matrix_cores (the library's default since round 4):
+    the bottom's first level is solved on the matrix cores whenever both sides have at most 96 unknowns, without an LDS budget
+    to meet (sc_multigrid.cpp build_fd, k_mg_bottom_mm); False = SC_FLAG_BOTTOM_F32, the LDS-resident float32 form."""
     planes = 0
-    for l in range(bottom_start(levels), len(levels)):
+    b = bottom_start(levels)
+    for l in range(b, len(levels)):
         dx, dy = levels[l]
         planes += _bottom_floats(dx, dy)
         nxp, nyp = (dx.n + 3) // 4 * 4, (dy.n + 3) // 4 * 4
         if dx.n > 128 or dy.n > 128:
             continue
+        if matrix_cores and l == b and dx.n <= 96 and dy.n <= 96:
+            return l
         if 4 * (planes + 2 * nxp * nxp + 2 * nyp * nyp + 3 * nxp * nyp) > MG_BOTTOM_LDS_BYTES:
             continue
         return l

@@ -49,6 +49,7 @@ SC_FLAG_OPENCV_GREY_MASK = 1 << 9
 SC_FLAG_FLOAT_L1 = 1 << 10
 SC_FLAG_FLOAT_FIELD = 1 << 11
 SC_FLAG_NO_STAGE_MARKS = 1 << 12
+SC_FLAG_BOTTOM_F32 = 1 << 13
 
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",

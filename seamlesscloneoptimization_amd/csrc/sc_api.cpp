@@ -230,12 +230,19 @@ static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int 
     fold.rect_dev = I->d_rect;
     fold.rect_host = I->h_rect + 4;
     I->erode_done = false;
+    I->scan_pending = false;
     if (predicted && !(I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) {
+        // A clone launched on a predicted box needs the scan's answer only at its end: the erode of the predicted ROI goes out
+        // alone and the scan rides in the pre-process launch behind it (device_clone, launch_preprocess) -- off the critical path.
         I->mpitch = round_up(predicted->W, 64);
         rc = ensure(I, I->d_M, (size_t)I->mpitch * predicted->H);
         if (rc) return rc;
-        launch_mask_stage(d_mask, mc, mr, ms, fold, *predicted, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+        launch_mask_erode3(d_mask, ms, mr, *predicted, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
         I->erode_done = true;
+        I->pending_scan = BboxTask();
+        I->pending_scan.mask = d_mask; I->pending_scan.mw = mc; I->pending_scan.mh = mr; I->pending_scan.mstep = ms;
+        I->pending_scan.fold = fold;
+        I->scan_pending = true;
     } else
     launch_mask_bbox(d_mask, mc, mr, ms, fold, I->stream);
     SC_HIP(I, hipGetLastError());
@@ -320,7 +327,8 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         I->f_half = mg_reads_half_rhs(I);
         I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
         launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
-                          I->stream, I->f_half, I->u_half, grey);
+                          I->stream, I->f_half, I->u_half, grey, I->scan_pending ? &I->pending_scan : nullptr);
+        I->scan_pending = false;
         if (pass == passes - 1 && (rc = tmark(I, 5))) return rc;
         I->info.sweep_launches = 0;
         I->spec_post.body_org = body_org; I->spec_post.bstep = bstep;
@@ -515,7 +523,7 @@ int sc_hip_set_solver(void *p, const sc_solver_opts *o)
         I->err = "mg_level1_sweeps must be 0 or 2..4";
         return SC_ERR_BAD_ARG;
     }
-    if (((o->flags ^ I->opts.flags) & SC_FLAG_VCYCLE_BOTTOM) || o->mg_direct_max != I->opts.mg_direct_max) I->mg.clear();   // the hierarchy (which bottom level is solved directly) depends on these only
+    if (((o->flags ^ I->opts.flags) & (SC_FLAG_VCYCLE_BOTTOM | SC_FLAG_BOTTOM_F32)) || o->mg_direct_max != I->opts.mg_direct_max) I->mg.clear();   // the hierarchy (which bottom level is solved directly) depends on these only
     if (o->mg_direct_max < 0) { I->err = "mg_direct_max must be >= 0"; return SC_ERR_BAD_ARG; }
     I->opts = *o;
     return SC_OK;
@@ -662,8 +670,8 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p, dfs,
                          (uint8_t *)I->d_body_roi.p, dfs, g, passes);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
-        if (guess) {      // the rectangle's read-back (recorded as ev[2]) finished long ago: this wait is free
-            SC_HIP(I, hipEventSynchronize(I->ev[2]));
+        if (guess) {      // the scan rode in the pre-process launch (mark 5 is recorded behind it) and finished long ago: this wait is free
+            SC_HIP(I, hipEventSynchronize(I->ev[5]));
             if (memcmp(guess, I->h_rect + 4, 4 * sizeof(int)) != 0) return SC_GUESS_WRONG;
         }
         // Interior back into the caller's image: linear D2H pieces of the compact ROI buffer into pinned staging

@@ -58,11 +58,12 @@ void launch_mask_erode_min7(const uint8_t *mask, int mstep, Geo g, uint8_t *M, i
 size_t mask_bbox_group_parts(const MaskJob *jobs, int n);            // ints of scratch the group scan needs (one set of extrema per workgroup)
 void launch_mask_bbox_group(const MaskJob *jobs, int n, hipStream_t s, int *parts);
 void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s);
-// bounding box of the whole mask + erode of the (predicted) ROI g in one launch
-void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, BboxFold fold, Geo g, uint8_t *M, int mpitch, hipStream_t s);
 // body_org: pointer to the pixel that corresponds to ROI (0,0); face_org likewise (patch + offset)
+// scan: the clone's bounding-box scan rides in this launch as extra workgroups (fold.nbx / nblocks / scan_rows are filled in here)
+struct BboxTask { const uint8_t *mask = nullptr; int mw = 0, mh = 0, mstep = 0; BboxFold fold; int scan_rows = 0; };
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
-                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false, bool grey = false);
+                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false, bool grey = false,
+                       const BboxTask *scan = nullptr);
 // bounding box the host assumed when it launched a clone before the device's answer was back (d_rect == nullptr: none)
 struct RectGuard { const int *d_rect = nullptr; int x0 = 0, x1 = 0, y0 = 0, y1 = 0; };
 // "Do not write": a device word the launches of one solve may set to that solve's generation number (a 16-bit fixed-point store
@@ -208,7 +209,12 @@ __host__ __device__ static inline long fd_lds_floats(int nxp, int nyp) { return 
 hipError_t mg_bottom_prepare();
 // per-size state built on the device (sc_mg_kernels.hip): the direct solve's matrices from the closed-form eigenpairs of the
 // level's two 1-D operators (nx, ny <= 128), and the zeroing of every plane of the levels >= 1 in one launch
-void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s);
+// mm != nullptr: also the operands of the matrix-core form (k_mg_bottom_mm), padded to NPX / NPY (32, 64 or 96)
+void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s, unsigned char *mm = nullptr, int NPX = 0, int NPY = 0);
+__host__ __device__ static inline long fd_mm_bytes(int NPX, int NPY) { return 4L * (2L * NPX * NPX + 2L * NPY * NPY + (long)NPX * NPY); }   // AX1 | AX2 | AY1 | AY2 | Dinv, float
+// the bottom's first level solved directly on the matrix cores: right-hand side in (Ftop), correction out (Utop), nx x ny unknowns
+struct MGBottomMM { const unsigned char *mm; Field Ftop, Utop; int nx, ny; };
+bool launch_mg_bottom_mm(const MGBottomMM &a, int NPX, int NPY, int C, hipStream_t s);
 struct ZeroJobs { enum { MAX = 48 }; void *p[MAX]; size_t n16[MAX]; int count; };     // n16: 16-byte units
 void launch_zero_multi(const ZeroJobs &z, hipStream_t s);
 void launch_mg_bottom(const MGBottomArgs &a, int C, hipStream_t s);

@@ -123,7 +123,9 @@ struct Instance {
     RectGuard guard;
     int last_mc = -1, last_mr = -1, last_rect[4] = { 0, 0, 0, 0 };
     int spec_cooldown = 0;
-    bool erode_done = false;   // the fused mask-stage launch already eroded the ROI device_clone is about to process
+    bool erode_done = false;   // the ROI device_clone is about to process has been eroded already (a clone launched on a predicted box)
+    BboxTask pending_scan;     // ... and its bounding-box scan has not gone out yet: it rides in the pre-process launch
+    bool scan_pending = false;
     bool bench_tag = false;   // sc_hip_field_time_sweeps: launch the second-symbol instantiations
     // multigrid hierarchy (level 0 aliases U0/U1/F)
     std::vector<DevBuf> mg_bufs;
@@ -135,6 +137,9 @@ struct Instance {
     // direct (fast-diagonalisation) solve inside the bottom kernel: level index relative to mg_bottom, or -1
     int fd_level = -1, fd_nxp = 0, fd_nyp = 0;
     DevBuf mg_fd;          // its matrices (built on the device, k_fd_build)
+    bool fd_mm = false;    // ... the matrix-core form serves it (k_mg_bottom_mm): operands at float offset fd_mm_off, padded to fd_npx x fd_npy
+    int fd_npx = 0, fd_npy = 0;
+    size_t fd_mm_off = 0;
     hipEvent_t ev_fd_fork = nullptr, ev_fd = nullptr;   // the build runs on `aux`: started behind ev_fd_fork, finished at ev_fd
     bool fd_pending = false;                            // ... and `stream` has not waited for ev_fd yet
     LowMode lm;

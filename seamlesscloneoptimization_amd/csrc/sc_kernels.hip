@@ -191,7 +191,7 @@ void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, BboxFold f
 // v_alignbyte, the ROI origin has arbitrary byte alignment), turns them into "== 255" flag bytes,
 // ANDs the seven byte-shifted views (horizontal 7-window for all four pixels at once) and keeps the
 // last seven such words in registers for the vertical AND.
-constexpr int ER_STRIP = 16;
+constexpr int ER_STRIP = 8;        // rows per lane (+ 6 halo rows): 16 made a 2048^2 erode 264 workgroups of 22 dependent-ish row loads each, 12.9 us
 
 __device__ __forceinline__ unsigned is255_flags(unsigned w)   // 0x80 in every byte that equals 255
 {
@@ -298,29 +298,6 @@ __global__ __launch_bounds__(256) void k_mask_erode_min7(const uint8_t *__restri
 void launch_mask_erode_min7(const uint8_t *mask, int mstep, Geo g, uint8_t *M, int mpitch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_mask_erode_min7, dim3((g.W + 63) / 64, (g.H + 15) / 16), dim3(256), 0, s, mask, mstep, g, M, mpitch);
-}
-
-// Whole mask stage in one launch, for a clone launched on a PREDICTED bounding box (sc_api.cpp): the erode of the
-// predicted ROI does not wait for the bounding box the same launch computes.  1-D grid; a workgroup does its share
-// of the scan (if it has one) and then its erode strip (if it has one) -- the two are independent.
-__global__ __launch_bounds__(256) void k_mask_stage(const uint8_t *__restrict__ mask, int mw, int mh, int mstep,
-                                                    BboxFold fold, int bb_nx, int bb_n, size_t mask_bytes, Geo g,
-                                                    uint8_t *__restrict__ M, int mpitch, int er_nx, int er_n)
-{
-    const int b = blockIdx.x;
-    if (b < bb_n) mask_bbox_block(mask, mw, mh, mstep, fold, b % bb_nx, b / bb_nx);     // block-uniform branch (it has barriers)
-    if (b < er_n) mask_erode3_block(mask, mstep, mask_bytes, g, M, mpitch, b % er_nx, b / er_nx);
-}
-
-void launch_mask_stage(const uint8_t *mask, int mw, int mh, int mstep, BboxFold fold, Geo g, uint8_t *M, int mpitch, hipStream_t s)
-{
-    const int chunks = (mw + 15 + 15) / 16;
-    const int bb_nx = (chunks + 63) / 64, bb_n = bb_nx * ((mh + 4 * BB_ROWS - 1) / (4 * BB_ROWS));
-    const int er_nx = ((g.W + 3) / 4 + 63) / 64, er_n = er_nx * ((g.H + 4 * ER_STRIP - 1) / (4 * ER_STRIP));
-    const size_t bytes = (size_t)mstep * (mh - 1) + (size_t)(g.x0 + g.W + 1);
-    fold.nbx = bb_nx; fold.nblocks = bb_n;
-    hipLaunchKernelGGL(k_mask_stage, dim3(std::max(bb_n, er_n)), dim3(256), 0, s, mask, mw, mh, mstep, fold, bb_nx, bb_n, bytes, g,
-                       M, mpitch, er_nx, er_n);
 }
 
 // The mask stage of a GROUP of clones (sc_hip_run_device_batch): both kernels are latency bound (a few hundred
@@ -499,12 +476,12 @@ template <bool HF, bool HU, bool GREY = false>
 __device__ __forceinline__ void preprocess_block(const uint8_t *__restrict__ body, int bstep,
                                                  const uint8_t *__restrict__ face, int fstep,
                                                  const uint8_t *__restrict__ M, int mpitch,
-                                                 const Field &U0, const Field &F, int c0)
+                                                 const Field &U0, const Field &F, int c0, int by)
 {
     __shared__ __attribute__((aligned(16))) unsigned sb[P4_TH + 2][P4_ROWD], sp[P4_TH + 2][P4_ROWD];
     __shared__ int ob[P4_TH + 2], op[P4_TH + 2];
     const int W = U0.W, H = U0.H;
-    const int tx0 = blockIdx.x * P4_TW, ty0 = blockIdx.y * P4_TH;
+    const int tx0 = blockIdx.x * P4_TW, ty0 = by * P4_TH;
     p4_stage(body, bstep, W, H, tx0, ty0, sb, ob);
     p4_stage(face, fstep, W, H, tx0, ty0, sp, op);
     __syncthreads();
@@ -588,13 +565,22 @@ __device__ __forceinline__ void preprocess_block(const uint8_t *__restrict__ bod
 }
 #undef P4_BYTE
 
-template <bool HF, bool HU, bool GREY = false>
+// BB: the launch also carries the bounding-box scan of the clone's mask, as extra rows of workgroups in front of the tile rows (round
+// 4).  A clone launched on a PREDICTED box needs the scan's answer only at its very end (the output launches' RectGuard, the
+// host's comparison), so the scan has no business on the critical path in front of the erode: it rides in this launch, which
+// depends on nothing the scan produces.  mask_bbox_block's last workgroup folds the parts as before.
+template <bool HF, bool HU, bool GREY = false, bool BB = false>
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ body, int bstep,
                                                      const uint8_t *__restrict__ face, int fstep,
                                                      const uint8_t *__restrict__ M, int mpitch,
-                                                     Field U0, Field U1, Field F)
+                                                     Field U0, Field U1, Field F, BboxTask bb)
 {
-    preprocess_block<HF, HU, GREY>(body, bstep, face, fstep, M, mpitch, U0, F, 0);
+    if (BB && (int)blockIdx.y < bb.scan_rows) {          // block-uniform; the scan's workgroups come FIRST: its ticket / fold chain is over long before the tiles are
+        const int b = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        if (b < bb.fold.nblocks) mask_bbox_block(bb.mask, bb.mw, bb.mh, bb.mstep, bb.fold, b % bb.fold.nbx, b / bb.fold.nbx);
+        return;
+    }
+    preprocess_block<HF, HU, GREY>(body, bstep, face, fstep, M, mpitch, U0, F, 0, (int)blockIdx.y - (BB ? bb.scan_rows : 0));
 }
 
 // a group of clones in one launch: blockIdx.z = member, which owns channels 3z..3z+2 of the group's fields
@@ -602,7 +588,7 @@ template <bool HF, bool HU>
 __global__ __launch_bounds__(256) void k_preprocess_group(ImageJobs t, int mpitch, Field U0, Field F)
 {
     const ImageJob &j = t.j[blockIdx.z];
-    preprocess_block<HF, HU>(j.body_org, j.bstep, j.face_org, j.fstep, j.M, mpitch, U0, F, 3 * blockIdx.z);
+    preprocess_block<HF, HU>(j.body_org, j.bstep, j.face_org, j.fstep, j.M, mpitch, U0, F, 3 * blockIdx.z, (int)blockIdx.y);
 }
 
 void launch_preprocess_group(const ImageJob *jobs, int n, int mpitch, Field U0, Field F, hipStream_t s, bool f_half, bool u_half)
@@ -622,13 +608,27 @@ void launch_preprocess_group(const ImageJob *jobs, int n, int mpitch, Field U0, 
 }
 
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
-                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half, bool u_half, bool grey)
+                       const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half, bool u_half, bool grey,
+                       const BboxTask *scan)
 {
     dim3 g4((U0.W + P4_TW - 1) / P4_TW, (U0.H + P4_TH - 1) / P4_TH);
-    if (grey) hipLaunchKernelGGL((k_preprocess<false, false, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
-    else if (f_half && u_half) hipLaunchKernelGGL((k_preprocess<true, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
-    else if (f_half) hipLaunchKernelGGL((k_preprocess<true, false>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
-    else hipLaunchKernelGGL((k_preprocess<false, false>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F);
+    BboxTask bb{};
+    if (scan && !grey) {                       // the mask's bounding-box scan as extra rows of workgroups
+        bb = *scan;
+        const int chunks = (bb.mw + 15 + 15) / 16;
+        bb.fold.nbx = (chunks + 63) / 64;
+        bb.fold.nblocks = bb.fold.nbx * ((bb.mh + 4 * BB_ROWS - 1) / (4 * BB_ROWS));
+        bb.scan_rows = (bb.fold.nblocks + (int)g4.x - 1) / (int)g4.x;
+        g4.y += (unsigned)bb.scan_rows;
+        if (f_half && u_half) hipLaunchKernelGGL((k_preprocess<true, true, false, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F, bb);
+        else if (f_half) hipLaunchKernelGGL((k_preprocess<true, false, false, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F, bb);
+        else hipLaunchKernelGGL((k_preprocess<false, false, false, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F, bb);
+        return;
+    }
+    if (grey) hipLaunchKernelGGL((k_preprocess<false, false, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F, bb);
+    else if (f_half && u_half) hipLaunchKernelGGL((k_preprocess<true, true>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F, bb);
+    else if (f_half) hipLaunchKernelGGL((k_preprocess<true, false>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F, bb);
+    else hipLaunchKernelGGL((k_preprocess<false, false>), g4, dim3(256), 0, s, body_org, bstep, face_org, fstep, M, mpitch, U0, U1, F, bb);
 }
 
 // Device-to-device refresh of the destinations of a group of clones (sc_batch_job.body_restore) in ONE launch: sixteen separate

@@ -34,7 +34,11 @@ void launch_zero_multi(const ZeroJobs &z, hipStream_t s)
 // from the closed-form eigenpairs of the two 1-D level operators (sc_fd_closed.h): one thread per eigenvalue (50 bisection
 // steps), then every thread fills its share of the ~5 n^2 entries with one double sine each.  ~15 us on one CU, once per new
 // ROI size, on the instance's second stream beside the first launches of the clone that needs it.
-__global__ __launch_bounds__(1024) void k_fd_build(float *__restrict__ m, int nx, int ny, int nxp, int nyp, float cwx, float dx, float cwy, float dy)
+// mm != nullptr: additionally the same four matrices as the operands of k_mg_bottom_mm (below), each row-major float
+// [NP][NP] with NP = 32, 64 or 96 (zero padded), in the orientation the product that uses it reads row by row:
+//     AX1[i][x] = Vx^-1[i][x]   AX2[x][i] = Vx[x][i]   AY1[j][y] = Vy^-1[j][y]   AY2[y][j] = Vy[y][j]   Dinv[j][i].
+__global__ __launch_bounds__(1024) void k_fd_build(float *__restrict__ m, int nx, int ny, int nxp, int nyp, float cwx, float dx, float cwy, float dy,
+                                                   unsigned char *__restrict__ mm, int NPX, int NPY)
 {
     __shared__ FdPair px[128], py[128];
     const int t = threadIdx.x;
@@ -62,11 +66,35 @@ __global__ __launch_bounds__(1024) void k_fd_build(float *__restrict__ m, int nx
         }
         m[e] = v;
     }
+    if (!mm) return;
+    const int ex = NPX * NPX, ey = NPY * NPY;
+    float *ax1 = reinterpret_cast<float *>(mm), *ax2 = ax1 + ex, *ay1 = ax2 + ex, *ay2 = ay1 + ey, *dinv = ay2 + ey;
+    for (int e = t; e < 2 * ex + 2 * ey + NPX * NPY; e += 1024) {
+        if (e < 2 * ex) {                                // AX1[i][x] (e < ex) and AX2[x][i]
+            const bool second = e >= ex;
+            const int r = second ? e - ex : e, row = r / NPX, k = r - row * NPX;
+            const int i = second ? k : row, x = second ? row : k;
+            float v = 0.f;
+            if (x < nx && i < nx) v = (float)(fd_component(px[i], x + 1, nx) * px[i].inv_norm * ((!second && x == nx - 1) ? 1.0 / (double)cwx : 1.0));
+            (second ? ax2 : ax1)[r] = v;
+        } else if (e < 2 * ex + 2 * ey) {                // AY1[j][y] and AY2[y][j]
+            const int q = e - 2 * ex;
+            const bool second = q >= ey;
+            const int r = second ? q - ey : q, row = r / NPY, k = r - row * NPY;
+            const int j = second ? k : row, y = second ? row : k;
+            float v = 0.f;
+            if (y < ny && j < ny) v = (float)(fd_component(py[j], y + 1, ny) * py[j].inv_norm * ((!second && y == ny - 1) ? 1.0 / (double)cwy : 1.0));
+            (second ? ay2 : ay1)[r] = v;
+        } else {
+            const int r = e - 2 * ex - 2 * ey, j = r / NPX, i = r - j * NPX;
+            dinv[r] = (j < ny && i < nx) ? (float)(1.0 / (py[j].lam + px[i].lam)) : 0.f;
+        }
+    }
 }
 
-void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s)
+void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s, unsigned char *mm, int NPX, int NPY)
 {
-    hipLaunchKernelGGL(k_fd_build, dim3(1), dim3(1024), 0, s, mats, g.x.n, g.y.n, nxp, nyp, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last);
+    hipLaunchKernelGGL(k_fd_build, dim3(1), dim3(1024), 0, s, mats, g.x.n, g.y.n, nxp, nyp, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last, mm, NPX, NPY);
 }
 
 // ---- general red-black half sweep (levels >= 1; ring = 0) ---------------------------------
@@ -618,6 +646,150 @@ __global__ __launch_bounds__(1024) void k_mg_bottom(MGBottomArgs a)
             if (x <= t.g.x.n) ug[(size_t)y * a.Utop.pitch + x] = u[y * t.pitch + x];
         }
     }
+}
+
+// ---- the bottom's direct solve on the matrix cores (round 4) -------------------------------------------------------------------
+// The usual case -- the bottom's FIRST level is the one solved directly (fd_level == 0), both sides at most 96 unknowns -- as four
+// products on v_mfma_f32_32x32x2_f32 (float32 in, float32 accumulate: the arithmetic of the SIMD form, to rounding order):
+//     G1 = F Vx^-T      G2 = (Vy^-1 G1) (.) Dinv      G3 = Vy G2      U = G3 Vx^T
+// k_mg_bottom's form of the same products (every operand staged in LDS, 2 x 4 register tiles on 1024 threads) took 16-17 us per
+// launch for one 63 x 63 level: 8 us of staging for 80 KB of matrices, then 4 x 2.5 us of LDS-bound inner products (DESIGN
+// appendix A, round 3; its float32-MFMA attempt kept that staging and layout and gained nothing).  Here the matrices never touch
+// LDS: k_fd_build wrote them row-major in the orientation each product reads, one wave owns one 32 x 32 output tile (NPY / 32 x
+// NPX / 32 waves, <= 9) and loads ITS rows' halves straight into registers -- lane half h takes k in [h K/2, (h+1) K/2), which
+// makes a lane's operands of all K/2 MFMAs one contiguous run --, everything requested at kernel entry together with the
+// right-hand side.  Between products a tile passes through LDS once, written in the layout the next product reads row-wise
+// (16-byte stores of four consecutive k as the next B operand; 4-byte stores as the last product's A operand), rows padded by
+// 16 bytes against bank conflicts.  (A split-bf16 form -- three MFMAs per product at 16 times the rate -- was measured first:
+// 2 us faster per launch, but its 2^-17 operand rounding times the 1 / lambda_min ~ 400 amplification of the low modes left a
+// relative 5e-4 in the correction: outside what the cycle tests allow against the numpy specification.  Not kept.)
+typedef float mm_f16 __attribute__((ext_vector_type(16)));
+// C / D layout of the 32 x 32 tile: register q of lane (r, h) is row (q & 3) + 8 (q >> 2) + 4 h, column r
+
+// NK floats: half h of row `row` of a row-major [.][2 NK] matrix
+template <int NK>
+__device__ __forceinline__ void mm_row_half(const float *__restrict__ m, int row, int h, float (&v)[NK])
+{
+    const float4 *p = reinterpret_cast<const float4 *>(m + (size_t)row * (2 * NK) + h * NK);
+#pragma unroll
+    for (int q = 0; q < NK / 4; ++q) { const float4 t = p[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+}
+template <int NK>
+__device__ __forceinline__ void mm_lds_half(const unsigned char *buf, int idx, int h, float (&v)[NK])
+{
+    constexpr int RS = 2 * NK * 4 + 16;
+    const float4 *p = reinterpret_cast<const float4 *>(buf + (size_t)idx * RS + h * NK * 4);
+#pragma unroll
+    for (int q = 0; q < NK / 4; ++q) { const float4 t = p[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+}
+template <int NK>
+__device__ __forceinline__ mm_f16 mm_product(const float (&a)[NK], const float (&b)[NK])
+{
+    mm_f16 c = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int s = 0; s < NK; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c, 0, 0, 0);
+    return c;
+}
+// the tile (tm, tn) as the B operand of a product that sums over its ROW index: [column][k = row], K = 2 NK
+template <int NK>
+__device__ __forceinline__ void mm_store_b(unsigned char *buf, const mm_f16 &d, int tm, int tn, int r, int h)
+{
+    constexpr int RS = 2 * NK * 4 + 16;
+    unsigned char *col = buf + (size_t)(32 * tn + r) * RS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4 *>(col + (32 * tm + 8 * g + 4 * h) * 4) = make_float4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]);
+}
+// ... as the A operand of a product that sums over its COLUMN index: [row][k = column]
+template <int NK>
+__device__ __forceinline__ void mm_store_a(unsigned char *buf, const mm_f16 &d, int tm, int tn, int r, int h)
+{
+    constexpr int RS = 2 * NK * 4 + 16;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        *reinterpret_cast<float *>(buf + (size_t)(32 * tm + (q & 3) + 8 * (q >> 2) + 4 * h) * RS + (32 * tn + r) * 4) = d[q];
+}
+
+// SKX, SKY: a side's padded size in units of 16 (2, 4 or 6: 32, 64 or 96 unknowns).  PRE: every matrix operand is requested at
+// kernel entry (4 waves, a SIMD each: registers to spare); else each product's matrix right before it (9 waves share the file).
+template <int SKX, int SKY>
+__global__ __launch_bounds__((SKX / 2) * (SKY / 2) * 64) void k_mg_bottom_mm(MGBottomMM a)
+{
+    constexpr int NPX = 16 * SKX, NPY = 16 * SKY, TX = NPX / 32, KX = NPX / 2, KY = NPY / 2;
+    constexpr bool PRE = SKX <= 4 && SKY <= 4;
+    constexpr int RSX = NPX * 4 + 16, RSY = NPY * 4 + 16;
+    constexpr int BUF = (NPX * RSY > NPY * RSX) ? NPX * RSY : NPY * RSX;
+    __shared__ __attribute__((aligned(16))) unsigned char buf0[BUF], buf1[BUF];
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tm = w / TX, tn = w % TX;
+    const int nx = a.nx, ny = a.ny;
+    const float *ax1 = reinterpret_cast<const float *>(a.mm), *ax2 = ax1 + NPX * NPX, *ay1 = ax2 + NPX * NPX, *ay2 = ay1 + NPY * NPY;
+    const float *dinv = ay2 + NPY * NPY;
+    float b1[KX], a2[KY], a3[KY], b4[KX];
+    mm_row_half<KX>(ax1, 32 * tn + r, h, b1);
+    if (PRE) { mm_row_half<KY>(ay1, 32 * tm + r, h, a2); mm_row_half<KY>(ay2, 32 * tm + r, h, a3); mm_row_half<KX>(ax2, 32 * tn + r, h, b4); }
+    // right-hand side: row y of this wave's row tile, the lane half's columns
+    const float *__restrict__ fg = a.Ftop.at(c);
+    const int y = 32 * tm + r;
+    float fv[KX];
+#pragma unroll
+    for (int s = 0; s < KX; ++s) {
+        const int x = h * KX + s;
+        const bool in = y < ny && x < nx;
+        const float v = fg[(size_t)((in ? y : 0) + 1) * a.Ftop.pitch + (in ? x : 0) + 1];
+        fv[s] = in ? v : 0.f;
+    }
+    float dv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dv[q] = dinv[(size_t)(32 * tm + (q & 3) + 8 * (q >> 2) + 4 * h) * NPX + 32 * tn + r];
+    // ---- G1 = F Vx^-T
+    mm_f16 acc = mm_product<KX>(fv, b1);
+    if (!PRE) mm_row_half<KY>(ay1, 32 * tm + r, h, a2);
+    mm_store_b<KY>(buf0, acc, tm, tn, r, h);
+    __syncthreads();
+    // ---- G2 = (Vy^-1 G1) (.) Dinv
+    {
+        float g[KY];
+        mm_lds_half<KY>(buf0, 32 * tn + r, h, g);
+        acc = mm_product<KY>(a2, g);
+    }
+    if (!PRE) mm_row_half<KY>(ay2, 32 * tm + r, h, a3);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] *= dv[q];
+    mm_store_b<KY>(buf1, acc, tm, tn, r, h);
+    __syncthreads();
+    // ---- G3 = Vy G2
+    {
+        float g[KY];
+        mm_lds_half<KY>(buf1, 32 * tn + r, h, g);
+        acc = mm_product<KY>(a3, g);
+    }
+    if (!PRE) mm_row_half<KX>(ax2, 32 * tn + r, h, b4);
+    mm_store_a<KX>(buf0, acc, tm, tn, r, h);
+    __syncthreads();
+    // ---- U = G3 Vx^T
+    {
+        float g[KX];
+        mm_lds_half<KX>(buf0, 32 * tm + r, h, g);
+        acc = mm_product<KX>(g, b4);
+    }
+    float *__restrict__ ug = a.Utop.at(c);
+    const int x = 32 * tn + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int yy = 32 * tm + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (yy < ny && x < nx) ug[(size_t)(yy + 1) * a.Utop.pitch + x + 1] = acc[q];
+    }
+}
+
+// NP = 32, 64 or 96 per direction; false: not a shape this path serves
+bool launch_mg_bottom_mm(const MGBottomMM &a, int NPX, int NPY, int C, hipStream_t s)
+{
+#define SC_MM(SX, SY) if (NPX == 16 * SX && NPY == 16 * SY) { hipLaunchKernelGGL((k_mg_bottom_mm<SX, SY>), dim3(C), dim3((SX / 2) * (SY / 2) * 64), 0, s, a); return true; }
+    SC_MM(2, 2) SC_MM(2, 4) SC_MM(2, 6) SC_MM(4, 2) SC_MM(4, 4) SC_MM(4, 6) SC_MM(6, 2) SC_MM(6, 4) SC_MM(6, 6)
+#undef SC_MM
+    return false;
 }
 
 hipError_t mg_bottom_prepare()

@@ -181,25 +181,30 @@ static int build_fd(Instance *I)
     I->fd_level = -1;
     if ((I->opts.flags & SC_FLAG_VCYCLE_BOTTOM) || I->mg_bottom >= I->mg.size()) return SC_OK;
     long planes = 0;
+    I->fd_mm = false;
     for (size_t l = I->mg_bottom; l < I->mg.size(); ++l) {
         const MGLevel &L = I->mg[l];
         planes += bottom_floats(L);
         const int nx = L.g.x.n, ny = L.g.y.n, nxp = round_up(nx, 4), nyp = round_up(ny, 4);
         const int dmax = I->opts.mg_direct_max > 0 ? std::min(I->opts.mg_direct_max, 128) : SC_MG_DIRECT_MAX_DEFAULT;
         if (nx > dmax || ny > dmax) continue;
-        if ((planes + fd_lds_floats(nxp, nyp)) * (long)sizeof(float) > (long)MG_BOTTOM_LDS_BYTES) continue;
-        const long nf = fd_mat_floats(nxp, nyp);
+        // the bottom's first level on the matrix cores (k_mg_bottom_mm): up to 96 unknowns per side, no LDS budget to meet
+        const bool mm = l == I->mg_bottom && nx <= 96 && ny <= 96 && !(I->opts.flags & SC_FLAG_BOTTOM_F32);
+        if (!mm && (planes + fd_lds_floats(nxp, nyp)) * (long)sizeof(float) > (long)MG_BOTTOM_LDS_BYTES) continue;
+        const long nf = (fd_mat_floats(nxp, nyp) + 15) & ~15L;          // the matrix-core operands behind the float matrices, 64-byte aligned
+        const int NPX = round_up(nx, 32), NPY = round_up(ny, 32);
         int rc;
-        if ((rc = ensure(I, I->mg_fd, sizeof(float) * (size_t)nf))) return rc;
+        if ((rc = ensure(I, I->mg_fd, sizeof(float) * (size_t)nf + (mm ? (size_t)fd_mm_bytes(NPX, NPY) : 0)))) return rc;
         // everything that read the previous matrices has been enqueued on the main stream: the build starts behind it
         SC_HIP(I, hipEventRecord(I->ev_fd_fork, I->stream));
         SC_HIP(I, hipStreamWaitEvent(I->aux, I->ev_fd_fork, 0));
-        launch_fd_build((float *)I->mg_fd.p, L.g, nxp, nyp, I->aux);
+        launch_fd_build((float *)I->mg_fd.p, L.g, nxp, nyp, I->aux, mm ? (unsigned char *)((float *)I->mg_fd.p + nf) : nullptr, NPX, NPY);
         SC_HIP(I, hipGetLastError());
         SC_HIP(I, hipEventRecord(I->ev_fd, I->aux));
         I->fd_pending = true;
         I->fd_level = (int)(l - I->mg_bottom);
         I->fd_nxp = nxp; I->fd_nyp = nyp;
+        I->fd_mm = mm; I->fd_npx = NPX; I->fd_npy = NPY; I->fd_mm_off = (size_t)nf;
         return SC_OK;
     }
     return SC_OK;
@@ -284,6 +289,13 @@ static int run_bottom(Instance *I, size_t l0, int pre, int post)
     if (I->fd_pending) {          // the matrices of a new hierarchy are being built on the second stream (build_fd)
         SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0));
         I->fd_pending = false;
+    }
+    if (I->fd_mm && I->fd_level == 0) {      // the usual case: this level solved directly on the matrix cores, nothing below it is visited
+        MGBottomMM m;
+        m.mm = (const unsigned char *)((const float *)I->mg_fd.p + I->fd_mm_off);
+        m.Ftop = I->mg[l0].F; m.Utop = I->mg[l0].U;
+        m.nx = I->mg[l0].g.x.n; m.ny = I->mg[l0].g.y.n;
+        if (launch_mg_bottom_mm(m, I->fd_npx, I->fd_npy, I->F.C, I->stream)) return SC_OK;
     }
     launch_mg_bottom(a, I->F.C, I->stream);
     return SC_OK;

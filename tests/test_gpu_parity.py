@@ -447,7 +447,9 @@ def test_extreme_inputs_stay_within_one(hip, oracles, kind):
     s = compare.image_diff_stats(want, body)
     assert s["max"] <= 1, compare.format_stats(s)
     if kind != "constant":
-        assert s["percent"] < 0.1, compare.format_stats(s)
+        # (the stop rule admits a predicted error of 0.025 grey levels; full-range noise at this size stops after three cycles at
+        #  0.002 since round 4 -- the bottom's 73 x 68 level is solved directly on the matrix cores -- where rounds 1-3 ran a fourth)
+        assert s["percent"] < 0.3, compare.format_stats(s)
     assert hip.info().sweeps <= 6
 
 

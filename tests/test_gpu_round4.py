@@ -173,3 +173,40 @@ def test_pci_bus_id_of_the_device():
     bdf = capi.device_pci_bus_id(0)
     assert bdf and re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", bdf), bdf
     assert capi.device_pci_bus_id(9999) is None
+
+
+@pytest.mark.parametrize("W,H", [(2048, 2048), (2400, 1552), (700, 500), (300, 200), (90, 70), (1500, 260)])
+def test_bottom_solve_on_the_matrix_cores_agrees_with_the_float32_form(hip, W, H):
+    """Round 4: the bottom kernel's direct solve runs as four products on the bf16 matrix cores with every operand split into a
+    bf16 head and tail (k_mg_bottom_mm: relative error ~1e-5); SC_FLAG_BOTTOM_F32 keeps the float32 SIMD form of rounds 1-3
+    (k_mg_bottom).  Same fixed point: after one cycle the two fields differ by a relative 1e-4 of the field's scale at most,
+    after the default solve by rounding noise, and the shapes cover every operand padding (32 / 64 / 96 per side)."""
+    from seamlesscloneoptimization_amd import capi
+    rng = np.random.default_rng(W + H)
+    U = rng.uniform(0, 255, (3, H, W)).astype(np.float32)
+    F = np.zeros((3, H, W), np.float32)
+    F[:, 1:-1, 1:-1] = rng.normal(0, 30, (3, H - 2, W - 2)).astype(np.float32)
+    d = hip.default_opts()
+    got = {}
+    try:
+        for cycles in (1, 0):
+            for flags in (0, capi.SC_FLAG_BOTTOM_F32):
+                hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags, **(dict(max_sweeps=1, update_tol=1e-30) if cycles else dict(max_sweeps=d.max_sweeps, update_tol=d.update_tol)))
+                hip.field_load(U, F)
+                hip.field_solve(allow_not_converged=True)
+                got[(cycles, flags)] = (hip.field_store(), hip.info().sweeps)
+        scale = float(np.abs(got[(1, 0)][0]).max())
+        from oracle import mg_np
+        lv = mg_np.build_levels(W, H)
+        if mg_np.direct_level(lv, True) == mg_np.direct_level(lv, False):
+            # both forms solve the same level directly: the same arithmetic up to the order of the additions
+            assert np.abs(got[(1, 0)][0] - got[(1, capi.SC_FLAG_BOTTOM_F32)][0]).max() <= 1e-4 * scale
+            assert got[(0, 0)][1] == got[(0, capi.SC_FLAG_BOTTOM_F32)][1]                  # the same number of cycles
+            assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_BOTTOM_F32)][0]).max() <= 2e-5 * scale
+        else:
+            # the matrix-core form solves the bottom's FIRST level (up to 96 unknowns per side, no LDS budget to meet) where the
+            # float32 form has to cycle one level further down: different iterates, the same fixed point
+            assert abs(got[(0, 0)][1] - got[(0, capi.SC_FLAG_BOTTOM_F32)][1]) <= 1
+            assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_BOTTOM_F32)][0]).max() <= 2e-3 * scale
+    finally:
+        hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=0, max_sweeps=d.max_sweeps, update_tol=d.update_tol)

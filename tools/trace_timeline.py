@@ -3,8 +3,9 @@ per kernel: start offset, duration, gap to the previous kernel (all us)."""
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a clone starts at k_mask_bbox
-starts = [i for i, r in enumerate(rows) if "k_mask_bbox" in r["Kernel_Name"] or "k_mask_stage" in r["Kernel_Name"]]   # k_mask_bbox_group too
+# a clone starts with its mask stage: k_mask_erode3 (launched on a predicted box: the scan rides in the pre-process launch) or k_mask_bbox
+ismask = lambda r: "k_mask_bbox" in r["Kernel_Name"] or "k_mask_erode" in r["Kernel_Name"]   # the group forms too
+starts = [i for i, r in enumerate(rows) if ismask(r) and (i == 0 or not ismask(rows[i - 1]))]
 a = starts[-1]
 b = len(rows)
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0
