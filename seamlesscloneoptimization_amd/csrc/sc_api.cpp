@@ -111,13 +111,17 @@ static int upload_rows(Instance *I, DevBuf &stage, void *d, size_t dpitch, const
     int rc = ensure_pinned(I, stage, dpitch * (size_t)rows);
     if (rc) return rc;
     uint8_t *s = (uint8_t *)stage.p;
-    // ~4 MB pieces: the DMA of piece k runs while piece k+1 is being packed
-    const int rows_per = (int)std::max<size_t>(1, ((size_t)4 << 20) / dpitch);
-    for (int y0 = 0; y0 < rows; y0 += rows_per) {
-        const int n = std::min(rows_per, rows - y0);
+    // Pieces: the DMA of piece k runs while piece k+1 is being packed.  The first piece is small (1 MB: the link starts moving
+    // early), the following ones grow to 8 MB.  (Measured against equal 4 MB pieces on one box: no difference beyond noise --
+    // the packing itself, 33-45 GB/s with eight threads, is what paces this path, not the DMA commands.)
+    size_t piece = (size_t)1 << 20;
+    for (int y0 = 0; y0 < rows;) {
+        const int n = std::min((int)std::max<size_t>(1, piece / dpitch), rows - y0);
         copy_rows(I, s + (size_t)y0 * dpitch, dpitch, h + (size_t)y0 * hpitch, hpitch, row_bytes, n);
         SC_HIP(I, hipMemcpyAsync((uint8_t *)d + (size_t)y0 * dpitch, s + (size_t)y0 * dpitch, dpitch * (size_t)(n - 1) + row_bytes,
                                  hipMemcpyHostToDevice, I->stream));
+        y0 += n;
+        piece = std::min(piece * 4, (size_t)8 << 20);
     }
     return SC_OK;
 }
@@ -304,9 +308,12 @@ static int check_roi(Instance *I, const Geo &g, int bc, int br)
 }
 
 // erode -> pre-process -> solve -> post-process on device-resident ROI origins
+// out_org / ostep: where the output bytes go (ROI origin, row step): the destination itself for device-resident images; the
+// host path hands a compact buffer of its own so that what comes back across PCIe is the ROI and nothing else
 static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, const uint8_t *face_org, int fstep,
-                        uint8_t *body_org, int bstep, const Geo &g, int passes)
+                        uint8_t *body_org, int bstep, const Geo &g, int passes, uint8_t *out_org = nullptr, int ostep = 0)
 {
+    if (!out_org) { out_org = body_org; ostep = bstep; }
     int rc;
     I->mpitch = round_up(g.W, 64);
     if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
@@ -331,7 +338,7 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         I->scan_pending = false;
         if (pass == passes - 1 && (rc = tmark(I, 5))) return rc;
         I->info.sweep_launches = 0;
-        I->spec_post.body_org = body_org; I->spec_post.bstep = bstep;
+        I->spec_post.body_org = out_org; I->spec_post.bstep = ostep;
         I->spec_post.ev_solved = nullptr;
         I->spec_post.armed = true; I->spec_post.done = false;
         solve_rc = solve(I);
@@ -343,7 +350,7 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
             if (pass == passes - 1 && (rc = tmark(I, 6))) return rc;
             LmNodes lm;
             if ((rc = output_nodes(I, lm))) return rc;
-            launch_postprocess(result(I), body_org, bstep, I->stream, I->guard, lm);      // (a solve that got here stored no 16-bit field or kept it in range)
+            launch_postprocess(result(I), out_org, ostep, I->stream, I->guard, lm);      // (a solve that got here stored no 16-bit field or kept it in range)
         } else if (pass == passes - 1) {
             I->tm[6] = nullptr;            // no mark between the last cycle and the post-process (an event there costs a
         }                                  // ~5 us bubble): ms_post is reported as 0 and ms_solve includes it
@@ -449,7 +456,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     (void)hipSetDevice(I->gpu);
     if (I->stream) (void)hipStreamSynchronize(I->stream);
     if (I->aux) (void)hipStreamSynchronize(I->aux);
-    DevBuf *bufs[] = { &I->d_face, &I->d_body_roi, &I->d_mask, &I->d_M, &I->d_U0, &I->d_U1, &I->d_F };
+    DevBuf *bufs[] = { &I->d_face, &I->d_body_roi, &I->d_out, &I->d_mask, &I->d_M, &I->d_U0, &I->d_U1, &I->d_F };
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
     if (I->mg_partial.p) (void)hipFree(I->mg_partial.p);
@@ -647,12 +654,14 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     int rc = validate_images(I, face, fc, fr, fs, body, bc, br, bs, mask, mc, mr, ms);
     if (rc) return rc;
     // --- mask to the device, bounding box
-    const int dms = round_up(mc, 256);
-    if ((rc = ensure(I, I->d_mask, (size_t)dms * mr))) return rc;
+    const bool whole_m = 4 * (size_t)mc >= 3 * (size_t)ms;      // (not a narrow view of a much wider image): one linear copy at the caller's step
+    const int dms = whole_m ? ms : round_up(mc, 256);
+    if ((rc = ensure(I, I->d_mask, (size_t)dms * mr + 64))) return rc;
     I->stage_marks = true;         // a host-image call is synchronous whatever bSync says: its timeline is always read
     I->marks_ends_only = false;
     if ((rc = tmark(I, 0))) return rc;
-    if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
+    if (whole_m) SC_HIP(I, hipMemcpyAsync(I->d_mask.p, mask, (size_t)ms * (mr - 1) + mc, hipMemcpyHostToDevice, I->stream));
+    else if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
     if ((rc = tmark(I, 1))) return rc;
     // One attempt on a given geometry: ROI of face/body to the device (the reference uploads both images whole),
     // clone, [check the predicted box], result back into the caller's image.  SC_GUESS_WRONG = the device found a
@@ -661,14 +670,30 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     auto attempt = [&](const Geo &g, const int *guess) -> int {
         int r;
         const int dfs = round_up(3 * g.W, 256);
-        if ((r = ensure(I, I->d_face, (size_t)dfs * g.H))) return r;
-        if ((r = ensure(I, I->d_body_roi, (size_t)dfs * g.H))) return r;
-        if ((r = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return r;
-        if ((r = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return r;
+        // An image whose ROI covers most of its rows (>= 3/4 of the row step: the patch always, the destination often) crosses
+        // PCIe as ONE linear copy of whole rows straight from the caller's memory at the caller's row step -- no packing pass,
+        // no helper threads; the kernels take any origin and step.  Packing 29 MB with eight threads ran at 33-45 GB/s on the
+        // boxes measured, under the link's 55; the direct copy: h2d 0.90 -> 0.67 ms of a 2048^2 call on the slower box.  A small
+        // ROI of a large image is still packed (row by row into pinned staging, one DMA per piece).  The library still issues
+        // no 2-D copies (appendix B).
+        const bool whole_f = 4 * 3 * (size_t)g.W >= 3 * (size_t)fs, whole_b = 4 * 3 * (size_t)g.W >= 3 * (size_t)bs;
+        const int fpitch = whole_f ? fs : dfs, bpitch = whole_b ? bs : dfs;
+        const size_t foff = whole_f ? 3 * (size_t)g.x0 : 0, boff = whole_b ? 3 * (size_t)g.ltx : 0;
+        if ((r = ensure(I, I->d_face, (size_t)fpitch * g.H + 64))) return r;
+        if ((r = ensure(I, I->d_body_roi, (size_t)bpitch * g.H + 64))) return r;
+        if ((r = ensure(I, I->d_out, (size_t)dfs * g.H + 64))) return r;
+        if (whole_f) SC_HIP(I, hipMemcpyAsync(I->d_face.p, face + (size_t)g.y0 * fs, (size_t)fs * (g.H - 1) + foff + 3 * (size_t)g.W, hipMemcpyHostToDevice, I->stream));
+        else if ((r = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return r;
+        if (whole_b) SC_HIP(I, hipMemcpyAsync(I->d_body_roi.p, body + (size_t)g.lty * bs, (size_t)bs * (g.H - 1) + boff + 3 * (size_t)g.W, hipMemcpyHostToDevice, I->stream));
+        else if ((r = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return r;
         if ((r = tmark(I, 3))) return r;
         const int passes = I->opts.reference_warmup ? 2 : 1;
-        r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p, dfs,
-                         (uint8_t *)I->d_body_roi.p, dfs, g, passes);
+        // the output bytes go to a compact buffer of their own (the interior only is written, and only that comes back); the
+        // reference's warm-up pass (two applications in place) needs the first result where the second reads it: the body buffer
+        uint8_t *const out_dev = passes > 1 ? (uint8_t *)I->d_body_roi.p + boff : (uint8_t *)I->d_out.p;
+        const int out_pitch = passes > 1 ? bpitch : dfs;
+        r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p + foff, fpitch,
+                         (uint8_t *)I->d_body_roi.p + boff, bpitch, g, passes, out_dev, out_pitch);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
         if (guess) {      // the scan rode in the pre-process launch (mark 5 is recorded behind it) and finished long ago: this wait is free
             SC_HIP(I, hipEventSynchronize(I->ev[5]));
@@ -681,22 +706,37 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         const int orows = g.H - 2;
         const size_t ob = 3 * (size_t)(g.W - 2);
         if (orows > 0 && g.W > 2) {
-            if ((r = ensure_pinned(I, I->h_out, (size_t)dfs * g.H))) return r;
+            const int dfs = out_pitch;            // (shadows the compact pitch: the warm-up variant returns at the body buffer's)
+            if ((r = ensure_pinned(I, I->h_out, (size_t)dfs * g.H + 64))) return r;
             uint8_t *dst_org = body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1);
-            const uint8_t *src = (const uint8_t *)I->d_body_roi.p + dfs;          // ROI row 1
+            const uint8_t *src = out_dev + dfs;                                   // ROI row 1
             uint8_t *stage = (uint8_t *)I->h_out.p + dfs;
-            int pieces = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)dfs * orows) >> 22));
-            const int rows_per = (orows + pieces - 1) / pieces;
-            pieces = (orows + rows_per - 1) / rows_per;
+            // pieces that SHRINK towards the end: the splice of piece k runs while piece k + 1 crosses the link, and what is left
+            // after the last DMA is the splice of a small piece only (equal pieces left 1/3 of the image to splice behind the link)
+            int starts[9], pieces = 0;
+            {
+                const size_t total = (size_t)dfs * orows;
+                size_t left = total;
+                int yy = 0;
+                while (yy < orows && pieces < 7) {
+                    size_t want = left > ((size_t)3 << 20) ? left / 2 : left;          // halves, down to ~1.5-3 MB
+                    int n = (int)std::max<size_t>(1, want / dfs);
+                    if (orows - yy - n < 8) n = orows - yy;
+                    starts[pieces++] = yy;
+                    yy += n; left = (size_t)dfs * (orows - yy);
+                }
+                if (yy < orows) starts[pieces++] = yy;
+                starts[pieces] = orows;
+            }
             for (int k = 0; k < pieces; ++k) {
-                const int y0 = k * rows_per, n = std::min(rows_per, orows - y0);
+                const int y0 = starts[k], n = starts[k + 1] - y0;
                 SC_HIP(I, hipMemcpyAsync(stage + (size_t)y0 * dfs, src + (size_t)y0 * dfs, (size_t)dfs * (n - 1) + 3 + ob,
                                          hipMemcpyDeviceToHost, I->stream));
                 SC_HIP(I, hipEventRecord(I->ev_chunk[k], I->stream));
             }
             SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
             for (int k = 0; k < pieces; ++k) {
-                const int y0 = k * rows_per, n = std::min(rows_per, orows - y0);
+                const int y0 = starts[k], n = starts[k + 1] - y0;
                 SC_HIP(I, hipEventSynchronize(I->ev_chunk[k]));
                 copy_rows(I, dst_org + (size_t)y0 * bs, (size_t)bs, stage + (size_t)y0 * dfs + 3, (size_t)dfs, ob, n);
             }
