@@ -599,12 +599,12 @@ def main():
     j_bytes = 12.0 * unknowns * max(j_depth, 1)
 
     # Counter figures (fabric bytes per launch, bytes per timed step) come from committed rocprofv3 --pmc passes of THIS command
-    # (tools/r3_profile.sh -> profiles/r3_pmc_traffic_bench.json).  They are only quoted when the capture matches the run:
+    # (tools/r4_profile.sh -> profiles/r4_pmc_traffic_bench.json).  They are only quoted when the capture matches the run:
     # same ROI / batch / group and the same library sources (capi.source_fingerprint); otherwise `traffic` is null and
     # `traffic_stale` says why -- a stale number is never passed on silently.
     profile, traffic_stale = None, None
     src_now = capi.source_fingerprint()
-    for name in ("r3_pmc_traffic_bench.json", "r2_pmc_traffic_bench.json"):
+    for name in ("r4_pmc_traffic_bench.json", "r3_pmc_traffic_bench.json"):
         try:
             profile = json.load(open(os.path.join(ROOT, "profiles", name)))
             profile["_file"] = "profiles/" + name
@@ -612,7 +612,7 @@ def main():
         except Exception:
             pass
     if profile is None:
-        traffic_stale = "no committed counter capture under profiles/ (run tools/r3_profile.sh on the GPU box)"
+        traffic_stale = "no committed counter capture under profiles/ (run tools/r4_profile.sh on the GPU box)"
     else:
         why = []
         for key, have in (("roi", args.roi), ("batch", args.batch), ("group", group)):
@@ -622,7 +622,7 @@ def main():
             why.append(f"library sources changed since the capture (fingerprint {profile.get('source_fingerprint', 'not recorded')} then, {src_now} now)")
         if why:
             traffic_stale = f"{profile['_file']} @ {profile.get('git', '?')} does not describe this run: " + "; ".join(why) + \
-                            " -- re-capture with tools/r3_profile.sh"
+                            " -- re-capture with tools/r4_profile.sh"
             profile = None
 
     def pmc_traffic(symbol, channels):
@@ -687,7 +687,7 @@ def main():
     # ---- BASELINE config 4: the single-sweep Jacobi kernels at a 4096^2 ROI -- the one configuration whose 604 MB working set
     #      (3 channels x (u, f, u')) exceeds the 256 MB Infinity Cache, i.e. genuinely streams from HBM.  Both forms the library
     #      has: rows rolling through registers (k_jacobi_roll<4>, the default) and the LDS-staged 256 x 32 tile with a 1-pixel halo
-    #      that the north-star names (k_jacobi<32>, sc_solver_opts.jacobi_tile_rows = 32).  Counter bytes: profiles/r3_c4_pmc.json.
+    #      that the north-star names (k_jacobi<32>, sc_solver_opts.jacobi_tile_rows = 32).  Counter bytes: profiles/r4_c4_pmc.json.
     roofline_c4 = None
     if not args.no_c4 and args.config == "c3":
         n4 = 4096
@@ -698,12 +698,12 @@ def main():
         del U4, F4
         bytes4 = 12.0 * (n4 - 2) * (n4 - 2) * 3
         try:
-            c4prof = json.load(open(os.path.join(ROOT, "profiles", "r3_c4_pmc.json")))
+            c4prof = json.load(open(os.path.join(ROOT, "profiles", "r4_c4_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r4_c4_pmc.json")) else "r3_c4_pmc.json")))
         except Exception:
             c4prof = None
         c4_stale = None if c4prof and c4prof.get("source_fingerprint") == src_now else \
-            ("no profiles/r3_c4_pmc.json" if not c4prof else f"profiles/r3_c4_pmc.json was captured from other library sources "
-             f"({c4prof.get('source_fingerprint')} then, {src_now} now): re-capture with tools/r3_profile.sh")
+            ("no profiles/r4_c4_pmc.json" if not c4prof else f"the committed config-4 capture was taken from other library sources "
+             f"({c4prof.get('source_fingerprint')} then, {src_now} now): re-capture with tools/r4_profile.sh")
         legs = {}
         for key, rows, sym, label in (("register_rolling", 0, "k_jacobi_roll<4, 1>", "k_jacobi_roll<4>: a wave owns 256 columns x 4 rows, rows y-1..y+4 roll through registers, no LDS, no barrier (default)"),
                                       ("lds_tile_16", 16, "k_jacobi<16, 0>", "k_jacobi<16>: LDS-staged 256 x 16 tile + 1-pixel halo, one barrier"),

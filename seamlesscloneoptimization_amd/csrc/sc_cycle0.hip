@@ -849,7 +849,10 @@ bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int swe
         // Round 4: a single clone's level 1 at 2048^2 is 555 eight-wave workgroups on 512 slots (two per CU): 43 of them make a second
         // round and the launch takes 18 us for 10 us of work.  Sixteen-wave workgroups (96-row windows, 76 of them exact instead of
         // 28 of 48; one per CU) need 210: one round.  Taken whenever it turns more than one round of the 8-wave form into one.
-        if (R4 == 6 && cn_blocks(F, 4, 6, 8) > 512 && cn_blocks(F, 4, 6, 16) <= 256) { launch_cn<4, 6, 128, 16>(Uout, F, Fc, g, s); return true; }
+        // ... and for a GROUP of clones (tens of rounds either way) whenever the 16-wave tiling needs fewer waves in total: 76 of 96
+        // rows exact instead of 28 of 48 (+0.7 % on the bench step, tools/ab_step.py).
+        const long b8 = cn_blocks(F, 4, 6, 8), b16 = cn_blocks(F, 4, 6, 16);
+        if (R4 == 6 && ((b8 > 512 && b16 <= 256) || (F.C > 3 && 2 * b16 < b8))) { launch_cn<4, 6, 128, 16>(Uout, F, Fc, g, s); return true; }
         R4 == 6 ? launch_cn<4, 6, 128>(Uout, F, Fc, g, s) : launch_cn<4, 4, 128>(Uout, F, Fc, g, s);
         return true;
     }

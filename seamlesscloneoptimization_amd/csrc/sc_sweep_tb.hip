@@ -304,7 +304,7 @@ long tb_big_side()
 // These launches are latency bound (a workgroup's life is a chain of barriers, not bandwidth), and at
 // ~100 VGPRs two workgroups fit a CU, so what matters is the number of rounds the grid needs over the
 // chip's 512 slots: take the smallest R whose grid fits one round; if none does (large levels) the
-// short 4-row bands won every measurement (tools/bench_configs.py c3/c4).
+// short 4-row bands won every measurement on single clones (tools/bench_configs.py c3/c4).
 int tb_gen_rows(int W, int H, int C, int hx, int hy)
 {
     if ((long)W * H >= tb_big_side() * tb_big_side()) return 8;
@@ -313,7 +313,10 @@ int tb_gen_rows(int W, int H, int C, int hx, int hy)
         const int rows = 8 * R - 2 * hy;
         if (nbx * ((H + rows - 1) / rows) * C <= 512) return R;
     }
-    return 4;
+    // Many rounds either way.  A single clone's large levels: the short 4-row bands (above).  A GROUP of clones (C > 3: tens of
+    // rounds, throughput not latency): 6-row bands -- 36 of 48 rows exact at depth 2 instead of 20 of 32 -- measured +0.9 % on the
+    // bench step of 32 x 2048^2 (round 4, tools/ab_step.py: 6.263 -> 6.205 ms, three alternating repetitions within 0.1 %).
+    return C > 3 ? 6 : 4;
 }
 
 // The same choice for launches of depth 3 or 4 (a level that does all its smoothing before the restriction): their halo

@@ -1,6 +1,6 @@
 """The barrier-free rolling red-black sweeps (k_rb_roll, SC_FLAG_ROLLING_SWEEPS) against the blocked ones (k_rb_tb): bit-exactness
 against the CPU sweeps over awkward shapes, then the time of a 4-sweep launch on a single clone's field (3 channels) and on a
-group's (48 channels).  Needs tools/experiments/rolling_sweeps.patch applied (the kernel was not kept: its header has the numbers).
+group's (48 channels).  Needs docs/dead_ends/rolling_sweeps.patch applied (the kernel was not kept: its header has the numbers).
 Run on the GPU box: python tests/tools/rolling_probe.py"""
 import sys, os, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -8,7 +8,7 @@ import numpy as np
 from seamlesscloneoptimization_amd import capi
 from oracle import oracle_c as oc
 if not hasattr(capi, "SC_FLAG_ROLLING_SWEEPS"):
-    sys.exit("rolling_probe.py: apply tools/experiments/rolling_sweeps.patch and rebuild first")
+    sys.exit("rolling_probe.py: apply docs/dead_ends/rolling_sweeps.patch and rebuild first")
 inst = capi.Instance(0)
 bad = 0
 for (W, H) in [(33, 17), (298, 192), (513, 129), (250, 300), (241, 257), (1030, 70), (700, 523), (481, 40), (3, 3), (5, 9), (255, 1031)]:
