@@ -162,7 +162,11 @@ typedef struct sc_solver_opts {
                                             (255 - M)/255 (OpenCV 3.4.5 modules/photo, Cloning::computeDerivatives / normalClone).
                                             Default: the reference's -- it thresholds (seamlessClone_imp.cpp:917, sum == 255 * 9:
                                             every value below 255 erodes to 0) and so only ever blends with 0 / 1.  On 0 / 255 masks
-                                            the two are bit-identical.  PARITY UNPINNED: OpenCV's source is not part of the
+                                            the two are bit-identical.  The BOUNDING BOX stays the reference's under this flag: all non-zero
+                                            pixels (seamlessClone_imp.cpp:943, `mask != 0`), i.e. OpenCV's erode and blend weights on the
+                                            reference's ROI; cv::seamlessClone itself takes the box of the pixels equal to 255 only, so for
+                                            a feathered mask its ROI (and Dirichlet ring) is smaller than the one used here.
+                                            PARITY UNPINNED: OpenCV's source is not part of the
                                             reference and none of its fixtures holds a grey mask; checked against a restatement
                                             of the published algorithm (oracle/).  Groups run one clone at a time with it.   */
 
@@ -347,6 +351,14 @@ SC_API int   sc_hip_pool_set_group(void *pool, int group);
 /* isolated timing of the fused level-0 multigrid cycle kernel on the state left by the last
  * MULTIGRID run (values are discarded; bench.py roofline) */
 SC_API int sc_hip_time_cycle0(void *instance, int launches, float *ms_per_launch);
+/* ... and of the other three level-0 launches a fast-path solve is made of, each under a second symbol of its own:
+ * form 0 = the full cycle (as sc_hip_time_cycle0), 1 = the full cycle before the judged one (16-bit field in, float out, leaves the
+ * float-table correction's cell shares), 2 = the judged cycle (two sweeps, output bytes), 3 = the first launch of a solve (two
+ * sweeps from the float16 initial field, no prolongation).  SC_ERR_BAD_ARG unless the last run was a default multigrid solve. */
+SC_API int sc_hip_time_cycle0_form(void *instance, int form, int launches, float *ms_per_launch);
+/* measurement: the launch-bound part of a multigrid cycle (levels 2 .. bottom .. 2 of the hierarchy the last multigrid run left,
+ * `*launches` dependent launches) `reps` times as plain launches and as replays of ONE captured HIP graph: ms per pass of each */
+SC_API int sc_hip_time_coarse_chain(void *instance, int reps, float *ms_eager, float *ms_graph, int *launches);
 
 /* Host-only (needs no GPU): 1 when the reference's float32 eigenvalue tables are singular for an ROI of w x h unknowns --
  * (float)(2 cos(PI/(n+1))) is exactly 2.0f in both directions (n >= ~12 870), so the reference's denominator

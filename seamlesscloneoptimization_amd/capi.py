@@ -195,6 +195,10 @@ def load():
     L.sc_hip_run_device_batch.restype = C.c_int
     L.sc_hip_time_cycle0.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.sc_hip_time_cycle0.restype = C.c_int
+    L.sc_hip_time_coarse_chain.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.sc_hip_time_coarse_chain.restype = C.c_int
+    L.sc_hip_time_cycle0_form.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.sc_hip_time_cycle0_form.restype = C.c_int
     L.sc_hip_reference_tables_singular.argtypes = [C.c_int, C.c_int]
     L.sc_hip_reference_tables_singular.restype = C.c_int
     L.sc_hip_selftest_host.argtypes = []
@@ -408,6 +412,25 @@ def _time_cycle0(self, launches: int = 100) -> float:
 
 
 Instance.time_cycle0 = _time_cycle0
+
+
+def _time_cycle0_form(self, form: int, launches: int = 100) -> float:
+    ms = C.c_float(0)
+    self._check(self.L.sc_hip_time_cycle0_form(self.h, int(form), int(launches), C.byref(ms)))
+    return float(ms.value)
+
+
+Instance.time_cycle0_form = _time_cycle0_form
+
+
+def _time_coarse_chain(self, reps: int = 50):
+    """(ms per pass as plain launches, ms per pass as HIP-graph replays, dependent launches per pass)"""
+    a, b, n = C.c_float(0), C.c_float(0), C.c_int(0)
+    self._check(self.L.sc_hip_time_coarse_chain(self.h, int(reps), C.byref(a), C.byref(b), C.byref(n)))
+    return float(a.value), float(b.value), int(n.value)
+
+
+Instance.time_coarse_chain = _time_coarse_chain
 
 
 class _Borrowed(Instance):

@@ -1320,4 +1320,42 @@ int sc_hip_time_cycle0(void *p, int launches, float *ms_per_launch)
     return SC_OK;
 }
 
+int sc_hip_time_cycle0_form(void *p, int form, int launches, float *ms_per_launch)
+{
+    if (form == 0) return sc_hip_time_cycle0(p, launches, ms_per_launch);
+    Instance *I = get(p);
+    if (I) field_moved(I);
+    if (!I || !ms_per_launch || launches < 1 || form < 1 || form > 3) return SC_ERR_BAD_ARG;
+    if (!I->F.p || I->mg.size() < 3 || !I->mg_partial.p || !mg_composes_level1(I) || !I->mg_l1_half || !I->mg_q16_last || !I->f_half) {
+        I->err = "time_cycle0_form: run a default multigrid clone first";
+        return SC_ERR_BAD_ARG;
+    }
+    SC_HIP(I, hipSetDevice(I->gpu));
+    float4 *bands = form == 1 ? lowmode_bands_buffer(I, 4) : nullptr;
+    LmNodes lm;
+    if (form == 2 && I->lm.CN.p && !I->lm.singular) { lm.CN = (const float *)I->lm.CN.p; lm.ny = I->lm.ny; lm.npitch = I->lm.npitch; }
+    auto once = [&]() {
+        // values are discarded: every form reads the fields in the format it expects (whatever bits they hold) and writes the partner
+        launch_cycle0_twin(form, result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
+                           (float *)I->mg_partial.p, I->stream, I->mg[2].U, I->mg[1].g, bands, lm);
+    };
+    once();
+    SC_HIP(I, hipEventRecord(I->ev_k0, I->stream));
+    for (int i = 0; i < launches; ++i) once();
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    lowmode_bands_written(I, nullptr);
+    *ms_per_launch = ev_ms(I->ev_k0, I->ev_k1) / (float)launches;
+    return SC_OK;
+}
+
+int sc_hip_time_coarse_chain(void *p, int reps, float *ms_eager, float *ms_graph, int *launches)
+{
+    Instance *I = get(p);
+    if (!I || reps < 1 || !ms_eager || !ms_graph || !launches) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    return mg_time_coarse_chain(I, reps, ms_eager, ms_graph, launches);
+}
+
 } // extern "C"

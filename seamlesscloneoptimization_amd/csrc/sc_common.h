@@ -152,6 +152,9 @@ int  cycle0_blocks(int W, int H, int C, int sweeps);
 int  launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
                             hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands = nullptr, bool l1_half = false,
                             int u_q16 = 0, AbortFlag sat = AbortFlag());     // sat: where a saturating 16-bit store reports itself
+// tagged twins of the other launches of a fast-path solve, for isolated timing (sc_cycle0.hip)
+int  launch_cycle0_twin(int form, Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, float *partial, hipStream_t s,
+                        Field E2, const MGGeom &g1, float4 *bands, const LmNodes &lm);
 // the last cycle with its result leaving as output bytes (planar, in Q's memory) instead of as a field; see sc_cycle0.hip
 int  launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
                        bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half = false);

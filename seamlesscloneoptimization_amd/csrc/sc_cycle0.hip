@@ -807,6 +807,23 @@ int launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGe
     return f_half ? launch_c0<2, true, 42>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm) : launch_c0<2, true, 40>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
 }
 
+// The other three level-0 launches of a fast-path solve under a second symbol (TAG bit 0), for isolated timing (sc_hip_time_cycle0_form):
+// form 1 = the full cycle before the judged one (16-bit field in, float out, leaves the correction's cell shares: in-step symbol
+// ..., 466>), 2 = the judged cycle writing output bytes (..., 186>), 3 = the first launch of a solve (float16 initial field in,
+// 16-bit field out, no prolongation: ..., 646>).  Form 0 (..., 914> -> 915>) is launch_cycle0_composed(tag = true).
+int launch_cycle0_twin(int form, Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, float *partial, hipStream_t s,
+                       Field E2, const MGGeom &g1, float4 *bands, const LmNodes &lm)
+{
+    ComposeArgs ca;
+    ca.E2 = E2; ca.g1 = g1;
+    switch (form) {
+    case 1: return launch_c0<4, true, 210 | 256 | 1>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands);
+    case 2: return launch_c0<2, true, 186 | 1>(Uin, Uout, F, Fc, U1, g, partial, s, ca, nullptr, lm);
+    case 3: launch_c0<2, false, 134 | 512 | 1>(Uin, Uout, F, Fc, Field(), g, partial, s); return 0;
+    default: return -1;
+    }
+}
+
 // tiling in y of a level-0 launch with `sweeps` sweeps: nby tile rows, tile row b processes field rows [b step - hy, + 64) in
 // eight 8-row bands (one per wave) and owns the output rows [b step, (b + 1) step)
 void cycle0_row_geometry(int H, int sweeps, int &nby, int &step, int &hy)

@@ -742,4 +742,45 @@ int mg_solve(Instance *I)
     return ok ? SC_OK : SC_ERR_NOT_CONVERGED;
 }
 
+// Measurement hook (sc_hip_time_coarse_chain): the launch-bound part of a cycle -- levels 2 .. bottom .. 2: seven dependent launches
+// for a 2048^2 clone, 2 % of the unknowns -- run `reps` times back to back on the hierarchy the last multigrid solve left, (a) as
+// plain launches and (b) captured once into a HIP graph and replayed.  hipEvents on the instance's stream around each batch.
+// Values are discarded (level 2's right-hand side is whatever the last cycle left there).
+int mg_time_coarse_chain(Instance *I, int reps, float *ms_eager, float *ms_graph, int *launches)
+{
+    if (I->mg.size() < 4 || I->mg_bottom < 3 || !mg_composes_level1(I)) { I->err = "time_coarse_chain: run a multigrid clone of at least ~500^2 first"; return SC_ERR_BAD_ARG; }
+    const sc_solver_opts &o = I->opts;
+    const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
+    int rc;
+    if (I->fd_pending) { SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0)); I->fd_pending = false; }
+    *launches = (int)(2 * (I->mg_bottom - 2) + 1);
+    if ((rc = vcycle(I, 2, pre, post))) return rc;                       // warm
+    SC_HIP(I, hipEventRecord(I->ev_k0, I->stream));
+    for (int i = 0; i < reps; ++i) if ((rc = vcycle(I, 2, pre, post))) return rc;
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    SC_HIP(I, hipStreamSynchronize(I->stream));
+    float ms = 0.f;
+    SC_HIP(I, hipEventElapsedTime(&ms, I->ev_k0, I->ev_k1));
+    *ms_eager = ms / (float)reps;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    SC_HIP(I, hipStreamBeginCapture(I->stream, hipStreamCaptureModeThreadLocal));
+    rc = vcycle(I, 2, pre, post);
+    hipError_t e = hipStreamEndCapture(I->stream, &graph);
+    if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); return rc ? rc : hip_fail(I, e, "hipStreamEndCapture"); }
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); return hip_fail(I, e, "hipGraphInstantiate"); }
+    (void)hipGraphLaunch(exec, I->stream);                                 // warm (uploads the executable graph)
+    SC_HIP(I, hipEventRecord(I->ev_k0, I->stream));
+    for (int i = 0; i < reps; ++i) (void)hipGraphLaunch(exec, I->stream);
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    e = hipStreamSynchronize(I->stream);
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return hip_fail(I, e, "hipStreamSynchronize");
+    SC_HIP(I, hipEventElapsedTime(&ms, I->ev_k0, I->ev_k1));
+    *ms_graph = ms / (float)reps;
+    return SC_OK;
+}
+
 } // namespace sc
