@@ -363,6 +363,12 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["batch_per_gpu"] == 8 and d["cpu_baseline"] is None
+    # round 4: every rank's own elapsed time and device travel with the line (rank r -> device r % ndev: both on this box's one GPU),
+    # and each rank pinned itself to its share of the cores before the library started its threads
+    pr = d["per_rank"]
+    assert len(pr["elapsed_ms"]) == 2 and all(t > 0 for t in pr["elapsed_ms"]) and pr["device"] == [0, 0] and pr["affinity"] == "auto"
+    assert abs(max(pr["elapsed_ms"]) - d["ms_per_step"] * d["steps"]) < 1e-2 * max(pr["elapsed_ms"]) + 0.05
+    assert 0 < pr["cores_of_rank0"] <= max(1, len(os.sched_getaffinity(0)) // 2 + 1)
 
 
 def test_config3_literal_rule_red_black_to_1e_4(hip, oracles):

@@ -210,3 +210,29 @@ def test_bottom_solve_on_the_matrix_cores_agrees_with_the_float32_form(hip, W, H
             assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_BOTTOM_F32)][0]).max() <= 2e-3 * scale
     finally:
         hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=0, max_sweeps=d.max_sweeps, update_tol=d.update_tol)
+
+
+def test_measurement_hooks_of_round_4(inst, oracles):
+    """sc_hip_time_cycle0_form (the four level-0 launches of a solve under tagged symbols) and sc_hip_time_coarse_chain (levels
+    2 .. bottom .. 2 as plain launches and as HIP-graph replays) run on the state a default multigrid clone leaves, return
+    positive times, refuse anything else, and leave the instance usable."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(1100, 1000, margin=32)
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, min(16, oc.max_threads()))
+    with pytest.raises(capi.SeamlessCloneError):
+        inst.time_cycle0_form(1, 2)                        # nothing has run yet
+    d = [inst.to_device(a) for a in (patch, dst, mask)]
+    inst.run_device(d[0], patch.shape, d[1], dst.shape, d[2], mask.shape, cx, cy)
+    assert inst.info().method == capi.SC_METHOD_MULTIGRID
+    times = [inst.time_cycle0_form(k, 3) for k in range(4)]
+    assert all(t > 0 for t in times) and times[3] < times[0] and times[2] < times[0]       # the two-sweep forms are shorter than the full cycle
+    eager, graph, n = inst.time_coarse_chain(5)
+    assert n == 5 and eager > 0 and graph > 0                                              # 1098 -> 548 -> 273 -> 136 | bottom 67: levels 2, 3 down and up + the bottom
+    with pytest.raises(capi.SeamlessCloneError):
+        inst.time_cycle0_form(7, 2)
+    body = dst.copy()
+    inst.run(patch, body, mask, cx, cy)                                                    # the instance still clones correctly
+    assert _dmax(body, want) <= 1
+    for p in d:
+        inst.free(p)
