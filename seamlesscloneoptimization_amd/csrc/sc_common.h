@@ -83,16 +83,21 @@ struct LmNodes { const float *CN = nullptr; int ny = 0, npitch = 0; };
 // the correction at the four pixels x .. x + 3 (x a multiple of 4: one 8-column cell) of row y, added to v; and the output
 // byte of a value: clamp to [0, 255], truncate (seamlessClone_imp.cpp:2091-2096).  One definition for the post-process and for
 // the multigrid launch that writes output bytes itself: the same operations in the same order.
-__device__ __forceinline__ void lm_add4(const LmNodes &lm, int c, int x, int y, float4 &v)
+// (p00, p01: the two nodes of the cell's upper node row, p10, p11: of its lower one)
+__device__ __forceinline__ void lm_add4_nodes(float p00, float p01, float p10, float p11, int x, int y, float4 &v)
 {
-    const float *__restrict__ p = lm.CN + ((size_t)c * lm.ny + (y >> 3)) * lm.npitch + (x >> 3);
     const float ty = 0.125f * (float)(y & 7);
-    const float l = __builtin_fmaf(ty, p[lm.npitch] - p[0], p[0]), r = __builtin_fmaf(ty, p[lm.npitch + 1] - p[1], p[1]);
+    const float l = __builtin_fmaf(ty, p10 - p00, p00), r = __builtin_fmaf(ty, p11 - p01, p01);
     const float dx = 0.125f * (r - l), a0 = __builtin_fmaf((float)(x & 7), dx, l);
     v.x += a0;
     v.y += a0 + dx;
     v.z += __builtin_fmaf(2.0f, dx, a0);
     v.w += __builtin_fmaf(3.0f, dx, a0);
+}
+__device__ __forceinline__ void lm_add4(const LmNodes &lm, int c, int x, int y, float4 &v)
+{
+    const float *__restrict__ p = lm.CN + ((size_t)c * lm.ny + (y >> 3)) * lm.npitch + (x >> 3);
+    lm_add4_nodes(p[0], p[1], p[lm.npitch], p[lm.npitch + 1], x, y, v);
 }
 __device__ __forceinline__ unsigned lm_byte(float d)
 {

@@ -633,12 +633,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         // the result leaves as output values: u + node correction (the arithmetic of the post-process, sc_kernels.hip),
         // clamped to [0, 255], truncated; plane c of Uout's memory, rows of P bytes.  The splice kernel interleaves.
         uint8_t *__restrict__ q = reinterpret_cast<uint8_t *>(Uout.p) + (size_t)c * Uout.plane;
+        // The lane's four pixels lie in ONE 8-column cell and its R = 8 rows in at most two cell rows: six node values serve the
+        // whole band (round 4; four loads per ROW before: 32 dependent-latency loads at the very end of the launch).  Requested
+        // together, clamped into the node grid; lm_add4_nodes is lm_add4's arithmetic, operation for operation.
+        const bool corr = lm.CN && x <= W - 2;   // the lane that holds only the ring column x = W - 1 would read node (x >> 3) + 1 == nx, one past the row (its byte is never spliced)
+        const int Yc0 = max(y0, 0) >> 3;
+        float nd[3][2] = { { 0.f, 0.f }, { 0.f, 0.f }, { 0.f, 0.f } };
+        if (corr) {
+            const float *__restrict__ pn = lm.CN + (size_t)c * lm.ny * lm.npitch + (x >> 3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float *row = pn + (size_t)min(Yc0 + k, lm.ny - 1) * lm.npitch;
+                nd[k][0] = row[0]; nd[k][1] = row[1];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int yr = wv * R + r, y = y0 + r;
             if (!(yr >= HY && yr < RH - HY && y >= 1 && y <= H - 2)) continue;
             float4 v = u[r];
-            if (lm.CN && x <= W - 2) lm_add4(lm, c, x, y, v);   // the lane that holds only the ring column x = W - 1 would read node (x >> 3) + 1 == nx, one past the row (its byte is never spliced)
+            if (corr) {
+                const bool second = (y >> 3) != Yc0;       // wave-uniform: the band's rows lie in cell rows Yc0 and Yc0 + 1
+                lm_add4_nodes(second ? nd[1][0] : nd[0][0], second ? nd[1][1] : nd[0][1], second ? nd[2][0] : nd[1][0], second ? nd[2][1] : nd[1][1], x, y, v);
+            }
             *reinterpret_cast<unsigned *>(q + (size_t)y * P + x) = lm_byte(v.x) | (lm_byte(v.y) << 8) | (lm_byte(v.z) << 16) | (lm_byte(v.w) << 24);
         }
         return;
