@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU box: the rocprofv3 evidence of round 4.  (1) kernel statistics of `python3 bench.py`; (2) four counter passes over the same
+# GPU box: the rocprofv3 evidence of round 4.  (The counter passes run bench.py without its float32-storage and new-size legs, so that
+# the step-traffic difference (3 steps - 1 step) / 2 is the DEFAULT step's alone; the statistics run keeps the float32 leg: its symbols
+# ..., 0> / 16> / 80> / 56> are that leg's launches.)  (1) kernel statistics of `python3 bench.py`; (2) four counter passes over the same
 # command (FETCH_SIZE / WRITE_SIZE x 3 steps / 1 step) -> <tag>_pmc_traffic_bench.json (copy to profiles/r4_pmc_traffic_bench.json);
 # (3) tools/c4_probe.py (BASELINE config 4, 4096^2) once without the profiler for the timings (counter collection serialises the
 #     launches and more than doubles their duration) and twice under it for FETCH_SIZE / WRITE_SIZE -> <tag>_c4_pmc.json (copy to
@@ -14,13 +16,13 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/${T}_stats $O/${T}_f3 $O/${T}_w3 $O/${T}_f1 $O/${T}_w1 $O/${T}_c4f $O/${T}_c4w
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -- python3 $R/bench.py --cpu-seconds 0 "$@" \
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -- python3 $R/bench.py --cpu-seconds 0 --no-new-size "$@" \
     > $O/${T}_bench_under_stats.json 2> $O/${T}_stats.err || { echo "stats run failed"; tail -5 $O/${T}_stats.err; exit 1; }
 cp $(ls $O/${T}_stats/*/*kernel_stats.csv | head -1) $O/${T}_kernel_stats.csv
 echo "stats done"
 for pass in "f3 FETCH_SIZE 3" "w3 WRITE_SIZE 3" "f1 FETCH_SIZE 1" "w1 WRITE_SIZE 1"; do
   set -- $pass
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/${T}_$1 -- python3 $R/bench.py --cpu-seconds 0 --no-c4 --warmup 0 --steps $3 --kernel-launches 6 \
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/${T}_$1 -- python3 $R/bench.py --cpu-seconds 0 --no-c4 --no-float32-leg --no-new-size --host-calls 3 --warmup 0 --steps $3 --kernel-launches 6 \
       > /dev/null 2> $O/${T}_$1.err || { echo "pmc pass $1 failed"; tail -5 $O/${T}_$1.err; exit 1; }
   echo "pass $1 done"
 done
