@@ -15,9 +15,12 @@ owns its own synthetic images (weak scaling: independent images, no data-path co
 value = total ROI Mpix / max-over-ranks wall time.  Each destination is restored from a pristine
 device copy before every clone (inside the timed region) so no clone starts from an already-converged field.
 
-The same JSON line carries `roofline` (the dominant kernel AS THE TIMED REGION RUNS IT -- the grouped level-0
-multigrid launch -- HIP-event timed on the library's stream), `pcie` (the drop-in host-image call) and
-`cpu_baseline` (the C restatement of what cv::seamlessClone computes, timed on the host cores; rank 0, N=1 only).
+The same JSON line carries `single_clone` (ONE 2048^2 clone alone: BASELINE config 3 as written), `value_float32_storage` (the
+same timed step with float32 fields throughout), `roofline` (the dominant kernel AS THE TIMED REGION RUNS IT -- the grouped
+level-0 multigrid launch -- HIP-event timed on the library's stream; plus all four level-0 launch forms of a solve), `pcie` (the
+drop-in host-image call: median / p95 / min of 24), `new_size` (the first call at a ROI size the instance has never seen),
+`per_rank` (every rank's own elapsed time and device) and `cpu_baseline` (the C restatement of what cv::seamlessClone
+computes, timed on the host cores; rank 0, N=1 only).
 """
 from __future__ import annotations
 
@@ -628,9 +631,10 @@ def main():
             "first_two_calls_ms": first_ms,
             "h2d_ms": stat(1), "device_ms": stat(2), "d2h_ms": stat(3), "stream_ms": stat(4),
             "Mpix_per_s_inclusive": round(W * H / (st_call["median"] * 1e-3) / 1e6, 1),
-            "note": "my_seamlessclone_api_imp_run on pageable numpy images, one clone, one instance: pack into pinned staging + H2D of "
-                    "the mask and of the ROI of face/body, clone, D2H + splice of the interior (never `value`); call_ms = host wall time of "
-                    "the call (median), stream_ms = hipEvent time from the first upload to the last download"}
+            "note": "my_seamlessclone_api_imp_run on pageable numpy images, one clone, one instance: mask, patch rows and destination rows "
+                    "cross PCIe as linear copies at the caller's row step (no packing: the ROI covers most of every row here), clone, the "
+                    "compact ROI back through pinned staging + splice of the interior into the caller's image (never `value`); call_ms = "
+                    "host wall time of the call (median), stream_ms = hipEvent time from the first upload to the last download"}
 
     # ---- sweep kernels named by the north-star, on freshly built float fields of the same images (single clone, 3 channels)
     spl = args.sweeps_per_launch            # 0: library default = fused kernels at their deepest depth

@@ -384,6 +384,10 @@ static int fft_build_dim(Instance *I, FftDim *&out, int n, const FftDim *keep)
     I->info.new_size = 1;
     const int logM = fft_logm(n), M = 1 << logM;
     int rc;
+    if (S.pending) {                  // a build nobody waited for yet: ordered in front of whatever follows on the main stream
+        SC_HIP(I, hipStreamWaitEvent(I->stream, S.ev_built, 0));      // (ensure() waits for that stream before it frees a buffer)
+        S.pending = false;
+    }
     const size_t bytes = sizeof(cx2<T>) * (3 * (size_t)M + 1);      // chirp[n + 1 <= M + 1] | bhat[M] | tw[M]: sized by M alone, so an entry is reallocated only when M grows
     D.n = 0;
     if ((rc = ensure(I, D.chirp, bytes))) return rc;

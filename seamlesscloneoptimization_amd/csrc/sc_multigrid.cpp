@@ -194,6 +194,10 @@ static int build_fd(Instance *I)
         const long nf = (fd_mat_floats(nxp, nyp) + 15) & ~15L;          // the matrix-core operands behind the float matrices, 64-byte aligned
         const int NPX = round_up(nx, 32), NPY = round_up(ny, 32);
         int rc;
+        if (I->fd_pending) {          // a build nobody waited for (a solve that never reached its bottom): order it in front of whatever
+            SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0));      // follows on the main stream -- ensure() below waits for that stream before it frees
+            I->fd_pending = false;
+        }
         if ((rc = ensure(I, I->mg_fd, sizeof(float) * (size_t)nf + (mm ? (size_t)fd_mm_bytes(NPX, NPY) : 0)))) return rc;
         // everything that read the previous matrices has been enqueued on the main stream: the build starts behind it
         SC_HIP(I, hipEventRecord(I->ev_fd_fork, I->stream));
