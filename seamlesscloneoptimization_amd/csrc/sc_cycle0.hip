@@ -238,6 +238,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     float ecc[PRO ? NE : 1];
     float2 e2r[COMP ? NQ : 1];
     float e2l[COMP ? NQ : 1];          // level-2 column x/4 - 1: source of the ghost value when x/4 itself is the ghost column
+    // Round 4: a lane loads only ITS OWN coarse columns -- level 1's x/2, x/2 + 1 (one 4- or 8-byte load per row) and level 2's x/4
+    // (one load per row) -- and takes column x/2 + 2 (= the right lane's x/2), x/4 + 1 and x/4 - 1 from the neighbouring lanes with one
+    // full-wave DPP shift each, after the loads have landed (PRO_SHARE below): 11 loads per lane instead of 27.  The wave's two end
+    // lanes have no neighbour: lane 63 fetches its level-2 column x/4 + 1 itself (its level-1 column x/2 + 2 only feeds the wave's very
+    // last fine column, which the column halo absorbs: 2T + 2 + 1 <= C0_HX, asserted below), lane 0's level-2 column x/4 - 1 only
+    // matters where x/4 is the ghost column of the domain's right end, two columns into a halo lane.  Where an address is clamped
+    // (lanes outside the domain) neighbours need not agree; those values are masked or never reach an exact output, as before.
+    static_assert(!PRO || GEN || 2 * T + 3 <= C0_HX, "column halo too small for the shared prolongation loads");
+    float e2b63[COMP ? NQ : 1];        // lane 63's own level-2 column x/4 + 1
     if (PRO) {
         const int cx = min(max(x >> 1, 0), E.pitch - 4), J = (y0 >> 1) - 1;
         if constexpr (L1H) {
@@ -246,7 +255,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
             for (int j = 0; j < NE; ++j) {
                 const __half *er = e + (size_t)min(max(J + j, 0), E.H - 1) * E.pitch + cx;      // cx is even: a 4-byte aligned pair
                 eab[j] = __half22float2(*reinterpret_cast<const __half2 *>(er));
-                ecc[j] = __half2float(er[2]);
             }
         } else {
         const float *__restrict__ e = E.at(c);
@@ -254,7 +262,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
         for (int j = 0; j < NE; ++j) {
             const float *er = e + (size_t)min(max(J + j, 0), E.H - 1) * E.pitch + cx;
             eab[j] = *reinterpret_cast<const float2 *>(er);
-            ecc[j] = er[2];
         }
         }
     }
@@ -264,8 +271,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const float *er = e2 + (size_t)min(max(Q + q, 0), comp.E2.H - 1) * comp.E2.pitch + qx;
-            e2r[q] = make_float2(er[0], er[1]);
-            e2l[q] = er[qx > 0 ? -1 : 0];
+            e2r[q].x = er[0];
+            e2b63[q] = 0.f;
+            if (lane == 63) e2b63[q] = er[1];
         }
     }
     if (!PRO) {   // with PRO the RHS is fetched after the prolongation
@@ -302,6 +310,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     // parity of the first coarse row of the window: with R a multiple of 4 and an even tile step in coarse rows it is T's
     constexpr bool JKNOWN = (R % 4 == 0) && ((RH / 2 - HY) % 2 == 0);
     if (PRO) {
+        // PRO_SHARE: the neighbours' columns (see the loads above)
+#pragma unroll
+        for (int j = 0; j < NE; ++j) ecc[j] = wave_from_right(eab[j].x);
+        if (COMP) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float own = e2r[q].x;
+                const float fr = wave_from_right(own), fl = wave_from_left(own);      // full-wave shifts: outside any lane-dependent branch
+                e2r[q].y = lane == 63 ? e2b63[q] : fr;
+                e2l[q] = fl;
+            }
+        }
         float m = 0.f;
         auto prolong = [&](auto checked) {
             constexpr bool CK = decltype(checked)::value;

@@ -191,7 +191,8 @@ void launch_mask_bbox(const uint8_t *mask, int mw, int mh, int mstep, BboxFold f
 // v_alignbyte, the ROI origin has arbitrary byte alignment), turns them into "== 255" flag bytes,
 // ANDs the seven byte-shifted views (horizontal 7-window for all four pixels at once) and keeps the
 // last seven such words in registers for the vertical AND.
-constexpr int ER_STRIP = 8;        // rows per lane (+ 6 halo rows): 16 made a 2048^2 erode 264 workgroups of 22 dependent-ish row loads each, 12.9 us
+constexpr int ER_STRIP = 8;        // rows per lane (+ 6 halo rows) of a SINGLE clone's erode: 16 made a 2048^2 erode 264 workgroups of 22 dependent-ish row loads each, 12.9 us against 9.9
+constexpr int ER_STRIP_GROUP = 16; // ... of a group's (throughput, not latency: 22 / 16 source rows per output row instead of 14 / 8; 8 against 16 in-step: no difference beyond noise)
 
 __device__ __forceinline__ unsigned is255_flags(unsigned w)   // 0x80 in every byte that equals 255
 {
@@ -199,6 +200,7 @@ __device__ __forceinline__ unsigned is255_flags(unsigned w)   // 0x80 in every b
     return ~((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t)) & 0x80808080u;
 }
 
+template <int STRIP>
 __device__ __forceinline__ void mask_erode3_block(const uint8_t *__restrict__ mask, int mstep, size_t mask_bytes,
                                                   const Geo &g, uint8_t *__restrict__ M, int mpitch, int bx, int by)
 {
@@ -206,7 +208,7 @@ __device__ __forceinline__ void mask_erode3_block(const uint8_t *__restrict__ ma
     const uintptr_t lo = (uintptr_t)mask & ~(uintptr_t)3, hi = ((uintptr_t)mask + mask_bytes - 1) & ~(uintptr_t)3;
     const int xw = bx * 64 + (threadIdx.x & 63);       // word column
     const int x = 4 * xw;
-    const int ys = (by * 4 + (threadIdx.x >> 6)) * ER_STRIP;
+    const int ys = (by * 4 + (threadIdx.x >> 6)) * STRIP;
     if (x >= g.W || ys >= g.H) return;
     // per-pixel ring-in-x mask for the four bytes of this word
     unsigned xring = 0;
@@ -233,13 +235,13 @@ __device__ __forceinline__ void mask_erode3_block(const uint8_t *__restrict__ ma
                __builtin_amdgcn_alignbyte(fb, fa, 3) & fb & __builtin_amdgcn_alignbyte(fc, fb, 1) &
                __builtin_amdgcn_alignbyte(fc, fb, 2);
     };
-    // all ER_STRIP + 6 horizontal words first (independent loads in flight together), then the
+    // all STRIP + 6 horizontal words first (independent loads in flight together), then the
     // vertical 7-row ANDs
-    unsigned hh[ER_STRIP + 6];
+    unsigned hh[STRIP + 6];
 #pragma unroll
-    for (int k = 0; k < ER_STRIP + 6; ++k) hh[k] = hrow(ys - 3 + k);
+    for (int k = 0; k < STRIP + 6; ++k) hh[k] = hrow(ys - 3 + k);
 #pragma unroll
-    for (int r = 0; r < ER_STRIP; ++r) {
+    for (int r = 0; r < STRIP; ++r) {
         const int y = ys + r;
         unsigned v = hh[r] & hh[r + 1] & hh[r + 2] & hh[r + 3] & hh[r + 4] & hh[r + 5] & hh[r + 6] & xring;
         if (y < 3 || y > g.H - 4) v = 0;
@@ -251,7 +253,7 @@ __device__ __forceinline__ void mask_erode3_block(const uint8_t *__restrict__ ma
 __global__ __launch_bounds__(256) void k_mask_erode3(const uint8_t *__restrict__ mask, int mstep, size_t mask_bytes,
                                                      Geo g, uint8_t *__restrict__ M, int mpitch)
 {
-    mask_erode3_block(mask, mstep, mask_bytes, g, M, mpitch, blockIdx.x, blockIdx.y);
+    mask_erode3_block<ER_STRIP>(mask, mstep, mask_bytes, g, M, mpitch, blockIdx.x, blockIdx.y);
 }
 
 void launch_mask_erode3(const uint8_t *mask, int mstep, int mask_rows, Geo g, uint8_t *M, int mpitch, hipStream_t s)
@@ -339,11 +341,12 @@ __global__ __launch_bounds__(256) void k_mask_bbox_fold_group(MaskJobs t, const 
     }
 }
 
+template <int STRIP>
 __global__ __launch_bounds__(256) void k_mask_erode3_group(MaskJobs t)
 {
     const MaskJob &j = t.j[blockIdx.z];
-    if ((int)blockIdx.x >= ((j.g.W + 3) / 4 + 63) / 64 || (int)blockIdx.y >= (j.g.H + 4 * ER_STRIP - 1) / (4 * ER_STRIP)) return;
-    mask_erode3_block(j.mask, j.mstep, j.mask_bytes, j.g, j.M, j.mpitch, blockIdx.x, blockIdx.y);
+    if ((int)blockIdx.x >= ((j.g.W + 3) / 4 + 63) / 64 || (int)blockIdx.y >= (j.g.H + 4 * STRIP - 1) / (4 * STRIP)) return;
+    mask_erode3_block<STRIP>(j.mask, j.mstep, j.mask_bytes, j.g, j.M, j.mpitch, blockIdx.x, blockIdx.y);
 }
 
 static void mask_bbox_group_grid(const MaskJob *jobs, int cnt, int &gx, int &gy)
@@ -393,9 +396,9 @@ void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s)
             // last row may be shorter than the step: count only what the caller guarantees
             t.j[i].mask_bytes = (size_t)t.j[i].mstep * (t.j[i].mh - 1) + (size_t)(t.j[i].g.x0 + t.j[i].g.W + 1);
             gx = std::max(gx, ((t.j[i].g.W + 3) / 4 + 63) / 64);
-            gy = std::max(gy, (t.j[i].g.H + 4 * ER_STRIP - 1) / (4 * ER_STRIP));
+            gy = std::max(gy, (t.j[i].g.H + 4 * ER_STRIP_GROUP - 1) / (4 * ER_STRIP_GROUP));
         }
-        hipLaunchKernelGGL(k_mask_erode3_group, dim3(gx, gy, cnt), dim3(256), 0, s, t);
+        hipLaunchKernelGGL(k_mask_erode3_group<ER_STRIP_GROUP>, dim3(gx, gy, cnt), dim3(256), 0, s, t);
     }
 }
 
