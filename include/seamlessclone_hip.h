@@ -194,6 +194,11 @@ typedef struct sc_solver_opts {
                                             (v_mfma_f32_32x32x2_f32, operands straight from memory into registers: k_mg_bottom_mm).
                                             Same arithmetic up to the order of the additions                                       */
 
+#define SC_FLAG_SEPARATE_TAIL  (1 << 14) /* multigrid: the level above the bottom and the bottom as the three launches of rounds 1-3 (pre-smoothing +
+                                            residual + restriction, direct solve, prolongation + post-smoothing).  Default since round 4 where
+                                            that level has at most 127 unknowns per side: ONE launch, the level in registers (k_mg_tail).
+                                            Same arithmetic per point                                                              */
+
 /* ---- statistics of the last run */
 typedef struct sc_run_info {
     int    x0, y0, W, H, ltx, lty;  /* patch offset, ROI size (ring included), ROI origin in body */
@@ -359,6 +364,11 @@ SC_API int sc_hip_time_cycle0_form(void *instance, int form, int launches, float
 /* measurement: the launch-bound part of a multigrid cycle (levels 2 .. bottom .. 2 of the hierarchy the last multigrid run left,
  * `*launches` dependent launches) `reps` times as plain launches and as replays of ONE captured HIP graph: ms per pass of each */
 SC_API int sc_hip_time_coarse_chain(void *instance, int reps, float *ms_eager, float *ms_graph, int *launches);
+/* measurement: the shader clock at the eleven phase boundaries of ONE k_mg_tail launch (the level above the bottom and the bottom in one
+ * launch, SC_FLAG_SEPARATE_TAIL) on the hierarchy the last multigrid run left: entry | right-hand side loaded | pre-smoothing | residual +
+ * restriction | the four products of the direct solve | prolongation | post-smoothing | stores issued.  SC_ERR_BAD_ARG unless that
+ * hierarchy runs its bottom this way. */
+SC_API int sc_hip_time_tail_phases(void *instance, unsigned long long *cycles11);
 
 /* Host-only (needs no GPU): 1 when the reference's float32 eigenvalue tables are singular for an ROI of w x h unknowns --
  * (float)(2 cos(PI/(n+1))) is exactly 2.0f in both directions (n >= ~12 870), so the reference's denominator

@@ -153,6 +153,11 @@ def direct_level(levels, matrix_cores=True):
     to meet (sc_multigrid.cpp build_fd, k_mg_bottom_mm); False = SC_FLAG_BOTTOM_F32, the LDS-resident float32 form."""
     planes = 0
     b = bottom_start(levels)
+    if matrix_cores and 2 <= b < len(levels) - 1:
+        # a first bottom level of 97 .. 127 unknowns on a side is smoothed (k_mg_tail), the level below it is solved directly
+        dx, dy = levels[b]
+        if (dx.n > 96 or dy.n > 96) and dx.n <= 127 and dy.n <= 127 and dx.nc <= 63 and dy.nc <= 63:
+            b += 1
     for l in range(b, len(levels)):
         dx, dy = levels[l]
         planes += _bottom_floats(dx, dy)

@@ -50,6 +50,7 @@ SC_FLAG_FLOAT_L1 = 1 << 10
 SC_FLAG_FLOAT_FIELD = 1 << 11
 SC_FLAG_NO_STAGE_MARKS = 1 << 12
 SC_FLAG_BOTTOM_F32 = 1 << 13
+SC_FLAG_SEPARATE_TAIL = 1 << 14
 
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",
@@ -197,6 +198,8 @@ def load():
     L.sc_hip_time_cycle0.restype = C.c_int
     L.sc_hip_time_coarse_chain.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.sc_hip_time_coarse_chain.restype = C.c_int
+    L.sc_hip_time_tail_phases.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    L.sc_hip_time_tail_phases.restype = C.c_int
     L.sc_hip_time_cycle0_form.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.sc_hip_time_cycle0_form.restype = C.c_int
     L.sc_hip_reference_tables_singular.argtypes = [C.c_int, C.c_int]
@@ -431,6 +434,16 @@ def _time_coarse_chain(self, reps: int = 50):
 
 
 Instance.time_coarse_chain = _time_coarse_chain
+
+
+def _time_tail_phases(self):
+    """shader-clock differences between the eleven phase boundaries of one k_mg_tail launch (ten numbers)"""
+    buf = (C.c_ulonglong * 11)()
+    self._check(self.L.sc_hip_time_tail_phases(self.h, buf))
+    return [int(buf[i + 1]) - int(buf[i]) for i in range(10)]
+
+
+Instance.time_tail_phases = _time_tail_phases
 
 
 class _Borrowed(Instance):

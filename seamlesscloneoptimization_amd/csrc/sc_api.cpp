@@ -1358,4 +1358,12 @@ int sc_hip_time_coarse_chain(void *p, int reps, float *ms_eager, float *ms_graph
     return mg_time_coarse_chain(I, reps, ms_eager, ms_graph, launches);
 }
 
+int sc_hip_time_tail_phases(void *p, unsigned long long *cycles11)
+{
+    Instance *I = get(p);
+    if (!I || !cycles11) return SC_ERR_BAD_ARG;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    return mg_time_tail_phases(I, cycles11);
+}
+
 } // extern "C"

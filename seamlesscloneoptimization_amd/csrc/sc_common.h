@@ -223,6 +223,10 @@ __host__ __device__ static inline long fd_mm_bytes(int NPX, int NPY) { return 4L
 // the bottom's first level solved directly on the matrix cores: right-hand side in (Ftop), correction out (Utop), nx x ny unknowns
 struct MGBottomMM { const unsigned char *mm; Field Ftop, Utop; int nx, ny; };
 bool launch_mg_bottom_mm(const MGBottomMM &a, int NPX, int NPY, int C, hipStream_t s);
+// the level above the bottom (F: its right-hand side, U: receives its finished correction) and the bottom in one launch
+// (sc_mg_kernels.hip, k_mg_tail); false: not a shape this path serves (the caller launches the three kernels it replaces)
+struct MGTail { const unsigned char *mm; Field F, U; MGGeom g; int pre, post; unsigned long long *stamps; };   // stamps: measurement only (11 shader-clock values of channel 0), else nullptr
+bool launch_mg_tail(const MGTail &a, int NPX, int NPY, int C, hipStream_t s);
 struct ZeroJobs { enum { MAX = 48 }; void *p[MAX]; size_t n16[MAX]; int count; };     // n16: 16-byte units
 void launch_zero_multi(const ZeroJobs &z, hipStream_t s);
 void launch_mg_bottom(const MGBottomArgs &a, int C, hipStream_t s);

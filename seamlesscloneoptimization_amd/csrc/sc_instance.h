@@ -191,6 +191,7 @@ int solve(Instance *I);
 bool mg_reads_half_rhs(const Instance *I);
 bool mg_level1_half(const Instance *I);      // sc_multigrid.cpp: level 1's right-hand side and correction are stored as float16 in the solve configured in I
 int mg_time_coarse_chain(Instance *I, int reps, float *ms_eager, float *ms_graph, int *launches);   // sc_multigrid.cpp
+int mg_time_tail_phases(Instance *I, unsigned long long *out11);                                       // sc_multigrid.cpp
 bool mg_composes_level1(const Instance *I);   // sc_multigrid.cpp   // sc_multigrid.cpp: would the solve configured in I->opts read a float16 F?
 int lowmode_correct(Instance *I, const Field &U, const Field &Out);   // sc_lowmode.hip: Out = U + float-table correction
 int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on = nullptr);      // on: another stream than the instance's          // the correction of U at the node rows (what the post-process adds)

@@ -792,6 +792,300 @@ bool launch_mg_bottom_mm(const MGBottomMM &a, int NPX, int NPY, int C, hipStream
     return false;
 }
 
+// ---- the level above the bottom AND the bottom in ONE launch (round 4) -----------------------------------------------------------
+// A single clone's cycle spends three dependent launches on 2 % of a percent of its unknowns: pre-smoothing + residual +
+// restriction of the level above the bottom ("A", 127 x 127 at a 2048^2 ROI: 5.4 us), the bottom's direct solve ("B", 63 x 63:
+// 12 us) and A's prolongation + post-smoothing (5.9 us) -- each mostly dispatch, a round trip to memory for a right-hand side the
+// previous launch has just written, and the end-of-kernel release.  Here one 512-thread workgroup per channel does all three:
+//   * level A lives in REGISTERS: lane l of wave w owns columns 2l, 2l+1 of rows 16w .. 16w+15 (field coordinates, ring included:
+//     A has at most 127 unknowns per side), left / right neighbours by full-wave DPP shifts, the rows above / below a wave's band
+//     through 1 KB of LDS per wave and one barrier per half sweep;
+//   * residual and restriction stay in registers too (coarse point (I, J) = (l, 8w + j) belongs to the lane that owns its fine
+//     centre), B's right-hand side goes to LDS in the layout the first product reads;
+//   * B is solved by k_mg_bottom_mm's four float32 MFMA products on the first (NPX / 32)(NPY / 32) <= 4 waves, whose matrix operands
+//     were requested at kernel entry and arrive while A is being smoothed;
+//   * B's solution is interpolated from LDS (ghost rule of sc_mg_device.h for the irregular last interval), A is post-smoothed
+//     and written out.
+// Same arithmetic per point as the launches it replaces (k_cycle0<.., GEN, ZEROIN>, k_mg_bottom_mm, k_rb_tb<.., PROLONG>).
+// One red-black half sweep of the lane's 16 rows x 2 columns.  GEN = false: a wave all of whose rows are regular unknowns (1 <= y < ny;
+// `top`: its first row is the ring row y = 0 and is left alone) -- six instructions per point, no per-row state.  GEN = true: the wave
+// that holds the level's last row (coefficients cn, 1 / (dx + d_last)) and the rows beyond it: per row two selects on scalar masks
+// (an inactive row's factor is 0: it stays 0), no branches either.
+template <int COLOR, bool GEN>
+__device__ __forceinline__ void tail_half(float2 (&u)[16], const float2 (&f)[16], const float2 hup, const float2 hdn, bool top, int y0, int ny,
+                                          float cny_last, float cw0, float cw1, float inR0, float inR1, float inL0, float inL1)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int y = y0 + i;                       // wave-uniform
+        const float2 up = (i == 0) ? hup : u[i - 1], dn = (i == 15) ? hdn : u[i + 1];
+        if (GEN) {
+            const bool act = y >= 1 && y <= ny, ylast = y == ny;
+            const float cn = ylast ? cny_last : 1.0f;
+            if (((i + COLOR) & 1) == 0) {           // (x + y + colour) even: the even column
+                const float l = wave_from_left(u[i].y);
+                const float inv = act ? (ylast ? inL0 : inR0) : 0.f;
+                u[i].x = ((__builtin_fmaf(cw0, l, u[i].y) + __builtin_fmaf(cn, up.x, dn.x)) - f[i].x) * inv;
+            } else {
+                const float r = wave_from_right(u[i].x);
+                const float inv = act ? (ylast ? inL1 : inR1) : 0.f;
+                u[i].y = ((__builtin_fmaf(cw1, u[i].x, r) + __builtin_fmaf(cn, up.y, dn.y)) - f[i].y) * inv;
+            }
+        } else if (((i + COLOR) & 1) == 0) {
+            const float l = wave_from_left(u[i].y);
+            const float v = ((__builtin_fmaf(cw0, l, u[i].y) + (up.x + dn.x)) - f[i].x) * inR0;
+            if (i > 0 || !top) u[i].x = v;
+        } else {
+            const float r = wave_from_right(u[i].x);
+            const float v = ((__builtin_fmaf(cw1, u[i].x, r) + (up.y + dn.y)) - f[i].y) * inR1;
+            if (i > 0 || !top) u[i].y = v;
+        }
+    }
+}
+
+// hx[i] = the residual of row y0 + i restricted along x into the lane's coarse column (fine centre 2 lane): weights 1/2, 1, wxa, wxb.
+// The half sweep before this was the second colour's: its points ((x + y) odd) satisfy their equations to rounding and their
+// residuals are taken as the zeros they are -- only the first colour's point of a row (column 2 lane in even rows, 2 lane + 1 in odd
+// ones) is evaluated.
+template <bool GEN>
+__device__ __forceinline__ void tail_residual(const float2 (&u)[16], const float2 (&f)[16], const float2 hup, const float2 hdn, bool top, int y0, int ny,
+                                              float cny_last, float dy_last, float cw0, float cw1, float dx0, float dx1, bool v0, bool v1,
+                                              float wxa, float wxb, float (&hx)[16])
+{
+    const float ddR0 = dx0 + 2.0f, ddR1 = dx1 + 2.0f, ddL0 = dx0 + dy_last, ddL1 = dx1 + dy_last;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int y = y0 + i;
+        const float2 up = (i == 0) ? hup : u[i - 1], dn = (i == 15) ? hdn : u[i + 1];
+        const bool act = GEN ? (y >= 1 && y <= ny) : (i > 0 || !top), ylast = GEN && y == ny;
+        const float cn = ylast ? cny_last : 1.0f;
+        if ((i & 1) == 0) {
+            const float l = wave_from_left(u[i].y);
+            float r0 = f[i].x - __builtin_fmaf(-(ylast ? ddL0 : ddR0), u[i].x, __builtin_fmaf(cw0, l, u[i].y) + (GEN ? __builtin_fmaf(cn, up.x, dn.x) : up.x + dn.x));
+            r0 = (act && v0) ? r0 : 0.f;
+            hx[i] = __builtin_fmaf(wxb, wave_from_right(r0), r0);
+        } else {
+            const float rr = wave_from_right(u[i].x);
+            float r1 = f[i].y - __builtin_fmaf(-(ylast ? ddL1 : ddR1), u[i].y, __builtin_fmaf(cw1, u[i].x, rr) + (GEN ? __builtin_fmaf(cn, up.y, dn.y) : up.y + dn.y));
+            r1 = (act && v1) ? r1 : 0.f;
+            hx[i] = __builtin_fmaf(wxa, r1, 0.5f * wave_from_left(r1));
+        }
+    }
+}
+
+template <int SKX, int SKY>
+__global__ __launch_bounds__(512) void k_mg_tail(MGTail a)
+{
+    constexpr int NPX = 16 * SKX, NPY = 16 * SKY, TX = NPX / 32, TY = NPY / 32, KX = NPX / 2, KY = NPY / 2;
+    constexpr int RSX = NPX * 4 + 16, RSY = NPY * 4 + 16;
+    constexpr int BUF = (NPX * RSY > NPY * RSX) ? NPX * RSY : NPY * RSX;
+    constexpr int PB = 65;                                                  // pitch of B's solution plane (coarse ring coordinates 0 .. 64)
+    constexpr int BUFA = (BUF > 65 * PB * 4) ? BUF : 65 * PB * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char buf0[BUF], bufA[BUFA];   // bufA: B's right-hand side, then the second product's result, then B's solution
+    __shared__ float2 edge[2][8][2][64];
+    __shared__ float hedge[8][2][64];
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tm = w / TX, tn = w % TX;
+    const bool mmw = w < TX * TY;
+    // measurement (sc_hip_time_tail_phases): the first thread of channel 0 leaves the shader clock at every phase boundary
+#define SC_TAIL_STAMP(K) do { if (a.stamps && threadIdx.x == 0 && c == 0) a.stamps[K] = __builtin_readcyclecounter(); } while (0)
+    SC_TAIL_STAMP(0);
+    const MGGeom &g = a.g;
+    const int nx = g.x.n, ny = g.y.n, ncx = g.x.nc, ncy = g.y.nc;
+    const float *ax1 = reinterpret_cast<const float *>(a.mm), *ax2 = ax1 + NPX * NPX, *ay1 = ax2 + NPX * NPX, *ay2 = ay1 + NPY * NPY;
+    const float *dinv = ay2 + NPY * NPY;
+    float b1[KX], a2[KY], a3[KY], b4[KX], dv[16];
+    // ---- level A: the lane's columns and their coefficients
+    const int x0 = 2 * lane, y0 = 16 * w, P = a.F.pitch;
+    const bool v0 = x0 >= 1 && x0 <= nx, v1 = x0 + 1 <= nx;
+    const float cw0 = (x0 == nx) ? g.x.cw_last : 1.0f, cw1 = (x0 + 1 == nx) ? g.x.cw_last : 1.0f;
+    const float dx0 = (x0 == nx) ? g.x.d_last : 2.0f, dx1 = (x0 + 1 == nx) ? g.x.d_last : 2.0f;
+    const float inR0 = v0 ? 1.0f / (dx0 + 2.0f) : 0.f, inR1 = v1 ? 1.0f / (dx1 + 2.0f) : 0.f;             // an unknown that does not exist stays 0
+    const float inL0 = v0 ? 1.0f / (dx0 + g.y.d_last) : 0.f, inL1 = v1 ? 1.0f / (dx1 + g.y.d_last) : 0.f;
+    float2 u[16], f[16];
+    float2 traw[16];                 // requested before the matrices: the first half sweep waits for these only
+    {
+        const float *__restrict__ fg = a.F.at(c);
+        const int xc = min(x0, P - 2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) traw[i] = *reinterpret_cast<const float2 *>(fg + (size_t)min(y0 + i, a.F.H - 1) * P + xc);
+    }
+    asm volatile("" ::: "memory");
+    if (mmw) {
+        mm_row_half<KX>(ax1, 32 * tn + r, h, b1);
+        mm_row_half<KY>(ay1, 32 * tm + r, h, a2);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const bool yok = y0 + i >= 1 && y0 + i <= ny;
+        f[i] = make_float2((yok && v0) ? traw[i].x : 0.f, (yok && v1) ? traw[i].y : 0.f);
+        u[i] = make_float2(0.f, 0.f);
+    }
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }          // measurement only: the right-hand side (and the first matrices) have arrived
+    SC_TAIL_STAMP(1);
+    float2 hup = make_float2(0.f, 0.f), hdn = hup;
+    int eb = 0;
+    // a wave's rows: all regular unknowns (rows 1 .. ny - 1; wave 0's ring row aside), or with the last row / rows beyond it, or none
+    const bool regular = y0 + 15 < ny, dead = y0 > ny, top = w == 0;
+#define SC_TAIL_HALF(COL)                                                                                                             \
+    if (regular) tail_half<COL, false>(u, f, hup, hdn, top, y0, ny, g.y.cw_last, cw0, cw1, inR0, inR1, inL0, inL1);                       \
+    else if (!dead) tail_half<COL, true>(u, f, hup, hdn, top, y0, ny, g.y.cw_last, cw0, cw1, inR0, inR1, inL0, inL1)
+    auto exchange = [&]() {
+        edge[eb][w][0][lane] = u[0];
+        edge[eb][w][1][lane] = u[15];
+        __syncthreads();
+        hup = (w > 0) ? edge[eb][w - 1][1][lane] : make_float2(0.f, 0.f);
+        hdn = (w < 7) ? edge[eb][w + 1][0][lane] : make_float2(0.f, 0.f);
+        eb ^= 1;
+    };
+    for (int s = 0; s < a.pre; ++s) {
+        if (s == 0) {                  // from a zero correction the first half sweep is u = -f / (dx + dy) on its colour
+            if (!dead) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int y = y0 + i;
+                    if (i & 1) u[i].y = -f[i].y * ((y == ny) ? inL1 : inR1);      // f is 0 where the row or the column does not exist
+                    else u[i].x = -f[i].x * ((y == ny) ? inL0 : inR0);
+                }
+            }
+        } else {
+            SC_TAIL_HALF(0);
+        }
+        exchange();
+        SC_TAIL_HALF(1);
+        exchange();
+    }
+    SC_TAIL_STAMP(2);
+    // ---- residual, restricted along x into the lane's coarse column I = lane (fine centre x0), then along y
+    {
+        float hx[16];
+        const float wxa = (lane == ncx) ? g.x.tw1 : 0.5f, wxb = (lane == ncx) ? g.x.tw2 : 0.0f;
+        if (dead) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hx[i] = 0.f;
+        } else if (regular) {
+            tail_residual<false>(u, f, hup, hdn, top, y0, ny, g.y.cw_last, g.y.d_last, cw0, cw1, dx0, dx1, v0, v1, wxa, wxb, hx);
+        } else {
+            tail_residual<true>(u, f, hup, hdn, top, y0, ny, g.y.cw_last, g.y.d_last, cw0, cw1, dx0, dx1, v0, v1, wxa, wxb, hx);
+        }
+        hedge[w][0][lane] = hx[0];
+        hedge[w][1][lane] = hx[15];
+        __syncthreads();
+        const float hu = (w > 0) ? hedge[w - 1][1][lane] : 0.f, hd = (w < 7) ? hedge[w + 1][0][lane] : 0.f;
+        const float fx = (lane == ncx) ? 2.0f * g.x.inv_last : 1.0f;
+        const int colw = (lane == 0) ? 63 : lane - 1;              // B's unknown I - 1; the lane without a coarse point zeroes the padding column
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int J = 8 * w + j;
+            const float wya = (J == ncy) ? g.y.tw1 : 0.5f, wyb = (J == ncy) ? g.y.tw2 : 0.0f, fy = (J == ncy) ? 2.0f * g.y.inv_last : 1.0f;
+            const float m = (j == 0) ? hu : hx[j == 0 ? 0 : 2 * j - 1], pn = (j == 7) ? hd : hx[j == 7 ? 0 : 2 * j + 2];
+            const float v = ((0.5f * m + hx[2 * j]) + wya * hx[2 * j + 1]) + wyb * pn;
+            const bool in = lane >= 1 && lane <= ncx && J >= 1 && J <= ncy;
+            const int roww = (J == 0) ? 63 : J - 1;
+            if (roww < NPY && colw < NPX) *reinterpret_cast<float *>(bufA + (size_t)roww * RSX + colw * 4) = in ? v * (fx * fy) : 0.f;
+        }
+    }
+    __syncthreads();
+    SC_TAIL_STAMP(3);
+    // ---- level B on the matrix cores (k_mg_bottom_mm's products; right-hand side from LDS, solution to LDS)
+    mm_f16 acc;
+    if (mmw) {
+        float fv[KX];
+        mm_lds_half<KX>(bufA, 32 * tm + r, h, fv);
+        mm_row_half<KY>(ay2, 32 * tm + r, h, a3);                   // two products ahead: arrives behind the first product's MFMAs
+        acc = mm_product<KX>(fv, b1);                               // G1 = F Vx^-T
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dv[q] = dinv[(size_t)(32 * tm + (q & 3) + 8 * (q >> 2) + 4 * h) * NPX + 32 * tn + r];
+        mm_store_b<KY>(buf0, acc, tm, tn, r, h);
+    }
+    __syncthreads();
+    SC_TAIL_STAMP(4);
+    if (mmw) {
+        float gq[KY];
+        mm_lds_half<KY>(buf0, 32 * tn + r, h, gq);
+        mm_row_half<KX>(ax2, 32 * tn + r, h, b4);
+        acc = mm_product<KY>(a2, gq);                               // G2 = (Vy^-1 G1) (.) Dinv
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] *= dv[q];
+        mm_store_b<KY>(bufA, acc, tm, tn, r, h);
+    }
+    __syncthreads();
+    SC_TAIL_STAMP(5);
+    if (mmw) {
+        float gq[KY];
+        mm_lds_half<KY>(bufA, 32 * tn + r, h, gq);
+        acc = mm_product<KY>(a3, gq);                               // G3 = Vy G2
+        mm_store_a<KX>(buf0, acc, tm, tn, r, h);
+    }
+    __syncthreads();
+    SC_TAIL_STAMP(6);
+    if (mmw) {
+        float gq[KX];
+        mm_lds_half<KX>(buf0, 32 * tm + r, h, gq);
+        acc = mm_product<KX>(gq, b4);                               // U = G3 Vx^T
+        float *ub = reinterpret_cast<float *>(bufA);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ub[(32 * tm + (q & 3) + 8 * (q >> 2) + 4 * h + 1) * PB + 32 * tn + r + 1] = acc[q];
+    }
+    __syncthreads();
+    SC_TAIL_STAMP(7);
+    // ---- A += P B (coarse rows 8w .. 8w + 8, columns lane and lane + 1), post-smoothing
+    {
+        const float *ub = reinterpret_cast<const float *>(bufA);
+        const float gx = 2.0f * g.x.tw1 - 1.0f, gy = 2.0f * g.y.tw1 - 1.0f;
+        float2 e[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int J = 8 * w + j, Jr = min(max(J, 1), max(ncy, 1));
+            const float E0 = ub[Jr * PB + lane], E1 = ub[Jr * PB + lane + 1], Em = ub[Jr * PB + max(lane - 1, 0)];
+            const float e0 = (lane >= 1 && lane <= ncx) ? E0 : ((lane == ncx + 1 && lane >= 2) ? gx * Em : 0.f);   // second tail point: the ghost column itself
+            const float e1 = (lane + 1 <= ncx) ? E1 : (lane == ncx ? gx * e0 : 0.f);
+            const float rs = (J >= 1 && J <= ncy) ? 1.0f : (J == ncy + 1 ? gy : 0.0f);
+            e[j] = make_float2(e0 * rs, (0.5f * e0 + 0.5f * e1) * rs);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int y = y0 + i;
+            const bool act = y >= 1 && y <= ny;
+            float2 cr = e[i >> 1];
+            if (i & 1) cr = make_float2(0.5f * cr.x + 0.5f * e[(i >> 1) + 1].x, 0.5f * cr.y + 0.5f * e[(i >> 1) + 1].y);
+            if (act && v0) u[i].x += cr.x;
+            if (act && v1) u[i].y += cr.y;
+        }
+    }
+    exchange();
+    SC_TAIL_STAMP(8);
+    for (int s = 0; s < a.post; ++s) {
+        SC_TAIL_HALF(0);
+        exchange();
+        SC_TAIL_HALF(1);
+        if (s + 1 < a.post) exchange();
+    }
+    SC_TAIL_STAMP(9);
+    float *__restrict__ ug = a.U.at(c);
+    if (x0 < a.U.pitch) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int y = y0 + i;
+            if (y >= 1 && y <= ny) *reinterpret_cast<float2 *>(ug + (size_t)y * a.U.pitch + x0) = u[i];
+        }
+    }
+    SC_TAIL_STAMP(10);
+#undef SC_TAIL_STAMP
+#undef SC_TAIL_HALF
+}
+
+// level A: at most 127 unknowns per side (g = its geometry, g.*.nc = level B's sizes <= 63); NPX / NPY: level B padded to 32 or 64
+bool launch_mg_tail(const MGTail &a, int NPX, int NPY, int C, hipStream_t s)
+{
+    if (a.g.x.n > 127 || a.g.y.n > 127 || a.g.x.nc > 63 || a.g.y.nc > 63 || a.g.x.nc > NPX || a.g.y.nc > NPY) return false;
+#define SC_TL(SX, SY) if (NPX == 16 * SX && NPY == 16 * SY) { hipLaunchKernelGGL((k_mg_tail<SX, SY>), dim3(C), dim3(512), 0, s, a); return true; }
+    SC_TL(2, 2) SC_TL(2, 4) SC_TL(4, 2) SC_TL(4, 4)
+#undef SC_TL
+    return false;
+}
+
 hipError_t mg_bottom_prepare()
 {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_mg_bottom), hipFuncAttributeMaxDynamicSharedMemorySize,

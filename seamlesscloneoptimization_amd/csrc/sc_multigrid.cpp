@@ -305,6 +305,33 @@ static int run_bottom(Instance *I, size_t l0, int pre, int post)
     return SC_OK;
 }
 
+// The level above the bottom and the bottom in one launch (k_mg_tail): level l is that level, the bottom's first level is the one
+// solved directly on the matrix cores with at most 64 padded unknowns per side, and l itself is a plain float level (>= 2: level 1
+// has its own composed / float16 forms).
+static bool tail_serves(const Instance *I, size_t l)
+{
+    if (l < 2 || l + 1 != I->mg_bottom || (I->opts.flags & SC_FLAG_SEPARATE_TAIL) || I->opts.sweeps_per_launch == 1) return false;
+    if (!I->fd_mm || I->fd_level != 0 || I->fd_npx > 64 || I->fd_npy > 64) return false;
+    if ((I->opts.mg_pre > 0 ? I->opts.mg_pre : 2) < 1) return false;          // the launch takes the residual of the colour swept last as zero
+    const MGGeom &g = I->mg[l].g;
+    return g.x.n <= 127 && g.y.n <= 127 && g.x.nc <= 63 && g.y.nc <= 63;
+}
+
+static int run_tail(Instance *I, size_t l, int pre, int post, bool &done, unsigned long long *stamps = nullptr)
+{
+    done = false;
+    MGTail t;
+    t.stamps = stamps;
+    t.mm = (const unsigned char *)((const float *)I->mg_fd.p + I->fd_mm_off);
+    t.F = I->mg[l].F; t.U = I->mg[l].U; t.g = I->mg[l].g; t.pre = pre; t.post = post;
+    if (I->fd_pending) {
+        SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0));
+        I->fd_pending = false;
+    }
+    done = launch_mg_tail(t, I->fd_npx, I->fd_npy, I->F.C, I->stream);
+    return SC_OK;
+}
+
 static int build_levels(Instance *I)
 {
     const int W = I->F.W, H = I->F.H, C = I->F.C;
@@ -355,6 +382,13 @@ static int build_levels(Instance *I)
     SC_HIP(I, hipGetLastError());
     I->mg[0].F = I->F;
     I->mg_bottom = bottom_start(I);
+    // A first bottom level too large for the matrix-core solve (97 .. 127 unknowns on a side) used to run as an LDS-resident
+    // V-cycle inside k_mg_bottom; since round 4 it is the level k_mg_tail keeps in registers, and the level below it (<= 63
+    // unknowns per side) is the one solved directly.
+    if (!(I->opts.flags & (SC_FLAG_VCYCLE_BOTTOM | SC_FLAG_BOTTOM_F32)) && I->opts.mg_direct_max <= 0 && I->mg_bottom >= 2 && I->mg_bottom + 1 < nl) {
+        const MGGeom &g = I->mg[I->mg_bottom].g;
+        if ((g.x.n > 96 || g.y.n > 96) && g.x.n <= 127 && g.y.n <= 127 && g.x.nc <= 63 && g.y.nc <= 63) I->mg_bottom += 1;
+    }
     I->mg_l1_half = false;        // fresh planes: all zero in either format
     return build_fd(I);
 }
@@ -391,6 +425,10 @@ static int vcycle(Instance *I, size_t l, int pre, int post, unsigned no_post = 0
     MGLevel &L = I->mg[l];
     int rc;
     if (l > 0 && l == I->mg_bottom) return run_bottom(I, l, pre, post);
+    if (!skip_post && tail_serves(I, l)) {
+        bool done = false;
+        if ((rc = run_tail(I, l, pre, post, done)) || done) return rc;
+    }
     if (l + 1 == I->mg.size()) { // coarsest level outside the bottom kernel: SOR with its optimal factor
         const int n = std::max(8, std::min(64, 2 * std::max(L.g.x.n, L.g.y.n)));
         if (l == 0) return run_sweeps(I, SC_METHOD_SOR, n, L.omega, 1);
@@ -757,7 +795,7 @@ int mg_time_coarse_chain(Instance *I, int reps, float *ms_eager, float *ms_graph
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
     int rc;
     if (I->fd_pending) { SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0)); I->fd_pending = false; }
-    *launches = (int)(2 * (I->mg_bottom - 2) + 1);
+    *launches = (int)(2 * (I->mg_bottom - 2) + 1) - (tail_serves(I, I->mg_bottom - 1) ? 2 : 0);
     if ((rc = vcycle(I, 2, pre, post))) return rc;                       // warm
     SC_HIP(I, hipEventRecord(I->ev_k0, I->stream));
     for (int i = 0; i < reps; ++i) if ((rc = vcycle(I, 2, pre, post))) return rc;
@@ -785,6 +823,28 @@ int mg_time_coarse_chain(Instance *I, int reps, float *ms_eager, float *ms_graph
     SC_HIP(I, hipEventElapsedTime(&ms, I->ev_k0, I->ev_k1));
     *ms_graph = ms / (float)reps;
     return SC_OK;
+}
+
+// Measurement hook (sc_hip_time_tail_phases): one k_mg_tail launch on the hierarchy the last multigrid solve left, with the shader
+// clock of channel 0's first thread at its eleven phase boundaries: entry | right-hand side in registers | pre-smoothing done |
+// residual + restriction done (level B's right-hand side in LDS) | products 1, 2, 3, 4 | prolongation + edge exchange |
+// post-smoothing | stores issued.  Differences are cycles of the shader clock.
+int mg_time_tail_phases(Instance *I, unsigned long long *out11)
+{
+    if (I->mg.size() < 4 || I->mg_bottom < 3 || !tail_serves(I, I->mg_bottom - 1)) { I->err = "time_tail_phases: the last run was not a multigrid solve whose bottom runs as k_mg_tail"; return SC_ERR_BAD_ARG; }
+    const sc_solver_opts &o = I->opts;
+    const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
+    unsigned long long *d = nullptr;
+    SC_HIP(I, hipMalloc(&d, 11 * sizeof(unsigned long long)));
+    bool done = false;
+    int rc = run_tail(I, I->mg_bottom - 1, pre, post, done);             // warm
+    if (!rc) rc = run_tail(I, I->mg_bottom - 1, pre, post, done, d);
+    hipError_t e = hipStreamSynchronize(I->stream);
+    if (!rc && e == hipSuccess && done) e = hipMemcpy(out11, d, 11 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(I, e, "time_tail_phases");
+    return done ? SC_OK : SC_ERR_BAD_ARG;
 }
 
 } // namespace sc

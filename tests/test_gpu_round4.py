@@ -212,6 +212,35 @@ def test_bottom_solve_on_the_matrix_cores_agrees_with_the_float32_form(hip, W, H
         hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=0, max_sweeps=d.max_sweeps, update_tol=d.update_tol)
 
 
+@pytest.mark.parametrize("W,H", [(2048, 2048), (1020, 1020), (2040, 1020), (1000, 700), (1900, 130), (505, 1010), (1018, 1016), (960, 530)])
+def test_level_above_the_bottom_and_bottom_in_one_launch(hip, W, H):
+    """Round 4 (k_mg_tail): where the level above the directly solved one has at most 127 unknowns per side, that level's
+    pre-smoothing + residual + restriction, the direct solve and the level's prolongation + post-smoothing are ONE launch with the
+    level in registers; SC_FLAG_SEPARATE_TAIL keeps the three launches on the same hierarchy.  Same arithmetic per point: after
+    one cycle the two fields agree to rounding (the residual's additions are ordered differently), the default solve takes the
+    same number of cycles.  Shapes: square, a thin level (waves without rows), both tail-point counts, 32- and 64-padded solves."""
+    from seamlesscloneoptimization_amd import capi
+    rng = np.random.default_rng(W * 3 + H)
+    U = rng.uniform(0, 255, (3, H, W)).astype(np.float32)
+    F = np.zeros((3, H, W), np.float32)
+    F[:, 1:-1, 1:-1] = rng.normal(0, 30, (3, H - 2, W - 2)).astype(np.float32)
+    d = hip.default_opts()
+    got = {}
+    try:
+        for cycles in (1, 0):
+            for flags in (0, capi.SC_FLAG_SEPARATE_TAIL):
+                hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags, **(dict(max_sweeps=1, update_tol=1e-30) if cycles else dict(max_sweeps=d.max_sweeps, update_tol=d.update_tol)))
+                hip.field_load(U, F)
+                hip.field_solve(allow_not_converged=True)
+                got[(cycles, flags)] = (hip.field_store(), hip.info().sweeps)
+        scale = float(np.abs(got[(1, 0)][0]).max())
+        assert np.abs(got[(1, 0)][0] - got[(1, capi.SC_FLAG_SEPARATE_TAIL)][0]).max() <= 2e-5 * scale, (W, H)
+        assert got[(0, 0)][1] == got[(0, capi.SC_FLAG_SEPARATE_TAIL)][1]
+        assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_SEPARATE_TAIL)][0]).max() <= 2e-5 * scale, (W, H)
+    finally:
+        hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=0, max_sweeps=d.max_sweeps, update_tol=d.update_tol)
+
+
 def test_measurement_hooks_of_round_4(inst, oracles):
     """sc_hip_time_cycle0_form (the four level-0 launches of a solve under tagged symbols) and sc_hip_time_coarse_chain (levels
     2 .. bottom .. 2 as plain launches and as HIP-graph replays) run on the state a default multigrid clone leaves, return
