@@ -614,27 +614,41 @@ def main():
         t0 = time.perf_counter()
         inst.run(patch, body, mask, cx, cy)
         first_ms.append(round((time.perf_counter() - t0) * 1e3, 4))
-    calls = []
-    for _ in range(max(3, args.host_calls)):
-        body[...] = dst
-        t0 = time.perf_counter()
-        inst.run(patch, body, mask, cx, cy)
-        t_host = (time.perf_counter() - t0) * 1e3
-        hi = inst.info()
-        calls.append((t_host, hi.ms_h2d, hi.ms_device_total, hi.ms_d2h, hi.ms_call))
+    host_result = body.copy()
+    flags0 = inst.get_solver().flags
 
-    def stat(k):
-        v = sorted(c[k] for c in calls)
+    def host_calls(n, flags):
+        inst.set_solver(flags=flags)
+        out = []
+        for _ in range(n):
+            body[...] = dst
+            t0 = time.perf_counter()
+            inst.run(patch, body, mask, cx, cy)
+            t_host = (time.perf_counter() - t0) * 1e3
+            hi = inst.info()
+            out.append((t_host, hi.ms_h2d, hi.ms_device_total, hi.ms_d2h, hi.ms_call))
+        if not np.array_equal(body, host_result):
+            raise SystemExit("bench: the drop-in call's result changed between calls")
+        return out
+    # the statistics of the call: no stage marks inside it (each is an event in the stream with a ~5 us bubble behind it); its stages: a
+    # second, shorter series with the marks
+    calls = host_calls(max(3, args.host_calls), flags0 | capi.SC_FLAG_NO_STAGE_MARKS)
+    marked = host_calls(max(3, args.host_calls // 3), flags0)
+    inst.set_solver(flags=flags0)
+
+    def stat(k, series=None):
+        v = sorted(c[k] for c in (series if series is not None else calls))
         return {"median": round(v[len(v) // 2], 4), "p95": round(v[min(len(v) - 1, int(round(0.95 * (len(v) - 1))))], 4), "min": round(v[0], 4)}
     st_call = stat(0)
     pcie = {"call_ms": st_call["median"], "call_ms_p95": st_call["p95"], "call_ms_min": st_call["min"], "calls_timed": len(calls),
-            "first_two_calls_ms": first_ms,
-            "h2d_ms": stat(1), "device_ms": stat(2), "d2h_ms": stat(3), "stream_ms": stat(4),
+            "first_two_calls_ms": first_ms, "call_ms_with_stage_marks": stat(0, marked),
+            "h2d_ms": stat(1, marked), "device_ms": stat(2, marked), "d2h_ms": stat(3, marked), "stream_ms": stat(4),
             "Mpix_per_s_inclusive": round(W * H / (st_call["median"] * 1e-3) / 1e6, 1),
             "note": "my_seamlessclone_api_imp_run on pageable numpy images, one clone, one instance: mask, patch rows and destination rows "
-                    "cross PCIe as linear copies at the caller's row step (no packing: the ROI covers most of every row here), clone, the "
-                    "compact ROI back through pinned staging + splice of the interior into the caller's image (never `value`); call_ms = "
-                    "host wall time of the call (median), stream_ms = hipEvent time from the first upload to the last download"}
+                    "cross PCIe as linear copies at the caller's row step (no packing: the ROI covers most of every row here), clone with the "
+                    "output bytes written into the destination rows on the device, those rows back as one linear copy into the caller's "
+                    "image (never `value`); call_ms = host wall time of the call (median, SC_FLAG_NO_STAGE_MARKS), stream_ms = hipEvent time "
+                    "from the first upload to the last download of the same calls; h2d / device / d2h from a second series with the marks"}
 
     # ---- sweep kernels named by the north-star, on freshly built float fields of the same images (single clone, 3 channels)
     spl = args.sweeps_per_launch            # 0: library default = fused kernels at their deepest depth

@@ -182,7 +182,7 @@ typedef struct sc_solver_opts {
                                             error).  Takes 2 bytes per unknown off four of the six field transfers between a
                                             solve's level-0 launches                                                           */
 
-#define SC_FLAG_NO_STAGE_MARKS  (1 << 12) /* sc_hip_run_device(..., bSync = true): record only the first and the last stage mark.  Every
+#define SC_FLAG_NO_STAGE_MARKS  (1 << 12) /* sc_hip_run_device(..., bSync = true) and the host-image call: record only the first and the last stage mark.  Every
                                             mark is an event in the stream with a ~5 us bubble behind it, so the per-stage timeline
                                             (ms_mask, ms_pre, ms_solve) costs a 2048^2 clone ~15 us; with this flag ms_device_total is the
                                             un-instrumented device time of the clone and the per-stage figures read 0 (all of it is booked

@@ -658,7 +658,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     const int dms = whole_m ? ms : round_up(mc, 256);
     if ((rc = ensure(I, I->d_mask, (size_t)dms * mr + 64))) return rc;
     I->stage_marks = true;         // a host-image call is synchronous whatever bSync says: its timeline is always read
-    I->marks_ends_only = false;
+    I->marks_ends_only = (I->opts.flags & SC_FLAG_NO_STAGE_MARKS) != 0;      // (... unless the caller gives the per-stage figures up for their ~5 us bubbles)
     if ((rc = tmark(I, 0))) return rc;
     if (whole_m) SC_HIP(I, hipMemcpyAsync(I->d_mask.p, mask, (size_t)ms * (mr - 1) + mc, hipMemcpyHostToDevice, I->stream));
     else if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
@@ -690,8 +690,12 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         const int passes = I->opts.reference_warmup ? 2 : 1;
         // the output bytes go to a compact buffer of their own (the interior only is written, and only that comes back); the
         // reference's warm-up pass (two applications in place) needs the first result where the second reads it: the body buffer
-        uint8_t *const out_dev = passes > 1 ? (uint8_t *)I->d_body_roi.p + boff : (uint8_t *)I->d_out.p;
-        const int out_pitch = passes > 1 ? bpitch : dfs;
+        // A destination uploaded as whole rows takes the output bytes in place as well: the rows then come back as ONE linear copy
+        // straight into the caller's image (what it overwrites outside the ROI's columns are the caller's own bytes, uploaded a
+        // moment ago) -- no pinned staging, no splice on the host behind the last DMA.
+        const bool inplace = whole_b && passes == 1 && (size_t)bs == 3 * (size_t)bc;      // (a view into a wider array keeps the staged path: nothing beyond the view's own pixels is ever written)
+        uint8_t *const out_dev = (passes > 1 || inplace) ? (uint8_t *)I->d_body_roi.p + boff : (uint8_t *)I->d_out.p;
+        const int out_pitch = (passes > 1 || inplace) ? bpitch : dfs;
         r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p + foff, fpitch,
                          (uint8_t *)I->d_body_roi.p + boff, bpitch, g, passes, out_dev, out_pitch);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
@@ -705,7 +709,11 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         // caller memory (the reference is effectively synchronous too: its D2H + host splice, imp.cpp:471).
         const int orows = g.H - 2;
         const size_t ob = 3 * (size_t)(g.W - 2);
-        if (orows > 0 && g.W > 2) {
+        if (orows > 0 && g.W > 2 && inplace) {
+            SC_HIP(I, hipMemcpyAsync(body + (size_t)(g.lty + 1) * bs + 3 * (size_t)(g.ltx + 1), out_dev + (size_t)out_pitch + 3,
+                                     (size_t)bs * (orows - 1) + ob, hipMemcpyDeviceToHost, I->stream));
+            SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+        } else if (orows > 0 && g.W > 2) {
             const int dfs = out_pitch;            // (shadows the compact pitch: the warm-up variant returns at the body buffer's)
             if ((r = ensure_pinned(I, I->h_out, (size_t)dfs * g.H + 64))) return r;
             uint8_t *dst_org = body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1);
