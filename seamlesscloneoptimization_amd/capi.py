@@ -51,6 +51,7 @@ SC_FLAG_FLOAT_FIELD = 1 << 11
 SC_FLAG_NO_STAGE_MARKS = 1 << 12
 SC_FLAG_BOTTOM_F32 = 1 << 13
 SC_FLAG_SEPARATE_TAIL = 1 << 14
+SC_FLAG_STAGED_RETURN = 1 << 15
 
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",

@@ -693,7 +693,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         // A destination uploaded as whole rows takes the output bytes in place as well: the rows then come back as ONE linear copy
         // straight into the caller's image (what it overwrites outside the ROI's columns are the caller's own bytes, uploaded a
         // moment ago) -- no pinned staging, no splice on the host behind the last DMA.
-        const bool inplace = whole_b && passes == 1 && (size_t)bs == 3 * (size_t)bc;      // (a view into a wider array keeps the staged path: nothing beyond the view's own pixels is ever written)
+        const bool inplace = whole_b && passes == 1 && (size_t)bs == 3 * (size_t)bc && !(I->opts.flags & SC_FLAG_STAGED_RETURN);      // (a view into a wider array keeps the staged path: nothing beyond the view's own pixels is ever written)
         uint8_t *const out_dev = (passes > 1 || inplace) ? (uint8_t *)I->d_body_roi.p + boff : (uint8_t *)I->d_out.p;
         const int out_pitch = (passes > 1 || inplace) ? bpitch : dfs;
         r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p + foff, fpitch,

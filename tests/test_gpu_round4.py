@@ -265,3 +265,33 @@ def test_measurement_hooks_of_round_4(inst, oracles):
     assert _dmax(body, want) <= 1
     for p in d:
         inst.free(p)
+
+
+def test_host_call_returns_rows_in_place_or_staged(inst, oracles):
+    """Round 4: a destination without row padding whose ROI covers most of its rows takes the output bytes in place on the device and
+    gets its rows back as one linear copy; SC_FLAG_STAGED_RETURN keeps the staged return that writes ROI bytes only; a view into a
+    wider array always does.  All three leave the same image, identical outside the ROI to what went in."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(1200, 1000, margin=24)
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, min(16, oc.max_threads()))
+    got = {}
+    try:
+        for name, flags in (("rows", 0), ("staged", capi.SC_FLAG_STAGED_RETURN)):
+            inst.set_solver(flags=flags)
+            body = dst.copy()
+            inst.run(patch, body, mask, cx, cy)
+            got[name] = body
+        inst.set_solver(flags=0)
+        wide = np.full((dst.shape[0], dst.shape[1] + 40, 3), 77, np.uint8)
+        view = wide[:, 20:-20]
+        view[...] = dst
+        inst.run(patch, view, mask, cx, cy)
+        got["view"] = view.copy()
+        assert (wide[:, :20] == 77).all() and (wide[:, -20:] == 77).all()
+    finally:
+        inst.set_solver(flags=0)
+    assert np.array_equal(got["rows"], got["staged"]) and np.array_equal(got["rows"], got["view"])
+    assert np.abs(got["rows"].astype(int) - want.astype(int)).max() <= 1
+    changed = np.argwhere((got["rows"] != dst).any(axis=2))
+    assert changed.size and changed[:, 0].min() >= 1 and changed[:, 1].min() >= 1       # nothing on the image border
