@@ -15,6 +15,10 @@ if len(sys.argv) > 4:
     extra["flags"] = int(sys.argv[4])
 if extra:
     inst.set_solver(**extra)
+if len(sys.argv) > 5:                                   # experiments: sc_solver_opts.reserved[0]
+    o_ = inst.get_solver(); o_.reserved[0] = int(sys.argv[5])
+    import ctypes as C_
+    assert inst.L.sc_hip_set_solver(inst.h, C_.byref(o_)) == 0
 dst, patch, mask, cx, cy = o.synth_inputs(roi, roi, margin=256)
 d_face, d_body, d_mask, d_keep = (inst.to_device(a) for a in (patch, dst, mask, dst))
 tot = []
