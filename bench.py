@@ -531,7 +531,7 @@ def main():
         solo_wall.append((time.perf_counter() - t0) * 1e3)
         solo_dev.append(inst.info().ms_device_total)
     inst.set_solver(flags=opts["flags"])
-    # the launch-bound part of a cycle (levels 2 .. bottom .. 2: seven dependent launches per cycle for this ROI) as plain launches
+    # the launch-bound part of a cycle (levels 2 .. bottom .. 2: five dependent launches per cycle for this ROI, seven before k_mg_tail) as plain launches
     # and as replays of one captured HIP graph, on the hierarchy this clone left
     chain = None
     if args.method == "mg":
@@ -542,6 +542,13 @@ def main():
                              "launched per pass (hipGraphLaunch), the plain form enqueues the same kernels one by one"}
         except capi.SeamlessCloneError as e:
             chain = {"error": str(e)}
+        if isinstance(chain, dict) and "error" not in chain:
+            try:        # the level above the bottom + the bottom in one launch: shader-clock cycles between its phase boundaries (channel 0)
+                ph = sorted(inst.time_tail_phases() for _ in range(5))[2]
+                chain["k_mg_tail_phase_cycles"] = dict(zip(["entry_to_rhs_in_registers", "pre_smoothing", "residual_and_restriction", "product_1", "product_2",
+                                                            "product_3", "product_4", "interpolation", "post_smoothing", "stores"], ph))
+            except capi.SeamlessCloneError:
+                pass        # this hierarchy runs the three launches (level above the bottom too large for the registers)
     solo_dev.sort(); solo_wall.sort()
     single_clone = {"ms": round(solo_dev[len(solo_dev) // 2], 4), "Mpix_per_s": round(W * H / (solo_dev[len(solo_dev) // 2] * 1e-3) / 1e6, 1),
                     "ms_min": round(solo_dev[0], 4), "wall_ms_median": round(solo_wall[len(solo_wall) // 2], 4), "cycles": int(inst.info().sweeps),

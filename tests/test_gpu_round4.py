@@ -260,6 +260,14 @@ def test_measurement_hooks_of_round_4(inst, oracles):
     assert n == 5 and eager > 0 and graph > 0                                              # 1098 -> 548 -> 273 -> 136 | bottom 67: levels 2, 3 down and up + the bottom
     with pytest.raises(capi.SeamlessCloneError):
         inst.time_cycle0_form(7, 2)
+    with pytest.raises(capi.SeamlessCloneError):
+        inst.time_tail_phases()                            # level 136 x 124 above the bottom: too wide for k_mg_tail's registers
+    dst2, patch2, mask2, cx2, cy2 = o.synth_inputs(1020, 1020, margin=32)
+    d2 = [inst.to_device(a) for a in (patch2, dst2, mask2)]
+    inst.run_device(d2[0], patch2.shape, d2[1], dst2.shape, d2[2], mask2.shape, cx2, cy2)
+    ph = inst.time_tail_phases()                           # 1018 -> 509 -> 254 -> 126 | 63: k_mg_tail
+    assert len(ph) == 10 and all(0 < v < 10**7 for v in ph)
+    assert inst.time_coarse_chain(5)[2] == 3              # levels 2 down, tail, 2 up
     body = dst.copy()
     inst.run(patch, body, mask, cx, cy)                                                    # the instance still clones correctly
     assert _dmax(body, want) <= 1
