@@ -147,17 +147,29 @@ def bottom_start(levels) -> int:
     return len(levels)
 
 
+def bottom_level(levels, matrix_cores=True):
+    """The library's I->mg_bottom (sc_multigrid.cpp build_levels): the first level handled by the bottom of the cycle.  Rounds
+    1-3 and SC_FLAG_BOTTOM_F32: the LDS-fit rule (bottom_start).  Default since round 4: the first level >= 2 with at most 127
+    unknowns per side is the deepest one smoothed (k_mg_tail holds it in registers) and the level below it is the bottom; a ROI
+    whose level 1 already fits the matrix-core solve (<= 96 per side) keeps that."""
+    b = bottom_start(levels)
+    if matrix_cores:
+        nl = len(levels)
+        a = next((l for l in range(2, nl - 1) if levels[l][0].n <= 127 and levels[l][1].n <= 127), 0)
+        level1_direct = nl > 1 and levels[1][0].n <= 96 and levels[1][1].n <= 96
+        if a and not (a == 2 and level1_direct):
+            b = a + 1
+        elif not level1_direct:
+            b = next((l for l in range(1, nl) if levels[l][0].n <= 96 and levels[l][1].n <= 96), b)
+    return b
+
+
 def direct_level(levels, matrix_cores=True):
     """Index of the level solved exactly (fast diagonalisation), or None.  matrix_cores (the library's default since round 4):
     the bottom's first level is solved on the matrix cores whenever both sides have at most 96 unknowns, without an LDS budget
     to meet (sc_multigrid.cpp build_fd, k_mg_bottom_mm); False = SC_FLAG_BOTTOM_F32, the LDS-resident float32 form."""
     planes = 0
-    b = bottom_start(levels)
-    if matrix_cores and 2 <= b < len(levels) - 1:
-        # a first bottom level of 97 .. 127 unknowns on a side is smoothed (k_mg_tail), the level below it is solved directly
-        dx, dy = levels[b]
-        if (dx.n > 96 or dy.n > 96) and dx.n <= 127 and dy.n <= 127 and dx.nc <= 63 and dy.nc <= 63:
-            b += 1
+    b = bottom_level(levels, matrix_cores)
     for l in range(b, len(levels)):
         dx, dy = levels[l]
         planes += _bottom_floats(dx, dy)
@@ -196,7 +208,7 @@ def composes_level1(levels) -> bool:
     """The fused GPU path runs level 1 with 4 pre-smoothing sweeps and no post-smoothing when it is a launched level with a
     level 2 below it: the level-0 launch then interpolates from "level-1 correction + interpolated level-2 correction"
     directly and level 1 needs no prolongation launch (sc_multigrid.cpp: mg_composes_level1)."""
-    return len(levels) >= 3 and bottom_start(levels) >= 2
+    return len(levels) >= 3 and bottom_level(levels) >= 2
 
 
 def no_post_levels(levels):

@@ -382,12 +382,21 @@ static int build_levels(Instance *I)
     SC_HIP(I, hipGetLastError());
     I->mg[0].F = I->F;
     I->mg_bottom = bottom_start(I);
-    // A first bottom level too large for the matrix-core solve (97 .. 127 unknowns on a side) used to run as an LDS-resident
-    // V-cycle inside k_mg_bottom; since round 4 it is the level k_mg_tail keeps in registers, and the level below it (<= 63
-    // unknowns per side) is the one solved directly.
-    if (!(I->opts.flags & (SC_FLAG_VCYCLE_BOTTOM | SC_FLAG_BOTTOM_F32)) && I->opts.mg_direct_max <= 0 && I->mg_bottom >= 2 && I->mg_bottom + 1 < nl) {
-        const MGGeom &g = I->mg[I->mg_bottom].g;
-        if ((g.x.n > 96 || g.y.n > 96) && g.x.n <= 127 && g.y.n <= 127 && g.x.nc <= 63 && g.y.nc <= 63) I->mg_bottom += 1;
+    // Default hierarchy since round 4: the deepest launched level ("A") is the first one (>= 2) with at most 127 unknowns per side --
+    // k_mg_tail holds it in registers -- and the level below it ("B", at most 63 per side) is the one solved directly, on the matrix
+    // cores, inside the same launch.  The LDS-fit rule above chose the bottom in rounds 1-3; where it landed on a level with 97 .. ~190
+    // unknowns on a side (ROIs like 2090 x 1632, 2500 x 1300, 3540^2: no matrix-core solve, an LDS-resident V-cycle inside
+    // k_mg_bottom instead) a cycle cost 60 us more than at the sizes next to it (0.55 against 0.38 ms for one clone).  Kept: a ROI
+    // whose level 1 already fits the matrix-core solve (<= 96 per side: solved there), the flags that ask for the older bottoms.
+    if (!(I->opts.flags & (SC_FLAG_VCYCLE_BOTTOM | SC_FLAG_BOTTOM_F32)) && I->opts.mg_direct_max <= 0) {
+        size_t a = 0;
+        for (size_t l = 2; l + 1 < nl && !a; ++l)
+            if (I->mg[l].g.x.n <= 127 && I->mg[l].g.y.n <= 127) a = l;
+        const bool level1_direct = nl > 1 && I->mg[1].g.x.n <= 96 && I->mg[1].g.y.n <= 96;
+        if (a && !(a == 2 && level1_direct)) I->mg_bottom = a + 1;
+        else if (!level1_direct)
+            for (size_t l = 1; l < nl; ++l)
+                if (I->mg[l].g.x.n <= 96 && I->mg[l].g.y.n <= 96) { I->mg_bottom = l; break; }
     }
     I->mg_l1_half = false;        // fresh planes: all zero in either format
     return build_fd(I);
