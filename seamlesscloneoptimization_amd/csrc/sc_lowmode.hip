@@ -468,14 +468,18 @@ void lowmode_bands_written(Instance *I, const float *field) { I->lm.bands_of = f
 // 4.9 update_tol (1.2 grey levels at the default 0.25; measured third-cycle updates are 0.06-0.09).  Worst case of the
 // difference therefore: max_ratio x 4.9 x update_tol = 0.015 grey levels at 2048^2 (max_ratio 0.012), 0.036 at 4096^2
 // (0.029); typical 0.001-0.003.  0: no correction is applied at all (exact tables, singular float tables, no unknowns);
-// 1: yes, that worst case stays below 0.05 grey levels; 2: no (ROIs beyond ~5000^2, where the float tables approach their
-// singularity and max_ratio exceeds 0.04): those take the field-keeping path.
+// 1: yes, that worst case stays below 0.05 grey levels; 3: only if the judged cycle's MEASURED update m keeps max_ratio x m below
+// the same 0.049 (the caller checks it beside the stop rule and repeats the cycle in the field-keeping form otherwise): ROIs
+// whose float tables are off by more than 4 % in their lowest modes -- everything beyond ~5000^2, and single sizes from ~3000^2
+// on where 2 cos(pi / (n + 1)) rounds unluckily (3120^2, 3330^2, 3470^2, 3610^2: those took the field-keeping path with its
+// serial correction and separate post-process until round 4, +8-10 % per clone; measured third-cycle updates are 0.06-0.09,
+// i.e. a difference of 0.004); 2: (lm_prepare failed) the field-keeping path.
 int lowmode_early_kind(Instance *I, float update_tol)
 {
     if (!wants_float_tables(I)) return 0;
     if (lm_prepare(I) != SC_OK) return 2;
     if (I->lm.singular) return 0;
-    return I->lm.max_ratio * 4.9 * (double)update_tol <= 0.049 ? 1 : 2;
+    return I->lm.max_ratio * 4.9 * (double)update_tol <= 0.049 ? 1 : 3;
 }
 
 // Node corrections of the field U (the instance's current shape): what the post-process adds (lm.CN == nullptr: nothing).

@@ -653,6 +653,7 @@ int mg_solve(Instance *I)
             return SC_OK;
         };
         bool early_ready = false;          // the node correction for the judged cycle's output is on its way (early_lm; CN == nullptr: none to add)
+        bool early_cond = false;           // ... and may be used only if the judged update turns out small enough (lowmode_early_kind 3)
         LmNodes early_lm;
         while (cyc < budget) {
             const bool comp1 = mg_composes_level1(I);
@@ -665,7 +666,12 @@ int mg_solve(Instance *I)
             // the judged cycle runs in its final form; when the float-table correction will follow it leaves the correction's
             // cell shares behind (sc_lowmode.hip), which saves the correction its own pass over the field
             const bool next_judged = !judged && !(cyc + 2 < 3 && cyc + 2 < budget && o.tol <= 0.f);
-            const int early = (out_wanted && next_judged) ? lowmode_early_kind(I, utol) : 2;
+            // lowmode_early_kind 3: the a-priori bound does not cover this size (the float tables' low modes are off by more than 4 %);
+            // the output may still carry the earlier iterate's correction IF the judged cycle's measured update keeps the difference
+            // below the same 0.049 grey levels -- decided with the stop rule, below (early_cond)
+            const int early_kind = (out_wanted && next_judged) ? lowmode_early_kind(I, utol) : 2;
+            const int early = early_kind == 3 ? 1 : early_kind;
+            if (out_wanted && next_judged) early_cond = early_kind == 3;
             float4 *const bands = (o.flags & SC_FLAG_SEPARATE_RESTRICT) ? nullptr
                                   : judged ? lowmode_bands_buffer(I, post) : early == 1 ? lowmode_bands_buffer(I, post + pre) : nullptr;
             if (judged && early_ready) {
@@ -689,7 +695,7 @@ int mg_solve(Instance *I)
                         }, m, m_prev))) return rc;
                     I->info.last_update = m;
                     if (saturated) { I->info.sweeps = cyc; return SC_RETRY_FLOAT_FIELD; }      // nothing was written (AbortFlag)
-                    if (stop_rule(m, m_prev)) { I->spec_post.done = true; I->out_direct = true; ok = true; break; }
+                    if (stop_rule(m, m_prev) && !(early_cond && I->lm.max_ratio * (double)m > 0.049)) { I->spec_post.done = true; I->out_direct = true; ok = true; break; }
                     // rejected: the same cycle again in the form that keeps the field, then on as usual
                     --cyc;
                     I->info.sweep_launches -= 1;
