@@ -278,7 +278,7 @@ def new_size_leg(capi, seed=4):
     frame meets a new size on most calls.  Device-resident images, synchronous calls, host wall time per call:
       * fresh: the very first call of a fresh instance at the reference's four published patch sizes (arena allocation,
         per-size state, code-object load of the kernels it touches: everything);
-      * stream: 64 clones with pseudo-random ROI sizes drawn from [100, 900]^2 and from [1000, 2400]^2 on one instance whose
+      * stream: 64 clones with pseudo-random ROI sizes drawn from [100, 720]^2 (the direct solve's range) and from [1000, 2400]^2 (multigrid) on one instance whose
         arena has been grown by one call at the largest size -- every call is a size the instance has never seen; right
         after each, the same call again (the size is cached now: steady state).  median / p95 of both and of the ratio."""
     import numpy as np
@@ -352,7 +352,7 @@ def new_size_leg(capi, seed=4):
         dev = upload(inst)
         call(inst, dev, 2402, 2402)                 # grow the arena once: from here on a new size costs its per-size state only
         call(inst, dev, 902, 902)
-        for name, lo, hi in (("roi_100_900", 100, 900), ("roi_1000_2400", 1000, 2400)):
+        for name, lo, hi in (("roi_100_720", 100, capi.SC_AUTO_DIRECT_MAX), ("roi_1000_2400", 1000, 2400)):
             first, steady, seen = [], [], set()
             while len(first) < 64:
                 pw, ph = int(rng.integers(lo, hi + 1)) + 2, int(rng.integers(lo, hi + 1)) + 2

@@ -72,7 +72,7 @@ enum sc_method {
                                 within +-1 of the float-table port, diff sums of the size the reference publishes for its
                                 own cuFFT path against OpenCV (PDF p3)                                           */
 };
-#define SC_AUTO_DIRECT_MAX 900
+#define SC_AUTO_DIRECT_MAX 720        /* round 4 (900 in round 3): the cycles got faster (0.222 against 0.231 ms at 750^2, 0.228 against 0.268 at 900^2) */
 #define SC_AUTO_THIN_MAX 4          /* ... and for thin ROIs (at most this many unknowns across, up to SC_AUTO_THIN_LONG_MAX along) */
 #define SC_AUTO_THIN_LONG_MAX 4096
 

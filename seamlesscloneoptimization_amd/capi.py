@@ -32,7 +32,7 @@ SC_METHOD_MULTIGRID = 3
 SC_METHOD_DST = 4
 SC_METHOD_AUTO = 5      # default: the FFT-form direct solve (double transforms) up to SC_AUTO_DIRECT_MAX unknowns per side, MULTIGRID above
 SC_METHOD_FFT = 6       # the reference's default back-end: FFT-based direct solve, float32, O(n^2 log n)
-SC_AUTO_DIRECT_MAX = 900
+SC_AUTO_DIRECT_MAX = 720
 SC_AUTO_THIN_MAX = 4
 SC_AUTO_THIN_LONG_MAX = 4096
 

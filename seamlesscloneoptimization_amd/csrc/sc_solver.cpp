@@ -29,7 +29,8 @@ int effective_method(const Instance *I)
     // the direct solve = the FFT form with double transforms (fft_in_double): the answer of the matrix form SC_METHOD_DST (both
     // are the reference's float-table arithmetic with exact transforms; measured diff sums against the port are identical) in
     // 0.09-0.29 ms of device time where the matrix form takes 0.17-0.37 and the cycles 0.18-0.35 (298x192 ... 896^2 ROIs; at 1024^2 the
-    // cycles win again: 0.295 against 0.313 ms -- tools/fft_probe.py)
+    // cycles win again: 0.295 against 0.313 ms -- tools/fft_probe.py; round 4, tools/size_probe.py [--mg]: the cycles win from ~730^2 on:
+    // 0.221 against 0.212 ms at 700^2, 0.222 against 0.231 at 750^2, 0.228 against 0.268 at 900^2)
     if (w <= SC_AUTO_DIRECT_MAX && h <= SC_AUTO_DIRECT_MAX) return SC_METHOD_FFT;
     // ROIs narrower than 7 pixels (the three erodes empty the mask: the exact solution is the destination itself, integers):
     // the reference's float tables put every mode ~1e-7 below its exact value, so its answer is v - epsilon and truncates to v - 1

@@ -477,7 +477,7 @@ def test_fixed16_field_between_the_level0_launches(hip, oracles):
 
 
 def test_default_path_fuzz_over_small_and_medium_shapes(inst, oracles):
-    """The default solver choice over 36 random ROI shapes up to ~1000 pixels a side (direct solve up to 900 unknowns, multigrid
+    """The default solver choice over 36 random ROI shapes up to ~1000 pixels a side (direct solve up to SC_AUTO_DIRECT_MAX unknowns, multigrid
     above; rectangular and elliptical masks; every FFT length from 32 to 2048): within one of the float-table port, and the
     direct solve's deviation stays at rounding level (a handful of channel values per clone)."""
     from seamlesscloneoptimization_amd import capi

@@ -132,7 +132,7 @@ def test_thirty_new_roi_sizes_back_to_back_on_one_instance(inst, oracles):
     """in a drop-in use every frame has its own mask, so a ROI size the instance has never seen is the
     norm.  Per-size state is now built on the device (bottom-solver matrices from closed-form eigenpairs, chirp / transform
     tables by the solver's own FFT, one zeroing launch for the hierarchy) and cached in small LRUs.  Thirty distinct sizes in a
-    row on one instance with the DEFAULT options -- direct solve below 900 unknowns per side, multigrid above, odd and even
+    row on one instance with the DEFAULT options -- direct solve up to SC_AUTO_DIRECT_MAX unknowns per side, multigrid above, odd and even
     sizes, irregular last intervals on every level --: each within one of the float-table port on its FIRST call, byte-identical
     when repeated (cached state = freshly built state), and a size that has been evicted from every cache in between gives the
     bytes of its first visit."""

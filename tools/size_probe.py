@@ -6,8 +6,9 @@ from seamlesscloneoptimization_amd import capi
 from oracle import mg_np
 import _synth as o
 inst = capi.Instance(0)
-inst.set_solver(flags=capi.SC_FLAG_NO_STAGE_MARKS)
-for a in sys.argv[1:]:
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+inst.set_solver(flags=capi.SC_FLAG_NO_STAGE_MARKS, **({"method": capi.SC_METHOD_MULTIGRID} if "--mg" in sys.argv else {}))
+for a in args:
     W, H = (int(v) for v in a.split("x"))
     dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=64)
     d = [inst.to_device(x) for x in (patch, dst, mask, dst)]
