@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ 
     __shared__ float Tt[LM_KB][64 + 1];
     __shared__ float St[64][LM_KB + 1];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x;
-    const int xt = blockIdx.x, nxt = gridDim.x, rs = blockIdx.y, nrs = gridDim.y, c = blockIdx.z;
+    // blockIdx.y = row split x block of LM_KB y-modes (round 4: the blocks used to be a loop inside the workgroup -- a tall ROI,
+    // 1000 x 8000, has two column tiles and 8 blocks: 24 workgroups ran 188 us)
+    const int nkb = (Kyp + LM_KB - 1) / LM_KB;
+    const int xt = blockIdx.x, nxt = gridDim.x, rs = blockIdx.y / nkb, nrs = gridDim.y / nkb, c = blockIdx.z;
     const int part = rs * nxt + xt;                              // this workgroup's partial product
     const int X = xt * 64 + lane;
     const float4 *__restrict__ cell = Cell + (size_t)c * cells_y * cells_x;
@@ -138,7 +141,8 @@ __global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ 
     // clamped cell coordinates, masked values: the loads stay branch-free and all of a batch are in flight together
     const int Xc0 = min(X, cells_x - 1), Xc1 = min(max(X - 1, 0), cells_x - 1);
     const bool mx0 = X < nx && X < cells_x, mx1 = X < nx && X >= 1 && X - 1 < cells_x;
-    for (int kb = 0; kb < Kyp; kb += LM_KB) {
+    {
+        const int kb = (blockIdx.y % nkb) * LM_KB;
         float acc[LM_KB];
 #pragma unroll
         for (int k = 0; k < LM_KB; ++k) acc[k] = 0.f;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void k_lm_cexpand(const float *__restrict__ Up
 #pragma unroll
                 for (int j = 0; j < LM_KB * LM_KB / 256; ++j) sum[j] = 0.f;
 #pragma unroll 2
-                for (int q = 0; q < nparts; ++q) {               // nparts is a multiple of LM_RS
+                for (int q = 0; q < nparts; ++q) {
                     const float *__restrict__ up = Upart + (((size_t)q * C + c) * Kyp + kb) * Kxp + lb;
 #pragma unroll
                     for (int j = 0; j < LM_KB * LM_KB / 256; ++j) {
@@ -500,10 +504,15 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on)
         L.bands_of = nullptr;  // used once: whoever touches the field afterwards need not know about the parts
     } else
     hipLaunchKernelGGL(k_lm_restrict, dim3((cells_x + 63) / 64, (cells_y + 3) / 4, U.C), dim3(256), 0, st, U, (float4 *)L.P.p, cells_x, cells_y);
-    hipLaunchKernelGGL(k_lm_cproject, dim3(nxt, LM_RS, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
+    // row splits of the projection: as few as fill the chip (every split is one more part for k_lm_cexpand to add: a wide ROI, 8000 x
+    // 1000, has 16 column tiles and needs none), at most LM_RS (what the parts buffer holds)
+    const int nkb = (L.Kyp + LM_KB - 1) / LM_KB;
+    int nrs = 1;
+    while (nrs < LM_RS && nxt * nrs * nkb * 3 < 192) nrs *= 2;      // (from the geometry alone, as for one clone: a group member's bytes are the clone's own)
+    hipLaunchKernelGGL(k_lm_cproject, dim3(nxt, nrs * nkb, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
                        (const float *)L.Sy.p, L.Kyp, (const float *)L.Sx.p, L.Kxp, upart);
     hipLaunchKernelGGL(k_lm_cexpand, dim3(nxt, (L.ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, st, (const float *)upart,
-                       nxt * LM_RS, U.C, (const float *)L.R.p, (const float *)L.Sx.p, L.Kxp, (const float *)L.Sy.p, L.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p);
+                       nxt * nrs, U.C, (const float *)L.R.p, (const float *)L.Sx.p, L.Kxp, (const float *)L.Sy.p, L.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p);
     SC_HIP(I, hipGetLastError());
     lm.CN = (const float *)L.CN.p;
     lm.ny = L.ny;

@@ -5,7 +5,8 @@ import numpy as np
 from seamlesscloneoptimization_amd import capi
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _synth as o
-roi = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+roi = sys.argv[1] if len(sys.argv) > 1 else '2048'
+roi_w, roi_h = (int(v) for v in roi.split('x')) if 'x' in roi else (int(roi), int(roi))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 inst = capi.Instance(0)
 extra = {}
@@ -19,7 +20,7 @@ if len(sys.argv) > 5:                                   # experiments: sc_solver
     o_ = inst.get_solver(); o_.reserved[0] = int(sys.argv[5])
     import ctypes as C_
     assert inst.L.sc_hip_set_solver(inst.h, C_.byref(o_)) == 0
-dst, patch, mask, cx, cy = o.synth_inputs(roi, roi, margin=256)
+dst, patch, mask, cx, cy = o.synth_inputs(roi_w, roi_h, margin=256)
 d_face, d_body, d_mask, d_keep = (inst.to_device(a) for a in (patch, dst, mask, dst))
 tot = []
 for i in range(n):
