@@ -202,6 +202,18 @@ __global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ 
     }
 }
 
+// The projection's parts added up once, in order, into part 0 (round 4).  k_lm_cexpand adds them itself -- every one of its
+// workgroups all of them: fine for the 16 parts of a 2048^2 ROI, 67 us for the 64 parts x 32 x 256 modes of an 8000 x 1000 one.
+__global__ __launch_bounds__(256) void k_lm_parts_sum(float *__restrict__ Upart, int nparts, size_t per_part, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < nparts; ++q) s += Upart[(size_t)q * per_part + i];
+    Upart[i] = s;
+}
+
 // Coarse expansion: Chat[k][l] = R[k][l] * (sum of the projection's parts, in order);  E[k][X] = sum_l Chat[k][l] SxN[X][l];
 // CN[c][Y][X] = sum_k SyN[Y][k] E[k][X] -- the correction at the nodes.  Workgroup = 64 node columns x (4 waves x LM_NPW node rows); E of the 64 columns is formed once per workgroup
 // (wave v takes 8 of every 32 modes, through LDS); then lane = X with the E column in registers, SyN rows as scalar loads.
@@ -511,8 +523,14 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on)
     while (nrs < LM_RS && nxt * nrs * nkb * 3 < 192) nrs *= 2;      // (from the geometry alone, as for one clone: a group member's bytes are the clone's own)
     hipLaunchKernelGGL(k_lm_cproject, dim3(nxt, nrs * nkb, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
                        (const float *)L.Sy.p, L.Kyp, (const float *)L.Sx.p, L.Kxp, upart);
+    int nparts = nxt * nrs;
+    if (nparts >= 32) {       // many parts (wide ROIs): one launch adds them, in the same order, instead of every expansion workgroup
+        const size_t per_part = (size_t)U.C * L.Kyp * L.Kxp;
+        hipLaunchKernelGGL(k_lm_parts_sum, dim3((unsigned)((per_part + 255) / 256)), dim3(256), 0, st, upart, nparts, per_part, per_part);
+        nparts = 1;
+    }
     hipLaunchKernelGGL(k_lm_cexpand, dim3(nxt, (L.ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, st, (const float *)upart,
-                       nxt * nrs, U.C, (const float *)L.R.p, (const float *)L.Sx.p, L.Kxp, (const float *)L.Sy.p, L.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p);
+                       nparts, U.C, (const float *)L.R.p, (const float *)L.Sx.p, L.Kxp, (const float *)L.Sy.p, L.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p);
     SC_HIP(I, hipGetLastError());
     lm.CN = (const float *)L.CN.p;
     lm.ny = L.ny;
