@@ -715,8 +715,9 @@ int mg_solve(Instance *I)
             if (!judged && early != 2) {       // the node correction the next cycle's output will carry, from this launch's field
                 early_lm = LmNodes();
                 // a group of clones: its coarse levels fill the chip, nothing to overlap (measured: -2 %); a small clone: the two
-                // cross-stream waits cost more than the 15-us chain they hide (154x100 ... 300x194 patches: +20 us)
-                if (early == 1 && (I->F.C > 3 || (size_t)I->F.W * I->F.H < (size_t)1 << 20)) {
+                // cross-stream waits cost more than the 15-us chain they hide (154x100 ... 300x194 patches: +20 us; neutral at 730^2 ... 800^2,
+                // -2..3 % from 900^2 on: the threshold is 0.79 Mpix, 1 Mpix until late in round 4)
+                if (early == 1 && (I->F.C > 3 || (size_t)I->F.W * I->F.H < (size_t)3 << 18)) {
                     if ((rc = lowmode_nodes(I, result(I), early_lm))) return rc;
                 } else if (early == 1) {       // one large clone: on the second stream, beside the coarse levels of the next cycle (-15 us of 500 at 2048^2)
                     SC_HIP(I, hipEventRecord(I->ev_fork, I->stream));

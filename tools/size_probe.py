@@ -8,6 +8,10 @@ import _synth as o
 inst = capi.Instance(0)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 inst.set_solver(flags=capi.SC_FLAG_NO_STAGE_MARKS, **({"method": capi.SC_METHOD_MULTIGRID} if "--mg" in sys.argv else {}))
+if "--r1" in sys.argv:                                 # experiments: sc_solver_opts.reserved[0] = 1
+    import ctypes as C_
+    o_ = inst.get_solver(); o_.reserved[0] = 1
+    assert inst.L.sc_hip_set_solver(inst.h, C_.byref(o_)) == 0
 for a in args:
     W, H = (int(v) for v in a.split("x"))
     dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=64)
