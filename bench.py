@@ -15,7 +15,7 @@ owns its own synthetic images (weak scaling: independent images, no data-path co
 value = total ROI Mpix / max-over-ranks wall time.  Each destination is restored from a pristine
 device copy before every clone (inside the timed region) so no clone starts from an already-converged field.
 
-The same JSON line carries `single_clone` (ONE 2048^2 clone alone: BASELINE config 3 as written), `value_float32_storage` (the
+The same JSON line carries `value_without_in_step_restore` (the step minus its destination refresh), `single_clone` (ONE 2048^2 clone alone: BASELINE config 3 as written), `value_float32_storage` (the
 same timed step with float32 fields throughout), `roofline` (the dominant kernel AS THE TIMED REGION RUNS IT -- the grouped
 level-0 multigrid launch -- HIP-event timed on the library's stream; plus all four level-0 launch forms of a solve), `pcie` (the
 drop-in host-image call: median / p95 / min of 24), `new_size` (the first call at a ROI size the instance has never seen),
@@ -61,6 +61,7 @@ def parse_args(argv=None):
                     help="N > 1: pin each rank (and the library threads it starts) to its share of the host cores (auto) or leave the mask alone")
     ap.add_argument("--host-calls", type=int, default=24, help="timed drop-in host-image calls of the `pcie` leg (median / p95 / min are reported)")
     ap.add_argument("--no-float32-leg", action="store_true", help="skip value_float32_storage (the same timed step with float32 fields and right-hand side)")
+    ap.add_argument("--no-fresh-leg", action="store_true", help="skip value_without_in_step_restore (up to 16 steps, each into its own pre-resident destinations: 0.43 GB of HBM per step)")
     ap.add_argument("--no-new-size", action="store_true", help="skip the new_size leg (first call at a ROI size the instance has not seen)")
     ap.add_argument("--no-c4", action="store_true", help="skip the roofline_c4 leg (config 4: single-sweep Jacobi kernels at a 4096^2 ROI, HBM bound)")
     ap.add_argument("--reference-table", action="store_true",
@@ -487,6 +488,34 @@ def main():
         value_f32 = (el32, max(i.info().sweeps for i in pool.instances))
         pool.set_solver(flags=opts["flags"])
         step()                                # back on the default's fields (level 1 re-zeroed) before anything else is measured
+    # ... and the same step without its destination restores: S steps, each cloning into its OWN pre-resident copies of the 32
+    # destinations (the clone is in place; `value` refreshes the same 32 images from pristine copies inside every step -- 0.5 GB of
+    # device copies, 2-3 % of the step -- so that any number of steps runs in fixed memory).  Reported beside `value`, never as it.
+    value_fresh = None
+    if args.method == "mg" and image_ids is None and not args.no_fresh_leg:
+        S = max(1, min(args.steps, 16))
+        fresh_sets, fresh_jobs = [], []
+        for k in range(S):
+            cj = pool.make_jobs(args.batch)
+            bodies = []
+            for b, j in enumerate(jobs):
+                nb = inst.malloc(j["n"])
+                inst.copy_d2d_async(nb, j["b0"], j["n"])
+                bodies.append(nb)
+                c, src = cj[b], cjobs[b]
+                c.face, c.face_cols, c.face_rows, c.face_step = src.face, src.face_cols, src.face_rows, src.face_step
+                c.body, c.body_cols, c.body_rows, c.body_step = nb, src.body_cols, src.body_rows, src.body_step
+                c.mask, c.mask_cols, c.mask_rows, c.mask_step = src.mask, src.mask_cols, src.mask_rows, src.mask_step
+                c.centerX, c.centerY, c.body_restore = src.centerX, src.centerY, None
+            fresh_sets.append(bodies); fresh_jobs.append(cj)
+        inst.sync()
+        step()                                # warm (restoring form)
+        elf = timed_region(comm, sync_all, lambda: [pool.run(cj, device_resident=True) for cj in fresh_jobs])
+        same = np.array_equal(inst.from_device(fresh_sets[-1][0], jobs[0]["host"][0].shape), inst.from_device(jobs[0]["b"], jobs[0]["host"][0].shape))
+        value_fresh = (elf, S, bool(same))
+        for bodies in fresh_sets:
+            for nb in bodies:
+                inst.free(nb)
     dst, patch, mask, cx, cy = jobs[0]["host"]
     out = inst.from_device(jobs[0]["b"], dst.shape)
     if not all(i.info().converged for i in pool.instances) or np.array_equal(out, dst):
@@ -837,6 +866,12 @@ def main():
                    "parallelism": f"{args.gpus} GPU(s) x {args.batch} independent images, no collective",
                    "cycles_or_sweeps": int(group_cycles)},
         "single_clone": single_clone,
+        "value_without_in_step_restore": ({"value": round(comm.sum(float(W * H * args.batch)) * value_fresh[1] / value_fresh[0] / 1e6, 2), "unit": "Mpix/s",
+                                           "ms_per_step": round(value_fresh[0] / value_fresh[1] * 1e3, 4), "steps": value_fresh[1],
+                                           "same_bytes_as_the_restoring_step": value_fresh[2],
+                                           "note": "the timed step of `value` minus its destination refresh: every step clones (in place) into its own "
+                                                   "copies of the destinations, resident before the clock starts; `value` keeps the refresh inside the step"}
+                                          if value_fresh else None),
         "value_float32_storage": ({"value": round(total_pix / value_f32[0] / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(value_f32[0] / args.steps * 1e3, 4),
                                    "cycles": int(value_f32[1]), "flags": "SC_FLAG_FLOAT_FIELD | SC_FLAG_FLOAT_RHS",
                                    "note": "the same timed step (same steps, same clock) with float32 storage throughout: field between the "
