@@ -241,11 +241,13 @@ static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int 
         I->mpitch = round_up(predicted->W, 64);
         rc = ensure(I, I->d_M, (size_t)I->mpitch * predicted->H);
         if (rc) return rc;
-        launch_mask_erode3(d_mask, ms, mr, *predicted, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
+        // (round 4, late: no erode launch either -- the pre-process tiles form the eroded mask themselves and leave it in d_M)
         I->erode_done = true;
         I->pending_scan = BboxTask();
         I->pending_scan.mask = d_mask; I->pending_scan.mw = mc; I->pending_scan.mh = mr; I->pending_scan.mstep = ms;
         I->pending_scan.fold = fold;
+        I->pending_scan.g = *predicted;
+        I->pending_scan.mask_bytes = (size_t)ms * (mr - 1) + (size_t)(predicted->x0 + predicted->W + 1);      // as launch_mask_erode3 counts them
         I->scan_pending = true;
     } else
     launch_mask_bbox(d_mask, mc, mr, ms, fold, I->stream);

@@ -331,3 +331,35 @@ def test_early_correction_where_the_a_priori_bound_does_not_cover_the_size(inst,
     for k, v in out.items():
         dv = np.abs(v.astype(np.int16) - want.astype(np.int16))
         assert dv.max() <= 1 and (dv > 0).mean() < 0.01, (k, int(dv.max()), float((dv > 0).mean()))
+
+
+@pytest.mark.parametrize("W,H", [(300, 200), (1100, 900), (517, 130)])
+def test_erode_inside_the_preprocess_tiles(inst, oracles, W, H):
+    """Round 4: a clone launched on a predicted bounding box has no erode launch -- the pre-process tiles form the eroded mask
+    themselves (k_mask_erode3's word arithmetic on 16 + 1 rows through LDS).  A ragged mask (ellipse with specks, holes and grey
+    pixels) is cloned three times: the first call's guess (whole interior) is wrong, the clone is repeated on the scanned box with
+    the standalone erode; the second and third predict the remembered box and take the fused form.  All three images are the same
+    and within one of the CPU port; SC_FLAG_NO_SPECULATE (standalone kernels throughout) agrees byte for byte."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, margin=24, ellipse=True)
+    rng = np.random.default_rng(W + 7 * H)
+    ys, xs = rng.integers(0, mask.shape[0], 40), rng.integers(0, mask.shape[1], 40)
+    mask = mask.copy()
+    mask[ys[:20], xs[:20]] = 0                      # holes
+    mask[ys[20:30], xs[20:30]] = 200                # grey pixels: not 255, so they erode like holes (seamlessClone_imp.cpp:917)
+    mask[ys[30:], xs[30:]] = 255                    # specks outside the ellipse
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+    outs = []
+    try:
+        for flags in (0, 0, 0, capi.SC_FLAG_NO_SPECULATE):
+            inst.set_solver(flags=flags)
+            body = dst.copy()
+            assert inst.run(patch, body, mask, cx, cy) == 0
+            outs.append(body)
+    finally:
+        inst.set_solver(flags=0)
+    for b in outs[1:]:
+        assert np.array_equal(b, outs[0])
+    d = np.abs(outs[0].astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
