@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the rocprofv3 evidence of round 4.  (The counter passes run bench.py without its float32-storage and new-size legs, so that
+# GPU box: the rocprofv3 evidence of round 4.  (The counter passes run bench.py without its float32-storage, no-restore and new-size legs, so that
 # the step-traffic difference (3 steps - 1 step) / 2 is the DEFAULT step's alone; the statistics run keeps the float32 leg: its symbols
 # ..., 0> / 16> / 80> / 56> are that leg's launches.)  (1) kernel statistics of `python3 bench.py`; (2) four counter passes over the same
 # command (FETCH_SIZE / WRITE_SIZE x 3 steps / 1 step) -> <tag>_pmc_traffic_bench.json (copy to profiles/r4_pmc_traffic_bench.json);
@@ -22,7 +22,7 @@ cp $(ls $O/${T}_stats/*/*kernel_stats.csv | head -1) $O/${T}_kernel_stats.csv
 echo "stats done"
 for pass in "f3 FETCH_SIZE 3" "w3 WRITE_SIZE 3" "f1 FETCH_SIZE 1" "w1 WRITE_SIZE 1"; do
   set -- $pass
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/${T}_$1 -- python3 $R/bench.py --cpu-seconds 0 --no-c4 --no-float32-leg --no-new-size --host-calls 3 --warmup 0 --steps $3 --kernel-launches 6 \
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/${T}_$1 -- python3 $R/bench.py --cpu-seconds 0 --no-c4 --no-float32-leg --no-fresh-leg --no-new-size --host-calls 3 --warmup 0 --steps $3 --kernel-launches 6 \
       > /dev/null 2> $O/${T}_$1.err || { echo "pmc pass $1 failed"; tail -5 $O/${T}_$1.err; exit 1; }
   echo "pass $1 done"
 done
