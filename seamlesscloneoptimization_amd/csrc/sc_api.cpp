@@ -335,6 +335,7 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         I->result_in_U1 = false;
         I->f_half = mg_reads_half_rhs(I);
         I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
+        if (I->scan_pending) I->pending_scan.M_out = (uint8_t *)I->d_M.p;      // the launch's tiles erode the mask themselves and leave it here
         launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
                           I->stream, I->f_half, I->u_half, grey, I->scan_pending ? &I->pending_scan : nullptr);
         I->scan_pending = false;

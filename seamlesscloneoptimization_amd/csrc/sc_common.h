@@ -62,7 +62,7 @@ void launch_mask_erode3_group(const MaskJob *jobs, int n, hipStream_t s);
 // scan: the clone's bounding-box scan rides in this launch as extra workgroups (fold.nbx / nblocks / scan_rows are filled in here)
 // g, mask_bytes: the launch's tiles also form the eroded mask of the (predicted) ROI `g` themselves, from the mask bytes (mask_bytes of them are
 // the caller's), and leave it in M as k_mask_erode3 would -- no erode launch in front of the pre-process
-struct BboxTask { const uint8_t *mask = nullptr; int mw = 0, mh = 0, mstep = 0; BboxFold fold; int scan_rows = 0; Geo g{}; size_t mask_bytes = 0; };
+struct BboxTask { const uint8_t *mask = nullptr; int mw = 0, mh = 0, mstep = 0; BboxFold fold; int scan_rows = 0; Geo g{}; size_t mask_bytes = 0; uint8_t *M_out = nullptr; };     // M_out: where the tiles leave the eroded mask (the buffer the launch's M argument names)
 void launch_preprocess(const uint8_t *body_org, int bstep, const uint8_t *face_org, int fstep,
                        const uint8_t *M, int mpitch, Field U0, Field U1, Field F, hipStream_t s, bool f_half = false, bool u_half = false, bool grey = false,
                        const BboxTask *scan = nullptr);

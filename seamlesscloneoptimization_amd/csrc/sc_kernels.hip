@@ -534,7 +534,7 @@ __device__ __forceinline__ void preprocess_block(const uint8_t *__restrict__ bod
             if (y < 3 || y > H - 4 || x < 0 || x >= W) v = 0u;
             v = (v >> 7) * 255u;
             ew[r][wq] = v;
-            if (r >= 1 && wq >= 1 && y < H && x < W) *reinterpret_cast<unsigned *>(const_cast<uint8_t *>(M) + (size_t)y * mpitch + x) = v;   // the tile's own rows and words
+            if (r >= 1 && wq >= 1 && y < H && x < W) *reinterpret_cast<unsigned *>(er->M_out + (size_t)y * mpitch + x) = v;   // the tile's own rows and words
         }
     }
     __syncthreads();
