@@ -3,9 +3,11 @@ per kernel: start offset, duration, gap to the previous kernel (all us)."""
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a clone starts with its mask stage: k_mask_erode3 (launched on a predicted box: the scan rides in the pre-process launch) or k_mask_bbox
-ismask = lambda r: "k_mask_bbox" in r["Kernel_Name"] or "k_mask_erode" in r["Kernel_Name"]   # the group forms too
-starts = [i for i, r in enumerate(rows) if ismask(r) and (i == 0 or not ismask(rows[i - 1]))]
+# a clone starts with its mask stage -- k_mask_bbox / k_mask_erode3 (the group forms too) -- or, launched on a predicted box since late
+# round 4, straight with the pre-process launch (which carries the scan and erodes the mask in its tiles)
+ismask = lambda r: "k_mask_bbox" in r["Kernel_Name"] or "k_mask_erode" in r["Kernel_Name"]
+ispre = lambda r: "k_preprocess" in r["Kernel_Name"]
+starts = [i for i, r in enumerate(rows) if (ismask(r) or ispre(r)) and (i == 0 or not ismask(rows[i - 1]))]
 a = starts[-1]
 b = len(rows)
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0
