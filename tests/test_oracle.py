@@ -368,3 +368,30 @@ def test_fixed16_field_in_the_first_stores_leaves_no_trace():
             e[fq] = U[1:-1, 1:-1] - ue[1]
         assert np.abs(e[True]).max() <= 1.01 * np.abs(e[False]).max() + 2e-4, cycles
         assert e[True].std() <= 1.01 * e[False].std() + 2e-5, cycles
+
+
+def test_bottom_level_rule_of_round_4():
+    """oracle/mg_np.bottom_level mirrors sc_multigrid.cpp build_levels: wherever a level >= 2 with at most 127 unknowns per side has a
+    level below it, the bottom is that level below (<= 63 per side: the pair k_mg_tail runs in one launch), unless level 1 itself
+    already fits the matrix-core solve; never deeper than necessary; thin ROIs without such a pair keep the LDS-fit rule."""
+    from oracle import mg_np
+    rng = np.random.default_rng(4)
+    seen_pair = seen_thin = 0
+    for _ in range(400):
+        W, H = int(rng.integers(40, 6000)), int(rng.integers(40, 6000))
+        lv = mg_np.build_levels(W, H)
+        b = mg_np.bottom_level(lv)
+        cand = [l for l in range(2, len(lv) - 1) if lv[l][0].n <= 127 and lv[l][1].n <= 127]
+        level1_direct = len(lv) > 1 and lv[1][0].n <= 96 and lv[1][1].n <= 96
+        if cand and not (cand[0] == 2 and level1_direct):
+            a = cand[0]
+            assert b == a + 1 and lv[b][0].n <= 63 and lv[b][1].n <= 63, (W, H, b)
+            assert a == 2 or lv[a - 1][0].n > 127 or lv[a - 1][1].n > 127          # the shallowest such level
+            assert mg_np.direct_level(lv) == b
+            seen_pair += 1
+        elif not cand and not level1_direct and not any(x.n <= 96 and y.n <= 96 for x, y in lv[1:]):
+            assert b == mg_np.bottom_start(lv)
+            seen_thin += 1
+    assert seen_pair > 300
+    lv = mg_np.build_levels(4000, 130)                       # 3998 x 128 -> ... -> 124 x 3: no pair, no level that fits the matrix cores
+    assert mg_np.bottom_level(lv) == mg_np.bottom_start(lv) and mg_np.direct_level(lv) is None
