@@ -20,5 +20,5 @@ for a in sys.argv[1:]:
     lv = mg_np.build_levels(W, H)
     d = mg_np.direct_level(lv)
     spec = mg_np.solve(U[0], F[0], cycles=1) if W * H < 600 * 600 else None
-    print(a, "levels", [(x.n, y.n) for x, y in lv[1:d + 1]], "tail-vs-separate", float(np.abs(got[0] - got[capi.SC_FLAG_SEPARATE_TAIL]).max()),
+    print(a, "levels", [(x.n, y.n) for x, y in lv[1:(d or 0) + 1]], "tail-vs-separate", float(np.abs(got[0] - got[capi.SC_FLAG_SEPARATE_TAIL]).max()),
           "vs spec", None if spec is None else (float(np.abs(got[0][0] - spec).max()), float(np.abs(got[capi.SC_FLAG_SEPARATE_TAIL][0] - spec).max())), flush=True)
