@@ -294,38 +294,46 @@ static void fft_radices(int logM, int lr[4], int &npass)
 // (Round 3 built them on the host: a serial radix-2 double FFT with cos / sin in its inner loop plus M sincos for the
 // twiddles, behind a stream synchronisation -- ~0.5 ms per direction at M = 2048, several times the 0.1-0.3 ms clone that
 // needed them.  The reference builds its per-size tables with a kernel inside every call: seamlessClone_imp.cpp:569-603.)
-// k_fft_tables: chirp c_m = exp(i pi m^2 / N), m = 0 .. n (phase reduced exactly: m^2 mod 2N in integers), and the twiddles
-// exp(-2 pi i k / M), in double, stored as T; `tw64` additionally receives the twiddles in double when the transform of the
-// chirp kernel below runs in double while T is float.
-template <typename T>
-__global__ __launch_bounds__(256) void k_fft_tables(cx2<T> *__restrict__ chirp, cx2<T> *__restrict__ tw, cx2<double> *__restrict__ tw64, int n, int M)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i <= n) {
-        const long long N2 = 4LL * (n + 1);
-        const long long q = ((long long)i * i) % N2;
-        double sn, cs;
-        sincospi((double)q / (double)(2 * (n + 1)), &sn, &cs);
-        chirp[i] = mk<T>((T)cs, (T)sn);
-    }
-    if (i < M) {
-        double sn, cs;
-        sincospi(-2.0 * (double)i / (double)M, &sn, &cs);
-        tw[i] = mk<T>((T)cs, (T)sn);
-        if (tw64) tw64[i] = mk<double>(cs, sn);
-    }
-}
-// k_fft_bhat: the transform of the chirp kernel b (b_0 = 1, b_m = b_{M-m} = conj(c_m), m = 1 .. n-1, zero elsewhere) by the SAME
-// in-LDS forward passes the solve uses -- their output order (digit reversed) is the order the pointwise product wants --
-// computed in TC (double whenever the row fits the LDS: M <= 8192) and stored as T with the 1/M of the inverse folded in.
+// The tables of one transform length: chirp c_m = exp(i pi m^2 / N), m = 0 .. n (phase reduced exactly: m^2 mod 2N in integers), the
+// twiddles exp(-2 pi i k / M), in double, stored as T (`tw64` additionally receives the twiddles in double when the transform of
+// the chirp kernel runs in double while T is float), and the transform of the chirp kernel b (b_0 = 1, b_m = b_{M-m} = conj(c_m),
+// m = 1 .. n-1, zero elsewhere) by the SAME in-LDS forward passes the solve uses -- their output order (digit reversed) is the order
+// the pointwise product wants -- computed in TC (double whenever the row fits the LDS: M <= 8192) and stored as T with the 1/M of
+// the inverse folded in.
+// k_fft_build (round 4, late): the tables of up to TWO transform lengths (the two directions of a solve) in ONE launch, one workgroup
+// per length -- until then two kernels per length (k_fft_tables, k_fft_bhat): a first call at a new ROI size spent four launches and two
+// forks on them, and a 300 x 200 clone is nine launches in all, bound by the host's enqueue time.  Same arithmetic, value for value:
+// the workgroup writes chirp and twiddles, then transforms the chirp kernel with the twiddles it has just written (visible to itself
+// behind the barrier).
 template <typename TC, typename T>
-__global__ __launch_bounds__(FFT_THREADS) void k_fft_bhat(FftPlan<TC> P, cx2<T> *__restrict__ bhat)
+struct FftBuild { cx2<T> *chirp, *bhat, *tw; cx2<double> *tw64; FftPlan<TC> P; };      // P.tw: the twiddles the build's own transform reads (tw, or tw64 when TC is double and T float)
+template <typename TC, typename T>
+struct FftBuildPair { FftBuild<TC, T> b[2]; };
+
+template <typename TC, typename T>
+__global__ __launch_bounds__(FFT_THREADS) void k_fft_build(FftBuildPair<TC, T> bp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fft_smem[];
     cx2<TC> *__restrict__ S = reinterpret_cast<cx2<TC> *>(fft_smem);
+    const FftBuild<TC, T> &B = bp.b[blockIdx.x];
+    const FftPlan<TC> &P = B.P;
     const int tid = threadIdx.x, n = P.n, M = P.M;
     const long long N2 = 4LL * (n + 1);
-    for (int i = tid; i < M; i += FFT_THREADS) {
+    for (int i = tid; i < max(M, n + 1); i += FFT_THREADS) {          // chirp and twiddles
+        if (i <= n) {
+            const long long q = ((long long)i * i) % N2;
+            double sn, cs;
+            sincospi((double)q / (double)(2 * (n + 1)), &sn, &cs);
+            B.chirp[i] = mk<T>((T)cs, (T)sn);
+        }
+        if (i < M) {
+            double sn, cs;
+            sincospi(-2.0 * (double)i / (double)M, &sn, &cs);
+            B.tw[i] = mk<T>((T)cs, (T)sn);
+            if (B.tw64) B.tw64[i] = mk<double>(cs, sn);
+        }
+    }
+    for (int i = tid; i < M; i += FFT_THREADS) {                      // the chirp kernel, then its transform
         const int m = i <= M / 2 ? i : M - i;
         cx2<TC> v = mk<TC>((TC)0, (TC)0);
         if (m == 0 && i == 0) v = mk<TC>((TC)1, (TC)0);
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_bhat(FftPlan<TC> P, cx2<T> 
         }
         S[fft_pad(i)] = v;
     }
+    __threadfence();
     __syncthreads();
     int lL = P.logM;
     for (int p = 0; p < P.npass; ++p) {
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_bhat(FftPlan<TC> P, cx2<T> 
     const TC inv = (TC)1 / (TC)M;
     for (int i = tid; i < M; i += FFT_THREADS) {
         const cx2<TC> v = S[fft_pad(i)];
-        bhat[i] = mk<T>((T)(v.x * inv), (T)(v.y * inv));
+        B.bhat[i] = mk<T>((T)(v.x * inv), (T)(v.y * inv));
     }
 }
 
@@ -367,9 +376,9 @@ static FftPlan<T> fft_plan_raw(const cx2<T> *chirp, int n, int logM)
     return P;
 }
 
-// The tables for n unknowns in precision T: from the instance's LRU, or built now on the second stream (the caller makes the
-// main stream wait for I->fft.ev_built before the first transform launch).  `keep`: an entry that must not be evicted (the
-// other direction of the same solve).
+// The tables for n unknowns in precision T: from the instance's LRU, or queued for a build on the second stream (fft_flush_builds:
+// both directions of a solve in one launch; the caller makes the main stream wait for I->fft.ev_built before the first transform
+// launch).  `keep`: an entry that must not be evicted (the other direction of the same solve).
 template <typename T>
 static int fft_build_dim(Instance *I, FftDim *&out, int n, const FftDim *keep)
 {
@@ -384,43 +393,87 @@ static int fft_build_dim(Instance *I, FftDim *&out, int n, const FftDim *keep)
     I->info.new_size = 1;
     const int logM = fft_logm(n), M = 1 << logM;
     int rc;
-    if (S.pending) {                  // a build nobody waited for yet: ordered in front of whatever follows on the main stream
+    if (S.pending && !S.forked && S.nreq == 0) {     // a build of an EARLIER solve nobody waited for: ordered in front of whatever follows on the main stream
         SC_HIP(I, hipStreamWaitEvent(I->stream, S.ev_built, 0));      // (ensure() waits for that stream before it frees a buffer)
         S.pending = false;
     }
     const size_t bytes = sizeof(cx2<T>) * (3 * (size_t)M + 1);      // chirp[n + 1 <= M + 1] | bhat[M] | tw[M]: sized by M alone, so an entry is reallocated only when M grows
     D.n = 0;
     if ((rc = ensure(I, D.chirp, bytes))) return rc;
-    const bool tc_double = dbl || logM <= FFT_MAX_LOGM - 1;      // the build's own transform in double whenever its row fits the LDS
-    if (tc_double && !dbl && (rc = ensure(I, S.tw64, sizeof(cx2<double>) * (size_t)M))) return rc;
+    D.n = n; D.logM = logM; D.dbl = dbl; D.used = ++S.tick;
+    S.req[S.nreq++] = &D;
+    out = &D;
+    return SC_OK;
+}
+
+// launches the queued builds (at most two: the directions of one solve) behind ONE fork of the second stream
+template <typename T>
+static int fft_flush_builds(Instance *I)
+{
+    FftState &S = I->fft;
+    if (S.nreq == 0) return SC_OK;
+    const bool dbl = sizeof(T) == sizeof(double);
+    int rc;
+    bool tcd[2] = { false, false };
+    size_t maxM = 0;
+    for (int k = 0; k < S.nreq; ++k) {
+        tcd[k] = dbl || S.req[k]->logM <= FFT_MAX_LOGM - 1;      // the build's own transform in double whenever its row fits the LDS
+        maxM = std::max(maxM, (size_t)1 << S.req[k]->logM);
+    }
+    if (!dbl && (tcd[0] || tcd[1]) && (rc = ensure(I, S.tw64, sizeof(cx2<double>) * 2 * maxM))) { for (int k = 0; k < S.nreq; ++k) S.req[k]->n = 0; S.nreq = 0; return rc; }
     if (!S.ev_fork) {
         SC_HIP(I, hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming));
         SC_HIP(I, hipEventCreateWithFlags(&S.ev_built, hipEventDisableTiming));
     }
-    // on the second stream, behind everything the main stream has been given so far (launches that still read the evicted tables)
-    SC_HIP(I, hipEventRecord(S.ev_fork, I->stream));
-    SC_HIP(I, hipStreamWaitEvent(I->aux, S.ev_fork, 0));
-    cx2<T> *chirp = (cx2<T> *)D.chirp.p, *bhat = chirp + (n + 1), *tw = bhat + M;
-    hipLaunchKernelGGL((k_fft_tables<T>), dim3((std::max(M, n + 1) + 255) / 256), dim3(256), 0, I->aux, chirp, tw,
-                       (tc_double && !dbl) ? (cx2<double> *)S.tw64.p : (cx2<double> *)nullptr, n, M);
-    if (dbl) {
-        FftPlan<double> P = fft_plan_raw<double>((const cx2<double> *)D.chirp.p, n, logM);
-        hipLaunchKernelGGL((k_fft_bhat<double, double>), dim3(1), dim3(FFT_THREADS), sizeof(cx2<double>) * (size_t)(fft_pad(M) + 1), I->aux, P, (cx2<double> *)bhat);
-    } else if (tc_double) {
-        FftPlan<double> P{};
-        P.tw = (const cx2<double> *)S.tw64.p;
-        P.n = n; P.logM = logM; P.M = M;
-        fft_radices(logM, P.lr, P.npass);
-        hipLaunchKernelGGL((k_fft_bhat<double, float>), dim3(1), dim3(FFT_THREADS), sizeof(cx2<double>) * (size_t)(fft_pad(M) + 1), I->aux, P, (cx2<float> *)bhat);
-    } else {
-        FftPlan<float> P = fft_plan_raw<float>((const cx2<float> *)D.chirp.p, n, logM);
-        hipLaunchKernelGGL((k_fft_bhat<float, float>), dim3(1), dim3(FFT_THREADS), sizeof(cx2<float>) * (size_t)(fft_pad(M) + 1), I->aux, P, (cx2<float> *)bhat);
+    // on the second stream, behind everything the main stream has been given so far (launches that still read the evicted tables);
+    // ONE fork per solve: the eigenvalue tables follow on the same stream (every fork is an event record on the main stream, a
+    // packet the next launch waits for)
+    if (!S.forked) {
+        SC_HIP(I, hipEventRecord(S.ev_fork, I->stream));
+        SC_HIP(I, hipStreamWaitEvent(I->aux, S.ev_fork, 0));
+        S.forked = true;
     }
+    auto fill = [&](auto &B, int k) {
+        using TC = typename std::remove_reference<decltype(B.P)>::type;
+        (void)sizeof(TC);
+        FftDim &D = *S.req[k];
+        const int M = 1 << D.logM;
+        cx2<T> *chirp = (cx2<T> *)D.chirp.p;
+        B.chirp = chirp; B.bhat = chirp + (D.n + 1); B.tw = B.bhat + M;
+        B.tw64 = (!dbl && tcd[k]) ? (cx2<double> *)S.tw64.p + (size_t)k * maxM : nullptr;
+        B.P.chirp = nullptr; B.P.bhat = nullptr;
+        B.P.n = D.n; B.P.logM = D.logM; B.P.M = M;
+        fft_radices(D.logM, B.P.lr, B.P.npass);
+    };
+    // directions whose builds run in the same arithmetic share a launch
+    for (int k = 0; k < S.nreq;) {
+        const int cnt = (k + 1 < S.nreq && tcd[k + 1] == tcd[k]) ? 2 : 1;
+        const size_t lds_elems = (size_t)fft_pad(1 << std::max(S.req[k]->logM, cnt > 1 ? S.req[k + 1]->logM : 0)) + 1;
+        if (dbl) {
+            if constexpr (sizeof(T) == sizeof(double)) {
+                FftBuildPair<double, double> bp{};
+                for (int q = 0; q < cnt; ++q) { fill(bp.b[q], k + q); bp.b[q].P.tw = bp.b[q].tw; }
+                hipLaunchKernelGGL((k_fft_build<double, double>), dim3(cnt), dim3(FFT_THREADS), sizeof(cx2<double>) * lds_elems, I->aux, bp);
+            }
+        } else if (tcd[k]) {
+            if constexpr (sizeof(T) == sizeof(float)) {
+                FftBuildPair<double, float> bp{};
+                for (int q = 0; q < cnt; ++q) { fill(bp.b[q], k + q); bp.b[q].P.tw = bp.b[q].tw64; }
+                hipLaunchKernelGGL((k_fft_build<double, float>), dim3(cnt), dim3(FFT_THREADS), sizeof(cx2<double>) * lds_elems, I->aux, bp);
+            }
+        } else {
+            if constexpr (sizeof(T) == sizeof(float)) {
+                FftBuildPair<float, float> bp{};
+                for (int q = 0; q < cnt; ++q) { fill(bp.b[q], k + q); bp.b[q].P.tw = bp.b[q].tw; }
+                hipLaunchKernelGGL((k_fft_build<float, float>), dim3(cnt), dim3(FFT_THREADS), sizeof(cx2<float>) * lds_elems, I->aux, bp);
+            }
+        }
+        k += cnt;
+    }
+    S.nreq = 0;
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipEventRecord(S.ev_built, I->aux));
     S.pending = true;
-    D.n = n; D.logM = logM; D.dbl = dbl; D.used = ++S.tick;
-    out = &D;
     return SC_OK;
 }
 
@@ -449,6 +502,8 @@ static int fft_fxy(Instance *I, FftFxy *&out, int w, int h)
     for (int i = 0; i < w; ++i) fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
     for (int j = 0; j < h; ++j) fy[j] = (float)(2.0 * std::cos(PIf / (h + 1.0) * (j + 1.0)));
     X.singular = !((fx[0] + fy[0]) - 4.0f < 0.0f);
+    // (on the main stream, behind the zero-fill ensure() gives a fresh buffer there: tried on the second stream beside the table
+    // build, the upload raced that fill -- eigenvalue tables of zeros whenever the main stream was still busy)
     SC_HIP(I, hipMemcpyAsync(X.d.p, X.hst.p, sizeof(float) * (size_t)(w + h), hipMemcpyHostToDevice, I->stream));
     SC_HIP(I, hipEventRecord(X.ev, I->stream));
     X.w = w; X.h = h; X.used = ++S.tick;
@@ -482,9 +537,9 @@ static hipError_t fft_opt_in_lds(Instance *I)
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_dst<2, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     // the table builders: a double row of up to 2^(FFT_MAX_LOGM - 1) points, or a float row of 2^FFT_MAX_LOGM
     const int bbytes = (int)(sizeof(cx2<double>) * (size_t)fft_pad(1 << (FFT_MAX_LOGM - 1))) + 64;
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_bhat<double, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bbytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_build<double, T>), hipFuncAttributeMaxDynamicSharedMemorySize, bbytes);
     if (e == hipSuccess && sizeof(T) == sizeof(float))
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_bhat<float, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bbytes);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_build<float, float>), hipFuncAttributeMaxDynamicSharedMemorySize, bbytes);
     done = e == hipSuccess;
     return e;
 }
@@ -504,8 +559,11 @@ static int fft_solve_t(Instance *I)
     int rc;
     FftDim *dw = nullptr, *dh = nullptr;
     FftFxy *X = nullptr;
+    S.forked = false;
+    S.nreq = 0;
     if ((rc = fft_build_dim<T>(I, dw, w, nullptr))) return rc;
-    if ((rc = fft_build_dim<T>(I, dh, h, dw))) return rc;
+    if ((rc = fft_build_dim<T>(I, dh, h, dw))) { for (int k = 0; k < S.nreq; ++k) S.req[k]->n = 0; S.nreq = 0; return rc; }      // (queued entries hold no tables yet)
+    if ((rc = fft_flush_builds<T>(I))) return rc;
     const size_t plane = (size_t)w * h;
     if ((rc = ensure(I, S.A, sizeof(T) * plane * C))) return rc;
     if ((rc = ensure(I, S.B, sizeof(T) * plane * C))) return rc;

@@ -53,7 +53,7 @@ struct DstState {
 };
 
 // FFT direct solve (sc_fft.hip): per-direction chirp / transform tables and the two work planes.  The tables of a transform
-// length are built ON THE DEVICE (k_fft_tables, k_fft_bhat) and kept in a small LRU: a caller whose mask changes with every
+// length are built ON THE DEVICE (k_fft_build: both directions of a solve in one launch) and kept in a small LRU: a caller whose mask changes with every
 // frame meets new ROI sizes all the time, and alternating between a few sizes costs nothing.
 struct FftDim { int n = 0, logM = 0; bool dbl = false; DevBuf chirp; unsigned long long used = 0; };   // chirp: chirp[n+1] | bhat[M] | tw[M] (complex float or double)
 struct FftFxy { int w = 0, h = 0; bool singular = false; DevBuf d, hst; hipEvent_t ev = nullptr; unsigned long long used = 0; };   // the reference's float tables fx[w] + fy[h]: device, pinned staging of its own, upload event
@@ -66,6 +66,9 @@ struct FftState {
     DevBuf tw64;                           // double twiddles of the build's own transform (float tables are built through a double FFT)
     hipEvent_t ev_fork = nullptr, ev_built = nullptr;   // the build runs on the instance's second stream
     bool pending = false;                  // ... and `stream` has not waited for ev_built yet
+    FftDim *req[2] = { nullptr, nullptr }; // tables queued for a build by the current solve (its two directions), launched together
+    int nreq = 0;
+    bool forked = false;                   // this solve has already put the second stream behind the main one (one fork per solve: both directions' tables and the eigenvalue tables ride on it)
 };
 
 struct MGLevel {
