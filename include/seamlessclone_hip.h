@@ -73,6 +73,10 @@ enum sc_method {
                                 own cuFFT path against OpenCV (PDF p3)                                           */
 };
 #define SC_AUTO_DIRECT_MAX 720        /* round 4 (900 in round 3): the cycles got faster (0.222 against 0.231 ms at 750^2, 0.228 against 0.268 at 900^2) */
+#define SC_AUTO_DIRECT_AREA 450000   /* round 4: ... also where the ROI has at most this many unknowns in all, whatever its shape (an elongated ROI's
+                                       transforms are short in one direction: 900 x 100 takes 0.10 ms directly, 0.19 in cycles), ... */
+#define SC_AUTO_NARROW_MAX 140      /* ... and where it is at most this many unknowns across -- both up to SC_AUTO_THIN_LONG_MAX along (the double
+                                       transform's limit): 4000 x 130 takes 0.37 ms directly, 0.45 in cycles                          */
 #define SC_AUTO_THIN_MAX 4          /* ... and for thin ROIs (at most this many unknowns across, up to SC_AUTO_THIN_LONG_MAX along) */
 #define SC_AUTO_THIN_LONG_MAX 4096
 

@@ -33,6 +33,8 @@ SC_METHOD_DST = 4
 SC_METHOD_AUTO = 5      # default: the FFT-form direct solve (double transforms) up to SC_AUTO_DIRECT_MAX unknowns per side, MULTIGRID above
 SC_METHOD_FFT = 6       # the reference's default back-end: FFT-based direct solve, float32, O(n^2 log n)
 SC_AUTO_DIRECT_MAX = 720
+SC_AUTO_DIRECT_AREA = 450000
+SC_AUTO_NARROW_MAX = 140
 SC_AUTO_THIN_MAX = 4
 SC_AUTO_THIN_LONG_MAX = 4096
 
@@ -52,6 +54,16 @@ SC_FLAG_NO_STAGE_MARKS = 1 << 12
 SC_FLAG_BOTTOM_F32 = 1 << 13
 SC_FLAG_SEPARATE_TAIL = 1 << 14
 SC_FLAG_STAGED_RETURN = 1 << 15
+
+def auto_takes_direct(w: int, h: int) -> bool:
+    """SC_METHOD_AUTO's choice for ONE clone with w x h unknowns (sc_solver.cpp effective_method): True = the direct solve (SC_METHOD_FFT,
+    double transforms), False = multigrid.  (A group of clones always takes the cycles; tol > 0 too.)"""
+    if w <= SC_AUTO_DIRECT_MAX and h <= SC_AUTO_DIRECT_MAX:
+        return True
+    if max(w, h) <= SC_AUTO_THIN_LONG_MAX and (w * h <= SC_AUTO_DIRECT_AREA or min(w, h) <= SC_AUTO_NARROW_MAX):
+        return True
+    return False
+
 
 ERR_NAMES = {
     SC_ERR_BAD_ARG: "SC_ERR_BAD_ARG", SC_ERR_BAD_SIZE: "SC_ERR_BAD_SIZE", SC_ERR_EMPTY_MASK: "SC_ERR_EMPTY_MASK",

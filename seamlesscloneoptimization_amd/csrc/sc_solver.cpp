@@ -32,6 +32,12 @@ int effective_method(const Instance *I)
     // cycles win again: 0.295 against 0.313 ms -- tools/fft_probe.py; round 4, tools/size_probe.py [--mg]: the cycles win from ~730^2 on:
     // 0.221 against 0.212 ms at 700^2, 0.222 against 0.231 at 750^2, 0.228 against 0.268 at 900^2)
     if (w <= SC_AUTO_DIRECT_MAX && h <= SC_AUTO_DIRECT_MAX) return SC_METHOD_FFT;
+    // elongated ROIs (round 4, tools/size_probe.py --fft / --mg): the transforms along the short side are short and few rows make the
+    // long ones -- 900 x 100: 0.101 ms directly against 0.191 in cycles, 1000 x 400: 0.164 / 0.199, 1500 x 200: 0.191 / 0.223,
+    // 2048 x 100: 0.172 / 0.222, 4000 x 130: 0.371 / 0.445 (130 x 4000: 0.345 / 0.559), 4090 x 60: 0.255 / 0.301; the cycles keep
+    // 1000 x 700 (0.250 / 0.237), 1200 x 600 (0.350 / 0.252), 2000 x 500 (0.335 / 0.278), 3000 x 300 (0.533 / 0.300)
+    if (std::max(w, h) <= SC_AUTO_THIN_LONG_MAX &&
+        ((long)w * h <= SC_AUTO_DIRECT_AREA || std::min(w, h) <= SC_AUTO_NARROW_MAX)) return SC_METHOD_FFT;
     // ROIs narrower than 7 pixels (the three erodes empty the mask: the exact solution is the destination itself, integers):
     // the reference's float tables put every mode ~1e-7 below its exact value, so its answer is v - epsilon and truncates to v - 1
     // almost everywhere.  Only the direct form reproduces that (it IS that arithmetic); it stays cheap while one side is tiny.

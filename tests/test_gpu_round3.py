@@ -65,13 +65,21 @@ def test_default_solver_choice_and_its_deviation_at_the_published_sizes(inst, or
     assert inst.info().method == capi.SC_METHOD_FFT and mx <= 1 and sm <= 44, (mx, sm)
     outside = body.copy(); outside[55:55 + 190, 652:652 + 296] = c["dst"][55:55 + 190, 652:652 + 296]
     assert np.array_equal(outside, c["dst"])
-    # one unknown more than the limit per side: multigrid (3 cycles), still within one of the port
+    # a few unknowns more than the limit per side (and more than SC_AUTO_DIRECT_AREA in all): multigrid (3 cycles), still within one of the port
     n = capi.SC_AUTO_DIRECT_MAX + 1
-    dst, patch, mask, cx, cy = _table_inputs(n + 4, 200)
+    dst, patch, mask, cx, cy = _table_inputs(n + 4, n + 4)
     body = dst.copy()
     assert inst.run(patch, body, mask, cx, cy) == 0
     assert inst.info().method == capi.SC_METHOD_MULTIGRID and inst.info().sweeps >= 3
     assert _dsum(body, oc.seamless_clone(dst, patch, mask, cx, cy, 4))[0] <= 1
+    # ... but an elongated ROI of the same width keeps the direct solve (round 4: few unknowns in all, or narrow): the port's bytes
+    for pw, ph in ((n + 4, 200), (1500, 130)):
+        dst, patch, mask, cx, cy = _table_inputs(pw, ph)
+        body = dst.copy()
+        assert inst.run(patch, body, mask, cx, cy) == 0
+        assert inst.info().method == capi.SC_METHOD_FFT and capi.auto_takes_direct(inst.info().W - 2, inst.info().H - 2)
+        mx, sm = _dsum(body, oc.seamless_clone(dst, patch, mask, cx, cy, 4))
+        assert mx <= 1 and sm <= 44 * 10, (pw, ph, mx, sm)
     # a residual-based stop is an iterative notion: tol > 0 keeps the cycles even for a small ROI
     inst.set_solver(tol=3e-5)
     dst, patch, mask, cx, cy = _table_inputs(154, 100)
@@ -496,7 +504,7 @@ def test_default_path_fuzz_over_small_and_medium_shapes(inst, oracles):
         i = inst.info()
         d = np.abs(body.astype(np.int16) - want.astype(np.int16))
         assert d.max() <= 1, (W, H, i.method, int(d.max()))
-        direct = max(i.W, i.H) - 2 <= capi.SC_AUTO_DIRECT_MAX
+        direct = capi.auto_takes_direct(i.W - 2, i.H - 2)
         assert i.method == (capi.SC_METHOD_FFT if direct else capi.SC_METHOD_MULTIGRID), (W, H, i.method)
         if direct and min(i.W, i.H) > 8:
             worst_direct = max(worst_direct, float((d > 0).sum()) / max(1.0, 3.0 * (i.W - 2) * (i.H - 2)))

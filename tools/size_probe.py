@@ -7,7 +7,10 @@ from oracle import mg_np
 import _synth as o
 inst = capi.Instance(0)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-inst.set_solver(flags=capi.SC_FLAG_NO_STAGE_MARKS, **({"method": capi.SC_METHOD_MULTIGRID} if "--mg" in sys.argv else {}))
+if "--fft" in sys.argv:                                # the default's direct solve (double transforms), forced
+    inst.set_solver(flags=capi.SC_FLAG_NO_STAGE_MARKS | capi.SC_FLAG_FFT_FP64, method=capi.SC_METHOD_FFT)
+else:
+    inst.set_solver(flags=capi.SC_FLAG_NO_STAGE_MARKS, **({"method": capi.SC_METHOD_MULTIGRID} if "--mg" in sys.argv else {}))
 if "--r1" in sys.argv:                                 # experiments: sc_solver_opts.reserved[0] = 1
     import ctypes as C_
     o_ = inst.get_solver(); o_.reserved[0] = 1
