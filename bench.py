@@ -45,7 +45,7 @@ def parse_args(argv=None):
     ap.add_argument("--roi", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=32, help="independent images per GPU per step")
     ap.add_argument("--streams", type=int, default=2, help="concurrent library instances (HIP streams) per GPU")
-    ap.add_argument("--group", type=int, default=16, help="clones of one ROI size a worker solves as ONE field of 3n channels (sc_hip_run_device_batch)")
+    ap.add_argument("--group", type=int, default=None, help="clones of one ROI size a worker solves as ONE field of 3n channels (sc_hip_run_device_batch); default 16, --config c5: the rank's images split evenly over its streams, at most 32 per group (64 x 1024^2 on one GPU: 2 x 32 = 19.5 Gpix/s, 2 x 16 = 18.3)")
     ap.add_argument("--method", default="mg", choices=["jacobi", "mg", "rbgs", "sor", "auto", "fft", "dst"],
                     help="solver of the timed region (default mg: what SC_METHOD_AUTO resolves to at the 2048^2 ROI of the metric)")
     ap.add_argument("--sweeps-per-launch", type=int, default=0)
@@ -422,7 +422,9 @@ def main():
         if args.batch == 0:
             sys.exit("bench.py --config c5: more ranks than images")
         args.streams = max(1, min(args.streams, args.batch))
-        args.group = max(1, min(args.group, -(-args.batch // args.streams)))
+        args.group = max(1, min(args.group if args.group else 32, -(-args.batch // args.streams)))
+    if not args.group:
+        args.group = 16
 
     ndev = capi.device_count()
     if ndev < 1:
