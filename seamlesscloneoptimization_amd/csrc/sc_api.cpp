@@ -679,7 +679,15 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         // boxes measured, under the link's 55; the direct copy: h2d 0.90 -> 0.67 ms of a 2048^2 call on the slower box.  A small
         // ROI of a large image is still packed (row by row into pinned staging, one DMA per piece).  The library still issues
         // no 2-D copies (appendix B).
-        const bool whole_f = 4 * 3 * (size_t)g.W >= 3 * (size_t)fs, whole_b = 4 * 3 * (size_t)g.W >= 3 * (size_t)bs;
+        // ... or the rows' bytes outside the ROI are few in all (a small ROI of a larger image -- the reference's published table:
+        // patches into a 1600 x 898 destination): the packed path has ~0.1 ms of fixed cost (helper threads, staging, the splice
+        // behind the last DMA), 3 MB more on the link cost 0.055 (600^2 ROI of a 1600-wide image: 0.475 -> 0.36 ms per call)
+        // -- but not more than twice the ROI's own bytes: a 300 x 194 patch of a 1600-wide image (0.76 MB around 0.17) is faster packed
+        // (0.20 against 0.25 ms)
+        constexpr size_t WHOLE_EXTRA_MAX = (size_t)3 << 20;
+        auto few_extra = [&](int step) { const size_t extra = ((size_t)step - 3 * (size_t)g.W) * g.H; return extra <= WHOLE_EXTRA_MAX && extra <= 2 * 3 * (size_t)g.W * g.H; };
+        const bool whole_f = 4 * 3 * (size_t)g.W >= 3 * (size_t)fs || few_extra(fs);
+        const bool whole_b = 4 * 3 * (size_t)g.W >= 3 * (size_t)bs || few_extra(bs);
         const int fpitch = whole_f ? fs : dfs, bpitch = whole_b ? bs : dfs;
         const size_t foff = whole_f ? 3 * (size_t)g.x0 : 0, boff = whole_b ? 3 * (size_t)g.ltx : 0;
         if ((r = ensure(I, I->d_face, (size_t)fpitch * g.H + 64))) return r;
