@@ -50,7 +50,7 @@ def parse_args(argv=None):
                     help="solver of the timed region (default mg: what SC_METHOD_AUTO resolves to at the 2048^2 ROI of the metric)")
     ap.add_argument("--sweeps-per-launch", type=int, default=0)
     ap.add_argument("--exact-tables", action="store_true", help="time the exact 5-point solution (SC_FLAG_EXACT_TABLES) instead of the reference's float-table answer")
-    ap.add_argument("--extra-flags", type=int, default=0, help="further sc_solver_opts.flags bits (A/B runs of a variant, e.g. 64 = SC_FLAG_SEPARATE_RESTRICT)")
+    ap.add_argument("--extra-flags", type=int, default=0, help="further sc_solver_opts.flags bits (A/B runs of a variant, e.g. 2048 = SC_FLAG_FLOAT_FIELD)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--kernel-launches", type=int, default=100, help="launches in the roofline micro-region")
     ap.add_argument("--config", default="c3", choices=["c3", "c5"],
@@ -672,6 +672,7 @@ def main():
     # second, shorter series with the marks
     calls = host_calls(max(3, args.host_calls), flags0 | capi.SC_FLAG_NO_STAGE_MARKS)
     marked = host_calls(max(3, args.host_calls // 3), flags0)
+    rows_ret = host_calls(max(3, args.host_calls // 2), flags0 | capi.SC_FLAG_NO_STAGE_MARKS | capi.SC_FLAG_ROWS_RETURN)
     inst.set_solver(flags=flags0)
 
     def stat(k, series=None):
@@ -679,13 +680,14 @@ def main():
         return {"median": round(v[len(v) // 2], 4), "p95": round(v[min(len(v) - 1, int(round(0.95 * (len(v) - 1))))], 4), "min": round(v[0], 4)}
     st_call = stat(0)
     pcie = {"call_ms": st_call["median"], "call_ms_p95": st_call["p95"], "call_ms_min": st_call["min"], "calls_timed": len(calls),
-            "first_two_calls_ms": first_ms, "call_ms_with_stage_marks": stat(0, marked),
+            "first_two_calls_ms": first_ms, "call_ms_with_stage_marks": stat(0, marked), "call_ms_rows_return": stat(0, rows_ret),
             "h2d_ms": stat(1, marked), "device_ms": stat(2, marked), "d2h_ms": stat(3, marked), "stream_ms": stat(4),
             "Mpix_per_s_inclusive": round(W * H / (st_call["median"] * 1e-3) / 1e6, 1),
             "note": "my_seamlessclone_api_imp_run on pageable numpy images, one clone, one instance: mask, patch rows and destination rows "
-                    "cross PCIe as linear copies at the caller's row step (no packing: the ROI covers most of every row here), clone with the "
-                    "output bytes written into the destination rows on the device, those rows back as one linear copy into the caller's "
-                    "image (never `value`); call_ms = host wall time of the call (median, SC_FLAG_NO_STAGE_MARKS), stream_ms = hipEvent time "
+                    "cross PCIe as linear copies at the caller's row step (no packing: the ROI covers most of every row here), clone, the "
+                    "compact ROI back through pinned staging and spliced into the caller's rows -- only ROI bytes are ever written (the "
+                    "default since round 5; call_ms_rows_return = the opt-in SC_FLAG_ROWS_RETURN, round 4's default: output bytes written "
+                    "into the destination rows on the device, those rows back as one linear copy into the caller's image) (never `value`); call_ms = host wall time of the call (median, SC_FLAG_NO_STAGE_MARKS), stream_ms = hipEvent time "
                     "from the first upload to the last download of the same calls; h2d / device / d2h from a second series with the marks"}
 
     # ---- sweep kernels named by the north-star, on freshly built float fields of the same images (single clone, 3 channels)

@@ -116,7 +116,8 @@ typedef struct sc_solver_opts {
     int   mg_direct_max;     /* multigrid bottom kernel: the first level whose sides are both at most this many unknowns is solved
                                 directly (fast diagonalisation); the LDS-resident levels above it cycle.  0 = default
                                 (SC_MG_DIRECT_MAX_DEFAULT); at most 128.  Same fixed point, slightly different iterates        */
-    int   reserved[1];
+    int   legacy_paths;      /* read only with SC_FLAG_LEGACY_PATHS: SC_LEGACY_* bits, the superseded launch forms to run instead of
+                                the defaults (A/B measurements and cross-checks of kernels whose decision is made)              */
 } sc_solver_opts;
 #define SC_MG_DIRECT_MAX_DEFAULT 128
 
@@ -143,10 +144,20 @@ typedef struct sc_solver_opts {
                                             eigenvalue tables are stored and combined in float32
                                             (seamlessClone_imp.cpp:596-599, :1651-1653) -- see DESIGN.md sec. 5,
                                             "float-table correction"                                            */
-#define SC_FLAG_SEPARATE_RESTRICT (1 << 6) /* float-table correction: the hat-weighted cell sums of the field come from
-                                            a pass of their own over it (k_lm_restrict); default: the level-0 multigrid
-                                            launch that writes the field leaves them behind.  Same cells, another order
-                                            of the additions (differences at float rounding level)               */
+#define SC_FLAG_LEGACY_PATHS   (1 << 6)  /* run the superseded launch forms named in sc_solver_opts.legacy_paths (round 5: one switch for the
+                                            A/B scaffolding of decisions that are made; rounds 2-4 had a public flag for each):           */
+#define SC_LEGACY_SEPARATE_RESTRICT 1    /*   float-table correction: the hat-weighted cell sums of the field come from a pass of their own
+                                            over it (k_lm_restrict); default: the level-0 multigrid launch that writes the field leaves them
+                                            behind.  Same cells, another order of the additions (differences at float rounding level)     */
+#define SC_LEGACY_BOTTOM_F32   2         /*   multigrid: the bottom kernel's direct solve as float32 SIMD inner products with every operand
+                                            staged in LDS (k_mg_bottom, rounds 1-3) on the hierarchy of those rounds.  Default since round 4
+                                            where the bottom's first level has at most 96 unknowns per side: four products on the matrix
+                                            cores in float32 (v_mfma_f32_32x32x2_f32: k_mg_bottom_mm).  Same arithmetic up to the order of
+                                            the additions                                                                               */
+#define SC_LEGACY_SEPARATE_TAIL 4        /*   multigrid: the level above the bottom and the bottom as the three launches of rounds 1-3
+                                            (pre-smoothing + residual + restriction, direct solve, prolongation + post-smoothing).  Default
+                                            since round 4 where that level has at most 127 unknowns per side: ONE launch, the level in
+                                            registers (k_mg_tail).  Same arithmetic per point                                            */
 #define SC_FLAG_KEEP_FIELD     (1 << 7)  /* sc_hip_run*: keep the solution field on the device (sc_hip_field_store,
                                             _residual, _finish after a run): the last multigrid cycle writes the field
                                             and a post-process launch reads it.  Default: that cycle writes the output
@@ -192,22 +203,13 @@ typedef struct sc_solver_opts {
                                             un-instrumented device time of the clone and the per-stage figures read 0 (all of it is booked
                                             under ms_post).  Results are unaffected                                              */
 
-#define SC_FLAG_BOTTOM_F32     (1 << 13) /* multigrid: the bottom kernel's direct solve as float32 SIMD inner products with every operand
-                                            staged in LDS (k_mg_bottom, rounds 1-3).  Default since round 4 where the bottom's first level
-                                            has at most 96 unknowns per side: four products on the matrix cores in float32
-                                            (v_mfma_f32_32x32x2_f32, operands straight from memory into registers: k_mg_bottom_mm).
-                                            Same arithmetic up to the order of the additions                                       */
-
-#define SC_FLAG_SEPARATE_TAIL  (1 << 14) /* multigrid: the level above the bottom and the bottom as the three launches of rounds 1-3 (pre-smoothing +
-                                            residual + restriction, direct solve, prolongation + post-smoothing).  Default since round 4 where
-                                            that level has at most 127 unknowns per side: ONE launch, the level in registers (k_mg_tail).
-                                            Same arithmetic per point                                                              */
-
-#define SC_FLAG_STAGED_RETURN  (1 << 15) /* host-image call: the result always comes back as the compact ROI through pinned staging and is spliced
-                                            into the caller's rows -- only ROI bytes of the caller's image are ever written, as in the reference
-                                            (seamlessClone_imp.cpp:470-483).  Default: a destination without row padding whose ROI covers most of
-                                            its rows gets those ROWS back as one linear copy (the pixels outside the ROI are rewritten with the
-                                            values they had when the call started; 0.05-0.1 ms faster at 2048^2)                      */
+#define SC_FLAG_ROWS_RETURN    (1 << 13) /* host-image call, OPT-IN (round 5; the default of late round 4): a destination without row padding whose
+                                            ROI covers most of its rows gets those ROWS back as one linear copy straight into the caller's image
+                                            (0.05-0.1 ms faster at 2048^2) -- the pixels of those rows OUTSIDE the ROI are rewritten with the
+                                            values they had when the call started, so nothing else may write them during the call (another
+                                            thread cloning into a disjoint ROI of the same image would lose its result).  Default: the result
+                                            comes back as the compact ROI through pinned staging and is spliced into the caller's rows -- only
+                                            ROI bytes of the caller's image are ever written, as in the reference (seamlessClone_imp.cpp:470-483) */
 
 /* ---- statistics of the last run */
 typedef struct sc_run_info {

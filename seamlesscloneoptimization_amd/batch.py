@@ -106,12 +106,17 @@ def _spawn_once(world: int, cmd: list[str], extra_env: dict | None, poll_s: floa
 
 
 # what a lost rendezvous looks like in a rank's stderr (gloo / c10d TCP store): the only failures worth a second launch
-_RENDEZVOUS_MARKS = ("address already in use", "EADDRINUSE", "Connection refused", "connection refused", "Timed out waiting",
-                     "timed out", "DistNetworkError", "Connection reset", "failed to connect", "TCPStore")
+# Only the stderr of the rank that failed FIRST is classified: when a rank dies of anything else (a GPU fault, an import
+# error) the survivors' gloo errors ("timed out", "Connection reset", "TCPStore ...") would match generic marks and repeat a
+# faulting GPU run.  The marks are the ones a taken port or a store that was never reachable produces.
+_RENDEZVOUS_MARKS = ("address already in use", "EADDRINUSE", "Connection refused", "connection refused")
 
 
 def _rendezvous_failure(report: dict) -> bool:
-    return any(m in e for e in report["stderr"] for m in _RENDEZVOUS_MARKS)
+    r = report.get("first_failed_rank")
+    if r is None or not (0 <= r < len(report["stderr"])):
+        return False
+    return any(m in report["stderr"][r] for m in _RENDEZVOUS_MARKS)
 
 
 def spawn_ranks(world: int, cmd: list[str], extra_env: dict | None = None, poll_s: float = 0.05, retries: int = 1):

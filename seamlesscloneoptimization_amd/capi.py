@@ -44,16 +44,15 @@ SC_FLAG_FLOAT_U0 = 1 << 2
 SC_FLAG_NO_COMPOSE_L1 = 1 << 3
 SC_FLAG_VCYCLE_BOTTOM = 1 << 4
 SC_FLAG_EXACT_TABLES = 1 << 5
-SC_FLAG_SEPARATE_RESTRICT = 1 << 6
+SC_FLAG_LEGACY_PATHS = 1 << 6      # run the superseded launch forms named in SolverOpts.legacy_paths (SC_LEGACY_* bits)
+SC_LEGACY_SEPARATE_RESTRICT, SC_LEGACY_BOTTOM_F32, SC_LEGACY_SEPARATE_TAIL = 1, 2, 4
 SC_FLAG_KEEP_FIELD = 1 << 7
 SC_FLAG_FFT_FP64 = 1 << 8
 SC_FLAG_OPENCV_GREY_MASK = 1 << 9
 SC_FLAG_FLOAT_L1 = 1 << 10
 SC_FLAG_FLOAT_FIELD = 1 << 11
 SC_FLAG_NO_STAGE_MARKS = 1 << 12
-SC_FLAG_BOTTOM_F32 = 1 << 13
-SC_FLAG_SEPARATE_TAIL = 1 << 14
-SC_FLAG_STAGED_RETURN = 1 << 15
+SC_FLAG_ROWS_RETURN = 1 << 13     # host-image call, opt-in: whole destination rows come back as one linear copy (default: ROI bytes only)
 
 def auto_takes_direct(w: int, h: int) -> bool:
     """SC_METHOD_AUTO's choice for ONE clone with w x h unknowns (sc_solver.cpp effective_method): True = the direct solve (SC_METHOD_FFT,
@@ -74,7 +73,7 @@ ERR_NAMES = {
 class SolverOpts(C.Structure):
     _fields_ = [("method", C.c_int), ("max_sweeps", C.c_int), ("tol", C.c_float), ("check_every", C.c_int),
                 ("omega", C.c_float), ("sweeps_per_launch", C.c_int), ("reference_warmup", C.c_int),
-                ("mg_pre", C.c_int), ("mg_post", C.c_int), ("update_tol", C.c_float), ("flags", C.c_int), ("jacobi_tile_rows", C.c_int), ("mg_level1_sweeps", C.c_int), ("mg_direct_max", C.c_int), ("reserved", C.c_int * 1)]
+                ("mg_pre", C.c_int), ("mg_post", C.c_int), ("update_tol", C.c_float), ("flags", C.c_int), ("jacobi_tile_rows", C.c_int), ("mg_level1_sweeps", C.c_int), ("mg_direct_max", C.c_int), ("legacy_paths", C.c_int)]
 
 
 class RunInfo(C.Structure):

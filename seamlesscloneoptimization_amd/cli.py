@@ -22,9 +22,13 @@ def main(argv=None) -> int:
     ap.add_argument("centerX", type=int); ap.add_argument("centerY", type=int); ap.add_argument("gpu", type=int)
     ap.add_argument("--out", help="write the blended image (.bmp or .yml)")
     ap.add_argument("--method", default="auto", choices=["auto", "mg", "dst", "fft", "sor", "rbgs", "jacobi"],
-                    help="auto (default): direct FFT solve (double) up to 900 unknowns per side, mg above; fft: the reference's default back-end (FFT-based direct solve, float32); mg: multigrid + float-table correction (the reference's arithmetic); dst: the reference's direct DST "
+                    help="auto (default): direct FFT solve (double) up to 720 unknowns per side (also elongated ROIs of at most 450 000 unknowns or at most 140 across), mg above; fft: the reference's default back-end (FFT-based direct solve, float32); mg: multigrid + float-table correction (the reference's arithmetic); dst: the reference's direct DST "
                          "solve on the fp64 matrix cores; sor / rbgs / jacobi: sweeps to a 2e-5 residual")
     ap.add_argument("--exact-tables", action="store_true", help="mg: return the exact solution of the 5-point system instead")
+    ap.add_argument("--dump-rhs", metavar="DIR",
+                    help="write the reference's SCDEBUG intermediates (seamlessClone_imp.cpp:2110-2117): DIR/ucMask0.yml (eroded ROI mask) and "
+                         "DIR/g{0,1,2}.yml (right-hand side with the Dirichlet ring folded in, planes in the reference's R,G,B order) -- "
+                         "what compare/vs.py:81-86 diffs against OpenCV's mod_diff{2,1,0}.yml")
     ap.add_argument("--reference-warmup", action="store_true",
                     help="clone twice in place like the reference binary (seamlessClone_imp.cu:303-318)")
     a = ap.parse_args(argv)
@@ -49,14 +53,39 @@ def main(argv=None) -> int:
         i = inst.info()
         print("device stages: %.3f msec (ROI %dx%d); transfers: H2D %.3f msec, D2H %.3f msec; solver %s: %d cycles/sweeps"
               % (i.ms_device_total, i.W, i.H, i.ms_h2d, i.ms_d2h, a.method, i.sweeps))
+        if a.dump_rhs:
+            dump_rhs(inst, a.dump_rhs, np.ascontiguousarray(src), np.ascontiguousarray(dst), np.ascontiguousarray(mask), a.centerX, a.centerY)
     finally:
         inst.destroy()
-    if a.out:
+    if a.out:      # the timed call's image (the warm-up's holds the same bytes)
         if a.out.endswith((".yml", ".yml.gz")):
-            ymlio.write_yml(a.out, body, name="result")
+            ymlio.write_yml(a.out, body2, name="result")
         else:
-            ymlio.write_bmp(a.out, body)
+            ymlio.write_bmp(a.out, body2)
     return 0
+
+
+def folded_rhs(lap: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """The reference's `g` (seamlessClone_imp.cpp:1983-2009): the interior of the divergence `lap` with the destination's ring
+    values subtracted on the four interior edges.  lap, B: [3][H][W] float32 planes (B, G, R) of the ROI; returns [3][H-2][W-2]."""
+    g = lap[:, 1:-1, 1:-1].astype(np.float32, copy=True)
+    g[:, :, 0] -= B[:, 1:-1, 0]
+    g[:, 0, :] -= B[:, 0, 1:-1]
+    g[:, :, -1] -= B[:, 1:-1, -1]
+    g[:, -1, :] -= B[:, -1, 1:-1]
+    return g
+
+
+def dump_rhs(inst, out_dir, src, dst, mask, cx, cy) -> None:
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    geo, M = inst.mask_stage(mask, cx, cy)
+    ymlio.write_yml(os.path.join(out_dir, "ucMask0.yml"), M, name="ucMask0")
+    geo, B, lap = inst.build_rhs(src, dst, mask, cx, cy)
+    g = folded_rhs(lap, B)
+    for ch in range(3):      # the reference's planes are R, G, B (seamlessClone_imp.cpp:374-376); ours follow the interleaved B, G, R
+        ymlio.write_yml(os.path.join(out_dir, "g%d.yml" % ch), g[2 - ch], name="g%d" % ch)
+    print("wrote %s/ucMask0.yml, g0.yml, g1.yml, g2.yml (%dx%d)" % (out_dir, g.shape[2], g.shape[1]))
 
 
 if __name__ == "__main__":

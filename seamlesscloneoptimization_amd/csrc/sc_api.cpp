@@ -23,6 +23,7 @@ int hip_fail(Instance *I, hipError_t e, const char *what)
 {
     if (I) {
         I->err = std::string(what) + ": " + hipGetErrorString(e);
+        I->scan_counter_dirty = true;      // a launch that never completed may have left the scan's arrival counter non-zero
     }
     return SC_ERR_HIP;
 }
@@ -235,6 +236,11 @@ static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int 
     fold.rect_host = I->h_rect + 4;
     I->erode_done = false;
     I->scan_pending = false;
+    I->scan_fence = nullptr;
+    if (I->scan_counter_dirty) {      // after a HIP error: the folding workgroup is the only one that resets the counter, and it may never have run
+        SC_HIP(I, hipMemsetAsync(fold.counter, 0, sizeof(unsigned), I->stream));
+        I->scan_counter_dirty = false;
+    }
     if (predicted && !(I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) {
         // A clone launched on a predicted box needs the scan's answer only at its end: the erode of the predicted ROI goes out
         // alone and the scan rides in the pre-process launch behind it (device_clone, launch_preprocess) -- off the critical path.
@@ -336,10 +342,17 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         I->f_half = mg_reads_half_rhs(I);
         I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
         if (I->scan_pending) I->pending_scan.M_out = (uint8_t *)I->d_M.p;      // the launch's tiles erode the mask themselves and leave it here
+        const bool had_scan = I->scan_pending;
         launch_preprocess(body_org, bstep, face_org, fstep, (const uint8_t *)I->d_M.p, I->mpitch, I->U0, I->U1, I->F,
                           I->stream, I->f_half, I->u_half, grey, I->scan_pending ? &I->pending_scan : nullptr);
         I->scan_pending = false;
         if (pass == passes - 1 && (rc = tmark(I, 5))) return rc;
+        if (had_scan) {
+            // the host compares the scan's rectangle (pinned mailbox) with its guess once THIS point of the stream has passed: mark 5
+            // when it was really recorded just now, else an event of its own (first and last marks only, or no marks at all)
+            if (pass == passes - 1 && I->stage_marks && I->tm[5] == I->ev[5]) I->scan_fence = I->ev[5];
+            else { SC_HIP(I, hipEventRecord(I->ev_scan, I->stream)); I->scan_fence = I->ev_scan; }
+        }
         I->info.sweep_launches = 0;
         I->spec_post.body_org = out_org; I->spec_post.bstep = ostep;
         I->spec_post.ev_solved = nullptr;
@@ -431,6 +444,7 @@ void *my_seamlessclone_api_imp_create_instance(int gpu_id)
     ok = ok && hipEventCreateWithFlags(&I->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&I->ev_fd_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&I->ev_fd, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&I->ev_scan, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_rect, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&I->h_red, 2 * sizeof(double), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void **)&I->d_rect, 64 * sizeof(int)) == hipSuccess;       // the rectangle; word 32: the scan's arrival counter
@@ -485,6 +499,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
     if (I->ev_fd_fork) (void)hipEventDestroy(I->ev_fd_fork);
     if (I->ev_fd) (void)hipEventDestroy(I->ev_fd);
+    if (I->ev_scan) (void)hipEventDestroy(I->ev_scan);
     if (I->d_rect) (void)hipFree(I->d_rect);
     if (I->d_rects.p) (void)hipFree(I->d_rects.p);
     if (I->d_bbox_parts.p) (void)hipFree(I->d_bbox_parts.p);
@@ -533,7 +548,7 @@ int sc_hip_set_solver(void *p, const sc_solver_opts *o)
         I->err = "mg_level1_sweeps must be 0 or 2..4";
         return SC_ERR_BAD_ARG;
     }
-    if (((o->flags ^ I->opts.flags) & (SC_FLAG_VCYCLE_BOTTOM | SC_FLAG_BOTTOM_F32)) || o->mg_direct_max != I->opts.mg_direct_max) I->mg.clear();   // the hierarchy (which bottom level is solved directly) depends on these only
+    if (((o->flags ^ I->opts.flags) & SC_FLAG_VCYCLE_BOTTOM) || legacy_path(*o, SC_LEGACY_BOTTOM_F32) != legacy_path(I->opts, SC_LEGACY_BOTTOM_F32) || o->mg_direct_max != I->opts.mg_direct_max) I->mg.clear();   // the hierarchy (which bottom level is solved directly) depends on these only
     if (o->mg_direct_max < 0) { I->err = "mg_direct_max must be >= 0"; return SC_ERR_BAD_ARG; }
     I->opts = *o;
     return SC_OK;
@@ -701,17 +716,22 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         const int passes = I->opts.reference_warmup ? 2 : 1;
         // the output bytes go to a compact buffer of their own (the interior only is written, and only that comes back); the
         // reference's warm-up pass (two applications in place) needs the first result where the second reads it: the body buffer
-        // A destination uploaded as whole rows takes the output bytes in place as well: the rows then come back as ONE linear copy
-        // straight into the caller's image (what it overwrites outside the ROI's columns are the caller's own bytes, uploaded a
-        // moment ago) -- no pinned staging, no splice on the host behind the last DMA.
-        const bool inplace = whole_b && passes == 1 && (size_t)bs == 3 * (size_t)bc && !(I->opts.flags & SC_FLAG_STAGED_RETURN);      // (a view into a wider array keeps the staged path: nothing beyond the view's own pixels is ever written)
+        // SC_FLAG_ROWS_RETURN (opt-in since round 5): a destination uploaded as whole rows takes the output bytes in place as well and the
+        // rows come back as ONE linear copy straight into the caller's image -- no pinned staging, no splice on the host behind the
+        // last DMA.  What it overwrites outside the ROI's columns are the caller's own bytes, uploaded a moment ago: harmless only
+        // while nobody else writes those pixels during the call, which the library cannot know (two calls cloning into disjoint ROIs
+        // of one image would lose each other's result) -- so the default writes ROI bytes only, as the reference does
+        // (seamlessClone_imp.cpp:470-483).
+        const bool inplace = whole_b && passes == 1 && (size_t)bs == 3 * (size_t)bc && (I->opts.flags & SC_FLAG_ROWS_RETURN);      // (a view into a wider array keeps the staged path: nothing beyond the view's own pixels is ever written)
         uint8_t *const out_dev = (passes > 1 || inplace) ? (uint8_t *)I->d_body_roi.p + boff : (uint8_t *)I->d_out.p;
         const int out_pitch = (passes > 1 || inplace) ? bpitch : dfs;
         r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p + foff, fpitch,
                          (uint8_t *)I->d_body_roi.p + boff, bpitch, g, passes, out_dev, out_pitch);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
-        if (guess) {      // the scan rode in the pre-process launch (mark 5 is recorded behind it) and finished long ago: this wait is free
-            SC_HIP(I, hipEventSynchronize(I->ev[5]));
+        if (guess) {      // the scan rode in the pre-process launch and finished long ago: this wait on the event behind that launch is free
+            if (I->scan_fence) SC_HIP(I, hipEventSynchronize(I->scan_fence));
+            else SC_HIP(I, hipStreamSynchronize(I->stream));      // (cannot happen: a clone launched on a guess always carries its scan)
+            I->scan_fence = nullptr;
             if (memcmp(guess, I->h_rect + 4, 4 * sizeof(int)) != 0) return SC_GUESS_WRONG;
         }
         // Interior back into the caller's image: linear D2H pieces of the compact ROI buffer into pinned staging

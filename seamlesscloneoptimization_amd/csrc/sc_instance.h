@@ -129,6 +129,10 @@ struct Instance {
     bool erode_done = false;   // the ROI device_clone is about to process has been eroded already (a clone launched on a predicted box)
     BboxTask pending_scan;     // ... and its bounding-box scan has not gone out yet: it rides in the pre-process launch
     bool scan_pending = false;
+    bool scan_counter_dirty = false;   // a call failed with a HIP error: zero the scan's arrival counter before the next scan (hip_fail)
+    // completion fence of a scan that rode in a pre-process launch: an event recorded right behind that launch, whatever the
+    // stage marks do (a stage mark is not a fence: SC_FLAG_NO_STAGE_MARKS records none there); nullptr: no scan went out
+    hipEvent_t ev_scan = nullptr, scan_fence = nullptr;
     bool bench_tag = false;   // sc_hip_field_time_sweeps: launch the second-symbol instantiations
     // multigrid hierarchy (level 0 aliases U0/U1/F)
     std::vector<DevBuf> mg_bufs;
@@ -170,6 +174,9 @@ struct Instance {
 
     bool ok() const { return magic == 0x5C10E001u; }
 };
+
+// a superseded launch form asked for (SC_FLAG_LEGACY_PATHS + sc_solver_opts.legacy_paths)
+inline bool legacy_path(const sc_solver_opts &o, int which) { return (o.flags & SC_FLAG_LEGACY_PATHS) && (o.legacy_paths & which); }
 
 // internal return code of a solve (never crosses the C ABI): a 16-bit fixed-point store saturated, no output was written;
 // repeat the pre-process and the solve with Instance::force_float_field set

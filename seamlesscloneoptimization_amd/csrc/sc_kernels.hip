@@ -132,8 +132,9 @@ __device__ __forceinline__ void mask_bbox_block(const uint8_t *__restrict__ mask
             __hip_atomic_store(&mine[1], maxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&mine[2], miny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&mine[3], maxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned ticket = __hip_atomic_fetch_add(fold.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // release: the parts above are visible to whoever observes this arrival (the language's ordering, not the hardware's
+            // habit of counting stores in vmcnt); the folding workgroup acquires below
+            const unsigned ticket = __hip_atomic_fetch_add(fold.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             red[0][0] = (ticket == (unsigned)fold.nblocks - 1u) ? 1 : 0;       // (the waves' extrema in red[][] have been consumed above)
         }
     }
@@ -141,6 +142,7 @@ __device__ __forceinline__ void mask_bbox_block(const uint8_t *__restrict__ mask
     __syncthreads();
     if (red[0][0] == 0 || wave != 0) return;
     // the last workgroup to arrive: every part is in memory
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     minx = INT_MAX; maxx = -1; miny = INT_MAX; maxy = -1;
     for (int i = lane; i < fold.nblocks; i += 64) {
         const int *p = fold.parts + 4 * i;

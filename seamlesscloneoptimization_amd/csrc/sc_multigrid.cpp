@@ -189,7 +189,7 @@ static int build_fd(Instance *I)
         const int dmax = I->opts.mg_direct_max > 0 ? std::min(I->opts.mg_direct_max, 128) : SC_MG_DIRECT_MAX_DEFAULT;
         if (nx > dmax || ny > dmax) continue;
         // the bottom's first level on the matrix cores (k_mg_bottom_mm): up to 96 unknowns per side, no LDS budget to meet
-        const bool mm = l == I->mg_bottom && nx <= 96 && ny <= 96 && !(I->opts.flags & SC_FLAG_BOTTOM_F32);
+        const bool mm = l == I->mg_bottom && nx <= 96 && ny <= 96 && !legacy_path(I->opts, SC_LEGACY_BOTTOM_F32);
         if (!mm && (planes + fd_lds_floats(nxp, nyp)) * (long)sizeof(float) > (long)MG_BOTTOM_LDS_BYTES) continue;
         const long nf = (fd_mat_floats(nxp, nyp) + 15) & ~15L;          // the matrix-core operands behind the float matrices, 64-byte aligned
         const int NPX = round_up(nx, 32), NPY = round_up(ny, 32);
@@ -310,7 +310,7 @@ static int run_bottom(Instance *I, size_t l0, int pre, int post)
 // has its own composed / float16 forms).
 static bool tail_serves(const Instance *I, size_t l)
 {
-    if (l < 2 || l + 1 != I->mg_bottom || (I->opts.flags & SC_FLAG_SEPARATE_TAIL) || I->opts.sweeps_per_launch == 1) return false;
+    if (l < 2 || l + 1 != I->mg_bottom || legacy_path(I->opts, SC_LEGACY_SEPARATE_TAIL) || I->opts.sweeps_per_launch == 1) return false;
     if (!I->fd_mm || I->fd_level != 0 || I->fd_npx > 64 || I->fd_npy > 64) return false;
     if ((I->opts.mg_pre > 0 ? I->opts.mg_pre : 2) < 1) return false;          // the launch takes the residual of the colour swept last as zero
     const MGGeom &g = I->mg[l].g;
@@ -388,7 +388,7 @@ static int build_levels(Instance *I)
     // unknowns on a side (ROIs like 2090 x 1632, 2500 x 1300, 3540^2: no matrix-core solve, an LDS-resident V-cycle inside
     // k_mg_bottom instead) a cycle cost 60 us more than at the sizes next to it (0.55 against 0.38 ms for one clone).  Kept: a ROI
     // whose level 1 already fits the matrix-core solve (<= 96 per side: solved there), the flags that ask for the older bottoms.
-    if (!(I->opts.flags & (SC_FLAG_VCYCLE_BOTTOM | SC_FLAG_BOTTOM_F32)) && I->opts.mg_direct_max <= 0) {
+    if (!(I->opts.flags & SC_FLAG_VCYCLE_BOTTOM) && !legacy_path(I->opts, SC_LEGACY_BOTTOM_F32) && I->opts.mg_direct_max <= 0) {
         size_t a = 0;
         for (size_t l = 2; l + 1 < nl && !a; ++l)
             if (I->mg[l].g.x.n <= 127 && I->mg[l].g.y.n <= 127) a = l;
@@ -672,7 +672,7 @@ int mg_solve(Instance *I)
             const int early_kind = (out_wanted && next_judged) ? lowmode_early_kind(I, utol) : 2;
             const int early = early_kind == 3 ? 1 : early_kind;
             if (out_wanted && next_judged) early_cond = early_kind == 3;
-            float4 *const bands = (o.flags & SC_FLAG_SEPARATE_RESTRICT) ? nullptr
+            float4 *const bands = legacy_path(o, SC_LEGACY_SEPARATE_RESTRICT) ? nullptr
                                   : judged ? lowmode_bands_buffer(I, post) : early == 1 ? lowmode_bands_buffer(I, post + pre) : nullptr;
             if (judged && early_ready) {
                 if (I->aux_pending) {          // the node correction is ready when the launch that adds it starts

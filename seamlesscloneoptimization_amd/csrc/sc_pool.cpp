@@ -146,6 +146,11 @@ int sc_hip_pool_set_solver(void *p, const sc_solver_opts *opts)
 {
     Pool *P = get_pool(p);
     if (!P || !opts) return SC_ERR_BAD_ARG;
+    // host jobs of one batch may share a destination (disjoint ROIs of one image): the whole-row return would let one job erase
+    // another's result, so the pool never takes it
+    sc_solver_opts o = *opts;
+    o.flags &= ~SC_FLAG_ROWS_RETURN;
+    opts = &o;
     for (void *i : P->inst) {
         const int rc = sc_hip_set_solver(i, opts);
         if (rc != SC_OK) return rc;

@@ -81,7 +81,7 @@ int main(int argc, const char *argv[])
     for (int i = 0; i < argc; ++i) printf("argv[%d]: %s\n", i, argv[i]);
     if (argc < 7 || argc > 9) {
         fprintf(stderr, "usage: %s src.yml dst.yml mask.yml centerX centerY gpu [out.bmp [auto|mg|exact|dst|fft]]\n"
-                        "  auto  (default) direct FFT solve in double up to 900 unknowns per side, mg above (SC_METHOD_AUTO)\n"
+                        "  auto  (default) direct FFT solve in double up to 720 unknowns per side (and elongated ROIs), mg above (SC_METHOD_AUTO)\n"
                         "  mg    multigrid + float-table correction: the reference's arithmetic\n"
                         "  exact multigrid, exact solution of the 5-point system (SC_FLAG_EXACT_TABLES)\n"
                         "  dst   the reference's direct DST solve on the fp64 matrix cores (SC_METHOD_DST)\n"

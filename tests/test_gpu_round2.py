@@ -429,7 +429,7 @@ def test_frozen_float_table_case_on_the_gpu(hip, golden_dir):
 def test_output_and_restriction_variants_agree(hip, oracles, W, H):
     """Default: the last multigrid cycle writes output bytes itself (node correction of the iterate one cycle earlier, whose
     cell shares the launch before it leaves behind: k_cycle0 `bands` + k_lm_bands_to_cells).  SC_FLAG_KEEP_FIELD: that cycle
-    writes the field (and the cell shares of that field), a post-process launch reads it.  SC_FLAG_SEPARATE_RESTRICT: the cell
+    writes the field (and the cell shares of that field), a post-process launch reads it.  SC_LEGACY_SEPARATE_RESTRICT: the cell
     shares come from a pass of their own over the field (k_lm_restrict).  Same arithmetic in another order / one cycle
     earlier: the corrected fields agree to float rounding, the images in all but a handful of pixels, each within one grey
     level of the float-table port.  Sizes: a single tile, tile seams in x (232-column step) and y (52- and 44-row steps),
@@ -441,13 +441,13 @@ def test_output_and_restriction_variants_agree(hip, oracles, W, H):
     geo, M = oc.mask_stage(mask, cx, cy)
     B, lap = oc.build_rhs(dst, patch, geo, M)
     want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
-    KEEP, SEP, NOSPEC, FF = capi.SC_FLAG_KEEP_FIELD, capi.SC_FLAG_SEPARATE_RESTRICT, capi.SC_FLAG_NO_SPECULATE, capi.SC_FLAG_FLOAT_FIELD
+    KEEP, SEP, NOSPEC, FF = capi.SC_FLAG_KEEP_FIELD, capi.SC_FLAG_LEGACY_PATHS, capi.SC_FLAG_NO_SPECULATE, capi.SC_FLAG_FLOAT_FIELD
     out, fields = {}, {}
     try:
         # (KEEP runs on float fields; FF = the byte-output path on float fields as well; 0 and SEP = the default, whose first two
         # stores of a solve are 16-bit fixed point: roundings of <= 1/128 two cycles before the output)
         for flags in (0, FF, SEP, NOSPEC, FF | NOSPEC, KEEP, KEEP | SEP, KEEP | NOSPEC):
-            hip.set_solver(flags=flags)
+            hip.set_solver(flags=flags, legacy_paths=capi.SC_LEGACY_SEPARATE_RESTRICT)      # (read only where SEP is set)
             for rep in range(2):                                     # the second call reuses buffers and the part maps
                 body = dst.copy()
                 assert hip.run(patch, body, mask, cx, cy) == 0
@@ -463,7 +463,7 @@ def test_output_and_restriction_variants_agree(hip, oracles, W, H):
             hip.field_lowmode()
             fields[flags] = hip.field_store()
     finally:
-        hip.set_solver(flags=0)
+        hip.set_solver(flags=0, legacy_paths=0)
     assert np.array_equal(out[0], out[NOSPEC]) and np.array_equal(out[KEEP], out[KEEP | NOSPEC]) and np.array_equal(out[FF], out[FF | NOSPEC])
     scale = max(1.0, float(np.abs(fields[0]).max()))
     for flags in (SEP, KEEP | SEP):
@@ -497,12 +497,12 @@ def test_restriction_parts_are_not_reused_after_the_field_moved(hip, oracles):
     hip.field_lowmode()
     got = hip.field_store()
     try:
-        hip.set_solver(flags=capi.SC_FLAG_SEPARATE_RESTRICT)
+        hip.set_solver(flags=capi.SC_FLAG_LEGACY_PATHS, legacy_paths=capi.SC_LEGACY_SEPARATE_RESTRICT)
         hip.field_load(moved, lap)
         hip.field_lowmode()
         ref = hip.field_store()
     finally:
-        hip.set_solver(flags=0)
+        hip.set_solver(flags=0, legacy_paths=0)
     assert np.array_equal(got, ref)
     hip.field_load(B, lap)
     hip.field_solve()

@@ -178,7 +178,7 @@ def test_pci_bus_id_of_the_device():
 @pytest.mark.parametrize("W,H", [(2048, 2048), (2400, 1552), (700, 500), (300, 200), (90, 70), (1500, 260)])
 def test_bottom_solve_on_the_matrix_cores_agrees_with_the_float32_form(hip, W, H):
     """Round 4: the bottom kernel's direct solve runs as four float32 products on the matrix cores (k_mg_bottom_mm,
-    v_mfma_f32_32x32x2_f32: the SIMD form's arithmetic up to the order of the additions); SC_FLAG_BOTTOM_F32 keeps the float32
+    v_mfma_f32_32x32x2_f32: the SIMD form's arithmetic up to the order of the additions); SC_LEGACY_BOTTOM_F32 (behind SC_FLAG_LEGACY_PATHS) keeps the float32
     SIMD form of rounds 1-3 (k_mg_bottom).  Same fixed point: after one cycle the two fields differ by a relative 1e-4 of the
     field's scale at most, after the default solve by rounding noise, and the shapes cover every operand padding (32 / 64 / 96
     per side)."""
@@ -191,8 +191,8 @@ def test_bottom_solve_on_the_matrix_cores_agrees_with_the_float32_form(hip, W, H
     got = {}
     try:
         for cycles in (1, 0):
-            for flags in (0, capi.SC_FLAG_BOTTOM_F32):
-                hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags, **(dict(max_sweeps=1, update_tol=1e-30) if cycles else dict(max_sweeps=d.max_sweeps, update_tol=d.update_tol)))
+            for flags in (0, capi.SC_FLAG_LEGACY_PATHS):
+                hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags, legacy_paths=capi.SC_LEGACY_BOTTOM_F32, **(dict(max_sweeps=1, update_tol=1e-30) if cycles else dict(max_sweeps=d.max_sweeps, update_tol=d.update_tol)))
                 hip.field_load(U, F)
                 hip.field_solve(allow_not_converged=True)
                 got[(cycles, flags)] = (hip.field_store(), hip.info().sweeps)
@@ -201,23 +201,23 @@ def test_bottom_solve_on_the_matrix_cores_agrees_with_the_float32_form(hip, W, H
         lv = mg_np.build_levels(W, H)
         if mg_np.direct_level(lv, True) == mg_np.direct_level(lv, False):
             # both forms solve the same level directly: the same arithmetic up to the order of the additions
-            assert np.abs(got[(1, 0)][0] - got[(1, capi.SC_FLAG_BOTTOM_F32)][0]).max() <= 1e-4 * scale
-            assert got[(0, 0)][1] == got[(0, capi.SC_FLAG_BOTTOM_F32)][1]                  # the same number of cycles
-            assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_BOTTOM_F32)][0]).max() <= 2e-5 * scale
+            assert np.abs(got[(1, 0)][0] - got[(1, capi.SC_FLAG_LEGACY_PATHS)][0]).max() <= 1e-4 * scale
+            assert got[(0, 0)][1] == got[(0, capi.SC_FLAG_LEGACY_PATHS)][1]                  # the same number of cycles
+            assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_LEGACY_PATHS)][0]).max() <= 2e-5 * scale
         else:
             # the matrix-core form solves the bottom's FIRST level (up to 96 unknowns per side, no LDS budget to meet) where the
             # float32 form has to cycle one level further down: different iterates, the same fixed point
-            assert abs(got[(0, 0)][1] - got[(0, capi.SC_FLAG_BOTTOM_F32)][1]) <= 1
-            assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_BOTTOM_F32)][0]).max() <= 2e-3 * scale
+            assert abs(got[(0, 0)][1] - got[(0, capi.SC_FLAG_LEGACY_PATHS)][1]) <= 1
+            assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_LEGACY_PATHS)][0]).max() <= 2e-3 * scale
     finally:
-        hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=0, max_sweeps=d.max_sweeps, update_tol=d.update_tol)
+        hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=0, legacy_paths=0, max_sweeps=d.max_sweeps, update_tol=d.update_tol)
 
 
 @pytest.mark.parametrize("W,H", [(2048, 2048), (1020, 1020), (2040, 1020), (1000, 700), (1900, 130), (505, 1010), (1018, 1016), (960, 530)])
 def test_level_above_the_bottom_and_bottom_in_one_launch(hip, W, H):
     """Round 4 (k_mg_tail): where the level above the directly solved one has at most 127 unknowns per side, that level's
     pre-smoothing + residual + restriction, the direct solve and the level's prolongation + post-smoothing are ONE launch with the
-    level in registers; SC_FLAG_SEPARATE_TAIL keeps the three launches on the same hierarchy.  Same arithmetic per point: after
+    level in registers; SC_LEGACY_SEPARATE_TAIL (behind SC_FLAG_LEGACY_PATHS) keeps the three launches on the same hierarchy.  Same arithmetic per point: after
     one cycle the two fields agree to rounding (the residual's additions are ordered differently), the default solve takes the
     same number of cycles.  Shapes: square, a thin level (waves without rows), both tail-point counts, 32- and 64-padded solves."""
     from seamlesscloneoptimization_amd import capi
@@ -229,17 +229,17 @@ def test_level_above_the_bottom_and_bottom_in_one_launch(hip, W, H):
     got = {}
     try:
         for cycles in (1, 0):
-            for flags in (0, capi.SC_FLAG_SEPARATE_TAIL):
-                hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags, **(dict(max_sweeps=1, update_tol=1e-30) if cycles else dict(max_sweeps=d.max_sweeps, update_tol=d.update_tol)))
+            for flags in (0, capi.SC_FLAG_LEGACY_PATHS):
+                hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags, legacy_paths=capi.SC_LEGACY_SEPARATE_TAIL, **(dict(max_sweeps=1, update_tol=1e-30) if cycles else dict(max_sweeps=d.max_sweeps, update_tol=d.update_tol)))
                 hip.field_load(U, F)
                 hip.field_solve(allow_not_converged=True)
                 got[(cycles, flags)] = (hip.field_store(), hip.info().sweeps)
         scale = float(np.abs(got[(1, 0)][0]).max())
-        assert np.abs(got[(1, 0)][0] - got[(1, capi.SC_FLAG_SEPARATE_TAIL)][0]).max() <= 2e-5 * scale, (W, H)
-        assert got[(0, 0)][1] == got[(0, capi.SC_FLAG_SEPARATE_TAIL)][1]
-        assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_SEPARATE_TAIL)][0]).max() <= 2e-5 * scale, (W, H)
+        assert np.abs(got[(1, 0)][0] - got[(1, capi.SC_FLAG_LEGACY_PATHS)][0]).max() <= 2e-5 * scale, (W, H)
+        assert got[(0, 0)][1] == got[(0, capi.SC_FLAG_LEGACY_PATHS)][1]
+        assert np.abs(got[(0, 0)][0] - got[(0, capi.SC_FLAG_LEGACY_PATHS)][0]).max() <= 2e-5 * scale, (W, H)
     finally:
-        hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=0, max_sweeps=d.max_sweeps, update_tol=d.update_tol)
+        hip.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=0, legacy_paths=0, max_sweeps=d.max_sweeps, update_tol=d.update_tol)
 
 
 def test_measurement_hooks_of_round_4(inst, oracles):
@@ -276,21 +276,22 @@ def test_measurement_hooks_of_round_4(inst, oracles):
 
 
 def test_host_call_returns_rows_in_place_or_staged(inst, oracles):
-    """Round 4: a destination without row padding whose ROI covers most of its rows takes the output bytes in place on the device and
-    gets its rows back as one linear copy; SC_FLAG_STAGED_RETURN keeps the staged return that writes ROI bytes only; a view into a
-    wider array always does.  All three leave the same image, identical outside the ROI to what went in."""
+    """Default (round 5; opt-out in late round 4): the staged return that writes ROI bytes only, as the reference does.
+    SC_FLAG_ROWS_RETURN: a destination without row padding whose ROI covers most of its rows takes the output bytes in place on the
+    device and gets its rows back as one linear copy; a view into a wider array always takes the staged return.  All three leave
+    the same image, identical outside the ROI to what went in."""
     from seamlesscloneoptimization_amd import capi
     o, oc = oracles
     dst, patch, mask, cx, cy = o.synth_inputs(1200, 1000, margin=24)
     want = oc.seamless_clone(dst, patch, mask, cx, cy, min(16, oc.max_threads()))
     got = {}
     try:
-        for name, flags in (("rows", 0), ("staged", capi.SC_FLAG_STAGED_RETURN)):
+        for name, flags in (("rows", capi.SC_FLAG_ROWS_RETURN), ("staged", 0)):
             inst.set_solver(flags=flags)
             body = dst.copy()
             inst.run(patch, body, mask, cx, cy)
             got[name] = body
-        inst.set_solver(flags=0)
+        inst.set_solver(flags=capi.SC_FLAG_ROWS_RETURN)
         wide = np.full((dst.shape[0], dst.shape[1] + 40, 3), 77, np.uint8)
         view = wide[:, 20:-20]
         view[...] = dst

@@ -20,8 +20,8 @@ for name, dst, patch in cases:
     mask = np.full(patch.shape[:2], 255, np.uint8)
     cx, cy = dst.shape[1] // 2, dst.shape[0] // 2
     want = o.seamless_clone(dst, patch, mask, cx, cy, float_tables=True)
-    for flags in (0, capi.SC_FLAG_BOTTOM_F32):
-        inst.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags)
+    for flags in (0, capi.SC_FLAG_LEGACY_PATHS):      # with legacy_paths = SC_LEGACY_BOTTOM_F32 (set below)
+        inst.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=flags, legacy_paths=capi.SC_LEGACY_BOTTOM_F32)
         body = dst.copy()
         inst.run(patch, body, mask, cx, cy, allow_not_converged=True)
         i = inst.info()
