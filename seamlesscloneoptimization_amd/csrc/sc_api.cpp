@@ -904,122 +904,43 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
 // field of 3n channels: every multigrid launch is n times larger (the coarse levels stop being launch-latency bound,
 // the level-1 grid fills whole rounds of workgroup slots) and there are 27 solver launches for the group instead of
 // 27 n.  Masks, positions and images are per clone (bounding box, erode, pre- and post-process each go out as one launch
-// for the group, blockIdx.z = member); the stop rule sees the largest correction of the group.  Groups with different ROI sizes, a
-// failing member or the reference's warm-up option run one after the other through sc_hip_run_device.
-int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
+// for the group, blockIdx.z = member); the stop rule sees the largest correction of the group.
+// Round 5: the members of a call are PARTITIONED by ROI size -- every sub-group of two or more same-size members shares one
+// set of launches, the rest run alone -- instead of the whole call falling back to one clone at a time as soon as one member
+// differs (a batch of real clones has a mask box per face / frame).  A failing member, the reference's warm-up option and
+// OpenCV's grey-mask semantics still run one after the other through sc_hip_run_device.
+namespace {
+
+constexpr int GROUP_RS = 32;      // ints between the rectangles of a group's scans: one 128-byte line each (eight rectangles in one line: 162 us for the group's scan instead of 20)
+
+// members idx[0..n) of `jobs` (all with the same ROI size) as one field of 3n channels.  guess: the predicted rectangles the
+// members were launched on (nullptr: their boxes are the device's), d_r: the device rectangles of ALL members of the call
+int run_same_size_members(Instance *I, sc_batch_job *jobs, const std::vector<int> &idx, const std::vector<Geo> &geo, const int *guess, int *d_r)
 {
-    Instance *I = get(p);
-    if (!I || !jobs || n <= 0) return SC_ERR_BAD_ARG;
-    I->err.clear();
-    I->info.field_retry = 0; I->info.new_size = 0;
-    SC_HIP(I, hipSetDevice(I->gpu));
-    auto one_by_one = [&]() -> int {
-        int worst = SC_OK;
-        for (int i = 0; i < n; ++i) {
-            sc_batch_job &j = jobs[i];
-            j.rc = sc_hip_run_device(p, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows, j.body_step,
-                                     j.mask, j.mask_cols, j.mask_rows, j.mask_step, j.centerX, j.centerY, false);
-            if (j.rc != SC_OK && worst == SC_OK) worst = j.rc;
-        }
-        return worst;
-    };
-    {   // refresh the destinations that ask for it: one launch per 16 (k_copy_group); odd alignments take the runtime's copy
-        CopyJobs cj{};
-        int cn = 0;
-        auto flush = [&]() { if (cn) { launch_copy_group(cj, cn, I->stream); cn = 0; } };
-        for (int i = 0; i < n; ++i) {
-            const sc_batch_job &j = jobs[i];
-            if (!j.body_restore) continue;
-            const size_t bytes = (size_t)j.body_step * j.body_rows;
-            if ((((uintptr_t)j.body | (uintptr_t)j.body_restore) & 15) != 0) {
-                SC_HIP(I, hipMemcpyAsync(j.body, j.body_restore, bytes, hipMemcpyDeviceToDevice, I->stream));
-                continue;
-            }
-            cj.dst[cn] = j.body; cj.src[cn] = j.body_restore; cj.bytes[cn] = bytes;
-            if (++cn == CopyJobs::MAX) flush();
-        }
-        flush();
-        SC_HIP(I, hipGetLastError());
-    }
-    if (n == 1 || I->opts.reference_warmup || (I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) return one_by_one();
-    for (int i = 0; i < n; ++i) {
-        const sc_batch_job &j = jobs[i];
-        if (validate_images(I, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows, j.body_step,
-                            j.mask, j.mask_cols, j.mask_rows, j.mask_step) != SC_OK) { I->err.clear(); return one_by_one(); }
-    }
-    I->stage_marks = false;
-    // --- bounding boxes of all masks, one read-back
+    const int n = (int)idx.size();
+    const Geo &g0 = geo[idx[0]];
     int rc;
-    // one rectangle per 128-byte line: the scans of different masks must not share a line for their atomics (eight
-    // rectangles in one line: 162 us for the group's scan instead of 20)
-    constexpr int RS = 32;
-    if ((rc = ensure(I, I->d_rects, (size_t)n * RS * sizeof(int)))) return rc;
-    if ((rc = ensure_pinned(I, I->h_rects, (size_t)n * 2 * RS * sizeof(int)))) return rc;
-    int *h_in = (int *)I->h_rects.p, *h_out = h_in + RS * n, *d_r = (int *)I->d_rects.p;
-    memset(h_in, 0, (size_t)n * RS * sizeof(int));
-    for (int i = 0; i < n; ++i) {
-        h_in[RS * i + 0] = jobs[i].mask_cols - 1; h_in[RS * i + 1] = 0; h_in[RS * i + 2] = jobs[i].mask_rows - 1; h_in[RS * i + 3] = 0;
-    }
-    SC_HIP(I, hipMemcpyAsync(d_r, h_in, (size_t)n * RS * sizeof(int), hipMemcpyHostToDevice, I->stream));
-    std::vector<MaskJob> mj(n);
-    for (int i = 0; i < n; ++i) {
-        mj[i] = MaskJob{};
-        mj[i].mask = jobs[i].mask; mj[i].mw = jobs[i].mask_cols; mj[i].mh = jobs[i].mask_rows; mj[i].mstep = jobs[i].mask_step;
-        mj[i].rect = d_r + RS * i;
-    }
-    if ((rc = ensure(I, I->d_bbox_parts, sizeof(int) * mask_bbox_group_parts(mj.data(), n)))) return rc;
-    launch_mask_bbox_group(mj.data(), n, I->stream, (int *)I->d_bbox_parts.p);
-    SC_HIP(I, hipGetLastError());
-    SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * RS * sizeof(int), hipMemcpyDeviceToHost, I->stream));
-    if (!I->ev_rects) SC_HIP(I, hipEventCreateWithFlags(&I->ev_rects, hipEventDisableTiming));
-    SC_HIP(I, hipEventRecord(I->ev_rects, I->stream));
-    // Like a single clone (predict_rect), the group is launched on PREDICTED bounding boxes -- the interior of every mask,
-    // which is what a mask that touches its four inner borders gives -- while the scans' answers are in flight: no host
-    // wait in front of the erodes.  Every member's splice carries its guess and writes nothing unless the device found
-    // that box; the host compares when the answers are in (they are by the time the solver has waited for its stop rule)
-    // and repeats the members that were guessed wrong, one by one on their true boxes.
-    std::vector<Geo> geo(n);
-    std::vector<int> guess(4 * (size_t)n);
-    bool speculative = !(I->opts.flags & SC_FLAG_NO_SPECULATE) && I->group_spec_cooldown == 0;
-    if (I->group_spec_cooldown > 0) --I->group_spec_cooldown;
-    for (int i = 0; i < n && speculative; ++i) {
-        int *r = &guess[4 * i];
-        r[0] = 1; r[1] = jobs[i].mask_cols - 2; r[2] = 1; r[3] = jobs[i].mask_rows - 2;
-        if (jobs[i].mask_cols < 3 || jobs[i].mask_rows < 3 || geo_from_rect(I, r, jobs[i].centerX, jobs[i].centerY, geo[i]) != SC_OK ||
-            check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) != SC_OK || geo[i].W != geo[0].W || geo[i].H != geo[0].H)
-            speculative = false;
-    }
-    I->err.clear();
-    if (!speculative) {
-        SC_HIP(I, hipStreamSynchronize(I->stream));
-        bool same = true;
-        for (int i = 0; i < n && same; ++i) {
-            if (geo_from_rect(I, h_out + RS * i, jobs[i].centerX, jobs[i].centerY, geo[i]) != SC_OK ||
-                check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) != SC_OK)
-                same = false;
-            else if (geo[i].W != geo[0].W || geo[i].H != geo[0].H)
-                same = false;
-        }
-        if (!same) { I->err.clear(); return one_by_one(); }
-    }
-    const Geo &g0 = geo[0];
-    // --- eroded masks, fields of 3n channels, right-hand sides
     I->mpitch = round_up(g0.W, 64);
     const size_t mplane = (size_t)I->mpitch * g0.H;
     if ((rc = ensure(I, I->d_M, mplane * n))) return rc;
     if ((rc = setup_fields(I, g0.W, g0.H, 3 * n))) return rc;
-    for (int i = 0; i < n; ++i) { mj[i].g = geo[i]; mj[i].M = (uint8_t *)I->d_M.p + mplane * i; mj[i].mpitch = I->mpitch; }
+    std::vector<MaskJob> mj(n);
+    std::vector<ImageJob> ij(n);
+    for (int k = 0; k < n; ++k) {
+        const int i = idx[k];
+        const sc_batch_job &j = jobs[i];
+        mj[k] = MaskJob{};
+        mj[k].mask = j.mask; mj[k].mw = j.mask_cols; mj[k].mh = j.mask_rows; mj[k].mstep = j.mask_step;
+        mj[k].rect = d_r + GROUP_RS * i;
+        mj[k].g = geo[i]; mj[k].M = (uint8_t *)I->d_M.p + mplane * k; mj[k].mpitch = I->mpitch;
+        ij[k].face_org = j.face + (size_t)geo[i].y0 * j.face_step + 3 * geo[i].x0; ij[k].fstep = j.face_step;
+        ij[k].body_org = j.body + (size_t)geo[i].lty * j.body_step + 3 * geo[i].ltx; ij[k].bstep = j.body_step;
+        ij[k].M = (const uint8_t *)I->d_M.p + mplane * k;
+        ij[k].d_rect = guess ? d_r + GROUP_RS * i : nullptr;
+        if (guess) { ij[k].rx0 = guess[4 * i]; ij[k].rx1 = guess[4 * i + 1]; ij[k].ry0 = guess[4 * i + 2]; ij[k].ry1 = guess[4 * i + 3]; }
+    }
     launch_mask_erode3_group(mj.data(), n, I->stream);
     I->erode_done = false;
-    std::vector<ImageJob> ij(n);
-    for (int i = 0; i < n; ++i) {
-        const sc_batch_job &j = jobs[i];
-        ij[i].face_org = j.face + (size_t)geo[i].y0 * j.face_step + 3 * geo[i].x0; ij[i].fstep = j.face_step;
-        ij[i].body_org = j.body + (size_t)geo[i].lty * j.body_step + 3 * geo[i].ltx; ij[i].bstep = j.body_step;
-        ij[i].M = (const uint8_t *)I->d_M.p + mplane * i;
-        ij[i].d_rect = speculative ? d_r + RS * i : nullptr;
-        ij[i].rx0 = guess[4 * i]; ij[i].rx1 = guess[4 * i + 1]; ij[i].ry0 = guess[4 * i + 2]; ij[i].ry1 = guess[4 * i + 3];
-    }
     int solve_rc = SC_OK;
     for (;;) {
         I->result_in_U1 = false;
@@ -1048,29 +969,154 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
         if ((rc = output_nodes(I, lm))) return rc;
         launch_postprocess_group(result(I), ij.data(), n, I->stream, lm);
     }
-    for (int i = 0; i < n; ++i) jobs[i].rc = solve_rc;
+    for (int k = 0; k < n; ++k) jobs[idx[k]].rc = solve_rc;
     SC_HIP(I, hipGetLastError());
-    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
     fill_info_geo(I, g0);
-    I->info.ms_h2d = I->info.ms_mask = I->info.ms_pre = I->info.ms_solve = I->info.ms_post = I->info.ms_d2h = I->info.ms_device_total = 0.f;
-    int worst = solve_rc;
-    if (speculative) {
-        SC_HIP(I, hipEventSynchronize(I->ev_rects));       // long since passed when the solver has waited for its stop rule
-        std::vector<int> wrong;
-        for (int i = 0; i < n; ++i)
-            if (memcmp(&guess[4 * i], h_out + RS * i, 4 * sizeof(int)) != 0) wrong.push_back(i);
-        if (!wrong.empty()) {
-            I->group_spec_cooldown = 8;
-            const sc_run_info keep = I->info;
-            for (int i : wrong) {                              // its destination was not touched: repeat it alone on its true box
-                sc_batch_job &j = jobs[i];
-                j.rc = sc_hip_run_device(p, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows, j.body_step,
-                                         j.mask, j.mask_cols, j.mask_rows, j.mask_step, j.centerX, j.centerY, false);
-                if (j.rc != SC_OK && (worst == SC_OK || worst == SC_ERR_NOT_CONVERGED)) worst = j.rc;
+    return solve_rc;
+}
+
+} // namespace
+
+int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
+{
+    Instance *I = get(p);
+    if (!I || !jobs || n <= 0) return SC_ERR_BAD_ARG;
+    I->err.clear();
+    I->info.field_retry = 0; I->info.new_size = 0;
+    SC_HIP(I, hipSetDevice(I->gpu));
+    auto worse = [](int worst, int rc) { return (rc != SC_OK && (worst == SC_OK || worst == SC_ERR_NOT_CONVERGED)) ? rc : worst; };
+    auto alone = [&](int i) -> int {
+        sc_batch_job &j = jobs[i];
+        j.rc = sc_hip_run_device(p, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows, j.body_step,
+                                 j.mask, j.mask_cols, j.mask_rows, j.mask_step, j.centerX, j.centerY, false);
+        return j.rc;
+    };
+    auto one_by_one = [&]() -> int {
+        int worst = SC_OK;
+        for (int i = 0; i < n; ++i) worst = worse(worst, alone(i));
+        return worst;
+    };
+    {   // refresh the destinations that ask for it: one launch per 16 (k_copy_group); odd alignments take the runtime's copy
+        CopyJobs cj{};
+        int cn = 0;
+        auto flush = [&]() { if (cn) { launch_copy_group(cj, cn, I->stream); cn = 0; } };
+        for (int i = 0; i < n; ++i) {
+            const sc_batch_job &j = jobs[i];
+            if (!j.body_restore) continue;
+            const size_t bytes = (size_t)j.body_step * j.body_rows;
+            if ((((uintptr_t)j.body | (uintptr_t)j.body_restore) & 15) != 0) {
+                SC_HIP(I, hipMemcpyAsync(j.body, j.body_restore, bytes, hipMemcpyDeviceToDevice, I->stream));
+                continue;
             }
-            if ((int)wrong.size() < n) I->info = keep;
+            cj.dst[cn] = j.body; cj.src[cn] = j.body_restore; cj.bytes[cn] = bytes;
+            if (++cn == CopyJobs::MAX) flush();
+        }
+        flush();
+        SC_HIP(I, hipGetLastError());
+    }
+    if (n == 1 || I->opts.reference_warmup || (I->opts.flags & SC_FLAG_OPENCV_GREY_MASK)) return one_by_one();
+    // members whose images do not even validate run alone (and report their own error); the others are candidates for a group
+    std::vector<char> usable(n, 1);
+    int nusable = 0;
+    for (int i = 0; i < n; ++i) {
+        const sc_batch_job &j = jobs[i];
+        if (validate_images(I, j.face, j.face_cols, j.face_rows, j.face_step, j.body, j.body_cols, j.body_rows, j.body_step,
+                            j.mask, j.mask_cols, j.mask_rows, j.mask_step) != SC_OK) usable[i] = 0;
+        else ++nusable;
+    }
+    I->err.clear();
+    if (nusable < 2) return one_by_one();
+    I->stage_marks = false;
+    // --- bounding boxes of all masks, one read-back
+    int rc;
+    constexpr int RS = GROUP_RS;
+    if ((rc = ensure(I, I->d_rects, (size_t)n * RS * sizeof(int)))) return rc;
+    if ((rc = ensure_pinned(I, I->h_rects, (size_t)n * 2 * RS * sizeof(int)))) return rc;
+    int *h_in = (int *)I->h_rects.p, *h_out = h_in + RS * n, *d_r = (int *)I->d_rects.p;
+    memset(h_in, 0, (size_t)n * RS * sizeof(int));
+    for (int i = 0; i < n; ++i) {
+        h_in[RS * i + 0] = jobs[i].mask_cols - 1; h_in[RS * i + 1] = 0; h_in[RS * i + 2] = jobs[i].mask_rows - 1; h_in[RS * i + 3] = 0;
+    }
+    SC_HIP(I, hipMemcpyAsync(d_r, h_in, (size_t)n * RS * sizeof(int), hipMemcpyHostToDevice, I->stream));
+    {
+        std::vector<MaskJob> mj;
+        mj.reserve(n);
+        for (int i = 0; i < n; ++i) {
+            if (!usable[i]) continue;
+            MaskJob m{};
+            m.mask = jobs[i].mask; m.mw = jobs[i].mask_cols; m.mh = jobs[i].mask_rows; m.mstep = jobs[i].mask_step;
+            m.rect = d_r + RS * i;
+            mj.push_back(m);
+        }
+        if ((rc = ensure(I, I->d_bbox_parts, sizeof(int) * mask_bbox_group_parts(mj.data(), (int)mj.size())))) return rc;
+        launch_mask_bbox_group(mj.data(), (int)mj.size(), I->stream, (int *)I->d_bbox_parts.p);
+    }
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * RS * sizeof(int), hipMemcpyDeviceToHost, I->stream));
+    if (!I->ev_rects) SC_HIP(I, hipEventCreateWithFlags(&I->ev_rects, hipEventDisableTiming));
+    SC_HIP(I, hipEventRecord(I->ev_rects, I->stream));
+    // Like a single clone (predict_rect), the members are launched on PREDICTED bounding boxes -- the interior of every mask,
+    // which is what a mask that touches its four inner borders gives -- while the scans' answers are in flight: no host
+    // wait in front of the erodes.  Every member's splice carries its guess and writes nothing unless the device found
+    // that box; the host compares when the answers are in (they are by the time the solver has waited for its stop rule)
+    // and repeats the members that were guessed wrong, one by one on their true boxes.
+    std::vector<Geo> geo(n);
+    std::vector<int> guess(4 * (size_t)n);
+    bool speculative = !(I->opts.flags & SC_FLAG_NO_SPECULATE) && I->group_spec_cooldown == 0;
+    if (I->group_spec_cooldown > 0) --I->group_spec_cooldown;
+    std::vector<char> grouped(n, 0);          // the member's geometry is known (or predicted) and fits its destination
+    if (speculative) {
+        for (int i = 0; i < n; ++i) {
+            if (!usable[i]) continue;
+            int *r = &guess[4 * i];
+            r[0] = 1; r[1] = jobs[i].mask_cols - 2; r[2] = 1; r[3] = jobs[i].mask_rows - 2;
+            // (a member whose guess does not fit -- a mask narrower than three pixels, a box that leaves the destination -- runs alone on its true box)
+            grouped[i] = jobs[i].mask_cols >= 3 && jobs[i].mask_rows >= 3 && geo_from_rect(I, r, jobs[i].centerX, jobs[i].centerY, geo[i]) == SC_OK &&
+                         check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) == SC_OK;
+        }
+    } else {
+        SC_HIP(I, hipStreamSynchronize(I->stream));
+        for (int i = 0; i < n; ++i) {
+            if (!usable[i]) continue;
+            grouped[i] = geo_from_rect(I, h_out + RS * i, jobs[i].centerX, jobs[i].centerY, geo[i]) == SC_OK &&
+                         check_roi(I, geo[i], jobs[i].body_cols, jobs[i].body_rows) == SC_OK;
         }
     }
+    I->err.clear();
+    // --- partition by ROI size (first-come order inside a sub-group and between them)
+    std::vector<std::vector<int>> parts;
+    for (int i = 0; i < n; ++i) {
+        if (!grouped[i]) continue;
+        bool placed = false;
+        for (auto &q : parts)
+            if (geo[q[0]].W == geo[i].W && geo[q[0]].H == geo[i].H) { q.push_back(i); placed = true; break; }
+        if (!placed) parts.push_back(std::vector<int>(1, i));
+    }
+    int worst = SC_OK;
+    sc_run_info keep{};
+    bool have_group = false;
+    std::vector<int> singles;
+    for (int i = 0; i < n; ++i) if (!grouped[i]) singles.push_back(i);
+    for (const auto &q : parts) {
+        if (q.size() < 2) { singles.push_back(q[0]); grouped[q[0]] = 0; continue; }
+        rc = run_same_size_members(I, jobs, q, geo, speculative ? guess.data() : nullptr, d_r);
+        if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;          // a HIP error: nothing more can be trusted on this stream
+        worst = worse(worst, rc);
+        keep = I->info; have_group = true;
+    }
+    SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+    I->info.ms_h2d = I->info.ms_mask = I->info.ms_pre = I->info.ms_solve = I->info.ms_post = I->info.ms_d2h = I->info.ms_device_total = 0.f;
+    if (have_group) keep = I->info;
+    if (speculative && have_group) {
+        SC_HIP(I, hipEventSynchronize(I->ev_rects));       // long since passed when the solver has waited for its stop rule
+        for (int i = 0; i < n; ++i)
+            if (grouped[i] && memcmp(&guess[4 * i], h_out + RS * i, 4 * sizeof(int)) != 0) {
+                I->group_spec_cooldown = 8;
+                singles.push_back(i);                          // its destination was not touched: repeat it alone on its true box
+            }
+    }
+    for (int i : singles) worst = worse(worst, alone(i));
+    if (have_group) I->info = keep;                            // the statistics of the (last) group, not of a straggler
     return worst;
 }
 

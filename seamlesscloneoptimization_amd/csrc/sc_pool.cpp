@@ -29,6 +29,11 @@ struct Pool {
     sc_batch_job *jobs = nullptr;
     int njobs = 0, device_resident = 0;
     int group = 1;                 // device-resident jobs a worker takes at a time (sc_hip_run_device_batch)
+    // group > 1: the batch's jobs ordered by predicted ROI size (`sorted`: a copy, `origin[k]` = its index in the caller's array) and
+    // cut into chunks of at most `group` members; `next` counts chunks then, jobs otherwise
+    std::vector<sc_batch_job> sorted;
+    std::vector<int> origin;
+    std::vector<std::pair<int, int>> chunks;       // first member, members
     std::atomic<int> next{ 0 };
     int generation = 0, finished_workers = 0;
     bool stop = false;
@@ -60,19 +65,26 @@ void worker(Pool *P, int k)
             if (P->stop) return;
             seen = P->generation;
         }
-        const int grp = (P->device_resident && P->group > 1) ? P->group : 1;
+        const bool chunked = !P->chunks.empty();
         for (;;) {
-            const int i = P->next.fetch_add(grp);
-            if (i >= P->njobs) break;
-            const int cnt = std::min(grp, P->njobs - i);
-            if (cnt > 1) {
-                // same-size clones of the group share one set of launches; per-job codes are filled in by the call
-                constexpr int unset = -2147483647;
-                for (int q = 0; q < cnt; ++q) P->jobs[i + q].rc = unset;
-                const int rc = sc_hip_run_device_batch(P->inst[k], P->jobs + i, cnt);
-                for (int q = 0; q < cnt; ++q)          // the call failed before it got to this member
-                    if (P->jobs[i + q].rc == unset) P->jobs[i + q].rc = (rc != SC_OK) ? rc : SC_ERR_HIP;
+            const int i = P->next.fetch_add(1);
+            if (chunked) {
+                if (i >= (int)P->chunks.size()) break;
+                const int first = P->chunks[i].first, cnt = P->chunks[i].second;
+                sc_batch_job *js = P->sorted.data() + first;
+                if (cnt > 1) {
+                    // same-size clones of the chunk share one set of launches; per-job codes are filled in by the call
+                    constexpr int unset = -2147483647;
+                    for (int q = 0; q < cnt; ++q) js[q].rc = unset;
+                    const int rc = sc_hip_run_device_batch(P->inst[k], js, cnt);
+                    for (int q = 0; q < cnt; ++q)          // the call failed before it got to this member
+                        if (js[q].rc == unset) js[q].rc = (rc != SC_OK) ? rc : SC_ERR_HIP;
+                } else {
+                    run_job(P->inst[k], js[0], P->device_resident);
+                }
+                for (int q = 0; q < cnt; ++q) P->jobs[P->origin[first + q]].rc = js[q].rc;
             } else {
+                if (i >= P->njobs) break;
                 run_job(P->inst[k], P->jobs[i], P->device_resident);
             }
         }
@@ -177,6 +189,35 @@ int sc_hip_pool_run(void *p, sc_batch_job *jobs, int n, int device_resident)
     {
         std::lock_guard<std::mutex> lk(P->mu);
         P->jobs = jobs; P->njobs = n; P->device_resident = device_resident;
+        P->chunks.clear();
+        if (device_resident && P->group > 1) {
+            // Bucket the jobs by the ROI size they will most likely have -- the interior of their mask, which is what a clone is
+            // launched on before the device's bounding box is back -- so that the members a worker takes together can share one set
+            // of launches (sc_hip_run_device_batch partitions what it is given by ROI size).  Round 4 took CONSECUTIVE jobs: one odd
+            // size in the caller's order demoted its whole group to one clone at a time.  Stable: equal sizes keep the caller's order.
+            P->origin.resize(n);
+            for (int i = 0; i < n; ++i) P->origin[i] = i;
+            std::stable_sort(P->origin.begin(), P->origin.end(), [&](int a, int b) {
+                if (jobs[a].mask_cols != jobs[b].mask_cols) return jobs[a].mask_cols < jobs[b].mask_cols;
+                return jobs[a].mask_rows < jobs[b].mask_rows;
+            });
+            P->sorted.resize(n);
+            for (int i = 0; i < n; ++i) P->sorted[i] = jobs[P->origin[i]];
+            // chunks of at most `group` members; a run of equal sizes is not cut in two by a chunk boundary that a shorter
+            // chunk in front of it avoids (sizes 3 x A then 16 x B with group 16: chunks of 3 and 16, not 16 and 3)
+            auto same = [&](int a, int b) { return P->sorted[a].mask_cols == P->sorted[b].mask_cols && P->sorted[a].mask_rows == P->sorted[b].mask_rows; };
+            int first = 0;
+            while (first < n) {
+                int end = std::min(n, first + P->group);
+                if (end < n && same(end - 1, end)) {          // the boundary would split a run of equal sizes
+                    int run0 = end - 1;
+                    while (run0 > first && same(run0 - 1, run0)) --run0;
+                    if (run0 > first) end = run0;              // ... end the chunk where that run starts (unless the run fills the chunk)
+                }
+                P->chunks.emplace_back(first, end - first);
+                first = end;
+            }
+        }
         P->next.store(0);
         P->finished_workers = 0;
         ++P->generation;
