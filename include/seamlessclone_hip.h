@@ -233,6 +233,8 @@ typedef struct sc_run_info {
                                        iterate left [-256, 768): possible when the mask mixes patch and destination gradients into a
                                        non-conservative field) -- nothing was written, the clone was repeated on float32 fields */
     int    new_size;                /* 1: this run built per-size state (multigrid hierarchy, transform or correction tables) */
+    int    group_members;           /* sc_hip_run_device_batch: members of the last set of launches the call shared (0: none were shared) */
+    int    group_ragged;            /* ... 1: those members had DIFFERENT ROI sizes (a size class, round 5): W, H above are the class's largest */
 } sc_run_info;
 
 /* ---- the reference's four entry points ------------------------------------------------- */
@@ -346,13 +348,16 @@ typedef struct sc_batch_job {
                                       this device image (body_step * body_rows bytes) before the clone */
     int rc;                        /* out: SC_OK or SC_ERR_* of this job */
 } sc_batch_job;
-/* n device-resident clones on ONE instance.  When their ROIs have the same size (W x H; masks, positions and
- * images are free) they are solved as one field of 3n channels: every solver launch is n times larger and there is one
+/* n device-resident clones on ONE instance.  Members whose ROIs have the same size (W x H; masks, positions and
+ * images are free) are solved as one field of 3n channels: every solver launch is n times larger and there is one
  * set of launches for the group, which is what fills a 256-CU GPU with small and medium ROIs.  Results are the ones the
  * clones get one by one (channels never interact), except that the stop rule sees the group's largest correction, so
  * every member gets the cycle count of the slowest.  The group is launched on predicted bounding boxes (the masks'
- * interiors); a member whose box turns out different is left untouched by the group and repeated alone.  Other groups
- * (different ROI sizes, a failing member) run one after the other.  jobs[i].rc receives each
+ * interiors); a member whose box turns out different is left untouched by the group and repeated alone.
+ * Round 5: the members of a call are PARTITIONED -- same-size members share launches as above; members of one SIZE CLASS
+ * (different sizes whose solves are the same program: same hierarchy depth and bottom solve, widths and heights within 1/8 of
+ * each other; default solver options) share them through a per-member geometry table the kernels read (csrc/sc_ragged.cpp),
+ * each member with the bytes of its solo run; what fits neither (and a failing member) runs alone.  jobs[i].rc receives each
  * clone's code; the call is asynchronous like sc_hip_run_device(..., false): sync the instance before reading bodies. */
 SC_API int   sc_hip_run_device_batch(void *instance, sc_batch_job *jobs, int n);
 SC_API void *sc_hip_pool_create(int gpu_id, int streams);
@@ -381,6 +386,15 @@ SC_API int sc_hip_time_coarse_chain(void *instance, int reps, float *ms_eager, f
  * restriction | the four products of the direct solve | prolongation | post-smoothing | stores issued.  SC_ERR_BAD_ARG unless that
  * hierarchy runs its bottom this way. */
 SC_API int sc_hip_time_tail_phases(void *instance, unsigned long long *cycles11);
+
+/* Host-only (needs no GPU): how sc_hip_run_device_batch / the pool would partition a batch whose members have these ROI sizes
+ * (wh[2i], wh[2i+1]: width and height, ring included) under `opts` (NULL: the defaults), at most `cap` members per group (<= 0: no
+ * limit): group_of[i] = the member's group, kind_of[i] (may be NULL) = 0 alone, 1 a same-size group, 2 a size class (different
+ * sizes, the same solve: csrc/sc_ragged.cpp).  Returns the number of groups, or SC_ERR_BAD_ARG. */
+/* Host-only: what decides a ROI size's class: out = { eligible, levels, level held by k_mg_tail, operand padding x, y of the level solved
+ * directly, mode-block padding x, y of the correction, its column tiles, its row splits, 1000 * nx + ny of the level solved directly } */
+SC_API int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[10]);
+SC_API int sc_hip_plan_groups(const int *wh, int n, int cap, const sc_solver_opts *opts, int *group_of, int *kind_of);
 
 /* Host-only (needs no GPU): 1 when the reference's float32 eigenvalue tables are singular for an ROI of w x h unknowns --
  * (float)(2 cos(PI/(n+1))) is exactly 2.0f in both directions (n >= ~12 870), so the reference's denominator

@@ -82,7 +82,8 @@ class RunInfo(C.Structure):
                 ("ms_h2d", C.c_float), ("ms_mask", C.c_float), ("ms_pre", C.c_float), ("ms_solve", C.c_float),
                 ("ms_post", C.c_float), ("ms_d2h", C.c_float), ("ms_device_total", C.c_float),
                 ("sweep_launches", C.c_int), ("last_update", C.c_float), ("device_bytes", C.c_size_t), ("method", C.c_int),
-                ("device", C.c_int), ("ms_call", C.c_float), ("field_retry", C.c_int), ("new_size", C.c_int)]
+                ("device", C.c_int), ("ms_call", C.c_float), ("field_retry", C.c_int), ("new_size", C.c_int),
+                ("group_members", C.c_int), ("group_ragged", C.c_int)]
 
 
 class BatchJob(C.Structure):
@@ -218,6 +219,10 @@ def load():
     L.sc_hip_reference_tables_singular.restype = C.c_int
     L.sc_hip_selftest_host.argtypes = []
     L.sc_hip_selftest_host.restype = C.c_int
+    L.sc_hip_plan_groups.argtypes = [i32p, C.c_int, C.c_int, C.POINTER(SolverOpts), i32p, i32p]
+    L.sc_hip_plan_groups.restype = C.c_int
+    L.sc_hip_plan_size.argtypes = [C.c_int, C.c_int, C.POINTER(SolverOpts), i32p]
+    L.sc_hip_plan_size.restype = C.c_int
     _lib = L
     return L
 
@@ -533,6 +538,28 @@ class Pool:
             self.close()
         except Exception:
             pass
+
+
+def plan_size(W: int, H: int, opts: "SolverOpts | None" = None) -> dict:
+    """Host-only: what decides the size class of a W x H ROI (ring included)."""
+    out = np.zeros(10, np.int32)
+    load().sc_hip_plan_size(int(W), int(H), C.byref(opts) if opts is not None else None, out.ctypes.data_as(i32p))
+    keys = ("eligible", "levels", "tail_level", "pad_x", "pad_y", "Kxp", "Kyp", "column_tiles", "row_splits", "direct_nx_ny")
+    return dict(zip(keys, out.tolist()))
+
+
+def plan_groups(sizes, cap: int = 0, opts: "SolverOpts | None" = None):
+    """Host-only: how a batch whose members have these ROI sizes [(W, H), ...] (ring included) is partitioned into sets of launches:
+    (group_of, kind_of) per member -- kind 0 alone, 1 a same-size group, 2 a size class (csrc/sc_ragged.cpp)."""
+    L = load()
+    wh = np.ascontiguousarray(np.asarray(sizes, np.int32).reshape(-1, 2))
+    n = wh.shape[0]
+    g = np.zeros(n, np.int32); k = np.zeros(n, np.int32)
+    rc = L.sc_hip_plan_groups(wh.ctypes.data_as(i32p), n, int(cap), C.byref(opts) if opts is not None else None,
+                              g.ctypes.data_as(i32p), k.ctypes.data_as(i32p))
+    if rc < 0:
+        raise SeamlessCloneError(rc, "plan_groups")
+    return g.tolist(), k.tolist()
 
 
 def source_fingerprint() -> str:

@@ -497,6 +497,9 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->fft.ev_fork) (void)hipEventDestroy(I->fft.ev_fork);
     if (I->fft.ev_built) (void)hipEventDestroy(I->fft.ev_built);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
+    for (DevBuf *b : { &I->rag.d_table, &I->rag.d_aux }) if (b->p) (void)hipFree(b->p);
+    if (I->rag.h_stage.p) (void)hipHostFree(I->rag.h_stage.p);
+    if (I->rag.ev) (void)hipEventDestroy(I->rag.ev);
     if (I->ev_fd_fork) (void)hipEventDestroy(I->ev_fd_fork);
     if (I->ev_fd) (void)hipEventDestroy(I->ev_fd);
     if (I->ev_scan) (void)hipEventDestroy(I->ev_scan);
@@ -667,7 +670,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     Instance *I = get(p);
     if (!I) return SC_ERR_BAD_ARG;
     I->err.clear();
-    I->info.field_retry = 0; I->info.new_size = 0;
+    I->info.field_retry = 0; I->info.new_size = 0; I->info.group_members = 0; I->info.group_ragged = 0;
     SC_HIP(I, hipSetDevice(I->gpu));
     int rc = validate_images(I, face, fc, fr, fs, body, bc, br, bs, mask, mc, mr, ms);
     if (rc) return rc;
@@ -836,7 +839,7 @@ int sc_hip_run_device(void *p, const uint8_t *d_face, int fc, int fr, int fs, ui
     Instance *I = get(p);
     if (!I) return SC_ERR_BAD_ARG;
     I->err.clear();
-    I->info.field_retry = 0; I->info.new_size = 0;
+    I->info.field_retry = 0; I->info.new_size = 0; I->info.group_members = 0; I->info.group_ragged = 0;
     SC_HIP(I, hipSetDevice(I->gpu));
     int rc = validate_images(I, d_face, fc, fr, fs, d_body, bc, br, bs, d_mask, mc, mr, ms);
     if (rc) return rc;
@@ -913,17 +916,27 @@ namespace {
 
 constexpr int GROUP_RS = 32;      // ints between the rectangles of a group's scans: one 128-byte line each (eight rectangles in one line: 162 us for the group's scan instead of 20)
 
-// members idx[0..n) of `jobs` (all with the same ROI size) as one field of 3n channels.  guess: the predicted rectangles the
+struct RagScope {      // leaves the size-class mode on every way out
+    Instance *I;
+    ~RagScope() { rag_end(I); }
+};
+
+// members idx[0..n) of `jobs` as one field of 3n channels: all with the same ROI size (plans == nullptr), or a SIZE CLASS (sc_ragged.cpp:
+// plans[k] = member idx[k]'s plan; the fields take the class's largest width and height).  guess: the predicted rectangles the
 // members were launched on (nullptr: their boxes are the device's), d_r: the device rectangles of ALL members of the call
-int run_same_size_members(Instance *I, sc_batch_job *jobs, const std::vector<int> &idx, const std::vector<Geo> &geo, const int *guess, int *d_r)
+int run_group_members(Instance *I, sc_batch_job *jobs, const std::vector<int> &idx, const std::vector<Geo> &geo, const int *guess, int *d_r,
+                      const std::vector<SizePlan> *plans)
 {
     const int n = (int)idx.size();
-    const Geo &g0 = geo[idx[0]];
+    Geo g0 = geo[idx[0]];
+    if (plans) for (int k = 1; k < n; ++k) { g0.W = std::max(g0.W, geo[idx[k]].W); g0.H = std::max(g0.H, geo[idx[k]].H); }
     int rc;
     I->mpitch = round_up(g0.W, 64);
     const size_t mplane = (size_t)I->mpitch * g0.H;
     if ((rc = ensure(I, I->d_M, mplane * n))) return rc;
     if ((rc = setup_fields(I, g0.W, g0.H, 3 * n))) return rc;
+    RagScope scope{ I };
+    if (plans && (rc = rag_begin(I, *plans))) return rc;
     std::vector<MaskJob> mj(n);
     std::vector<ImageJob> ij(n);
     for (int k = 0; k < n; ++k) {
@@ -938,6 +951,7 @@ int run_same_size_members(Instance *I, sc_batch_job *jobs, const std::vector<int
         ij[k].M = (const uint8_t *)I->d_M.p + mplane * k;
         ij[k].d_rect = guess ? d_r + GROUP_RS * i : nullptr;
         if (guess) { ij[k].rx0 = guess[4 * i]; ij[k].rx1 = guess[4 * i + 1]; ij[k].ry0 = guess[4 * i + 2]; ij[k].ry1 = guess[4 * i + 3]; }
+        if (plans) { ij[k].W = geo[i].W; ij[k].H = geo[i].H; }
     }
     launch_mask_erode3_group(mj.data(), n, I->stream);
     I->erode_done = false;
@@ -972,6 +986,7 @@ int run_same_size_members(Instance *I, sc_batch_job *jobs, const std::vector<int
     for (int k = 0; k < n; ++k) jobs[idx[k]].rc = solve_rc;
     SC_HIP(I, hipGetLastError());
     fill_info_geo(I, g0);
+    I->info.group_members = n; I->info.group_ragged = plans ? 1 : 0;
     return solve_rc;
 }
 
@@ -982,7 +997,7 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     Instance *I = get(p);
     if (!I || !jobs || n <= 0) return SC_ERR_BAD_ARG;
     I->err.clear();
-    I->info.field_retry = 0; I->info.new_size = 0;
+    I->info.field_retry = 0; I->info.new_size = 0; I->info.group_members = 0; I->info.group_ragged = 0;
     SC_HIP(I, hipSetDevice(I->gpu));
     auto worse = [](int worst, int rc) { return (rc != SC_OK && (worst == SC_OK || worst == SC_ERR_NOT_CONVERGED)) ? rc : worst; };
     auto alone = [&](int i) -> int {
@@ -1083,23 +1098,34 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
         }
     }
     I->err.clear();
-    // --- partition by ROI size (first-come order inside a sub-group and between them)
-    std::vector<std::vector<int>> parts;
+    // --- partition (first-come order inside a sub-group and between them): same-size members share one set of launches as they
+    //     are, members of one size class (sc_ragged.cpp: different sizes, the same solve) through the per-member table
+    std::vector<int> cand;
+    std::vector<SizePlan> plans;
     for (int i = 0; i < n; ++i) {
         if (!grouped[i]) continue;
-        bool placed = false;
-        for (auto &q : parts)
-            if (geo[q[0]].W == geo[i].W && geo[q[0]].H == geo[i].H) { q.push_back(i); placed = true; break; }
-        if (!placed) parts.push_back(std::vector<int>(1, i));
+        cand.push_back(i);
+        plans.emplace_back();
+        plan_size(I->opts, geo[i].W, geo[i].H, plans.back());
     }
+    std::vector<std::vector<int>> parts;          // indices into cand / plans
+    plan_groups(plans, n, parts);
     int worst = SC_OK;
     sc_run_info keep{};
     bool have_group = false;
     std::vector<int> singles;
     for (int i = 0; i < n; ++i) if (!grouped[i]) singles.push_back(i);
-    for (const auto &q : parts) {
-        if (q.size() < 2) { singles.push_back(q[0]); grouped[q[0]] = 0; continue; }
-        rc = run_same_size_members(I, jobs, q, geo, speculative ? guess.data() : nullptr, d_r);
+    for (const auto &pq : parts) {
+        if (pq.size() < 2) { singles.push_back(cand[pq[0]]); grouped[cand[pq[0]]] = 0; continue; }
+        std::vector<int> q(pq.size());
+        std::vector<SizePlan> qp;
+        bool uniform = true;
+        for (size_t k = 0; k < pq.size(); ++k) {
+            q[k] = cand[pq[k]];
+            uniform = uniform && geo[q[k]].W == geo[q[0]].W && geo[q[k]].H == geo[q[0]].H;
+        }
+        if (!uniform) for (int k : pq) qp.push_back(plans[k]);
+        rc = run_group_members(I, jobs, q, geo, speculative ? guess.data() : nullptr, d_r, uniform ? nullptr : &qp);
         if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;          // a HIP error: nothing more can be trusted on this stream
         worst = worse(worst, rc);
         keep = I->info; have_group = true;
@@ -1118,6 +1144,38 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     for (int i : singles) worst = worse(worst, alone(i));
     if (have_group) I->info = keep;                            // the statistics of the (last) group, not of a straggler
     return worst;
+}
+
+int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[10])
+{
+    if (!out) return SC_ERR_BAD_ARG;
+    sc_solver_opts o;
+    if (opts) o = *opts; else sc_hip_default_opts(&o);
+    SizePlan p;
+    plan_size(o, W, H, p);
+    const int v[10] = { p.ok ? 1 : 0, p.nl, p.tail, p.npx, p.npy, p.Kxp, p.Kyp, p.nxt, p.nrs, p.nl > p.tail && p.tail > 0 ? p.g[p.tail].x.nc * 1000 + p.g[p.tail].y.nc : 0 };
+    memcpy(out, v, sizeof(v));
+    return SC_OK;
+}
+
+int sc_hip_plan_groups(const int *wh, int n, int cap, const sc_solver_opts *opts, int *group_of, int *kind_of)
+{
+    if (!wh || n < 1 || !group_of) return SC_ERR_BAD_ARG;
+    sc_solver_opts o;
+    if (opts) o = *opts; else sc_hip_default_opts(&o);
+    std::vector<SizePlan> plans(n);
+    for (int i = 0; i < n; ++i) plan_size(o, wh[2 * i], wh[2 * i + 1], plans[i]);
+    std::vector<std::vector<int>> groups;
+    plan_groups(plans, cap > 0 ? cap : n, groups);
+    for (size_t g = 0; g < groups.size(); ++g) {
+        bool uniform = true;
+        for (int i : groups[g]) uniform = uniform && plans[i].W == plans[groups[g][0]].W && plans[i].H == plans[groups[g][0]].H;
+        for (int i : groups[g]) {
+            group_of[i] = (int)g;
+            if (kind_of) kind_of[i] = groups[g].size() < 2 ? 0 : uniform ? 1 : 2;
+        }
+    }
+    return (int)groups.size();
 }
 
 int sc_hip_reference_tables_singular(int w, int h)

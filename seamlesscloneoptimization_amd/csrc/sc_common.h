@@ -44,7 +44,8 @@ struct MaskJobs { enum { MAX = 16 }; MaskJob j[MAX]; };     // by value in the k
 // pre- / post-process of the members of a group: ROI origins in the images and the member's eroded mask; member i owns
 // channels 3i..3i+2 of the fields (blockIdx.z = i)
 struct ImageJob { const uint8_t *face_org; int fstep; uint8_t *body_org; int bstep; const uint8_t *M;
-                  const int *d_rect; int rx0, rx1, ry0, ry1; };   // d_rect != nullptr: the member ran on a PREDICTED bounding box and is spliced only if the device found exactly that box (RectGuard semantics)
+                  const int *d_rect; int rx0, rx1, ry0, ry1;
+                  int W, H; };      // W > 0: the member's own ROI size inside fields laid out for a larger one (a size class, RagMember); 0: the fields' size   // d_rect != nullptr: the member ran on a PREDICTED bounding box and is spliced only if the device found exactly that box (RectGuard semantics)
 struct ImageJobs { enum { MAX = 16 }; ImageJob j[MAX]; };
 
 // ---------------------------------------------------------------- kernel launchers (sc_kernels.hip)
@@ -139,8 +140,9 @@ int  tb_gen_rows(int W, int H, int C, int hx, int hy);   // band height (rows pe
 int  tb_gen_rows_deep(int W, int H, int C, int hx, int hy);   // the same for launches of depth 3 or 4: 4 or 6
 struct MGGeom;
 struct ComposeArgs;
+struct RagMember;
 constexpr int TBM_PLAIN = 0, TBM_PROLONG = 1, TBM_ZEROIN = 4;   // mode of launch_rb_tb_gen
-bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s);
+bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s, const RagMember *rag = nullptr, int lev = 0);
 int  launch_rb_tb_prolong0(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, Field E, float *partial, hipStream_t s);
 int  tb_blocks_level0(int W, int H, int C, int sweeps);
 void launch_max_final(const float *d_partial, int n, unsigned *d_out, hipStream_t s);
@@ -149,7 +151,8 @@ void launch_max_final2(const float *d_a, int na, const float *d_b, int nb, unsig
 // residual + restriction into Fc.  Returns #partials written, 0 without prolong, -1 if unsupported.
 int  launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
                    float *partial, hipStream_t s, bool tag = false, bool f_half = false, bool u_half = false,
-                   bool final_cycle = false, float4 *bands = nullptr, bool l1_half = false, bool q16_out = false, AbortFlag sat = AbortFlag());
+                   bool final_cycle = false, float4 *bands = nullptr, bool l1_half = false, bool q16_out = false, AbortFlag sat = AbortFlag(),
+                   const RagMember *rag = nullptr);      // rag (here and below): the launch serves a size class, see RagMember
 // bands (final form, or 4 sweeps with prolongation): receives the cell shares of the float-table correction of the field the
 // launch writes, two float4 per (channel, tile row, wave, 8-column cell) -- see k_cycle0 and sc_lowmode.hip
 void cycle0_row_geometry(int H, int sweeps, int &nby, int &step, int &hy);
@@ -158,15 +161,16 @@ int  cycle0_blocks(int W, int H, int C, int sweeps);
 // (sc_cycle0.hip, ComposeArgs); -1: combination not instantiated
 int  launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
                             hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands = nullptr, bool l1_half = false,
-                            int u_q16 = 0, AbortFlag sat = AbortFlag());     // sat: where a saturating 16-bit store reports itself
+                            int u_q16 = 0, AbortFlag sat = AbortFlag(), const RagMember *rag = nullptr);     // sat: where a saturating 16-bit store reports itself
 // tagged twins of the other launches of a fast-path solve, for isolated timing (sc_cycle0.hip)
 int  launch_cycle0_twin(int form, Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, float *partial, hipStream_t s,
                         Field E2, const MGGeom &g1, float4 *bands, const LmNodes &lm);
 // the last cycle with its result leaving as output bytes (planar, in Q's memory) instead of as a field; see sc_cycle0.hip
 int  launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
-                       bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half = false);
+                       bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half = false, const RagMember *rag = nullptr);
 // coarse level: zero-guess pre-smoothing + residual + restriction fused (Uout = smoothed correction, Fc = next RHS)
-bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s, bool half_io = false);
+bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s, bool half_io = false,
+                         const RagMember *rag = nullptr, int lev = 0);
 
 // residual: d_out[0] = sum r^2, d_out[1] = sum lap^2 (double); d_partials holds >= 2*max_blocks doubles
 int  residual_max_blocks();
@@ -189,6 +193,25 @@ struct MGGeom { MGDim x, y; };
 // Composed prolongation source (sc_mg_device.h): the level interpolated from ran without post-smoothing and without a
 // prolongation launch of its own; E2 = finished correction of the level below it, g1 = its geometry (transfer to that level).
 struct ComposeArgs { Field E2; MGGeom g1; };
+
+// ---- size classes ("ragged groups", round 5): clones of DIFFERENT ROI sizes through one set of solver launches -----------------
+// The members of a class share the fields' strides (pitch and plane of the class's largest width / height on every level), the
+// launch grids (sized for the class) and every compile-time choice (hierarchy depth, the bottom solve's operand padding, the
+// correction's mode-block counts); everything that depends on a member's own W x H is read from this table by member index
+// (channel / 3: a wave-uniform scalar load) at kernel entry: its field size on every level, the level geometries, its bottom
+// matrices, its float-table correction tables.  Tiles beyond a member's extent exit.  Every member's arithmetic is, operation for
+// operation, that of its solo run: same bytes alone, in a same-size group or in a class.
+constexpr int RAG_MAX_LEVELS = 12;
+struct RagMember {
+    int W, H;                                  // level-0 field, ring included
+    int lw[RAG_MAX_LEVELS], lh[RAG_MAX_LEVELS]; // level-l field, ring included (lw[0] = W): clamp bounds of a member's loads
+    MGGeom g[RAG_MAX_LEVELS];                  // level l and its transfer to l + 1
+    const unsigned char *mm;                   // matrix-core operands of the member's directly solved level (k_mg_tail)
+    // float-table correction (sc_lowmode.hip): the member's node grid, its split of the projection and its tables
+    int lm_nx, lm_ny, lm_cells_y, lm_nxt, lm_nrs, lm_nparts, lm_Kx, lm_Ky;     // nodes, cell rows, column tiles / row splits / parts of the projection, modes kept
+    const float *lm_Sx, *lm_Sy, *lm_R;
+    const int *lm_map[2];                      // parts of each cell row for the 2- and the 4-sweep tiling of a level-0 launch
+};
 
 void launch_rb_half_gen(Field U, Field F, int color, float omega, MGGeom g, hipStream_t s);
 void launch_residual_restrict(Field U, Field F, Field Fc, MGGeom g, hipStream_t s); // Fc = 4 * normalised P^T (F - A U)
@@ -221,13 +244,15 @@ hipError_t mg_bottom_prepare();
 // level's two 1-D operators (nx, ny <= 128), and the zeroing of every plane of the levels >= 1 in one launch
 // mm != nullptr: also the operands of the matrix-core form (k_mg_bottom_mm), padded to NPX / NPY (32, 64 or 96)
 void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s, unsigned char *mm = nullptr, int NPX = 0, int NPY = 0);
+void launch_fd_build_rag(const RagMember *rag, int members, int lev, int NPX, int NPY, hipStream_t s);   // the operands of every member of a size class, one launch
 __host__ __device__ static inline long fd_mm_bytes(int NPX, int NPY) { return 4L * (2L * NPX * NPX + 2L * NPY * NPY + (long)NPX * NPY); }   // AX1 | AX2 | AY1 | AY2 | Dinv, float
 // the bottom's first level solved directly on the matrix cores: right-hand side in (Ftop), correction out (Utop), nx x ny unknowns
 struct MGBottomMM { const unsigned char *mm; Field Ftop, Utop; int nx, ny; };
 bool launch_mg_bottom_mm(const MGBottomMM &a, int NPX, int NPY, int C, hipStream_t s);
 // the level above the bottom (F: its right-hand side, U: receives its finished correction) and the bottom in one launch
 // (sc_mg_kernels.hip, k_mg_tail); false: not a shape this path serves (the caller launches the three kernels it replaces)
-struct MGTail { const unsigned char *mm; Field F, U; MGGeom g; int pre, post; unsigned long long *stamps; };   // stamps: measurement only (11 shader-clock values of channel 0), else nullptr
+struct MGTail { const unsigned char *mm; Field F, U; MGGeom g; int pre, post; unsigned long long *stamps;
+                const RagMember *rag; int lev; };      // rag != nullptr: a size class -- g, mm and F's row count are member (channel / 3)'s own, at its level `lev`   // stamps: measurement only (11 shader-clock values of channel 0), else nullptr
 bool launch_mg_tail(const MGTail &a, int NPX, int NPY, int C, hipStream_t s);
 struct ZeroJobs { enum { MAX = 48 }; void *p[MAX]; size_t n16[MAX]; int count; };     // n16: 16-byte units
 void launch_zero_multi(const ZeroJobs &z, hipStream_t s);

@@ -179,11 +179,17 @@ __device__ __forceinline__ float c0_comp(const float4 &v, int k) { return k == 0
 // 8-bit output values: float-table node correction added, clamped, truncated) instead of as a field; bit 6: the launch
 // leaves the float-table correction's cell shares of the field it writes in `bands` (the last-cycle form does so whenever
 // `bands` is not null)
+// TAG bit 10 (round 5): the launch serves a SIZE CLASS (RagMember, sc_common.h) -- the fields' strides and the grid are the class's,
+// everything else (field size, this level's and the next one's geometry, the coarse planes' row counts) is the member's, read from
+// rag[channel / 3] (a scalar load) at entry; `lev` = the level of Uin / F in the member's hierarchy.  Tiles beyond the member's
+// extent leave (their partial maximum is 0).
 template <int T, int NW, int R, bool PRO, bool GEN, bool ZEROIN, int TAG = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, MGGeom g,
-                                                    float *__restrict__ partial, ComposeArgs comp, float4 *__restrict__ bands, LmNodes lm, AbortFlag sat)
+                                                    float *__restrict__ partial, ComposeArgs comp, float4 *__restrict__ bands, LmNodes lm, AbortFlag sat,
+                                                    const RagMember *__restrict__ rag, int lev)
 {
     constexpr int HY = 2 * T + 2, RH = NW * R;
+    constexpr bool RAG = (TAG & 1024) != 0;
     constexpr bool COMP = (TAG & 16) != 0;      // E is U1; the interpolated level-2 correction is added on the fly (ComposeArgs)
     static_assert(!COMP || (PRO && !GEN && R % 2 == 0), "composition of two prolongations exists on level 0 only");
     constexpr bool FINAL = (TAG & 8) != 0;      // prolongation + post-smoothing only: the cycle the stop rule is expected to accept
@@ -210,11 +216,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
     __shared__ float2 hedge[2][NW][64];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR: row tests become scalar
-    const int W = Uin.W, H = Uin.H, P = Uin.pitch;
+    int W = Uin.W, H = Uin.H;
+    const int P = Uin.pitch;
     // 1-D launch; the tile this workgroup owns is chosen so that neighbouring tiles share an XCD (L2)
     const int nbx = (W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX), nby = (H + (RH - 2 * HY) - 1) / (RH - 2 * HY);
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int bx = tile % nbx, by = (tile / nbx) % nby, c = tile / (nbx * nby);
+    if constexpr (RAG) {
+        const RagMember &m = rag[c / 3];
+        W = m.lw[lev]; H = m.lh[lev];
+        if (bx * (256 - 2 * C0_HX) >= W || by * (RH - 2 * HY) >= H) {      // nothing of this member in the tile's exact output (block-uniform, before any barrier)
+            if (PRO && threadIdx.x == 0) partial[tile] = 0.f;
+            return;
+        }
+        g = m.g[lev];
+        if (PRO) E.H = m.lh[lev + 1];
+        if ((TAG & 16) != 0) { comp.g1 = m.g[lev + 1]; comp.E2.H = m.lh[lev + 2]; }
+    }
     const int x = bx * (256 - 2 * C0_HX) - C0_HX + 4 * lane;
     const int y0 = by * (RH - 2 * HY) - HY + wv * R;       // even
     float4 u[R], f[HF ? 1 : R];
@@ -718,14 +736,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4))) vo
 
 constexpr int C0_NW = 8, C0_R = 8;
 
+// the level-0 forms a size class can meet (the default fast path and its continuation on float fields): first launch 134 | 512 / 134,
+// catch-up 130, full cycles 146 | 768 / 146, full cycles leaving cell shares 210 | 256 / 210, final cycle as a field 154, as bytes 186
+constexpr bool c0_rag_form(int TAG)
+{
+    return TAG == (134 | 512) || TAG == 134 || TAG == 130 || TAG == (146 | 768) || TAG == 146 || TAG == (210 | 256) || TAG == 210 ||
+           TAG == 154 || TAG == 186;
+}
+
+// rag != nullptr: the launch serves a size class (k_cycle0 TAG bit 10); -1 where that form is not instantiated
 template <int T, bool PRO, int TAG = 0, int NW = C0_NW>
 static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s,
-                     const ComposeArgs &comp = ComposeArgs(), float4 *bands = nullptr, const LmNodes &lm = LmNodes(), const AbortFlag &sat = AbortFlag())
+                     const ComposeArgs &comp = ComposeArgs(), float4 *bands = nullptr, const LmNodes &lm = LmNodes(), const AbortFlag &sat = AbortFlag(),
+                     const RagMember *rag = nullptr)
 {
     constexpr int RH = NW * C0_R, HY = 2 * T + 2;
     const int blocks = ((Uin.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
+    if (rag) {
+        if constexpr (c0_rag_form(TAG) && NW == C0_NW)
+            hipLaunchKernelGGL((k_cycle0<T, NW, C0_R, PRO, false, false, TAG | 1024>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, Fc, E,
+                               g, partial, comp, bands, lm, sat, rag, 0);
+        else return -1;
+        return blocks;
+    }
     hipLaunchKernelGGL((k_cycle0<T, NW, C0_R, PRO, false, false, TAG>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, Fc, E,
-                       g, partial, comp, bands, lm, sat);
+                       g, partial, comp, bands, lm, sat, (const RagMember *)nullptr, 0);
     return blocks;
 }
 
@@ -741,10 +776,20 @@ static int launch_c0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MG
 // bit 1 (value 2) set: so will Uout, clear: Uout leaves as float (the launch before the judged cycle).
 int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, const MGGeom &g, int sweeps, float *partial,
                            hipStream_t s, bool tag, bool f_half, bool final_cycle, Field E2, const MGGeom &g1, float4 *bands, bool l1_half,
-                           int u_q16, AbortFlag sat)
+                           int u_q16, AbortFlag sat, const RagMember *rag)
 {
     ComposeArgs ca;
     ca.E2 = E2; ca.g1 = g1;
+    if (rag) {      // a size class: the default fast path's forms only (float16 right-hand side and level 1)
+        if (!l1_half || !f_half || tag) return -1;
+        if (final_cycle) return (sweeps == 2 && !u_q16) ? launch_c0<2, true, 154>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands, LmNodes(), AbortFlag(), rag) : -1;
+        if (sweeps != 4) return -1;
+        if (u_q16 == 3) return bands ? -1 : launch_c0<4, true, 146 | 768>(Uin, Uout, F, Fc, U1, g, partial, s, ca, nullptr, LmNodes(), sat, rag);
+        if (u_q16 == 1) return bands ? launch_c0<4, true, 210 | 256>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands, LmNodes(), AbortFlag(), rag) : -1;
+        if (u_q16) return -1;
+        return bands ? launch_c0<4, true, 210>(Uin, Uout, F, Fc, U1, g, partial, s, ca, bands, LmNodes(), AbortFlag(), rag)
+                     : launch_c0<4, true, 146>(Uin, Uout, F, Fc, U1, g, partial, s, ca, nullptr, LmNodes(), AbortFlag(), rag);
+    }
     if (u_q16) {
         if (!l1_half || !f_half || final_cycle || sweeps != 4) return -1;
         if (!(u_q16 & 2)) {
@@ -776,14 +821,16 @@ int launch_cycle0_composed(Field Uin, Field Uout, Field F, Field Fc, Field U1, c
 // Uin hold float16 values (same element layout).  Returns the number of partial maxima written (0 without prolong), or -1
 // for an unsupported depth.
 int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeom &g, int sweeps, bool prolong,
-                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle, float4 *bands, bool l1_half, bool q16_out, AbortFlag sat)
+                  float *partial, hipStream_t s, bool tag, bool f_half, bool u_half, bool final_cycle, float4 *bands, bool l1_half, bool q16_out, AbortFlag sat,
+                  const RagMember *rag)
 {
     if (q16_out && !(l1_half && u_half)) return -1;      // the first launch of a clone on the fast path only
+    if (rag && !l1_half) return -1;                      // a size class: the fast path's forms only
     if (l1_half) {     // level 1 keeps float16 fields (the composed schedule): the launches without a prolongation write its right-hand side
         if (prolong || final_cycle || !f_half || tag || sweeps != 2) return -1;
-        if (q16_out) launch_c0<2, false, 134 | 512>(Uin, Uout, F, Fc, E, g, partial, s, ComposeArgs(), nullptr, LmNodes(), sat);
-        else if (u_half) launch_c0<2, false, 134>(Uin, Uout, F, Fc, E, g, partial, s);
-        else launch_c0<2, false, 130>(Uin, Uout, F, Fc, E, g, partial, s);
+        if (q16_out) launch_c0<2, false, 134 | 512>(Uin, Uout, F, Fc, E, g, partial, s, ComposeArgs(), nullptr, LmNodes(), sat, rag);
+        else if (u_half) launch_c0<2, false, 134>(Uin, Uout, F, Fc, E, g, partial, s, ComposeArgs(), nullptr, LmNodes(), AbortFlag(), rag);
+        else launch_c0<2, false, 130>(Uin, Uout, F, Fc, E, g, partial, s, ComposeArgs(), nullptr, LmNodes(), AbortFlag(), rag);
         return 0;
     }
     if (final_cycle) {   // prolongation + `sweeps` post-smoothing sweeps, nothing restricted
@@ -829,10 +876,15 @@ int launch_cycle0(Field Uin, Field Uout, Field F, Field Fc, Field E, const MGGeo
 // E = the finished level-1 correction) + two post-smoothing sweeps; Q (a field's memory: plane c at Q.p + c Q.plane BYTES,
 // rows of Q.pitch bytes) receives the output values, lm the node correction to add (CN == nullptr: none).
 int launch_cycle0_out(Field Uin, Field Q, Field F, Field Fc, Field E, const MGGeom &g, float *partial, hipStream_t s, bool f_half,
-                      bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half)
+                      bool composed, Field E2, const MGGeom &g1, const LmNodes &lm, bool l1_half, const RagMember *rag)
 {
     ComposeArgs ca;
     if (l1_half && !(composed && f_half)) return -1;
+    if (rag) {
+        if (!(composed && f_half && l1_half)) return -1;
+        ca.E2 = E2; ca.g1 = g1;
+        return launch_c0<2, true, 186>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm, AbortFlag(), rag);
+    }
     if (composed && f_half && !l1_half) {
         ca.E2 = E2; ca.g1 = g1;
         return launch_c0<2, true, 58>(Uin, Q, F, Fc, E, g, partial, s, ca, nullptr, lm);
@@ -877,14 +929,24 @@ int cycle0_blocks(int W, int H, int C, int sweeps)
 
 // Coarse levels (l >= 1): pre-smoothing from a zero correction + residual + restriction in one
 // launch.  Uout receives the smoothed correction, Fc the next level's RHS.
+// rag / lev: a size class (k_cycle0 TAG bit 10): level `lev` of every member's own hierarchy; instantiated for the depths the default
+// schedule uses -- four sweeps on float16 fields (level 1) and two on float ones (the levels below it)
 template <int T, int R, int TAG = 0, int NW = C0_NW>
-static void launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_t s)
+static bool launch_cn(Field Uout, Field F, Field Fc, const MGGeom &g, hipStream_t s, const RagMember *rag = nullptr, int lev = 0)
 {
     constexpr int RH = NW * R, HY = 2 * T + 2;
     Field none{};
     const int blocks = ((F.W + (256 - 2 * C0_HX) - 1) / (256 - 2 * C0_HX)) * ((F.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * F.C;
+    if (rag) {
+        if constexpr ((T == 4 && TAG == 128 && R != 8) || (T == 2 && TAG == 0 && NW == C0_NW))
+            hipLaunchKernelGGL((k_cycle0<T, NW, R, false, true, true, TAG | 1024>), dim3(blocks), dim3(NW * 64), 0, s, F, Uout, F, Fc, none, g,
+                               (float *)nullptr, ComposeArgs(), (float4 *)nullptr, LmNodes(), AbortFlag(), rag, lev);
+        else return false;
+        return true;
+    }
     hipLaunchKernelGGL((k_cycle0<T, NW, R, false, true, true, TAG>), dim3(blocks), dim3(NW * 64), 0, s, F /*unused Uin: geometry only*/,
-                       Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs(), (float4 *)nullptr, LmNodes(), AbortFlag());
+                       Uout, F, Fc, none, g, (float *)nullptr, ComposeArgs(), (float4 *)nullptr, LmNodes(), AbortFlag(), (const RagMember *)nullptr, 0);
+    return true;
 }
 
 // workgroups of a coarse-level launch with NW waves of R rows each at depth T
@@ -895,8 +957,20 @@ static int cn_blocks(const Field &F, int T, int R, int NW)
 }
 
 // half_io: the level's own right-hand side and the correction it writes are float16 (level 1 of the composed schedule, 4 sweeps)
-bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s, bool half_io)
+bool launch_cycle_coarse(Field Uout, Field F, Field Fc, const MGGeom &g, int sweeps, hipStream_t s, bool half_io, const RagMember *rag, int lev)
 {
+    if (rag) {          // a size class: the same choices from the class's dimensions
+        if (half_io) {
+            if (sweeps != 4) return false;
+            const int R4 = tb_gen_rows_deep(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
+            const long b8 = cn_blocks(F, 4, 6, 8), b16 = cn_blocks(F, 4, 6, 16);
+            if (R4 == 6 && ((b8 > 512 && b16 <= 256) || (F.C > 3 && 2 * b16 < b8))) return launch_cn<4, 6, 128, 16>(Uout, F, Fc, g, s, rag, lev);
+            return R4 == 6 ? launch_cn<4, 6, 128>(Uout, F, Fc, g, s, rag, lev) : launch_cn<4, 4, 128>(Uout, F, Fc, g, s, rag, lev);
+        }
+        if (sweeps != 2) return false;
+        const int R = tb_gen_rows(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);
+        return R == 8 ? launch_cn<2, 8>(Uout, F, Fc, g, s, rag, lev) : R == 6 ? launch_cn<2, 6>(Uout, F, Fc, g, s, rag, lev) : launch_cn<2, 4>(Uout, F, Fc, g, s, rag, lev);
+    }
     if (half_io) {
         if (sweeps != 4) return false;
         const int R4 = tb_gen_rows_deep(F.W, F.H, F.C, C0_HX, 2 * sweeps + 2);

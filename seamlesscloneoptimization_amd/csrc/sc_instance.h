@@ -32,6 +32,7 @@ struct LowMode {
     DevBuf B;                              // cell-share parts left by a level-0 launch [C][band rows][cells_x][2] float4
     struct PartMap { DevBuf d, h; int H = 0, sweeps = 0; } maps[2];      // parts of each cell row (device, pinned) for the 2- and the 4-sweep tiling
     PartMap *map_used = nullptr;
+    int rag_tiling = 0;                    // a size class: which of the members' two maps the last bands buffer belongs to (0: 2 sweeps, 1: 4)
     int band_rows = 0;
     const float *bands_of = nullptr;       // the field whose parts B holds (nullptr: none); cleared whenever a solve starts or moves on
     DevBuf Sx, Sy, R, P, E, CN;            // Sx[nx][Kxp], Sy[ny][Kyp] (sines at the nodes), R[Kyp][Kxp] -- views of the current entry of `tables` --, P = cell shares float4[C][cells_y][cells_x], E = partial products of the coarse projection [parts][C][Kyp][Kxp], CN[C][ny][npitch]
@@ -75,6 +76,38 @@ struct MGLevel {
     Field U, F, T;   // correction, RHS, scratch (residual field); level 0 aliases the instance fields
     MGGeom g;        // geometry of this level and of its transfer to the next coarser one
     float omega = 1.f; // SOR factor used when this is the coarsest level
+};
+
+// ---- size classes (sc_ragged.cpp; RagMember in sc_common.h) -------------------------------------------------------------------
+// What one ROI size needs in order to share a set of launches with OTHER sizes: host arithmetic only.
+struct SizePlan {
+    int W = 0, H = 0;
+    bool ok = false;                    // the default fast path serves this size inside a class (else: same-size groups, or alone)
+    int nl = 0, tail = 0;               // levels of its hierarchy; the level k_mg_tail holds (the one below it is solved directly)
+    int npx = 0, npy = 0;               // padding of the directly solved level's operands (32 or 64 per side)
+    int Kx = 0, Ky = 0, Kxp = 0, Kyp = 0, nx = 0, ny = 0, cells_y = 0, nxt = 0, nrs = 0;     // float-table correction
+    double max_ratio = 0.0;
+    std::vector<MGGeom> g;
+    // same compile-time choices and launch shapes, and strides that waste at most ~1/8 per direction
+    bool same_class(const SizePlan &o) const
+    {
+        return ok && o.ok && tail == o.tail && npx == o.npx && npy == o.npy && Kxp == o.Kxp && Kyp == o.Kyp;      // (levels below the directly solved one are never visited: their number is free)
+    }
+};
+bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p);     // fills p; returns p.ok
+// members (any order) -> groups that can each share one set of launches: a size class (two or more DIFFERENT sizes), a same-size
+// group, or a single; `cap` = most members per group.  groups[k] lists indices into `plans`.
+void plan_groups(const std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups);
+
+struct RagState {
+    const RagMember *dev = nullptr;     // the members' table on the device WHILE a size class is being processed, else nullptr
+    std::vector<RagMember> host;        // the same table (device pointers filled in)
+    int n = 0;
+    int nl = 0, tail = 0, npx = 0, npy = 0, Kxp = 0, Kyp = 0;     // the class's constants
+    int max_nx = 0, max_ny = 0, max_nxt = 0, max_nrs = 0, max_cells_y = 0;
+    double max_ratio = 0.0;
+    DevBuf d_table, d_aux, h_stage;     // RagMember[n] | R tables, part maps, Sx, Sy, bottom operands | pinned staging of what the host writes
+    hipEvent_t ev = nullptr;            // behind the upload out of h_stage
 };
 
 struct Instance {
@@ -150,6 +183,7 @@ struct Instance {
     hipEvent_t ev_fd_fork = nullptr, ev_fd = nullptr;   // the build runs on `aux`: started behind ev_fd_fork, finished at ev_fd
     bool fd_pending = false;                            // ... and `stream` has not waited for ev_fd yet
     LowMode lm;
+    RagState rag;
     DstState dst;
     FftState fft;
     bool fft_lds_float = false, fft_lds_double = false;   // this instance's device has the FFT kernels opted in to > 64 KB of LDS (sc_fft.hip)
@@ -211,6 +245,14 @@ int lowmode_part_map_selftest();                                     // host-onl
 int lowmode_early_kind(Instance *I, float update_tol);                // see sc_lowmode.hip
 void lowmode_bands_written(Instance *I, const float *field);       // the launch went in: B describes `field` (nullptr: nothing)
 int lowmode_count(int n);
+bool lowmode_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double &max_ratio);   // the correction's ratio table (R may be nullptr: statistics only); false: singular
+bool lowmode_part_map(int H, int sweeps, std::vector<int> &m, int &band_rows);
+int lowmode_projection_splits(int nxt, int nkb);                      // row splits of the coarse projection for a ROI with nxt column tiles
+void launch_lm_tables_rag(const RagMember *rag, int members, int max_rows, int Kxp, int Kyp, hipStream_t s);
+void mg_plan_levels(int W, int H, std::vector<MGGeom> &g);           // sc_multigrid.cpp
+size_t mg_default_tail_level(const std::vector<MGGeom> &g);
+int rag_begin(Instance *I, const std::vector<SizePlan> &members);     // sc_ragged.cpp: table + tables of a size class on the device; sets I->rag.dev
+void rag_end(Instance *I);
 int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST
 int fft_solve(Instance *I, bool fp64);                                // sc_fft.hip: SC_METHOD_FFT (fp64: SC_FLAG_FFT_FP64)
 bool fft_supported(int w, int h, bool fp64);

@@ -647,6 +647,10 @@ template <bool HF, bool HU>
 __global__ __launch_bounds__(256) void k_preprocess_group(ImageJobs t, int mpitch, Field U0, Field F)
 {
     const ImageJob &j = t.j[blockIdx.z];
+    if (j.W > 0) {      // a member of a size class: its own ROI inside the class's strides; tiles beyond it have nothing to do (block-uniform)
+        if ((int)blockIdx.x * P4_TW >= j.W || (int)blockIdx.y * P4_TH >= j.H) return;
+        U0.W = F.W = j.W; U0.H = F.H = j.H;
+    }
     preprocess_block<HF, HU>(j.body_org, j.bstep, j.face_org, j.fstep, j.M, mpitch, U0, F, 3 * blockIdx.z, (int)blockIdx.y);
 }
 
@@ -799,6 +803,7 @@ __global__ __launch_bounds__(256) void k_postprocess_group(Field U, ImageJobs t,
     if (abort_set(ab)) return;
     const ImageJob &j = t.j[blockIdx.z];
     if (j.d_rect && (j.d_rect[0] != j.rx0 || j.d_rect[1] != j.rx1 || j.d_rect[2] != j.ry0 || j.d_rect[3] != j.ry1)) return;
+    if (j.W > 0) { U.W = j.W; U.H = j.H; }          // a member of a size class (the node grid's strides stay the class's)
     postprocess_block<LM>(U, j.body_org, j.bstep, 3 * blockIdx.z, lm);
 }
 
@@ -848,6 +853,7 @@ __global__ __launch_bounds__(256) void k_splice_planar_group(Field Q, ImageJobs 
     if (abort_set(ab)) return;
     const ImageJob &j = t.j[blockIdx.z];
     if (j.d_rect && (j.d_rect[0] != j.rx0 || j.d_rect[1] != j.rx1 || j.d_rect[2] != j.ry0 || j.d_rect[3] != j.ry1)) return;
+    if (j.W > 0) { Q.W = j.W; Q.H = j.H; }          // a member of a size class
     splice_block(Q, j.body_org, j.bstep, 3 * blockIdx.z);
 }
 

@@ -60,6 +60,26 @@ __global__ __launch_bounds__(256) void k_lm_table(float *__restrict__ S, int n, 
     S[id] = v;
 }
 
+// the tables of every member of a size class in one launch: blockIdx.y = 2 * member + direction (0: Sx, 1: Sy), into the member's
+// own tables (RagMember::lm_Sx / lm_Sy, row pitch Kxp / Kyp = the class's)
+__global__ __launch_bounds__(256) void k_lm_table_rag(const RagMember *__restrict__ rag, int Kxp, int Kyp)
+{
+    const RagMember &m = rag[blockIdx.y >> 1];
+    const bool ydir = (blockIdx.y & 1) != 0;
+    float *__restrict__ S = const_cast<float *>(ydir ? m.lm_Sy : m.lm_Sx);
+    const int n = (ydir ? m.H : m.W) - 2, rows = ydir ? m.lm_ny : m.lm_nx, K = ydir ? m.lm_Ky : m.lm_Kx, Kp = ydir ? Kyp : Kxp;
+    for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < (long)rows * Kp; id += (long)gridDim.x * 256) {
+        const int r = (int)(id / Kp), l = (int)(id % Kp);
+        float v = 0.f;
+        if (l < K) {
+            const long mm = 2L * (n + 1);
+            const long q = ((long)LM_HAT * r * (l + 1)) % mm;
+            v = (float)sinpi((double)q / (double)(n + 1));
+        }
+        S[id] = v;
+    }
+}
+
 // Restriction with the transpose of the bilinear interpolation: every 8 x 8 cell of the field (field rows 8Yc.., columns
 // 8Xc..) sends its hat-weighted sums to its four corner nodes: Cell[c][Yc][Xc] = (a00, a01, a10, a11) for the nodes
 // (Yc,Xc), (Yc,Xc+1), (Yc+1,Xc), (Yc+1,Xc+1).  Interior values only (ring and pads count as zero).  One pass over U:
@@ -104,10 +124,18 @@ __global__ __launch_bounds__(256) void k_lm_restrict(Field U, float4 *__restrict
 // The same cell shares from the parts the final level-0 multigrid launch left (k_cycle0, `bands`): cell row Yc receives part A of
 // the bands that start in it and part B of the bands that start in the cell row above; map[Yc][e] = 2 * band row + part, or -1,
 // in ascending order (built on the host from the launch's tiling) -- a fixed order of at most four additions.
+// rag (here and in the two kernels below): a size class -- strides (cells_x, cells_y, C, Kxp, Kyp, npitch) and grids are the class's,
+// the extents, the tables and the split of the sums are member (channel / 3)'s own, so that every sum runs in the order of its solo run
 __global__ __launch_bounds__(256) void k_lm_bands_to_cells(const float4 *__restrict__ bands, int band_rows, const int *__restrict__ map,
-                                                           float4 *__restrict__ Cell, int cells_x, int cells_y, int W)
+                                                           float4 *__restrict__ Cell, int cells_x, int cells_y, int W,
+                                                           const RagMember *__restrict__ rag, int tiling)
 {
     const int Xc = blockIdx.x * 256 + threadIdx.x, Yc = blockIdx.y, c = blockIdx.z;
+    if (rag) {
+        const RagMember &m = rag[c / 3];
+        if (Yc >= m.lm_cells_y) return;
+        map = m.lm_map[tiling]; W = m.W;
+    }
     if (Xc >= cells_x) return;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -124,7 +152,7 @@ __global__ __launch_bounds__(256) void k_lm_bands_to_cells(const float4 *__restr
 // in a fixed order).  Workgroup = 64 node columns (lane = X), the four waves split the node rows and meet in LDS.
 __global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ Cell, int cells_x, int cells_y, int nx, int ny, int C,
                                                       const float *__restrict__ SyN, int Kyp, const float *__restrict__ SxN, int Kxp,
-                                                      float *__restrict__ Upart)
+                                                      float *__restrict__ Upart, const RagMember *__restrict__ rag)
 {
     __shared__ float red[4][LM_KB][64];
     __shared__ float Tt[LM_KB][64 + 1];
@@ -133,10 +161,17 @@ __global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ 
     // blockIdx.y = row split x block of LM_KB y-modes (round 4: the blocks used to be a loop inside the workgroup -- a tall ROI,
     // 1000 x 8000, has two column tiles and 8 blocks: 24 workgroups ran 188 us)
     const int nkb = (Kyp + LM_KB - 1) / LM_KB;
-    const int xt = blockIdx.x, nxt = gridDim.x, rs = blockIdx.y / nkb, nrs = gridDim.y / nkb, c = blockIdx.z;
+    const int xt = blockIdx.x, rs = blockIdx.y / nkb, c = blockIdx.z;
+    int nxt = gridDim.x, nrs = gridDim.y / nkb;
+    const float4 *__restrict__ cell = Cell + (size_t)c * cells_y * cells_x;      // (strides: before a member's own cell-row count replaces cells_y)
+    if (rag) {
+        const RagMember &m = rag[c / 3];
+        nxt = m.lm_nxt; nrs = m.lm_nrs;
+        if (xt >= nxt || rs >= nrs) return;                     // block-uniform, before any barrier
+        nx = m.lm_nx; ny = m.lm_ny; cells_y = m.lm_cells_y; SyN = m.lm_Sy; SxN = m.lm_Sx;
+    }
     const int part = rs * nxt + xt;                              // this workgroup's partial product
     const int X = xt * 64 + lane;
-    const float4 *__restrict__ cell = Cell + (size_t)c * cells_y * cells_x;
     const int rows_per = (ny + 4 * nrs - 1) / (4 * nrs), Ya = (rs * 4 + wv) * rows_per, Yb = min(ny, Ya + rows_per);
     // clamped cell coordinates, masked values: the loads stay branch-free and all of a batch are in flight together
     const int Xc0 = min(X, cells_x - 1), Xc1 = min(max(X - 1, 0), cells_x - 1);
@@ -220,12 +255,18 @@ __global__ __launch_bounds__(256) void k_lm_parts_sum(float *__restrict__ Upart,
 __global__ __launch_bounds__(256) void k_lm_cexpand(const float *__restrict__ Upart, int nparts, int C, const float *__restrict__ R,
                                                     const float *__restrict__ SxN, int Kxp,
                                                     const float *__restrict__ SyN, int Kyp, int nx, int ny, int npitch,
-                                                    float *__restrict__ CN)
+                                                    float *__restrict__ CN, const RagMember *__restrict__ rag)
 {
     __shared__ __attribute__((aligned(16))) float Ch[LM_KB][LM_KB + 4];
     __shared__ float Es[LM_KB][64];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x;
     const int c = blockIdx.z;
+    float *__restrict__ const cn_plane = CN + (size_t)c * ny * npitch;      // (strides: the launch's ny, before a member's own replaces it)
+    if (rag) {
+        const RagMember &m = rag[c / 3];
+        if ((int)blockIdx.x >= m.lm_nxt || (int)blockIdx.y * 4 * LM_NPW >= m.lm_ny) return;      // block-uniform, before any barrier
+        nparts = m.lm_nparts; R = m.lm_R; SxN = m.lm_Sx; SyN = m.lm_Sy; nx = m.lm_nx; ny = m.lm_ny;
+    }
     const int X = blockIdx.x * 64 + lane, Xs = min(X, nx - 1);
     const int Y0 = (blockIdx.y * 4 + wv) * LM_NPW;
     float cn[LM_NPW];
@@ -288,7 +329,7 @@ __global__ __launch_bounds__(256) void k_lm_cexpand(const float *__restrict__ Up
         }
     }
     if (X >= npitch) return;
-    float *__restrict__ o = CN + (size_t)c * ny * npitch + X;
+    float *__restrict__ o = cn_plane + X;
 #pragma unroll
     for (int q = 0; q < LM_NPW; ++q)
         if (Y0 + q < ny) o[(size_t)(Y0 + q) * npitch] = (X < nx) ? cn[q] : 0.f;
@@ -312,6 +353,25 @@ __global__ __launch_bounds__(256) void k_lm_apply(Field U, Field Out, LmNodes lm
 // Returns false when the reference's arithmetic is SINGULAR for this size: beyond ~12 870 pixels in both directions
 // 2 cos(pi/(n+1)) rounds to 2.0f, the float denominator of the lowest mode is zero and the reference divides by zero
 // (its result is NaN).  There is nothing to reproduce then: the caller applies no correction (exact system).
+static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double &max_ratio);
+bool lowmode_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double &max_ratio) { return build_ratio(w, h, Kx, Ky, Kxp, R, max_ratio); }
+
+// row splits of the coarse projection: as few as fill the chip (every split is one more part for k_lm_cexpand to add: a wide ROI, 8000 x
+// 1000, has 16 column tiles and needs none), at most LM_RS (what the parts buffer holds) -- from the geometry alone, as for one clone: a
+// group member's bytes are the clone's own
+int lowmode_projection_splits(int nxt, int nkb)
+{
+    int nrs = 1;
+    while (nrs < LM_RS && nxt * nrs * nkb * 3 < 192) nrs *= 2;
+    return nrs;
+}
+
+void launch_lm_tables_rag(const RagMember *rag, int members, int max_rows, int Kxp, int Kyp, hipStream_t s)
+{
+    const unsigned gx = (unsigned)std::max<size_t>(1, ((size_t)max_rows * (size_t)std::max(Kxp, Kyp) + 255) / 256);
+    hipLaunchKernelGGL(k_lm_table_rag, dim3(gx, 2 * members), dim3(256), 0, s, rag, Kxp, Kyp);
+}
+
 static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double &max_ratio)
 {
     max_ratio = 0.0;
@@ -331,18 +391,39 @@ static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double 
     const double scale = 4.0 / ((w + 1.0) * (h + 1.0));
     for (int j = 0; j < Ky; ++j)
         for (int i = 0; i < Kxp; ++i) {
-            if (i >= Kx) { R[(size_t)j * Kxp + i] = 0.f; continue; }
+            if (i >= Kx) { if (R) R[(size_t)j * Kxp + i] = 0.f; continue; }
             const double den_e = -4.0 * (sa2[i] + sb2[j]);
             const float den_f = (fx[i] + fy[j]) - 4.0f;
-            R[(size_t)j * Kxp + i] = (den_f < 0.0f) ? (float)((den_e / (double)den_f - 1.0) * scale) : 0.0f;
+            if (R) R[(size_t)j * Kxp + i] = (den_f < 0.0f) ? (float)((den_e / (double)den_f - 1.0) * scale) : 0.0f;
             if (den_f < 0.0f) max_ratio = std::max(max_ratio, std::fabs(den_e / (double)den_f - 1.0));
         }
     return (fx[0] + fy[0]) - 4.0f < 0.0f;          // the lowest mode has the denominator closest to zero
 }
 
 // (Re)builds the tables for the fields currently bound to the instance; no-op when the geometry is unchanged.
+// A size class: the members' tables are on the device already (rag_begin, sc_ragged.cpp); what is left are the class-sized work
+// buffers.  L's geometry holds the class's strides and maxima.
+static int lm_prepare_rag(Instance *I)
+{
+    LowMode &L = I->lm;
+    const RagState &R = I->rag;
+    const int H = I->F.H, C = I->F.C, pitch = I->F.pitch;
+    const int cells_x = pitch / LM_HAT, cells_y = (H + LM_HAT - 1) / LM_HAT;
+    const int npitch = round_up(R.max_nx, 4);
+    int rc;
+    if ((rc = ensure(I, L.P, sizeof(float4) * (size_t)C * cells_y * cells_x))) return rc;
+    if ((rc = ensure(I, L.E, sizeof(float) * (size_t)R.max_nxt * LM_RS * C * R.Kyp * R.Kxp))) return rc;
+    if ((rc = ensure(I, L.CN, sizeof(float) * (size_t)C * R.max_ny * npitch))) return rc;
+    L.C = C;
+    L.w = L.h = 0;                             // (the views Sx / Sy / R are not used by a class: the next ordinary clone binds its own)
+    L.singular = false; L.max_ratio = R.max_ratio;
+    L.Kx = L.Ky = 0; L.Kxp = R.Kxp; L.Kyp = R.Kyp; L.nx = R.max_nx; L.ny = R.max_ny; L.npitch = npitch;
+    return SC_OK;
+}
+
 static int lm_prepare(Instance *I)
 {
+    if (I->rag.dev) return lm_prepare_rag(I);
     LowMode &L = I->lm;
     const int W = I->F.W, H = I->F.H, C = I->F.C, pitch = I->F.pitch;
     const int w = W - 2, h = H - 2;
@@ -460,6 +541,12 @@ float4 *lowmode_bands_buffer(Instance *I, int sweeps)
     cycle0_row_geometry(H, sweeps, nby, step, hy);
     int band_rows = nby * 8;
     if (ensure(I, L.B, sizeof(float4) * 2 * (size_t)C * band_rows * cells_x) != SC_OK) return nullptr;
+    if (I->rag.dev) {                                       // a size class: every member's two maps are in its table entry
+        if (sweeps != 2 && sweeps != 4) return nullptr;
+        L.rag_tiling = sweeps > 2;
+        L.band_rows = band_rows;
+        return (float4 *)L.B.p;
+    }
     LowMode::PartMap &M = L.maps[sweeps > 2];              // the two tilings a solve uses (2 and 4 sweeps) keep a map each
     L.map_used = &M;
     if (M.H != H || M.sweeps != sweeps || !M.d.p) {
@@ -510,19 +597,36 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on)
     if (L.singular) return SC_OK;                  // the reference's float tables divide by zero at this size: exact system
     const int cells_x = U.pitch / LM_HAT, cells_y = (U.H + LM_HAT - 1) / LM_HAT, nxt = (L.nx + 63) / 64;
     float *upart = (float *)L.E.p;
+    if (I->rag.dev) {
+        // a size class: the same three launches on the class's grid; extents, tables and the split of every sum are each member's own
+        const RagState &R = I->rag;
+        if (!(L.bands_of && L.bands_of == U.p)) { I->err = "size class: the correction needs the cell shares of the level-0 launch"; return SC_ERR_BAD_ARG; }
+        const int nkb = (R.Kyp + LM_KB - 1) / LM_KB;
+        hipLaunchKernelGGL(k_lm_bands_to_cells, dim3((cells_x + 255) / 256, cells_y, U.C), dim3(256), 0, st, (const float4 *)L.B.p,
+                           L.band_rows, (const int *)nullptr, (float4 *)L.P.p, cells_x, cells_y, U.W, R.dev, L.rag_tiling);
+        L.bands_of = nullptr;
+        hipLaunchKernelGGL(k_lm_cproject, dim3(R.max_nxt, R.max_nrs * nkb, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
+                           (const float *)nullptr, R.Kyp, (const float *)nullptr, R.Kxp, upart, R.dev);
+        hipLaunchKernelGGL(k_lm_cexpand, dim3(R.max_nxt, (R.max_ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, st, (const float *)upart,
+                           1, U.C, (const float *)nullptr, (const float *)nullptr, R.Kxp, (const float *)nullptr, R.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p, R.dev);
+        SC_HIP(I, hipGetLastError());
+        lm.CN = (const float *)L.CN.p;
+        lm.ny = L.ny;
+        lm.npitch = L.npitch;
+        return SC_OK;
+    }
     if (L.bands_of && L.bands_of == U.p) {       // the final level-0 launch left the cell shares in parts: no further pass over U
         hipLaunchKernelGGL(k_lm_bands_to_cells, dim3((cells_x + 255) / 256, cells_y, U.C), dim3(256), 0, st, (const float4 *)L.B.p,
-                           L.band_rows, (const int *)L.map_used->d.p, (float4 *)L.P.p, cells_x, cells_y, U.W);
+                           L.band_rows, (const int *)L.map_used->d.p, (float4 *)L.P.p, cells_x, cells_y, U.W, (const RagMember *)nullptr, 0);
         L.bands_of = nullptr;  // used once: whoever touches the field afterwards need not know about the parts
     } else
     hipLaunchKernelGGL(k_lm_restrict, dim3((cells_x + 63) / 64, (cells_y + 3) / 4, U.C), dim3(256), 0, st, U, (float4 *)L.P.p, cells_x, cells_y);
     // row splits of the projection: as few as fill the chip (every split is one more part for k_lm_cexpand to add: a wide ROI, 8000 x
     // 1000, has 16 column tiles and needs none), at most LM_RS (what the parts buffer holds)
     const int nkb = (L.Kyp + LM_KB - 1) / LM_KB;
-    int nrs = 1;
-    while (nrs < LM_RS && nxt * nrs * nkb * 3 < 192) nrs *= 2;      // (from the geometry alone, as for one clone: a group member's bytes are the clone's own)
+    const int nrs = lowmode_projection_splits(nxt, nkb);
     hipLaunchKernelGGL(k_lm_cproject, dim3(nxt, nrs * nkb, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
-                       (const float *)L.Sy.p, L.Kyp, (const float *)L.Sx.p, L.Kxp, upart);
+                       (const float *)L.Sy.p, L.Kyp, (const float *)L.Sx.p, L.Kxp, upart, (const RagMember *)nullptr);
     int nparts = nxt * nrs;
     if (nparts >= 32) {       // many parts (wide ROIs): one launch adds them, in the same order, instead of every expansion workgroup
         const size_t per_part = (size_t)U.C * L.Kyp * L.Kxp;
@@ -530,7 +634,7 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on)
         nparts = 1;
     }
     hipLaunchKernelGGL(k_lm_cexpand, dim3(nxt, (L.ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, st, (const float *)upart,
-                       nparts, U.C, (const float *)L.R.p, (const float *)L.Sx.p, L.Kxp, (const float *)L.Sy.p, L.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p);
+                       nparts, U.C, (const float *)L.R.p, (const float *)L.Sx.p, L.Kxp, (const float *)L.Sy.p, L.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p, (const RagMember *)nullptr);
     SC_HIP(I, hipGetLastError());
     lm.CN = (const float *)L.CN.p;
     lm.ny = L.ny;

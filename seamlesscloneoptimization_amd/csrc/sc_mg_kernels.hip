@@ -37,15 +37,15 @@ void launch_zero_multi(const ZeroJobs &z, hipStream_t s)
 // mm != nullptr: additionally the same four matrices as the operands of k_mg_bottom_mm (below), each row-major float
 // [NP][NP] with NP = 32, 64 or 96 (zero padded), in the orientation the product that uses it reads row by row:
 //     AX1[i][x] = Vx^-1[i][x]   AX2[x][i] = Vx[x][i]   AY1[j][y] = Vy^-1[j][y]   AY2[y][j] = Vy[y][j]   Dinv[j][i].
-__global__ __launch_bounds__(1024) void k_fd_build(float *__restrict__ m, int nx, int ny, int nxp, int nyp, float cwx, float dx, float cwy, float dy,
-                                                   unsigned char *__restrict__ mm, int NPX, int NPY)
+__device__ __forceinline__ void fd_build_block(float *__restrict__ m, int nx, int ny, int nxp, int nyp, float cwx, float dx, float cwy, float dy,
+                                               unsigned char *__restrict__ mm, int NPX, int NPY)
 {
     __shared__ FdPair px[128], py[128];
     const int t = threadIdx.x;
     if (t < nx) px[t] = fd_pair(t, nx, (double)cwx, (double)dx);
     if (t >= 128 && t - 128 < ny) py[t - 128] = fd_pair(t - 128, ny, (double)cwy, (double)dy);
     __syncthreads();
-    const int nxx = nxp * nxp, nyy = nyp * nyp, total = 2 * nxx + 2 * nyy + nxp * nyp;
+    const int nxx = nxp * nxp, nyy = nyp * nyp, total = m ? 2 * nxx + 2 * nyy + nxp * nyp : 0;      // m == nullptr: the matrix-core operands only
     for (int e = t; e < total; e += 1024) {
         float v = 0.f;
         if (e < nxx) {                                   // Mx1[x][i] = Vx^-1[i][x] = q_i(x) ee_x
@@ -90,6 +90,26 @@ __global__ __launch_bounds__(1024) void k_fd_build(float *__restrict__ m, int nx
             dinv[r] = (j < ny && i < nx) ? (float)(1.0 / (py[j].lam + px[i].lam)) : 0.f;
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_fd_build(float *__restrict__ m, int nx, int ny, int nxp, int nyp, float cwx, float dx, float cwy, float dy,
+                                                   unsigned char *__restrict__ mm, int NPX, int NPY)
+{
+    fd_build_block(m, nx, ny, nxp, nyp, cwx, dx, cwy, dy, mm, NPX, NPY);
+}
+
+// the same for every member of a size class in ONE launch (blockIdx.x = member): the matrix-core operands only, each member's
+// where its table entry says (RagMember::mm), from the geometry of its own level `lev` (the level solved directly)
+__global__ __launch_bounds__(1024) void k_fd_build_rag(const RagMember *__restrict__ rag, int lev, int NPX, int NPY)
+{
+    const RagMember &m = rag[blockIdx.x];
+    const MGGeom g = m.g[lev];
+    fd_build_block(nullptr, g.x.n, g.y.n, 0, 0, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last, const_cast<unsigned char *>(m.mm), NPX, NPY);
+}
+
+void launch_fd_build_rag(const RagMember *rag, int members, int lev, int NPX, int NPY, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fd_build_rag, dim3(members), dim3(1024), 0, s, rag, lev, NPX, NPY);
 }
 
 void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s, unsigned char *mm, int NPX, int NPY)
@@ -873,7 +893,7 @@ __device__ __forceinline__ void tail_residual(const float2 (&u)[16], const float
     }
 }
 
-template <int SKX, int SKY>
+template <int SKX, int SKY, bool RAG = false>
 __global__ __launch_bounds__(512) void k_mg_tail(MGTail a)
 {
     constexpr int NPX = 16 * SKX, NPY = 16 * SKY, TX = NPX / 32, TY = NPY / 32, KX = NPX / 2, KY = NPY / 2;
@@ -891,9 +911,18 @@ __global__ __launch_bounds__(512) void k_mg_tail(MGTail a)
     // measurement (sc_hip_time_tail_phases): the first thread of channel 0 leaves the shader clock at every phase boundary
 #define SC_TAIL_STAMP(K) do { if (a.stamps && threadIdx.x == 0 && c == 0) a.stamps[K] = __builtin_readcyclecounter(); } while (0)
     SC_TAIL_STAMP(0);
-    const MGGeom &g = a.g;
+    // RAG: a size class (RagMember, sc_common.h) -- this channel's member has its own level geometry, its own matrices (padded like
+    // everybody's in the class) and its own row count of the right-hand side plane; strides are the class's
+    MGGeom gl = a.g;
+    const unsigned char *mmp = a.mm;
+    int FH = a.F.H;
+    if constexpr (RAG) {
+        const RagMember &m = a.rag[c / 3];
+        gl = m.g[a.lev]; mmp = m.mm; FH = m.lh[a.lev];
+    }
+    const MGGeom &g = gl;
     const int nx = g.x.n, ny = g.y.n, ncx = g.x.nc, ncy = g.y.nc;
-    const float *ax1 = reinterpret_cast<const float *>(a.mm), *ax2 = ax1 + NPX * NPX, *ay1 = ax2 + NPX * NPX, *ay2 = ay1 + NPY * NPY;
+    const float *ax1 = reinterpret_cast<const float *>(mmp), *ax2 = ax1 + NPX * NPX, *ay1 = ax2 + NPX * NPX, *ay2 = ay1 + NPY * NPY;
     const float *dinv = ay2 + NPY * NPY;
     float b1[KX], a2[KY], a3[KY], b4[KX], dv[16];
     // ---- level A: the lane's columns and their coefficients
@@ -909,7 +938,7 @@ __global__ __launch_bounds__(512) void k_mg_tail(MGTail a)
         const float *__restrict__ fg = a.F.at(c);
         const int xc = min(x0, P - 2);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) traw[i] = *reinterpret_cast<const float2 *>(fg + (size_t)min(y0 + i, a.F.H - 1) * P + xc);
+        for (int i = 0; i < 16; ++i) traw[i] = *reinterpret_cast<const float2 *>(fg + (size_t)min(y0 + i, FH - 1) * P + xc);
     }
     asm volatile("" ::: "memory");
     if (mmw) {
@@ -1079,8 +1108,11 @@ __global__ __launch_bounds__(512) void k_mg_tail(MGTail a)
 // level A: at most 127 unknowns per side (g = its geometry, g.*.nc = level B's sizes <= 63); NPX / NPY: level B padded to 32 or 64
 bool launch_mg_tail(const MGTail &a, int NPX, int NPY, int C, hipStream_t s)
 {
-    if (a.g.x.n > 127 || a.g.y.n > 127 || a.g.x.nc > 63 || a.g.y.nc > 63 || a.g.x.nc > NPX || a.g.y.nc > NPY) return false;
-#define SC_TL(SX, SY) if (NPX == 16 * SX && NPY == 16 * SY) { hipLaunchKernelGGL((k_mg_tail<SX, SY>), dim3(C), dim3(512), 0, s, a); return true; }
+    if (a.g.x.n > 127 || a.g.y.n > 127 || a.g.x.nc > 63 || a.g.y.nc > 63 || a.g.x.nc > NPX || a.g.y.nc > NPY) return false;      // (a size class: a.g holds the class's maxima)
+#define SC_TL(SX, SY) if (NPX == 16 * SX && NPY == 16 * SY) {                                                                           \
+        if (a.rag) hipLaunchKernelGGL((k_mg_tail<SX, SY, true>), dim3(C), dim3(512), 0, s, a);                                          \
+        else hipLaunchKernelGGL((k_mg_tail<SX, SY, false>), dim3(C), dim3(512), 0, s, a);                                               \
+        return true; }
     SC_TL(2, 2) SC_TL(2, 4) SC_TL(4, 2) SC_TL(4, 4)
 #undef SC_TL
     return false;

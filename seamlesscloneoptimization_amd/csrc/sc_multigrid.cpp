@@ -324,6 +324,7 @@ static int run_tail(Instance *I, size_t l, int pre, int post, bool &done, unsign
     t.stamps = stamps;
     t.mm = (const unsigned char *)((const float *)I->mg_fd.p + I->fd_mm_off);
     t.F = I->mg[l].F; t.U = I->mg[l].U; t.g = I->mg[l].g; t.pre = pre; t.post = post;
+    t.rag = I->rag.dev; t.lev = (int)l;
     if (I->fd_pending) {
         SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0));
         I->fd_pending = false;
@@ -332,13 +333,10 @@ static int run_tail(Instance *I, size_t l, int pre, int post, bool &done, unsign
     return SC_OK;
 }
 
-static int build_levels(Instance *I)
+// The ladder of levels of a W x H field (ring included): the geometry of every level (and of its transfer to the next coarser one).
+// Host arithmetic only; the size-class planner (sc_ragged.cpp) runs it per member.
+void mg_plan_levels(int W, int H, std::vector<MGGeom> &g)
 {
-    const int W = I->F.W, H = I->F.H, C = I->F.C;
-    if (!I->mg.empty() && I->mg[0].F.p == I->F.p && I->mg[0].F.W == W && I->mg[0].F.H == H && I->mg[0].F.C == C)
-        return SC_OK;
-    I->info.new_size = 1;
-    I->mg.clear();
     struct L1 { int nx, ny; double ax, ay; };
     std::vector<L1> ls;
     ls.push_back({ W - 2, H - 2, 1.0, 1.0 });
@@ -350,18 +348,50 @@ static int build_levels(Instance *I)
         ls.push_back(c);
     }
     const size_t nl = ls.size();
+    g.resize(nl);
+    for (size_t l = 0; l < nl; ++l) {
+        const int ncx = (l + 1 < nl) ? ls[l + 1].nx : 0, ncy = (l + 1 < nl) ? ls[l + 1].ny : 0;
+        g[l].x = make_dim(ls[l].nx, ls[l].ax, ncx);
+        g[l].y = make_dim(ls[l].ny, ls[l].ay, ncy);
+    }
+}
+
+// The default hierarchy's deepest launched level (see build_levels): the first level >= 2 with at most 127 unknowns per side, held in
+// registers by k_mg_tail with the level below it solved directly in the same launch; 0: this ladder ends differently (its level 1
+// already fits the matrix-core solve, or no such level exists)
+size_t mg_default_tail_level(const std::vector<MGGeom> &g)
+{
+    const size_t nl = g.size();
+    size_t a = 0;
+    for (size_t l = 2; l + 1 < nl && !a; ++l)
+        if (g[l].x.n <= 127 && g[l].y.n <= 127) a = l;
+    const bool level1_direct = nl > 1 && g[1].x.n <= 96 && g[1].y.n <= 96;
+    return (a && !(a == 2 && level1_direct)) ? a : 0;
+}
+
+static int build_levels_rag(Instance *I);
+
+static int build_levels(Instance *I)
+{
+    if (I->rag.dev) return build_levels_rag(I);
+    const int W = I->F.W, H = I->F.H, C = I->F.C;
+    if (!I->mg.empty() && I->mg[0].F.p == I->F.p && I->mg[0].F.W == W && I->mg[0].F.H == H && I->mg[0].F.C == C)
+        return SC_OK;
+    I->info.new_size = 1;
+    I->mg.clear();
+    std::vector<MGGeom> plan;
+    mg_plan_levels(W, H, plan);
+    const size_t nl = plan.size();
     if (I->mg_bufs.size() < 3 * nl) I->mg_bufs.resize(3 * nl);
     I->mg.resize(nl);
     ZeroJobs zj{};
     for (size_t l = 0; l < nl; ++l) {
         MGLevel &L = I->mg[l];
-        const int ncx = (l + 1 < nl) ? ls[l + 1].nx : 0, ncy = (l + 1 < nl) ? ls[l + 1].ny : 0;
-        L.g.x = make_dim(ls[l].nx, ls[l].ax, ncx);
-        L.g.y = make_dim(ls[l].ny, ls[l].ay, ncy);
-        const double rho = 0.5 * (std::cos(M_PI / (ls[l].nx + 1.0)) + std::cos(M_PI / (ls[l].ny + 1.0)));
+        L.g = plan[l];
+        const double rho = 0.5 * (std::cos(M_PI / (L.g.x.n + 1.0)) + std::cos(M_PI / (L.g.y.n + 1.0)));
         L.omega = (float)(2.0 / (1.0 + std::sqrt(std::max(0.0, 1.0 - rho * rho))));
         if (l == 0) continue; // level 0 aliases the instance fields, bound per cycle
-        const int Wl = ls[l].nx + 2, Hl = ls[l].ny + 2;
+        const int Wl = L.g.x.n + 2, Hl = L.g.y.n + 2;
         Field proto = level_field(nullptr, Wl, Hl, C);
         for (int k = 0; k < 3; ++k) {
             int rc = ensure(I, I->mg_bufs[3 * l + k], proto.bytes() + 4096);
@@ -389,17 +419,70 @@ static int build_levels(Instance *I)
     // k_mg_bottom instead) a cycle cost 60 us more than at the sizes next to it (0.55 against 0.38 ms for one clone).  Kept: a ROI
     // whose level 1 already fits the matrix-core solve (<= 96 per side: solved there), the flags that ask for the older bottoms.
     if (!(I->opts.flags & SC_FLAG_VCYCLE_BOTTOM) && !legacy_path(I->opts, SC_LEGACY_BOTTOM_F32) && I->opts.mg_direct_max <= 0) {
-        size_t a = 0;
-        for (size_t l = 2; l + 1 < nl && !a; ++l)
-            if (I->mg[l].g.x.n <= 127 && I->mg[l].g.y.n <= 127) a = l;
+        const size_t a = mg_default_tail_level(plan);
         const bool level1_direct = nl > 1 && I->mg[1].g.x.n <= 96 && I->mg[1].g.y.n <= 96;
-        if (a && !(a == 2 && level1_direct)) I->mg_bottom = a + 1;
+        if (a) I->mg_bottom = a + 1;
         else if (!level1_direct)
             for (size_t l = 1; l < nl; ++l)
                 if (I->mg[l].g.x.n <= 96 && I->mg[l].g.y.n <= 96) { I->mg_bottom = l; break; }
     }
     I->mg_l1_half = false;        // fresh planes: all zero in either format
     return build_fd(I);
+}
+
+// The hierarchy of a SIZE CLASS (RagState, sc_instance.h): level planes at the class's strides -- the largest width and height any
+// member has on that level --, every plane zeroed (a member's ring and what lies beyond it must be zero, and the slot may have held a
+// larger member a call ago), the members' bottom matrices by one launch on the second stream.  The per-member geometries are in the
+// table on the device; I->mg[l].g holds the class's MAXIMA (grid sizes and the launchers' shape tests read those).
+static int build_levels_rag(Instance *I)
+{
+    RagState &R = I->rag;
+    const int C = I->F.C, n = R.n;
+    const size_t nl = (size_t)R.nl;
+    I->info.new_size = 1;
+    I->mg.clear();
+    if (I->mg_bufs.size() < 3 * nl) I->mg_bufs.resize(3 * nl);
+    I->mg.resize(nl);
+    ZeroJobs zj{};
+    for (size_t l = 0; l < nl; ++l) {
+        MGLevel &L = I->mg[l];
+        L.g = R.host[0].g[l];
+        for (int i = 1; i < n; ++i) {
+            const MGGeom &g = R.host[i].g[l];
+            L.g.x.n = std::max(L.g.x.n, g.x.n); L.g.x.nc = std::max(L.g.x.nc, g.x.nc);
+            L.g.y.n = std::max(L.g.y.n, g.y.n); L.g.y.nc = std::max(L.g.y.nc, g.y.nc);
+        }
+        L.omega = 1.f;
+        if (l == 0) continue;
+        const int Wl = L.g.x.n + 2, Hl = L.g.y.n + 2;
+        Field proto = level_field(nullptr, Wl, Hl, C);
+        for (int k = 0; k < 3; ++k) {
+            int rc = ensure(I, I->mg_bufs[3 * l + k], proto.bytes() + 4096);
+            if (rc) return rc;
+        }
+        L.U = level_field(I->mg_bufs[3 * l + 0].p, Wl, Hl, C);
+        L.F = level_field(I->mg_bufs[3 * l + 1].p, Wl, Hl, C);
+        L.T = level_field(I->mg_bufs[3 * l + 2].p, Wl, Hl, C);
+        for (const Field *f : { &L.U, &L.F, &L.T }) {
+            if (zj.count == ZeroJobs::MAX) { launch_zero_multi(zj, I->stream); zj.count = 0; }
+            zj.p[zj.count] = f->p; zj.n16[zj.count] = (f->bytes() + 15) / 16; ++zj.count;
+        }
+    }
+    launch_zero_multi(zj, I->stream);
+    SC_HIP(I, hipGetLastError());
+    I->mg[0].F = I->F;
+    I->mg_bottom = (size_t)R.tail + 1;
+    I->mg_l1_half = false;
+    // the class's bottom: every member's level below `tail` solved directly on the matrix cores inside k_mg_tail, operands padded alike
+    I->fd_level = 0; I->fd_mm = true; I->fd_npx = R.npx; I->fd_npy = R.npy; I->fd_nxp = I->fd_nyp = 0; I->fd_mm_off = 0;
+    if (I->fd_pending) { SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0)); I->fd_pending = false; }
+    SC_HIP(I, hipEventRecord(I->ev_fd_fork, I->stream));          // behind the table's upload and everything that read the previous matrices
+    SC_HIP(I, hipStreamWaitEvent(I->aux, I->ev_fd_fork, 0));
+    launch_fd_build_rag(R.dev, n, R.tail + 1, R.npx, R.npy, I->aux);
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipEventRecord(I->ev_fd, I->aux));
+    I->fd_pending = true;
+    return SC_OK;
 }
 
 // Smoothing of a coarse level (l >= 1) with the fused general kernel; U <-> T ping-pong, both
@@ -411,7 +494,10 @@ static int smooth_gen(Instance *I, size_t l, int n, int mode, Field E)
     int left = n;
     while (left > 0) {
         const int T = std::min(2, left);
-        if (!launch_rb_tb_gen(L.U, L.T, L.F, T, L.g, mode, E, I->stream)) break;
+        if (!launch_rb_tb_gen(L.U, L.T, L.F, T, L.g, mode, E, I->stream, I->rag.dev, (int)l)) {
+            if (I->rag.dev) { I->err = "size class: coarse-level form not instantiated"; return SC_ERR_BAD_ARG; }
+            break;
+        }
         std::swap(L.U, L.T);
         mode = TBM_PLAIN;
         left -= T;
@@ -437,6 +523,7 @@ static int vcycle(Instance *I, size_t l, int pre, int post, unsigned no_post = 0
     if (!skip_post && tail_serves(I, l)) {
         bool done = false;
         if ((rc = run_tail(I, l, pre, post, done)) || done) return rc;
+        if (I->rag.dev) { I->err = "size class: the bottom launch does not serve this shape"; return SC_ERR_BAD_ARG; }
     }
     if (l + 1 == I->mg.size()) { // coarsest level outside the bottom kernel: SOR with its optimal factor
         const int n = std::max(8, std::min(64, 2 * std::max(L.g.x.n, L.g.y.n)));
@@ -460,9 +547,11 @@ static int vcycle(Instance *I, size_t l, int pre, int post, unsigned no_post = 0
     if (l == 0) {
         if ((rc = run_sweeps(I, SC_METHOD_RBGS, pre_here, 1.0f, I->opts.sweeps_per_launch))) return rc;
     } else if (pre_here > 0 && I->opts.sweeps_per_launch != 1 &&
-               launch_cycle_coarse(L.T, L.F, Lc.F, L.g, pre_here, I->stream, l == 1 && skip_post && mg_level1_half(I))) {
+               launch_cycle_coarse(L.T, L.F, Lc.F, L.g, pre_here, I->stream, l == 1 && skip_post && mg_level1_half(I), I->rag.dev, (int)l)) {
         std::swap(L.U, L.T);      // one launch did all three
         restricted = true;
+    } else if (I->rag.dev) {
+        I->err = "size class: coarse-level form not instantiated"; return SC_ERR_BAD_ARG;
     } else if (pre_here > 0) {
         if ((rc = smooth_gen(I, l, pre_here, TBM_ZEROIN, Field{}))) return rc;
     } else {
@@ -599,7 +688,7 @@ int mg_solve(Instance *I)
         I->sat = sat;
         // on the float16 path the pre-process stored the initial field as float16 as well (first launch only)
         if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
-                          I->stream, false, I->f_half, I->u_half, false, nullptr, l1h, q16, sat) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
+                          I->stream, false, I->f_half, I->u_half, false, nullptr, l1h, q16, sat, I->rag.dev) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
         I->result_in_U1 = !I->result_in_U1;
         I->u_half = false;             // consumed: both U buffers hold float (or 16-bit fixed point: u_q16) from here on
         I->u_q16 = I->mg_q16_last = q16;
@@ -680,7 +769,7 @@ int mg_solve(Instance *I)
                     I->aux_pending = false;
                 }
                 const int nbo = launch_cycle0_out(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g, part_now,
-                                                  I->stream, I->f_half, comp1, comp1 ? I->mg[2].U : Field(), comp1 ? I->mg[1].g : MGGeom(), early_lm, l1h);
+                                                  I->stream, I->f_half, comp1, comp1 ? I->mg[2].U : Field(), comp1 ? I->mg[1].g : MGGeom(), early_lm, l1h, I->rag.dev);
                 early_ready = false;
                 if (nbo > 0) {
                     I->info.sweep_launches += 1;
@@ -704,7 +793,7 @@ int mg_solve(Instance *I)
             const int nb = comp1
                 ? launch_cycle0_composed(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U, I->mg[0].g,
                                          judged ? post : post + pre, part_now, I->stream, false, I->f_half, judged,
-                                         I->mg[2].U, I->mg[1].g, bands, l1h, I->u_q16 ? (next_judged ? 1 : 3) : 0, sat)
+                                         I->mg[2].U, I->mg[1].g, bands, l1h, I->u_q16 ? (next_judged ? 1 : 3) : 0, sat, I->rag.dev)
                 : launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, I->mg[1].U,
                                 I->mg[0].g, judged ? post : post + pre, true, part_now, I->stream,
                                 false, I->f_half, false, judged, bands);
@@ -765,7 +854,7 @@ int mg_solve(Instance *I)
             I->spec_post.done = false;     // not converged: the field moves on, the output is written again later
             if (cyc < budget) {            // catch up: pre-smoothing + residual + restriction for the next cycle
                 if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false,
-                                  nullptr, I->stream, false, I->f_half, false, false, nullptr, l1h) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
+                                  nullptr, I->stream, false, I->f_half, false, false, nullptr, l1h, false, AbortFlag(), I->rag.dev) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
                 I->result_in_U1 = !I->result_in_U1;
                 lowmode_bands_written(I, nullptr);
                 I->info.sweep_launches += 1;

@@ -29,8 +29,8 @@ struct Pool {
     sc_batch_job *jobs = nullptr;
     int njobs = 0, device_resident = 0;
     int group = 1;                 // device-resident jobs a worker takes at a time (sc_hip_run_device_batch)
-    // group > 1: the batch's jobs ordered by predicted ROI size (`sorted`: a copy, `origin[k]` = its index in the caller's array) and
-    // cut into chunks of at most `group` members; `next` counts chunks then, jobs otherwise
+    // group > 1: the batch's jobs gathered into groups that can share launches (`sorted`: a copy in group order, `origin[k]` = its index
+    // in the caller's array), one chunk of at most `group` members each; `next` counts chunks then, jobs otherwise
     std::vector<sc_batch_job> sorted;
     std::vector<int> origin;
     std::vector<std::pair<int, int>> chunks;       // first member, members
@@ -191,31 +191,26 @@ int sc_hip_pool_run(void *p, sc_batch_job *jobs, int n, int device_resident)
         P->jobs = jobs; P->njobs = n; P->device_resident = device_resident;
         P->chunks.clear();
         if (device_resident && P->group > 1) {
-            // Bucket the jobs by the ROI size they will most likely have -- the interior of their mask, which is what a clone is
-            // launched on before the device's bounding box is back -- so that the members a worker takes together can share one set
-            // of launches (sc_hip_run_device_batch partitions what it is given by ROI size).  Round 4 took CONSECUTIVE jobs: one odd
-            // size in the caller's order demoted its whole group to one clone at a time.  Stable: equal sizes keep the caller's order.
-            P->origin.resize(n);
-            for (int i = 0; i < n; ++i) P->origin[i] = i;
-            std::stable_sort(P->origin.begin(), P->origin.end(), [&](int a, int b) {
-                if (jobs[a].mask_cols != jobs[b].mask_cols) return jobs[a].mask_cols < jobs[b].mask_cols;
-                return jobs[a].mask_rows < jobs[b].mask_rows;
+            // Form the groups a worker takes at a time from the ROI size every job will most likely have -- the interior of its mask,
+            // which is what a clone is launched on before the device's bounding box is back: same-size jobs and jobs of one size class
+            // (sc_ragged.cpp: different sizes, the same solve) share one set of launches inside sc_hip_run_device_batch.  Round 4 took
+            // CONSECUTIVE jobs and ran a group with one odd size one clone at a time.  Largest groups first: the stragglers at the end
+            // of a batch are the cheap ones.
+            sc_solver_opts o;
+            sc_hip_get_solver(P->inst[0], &o);
+            std::vector<SizePlan> plans(n);
+            for (int i = 0; i < n; ++i) plan_size(o, jobs[i].mask_cols - 2, jobs[i].mask_rows - 2, plans[i]);
+            std::vector<std::vector<int>> groups;
+            plan_groups(plans, P->group, groups);
+            std::stable_sort(groups.begin(), groups.end(), [&](const std::vector<int> &x, const std::vector<int> &y) {
+                auto px = [&](const std::vector<int> &g) { long t = 0; for (int i : g) t += (long)plans[i].W * plans[i].H; return t; };
+                return px(x) > px(y);
             });
-            P->sorted.resize(n);
-            for (int i = 0; i < n; ++i) P->sorted[i] = jobs[P->origin[i]];
-            // chunks of at most `group` members; a run of equal sizes is not cut in two by a chunk boundary that a shorter
-            // chunk in front of it avoids (sizes 3 x A then 16 x B with group 16: chunks of 3 and 16, not 16 and 3)
-            auto same = [&](int a, int b) { return P->sorted[a].mask_cols == P->sorted[b].mask_cols && P->sorted[a].mask_rows == P->sorted[b].mask_rows; };
-            int first = 0;
-            while (first < n) {
-                int end = std::min(n, first + P->group);
-                if (end < n && same(end - 1, end)) {          // the boundary would split a run of equal sizes
-                    int run0 = end - 1;
-                    while (run0 > first && same(run0 - 1, run0)) --run0;
-                    if (run0 > first) end = run0;              // ... end the chunk where that run starts (unless the run fills the chunk)
-                }
-                P->chunks.emplace_back(first, end - first);
-                first = end;
+            P->origin.clear();
+            P->sorted.clear();
+            for (const auto &g : groups) {
+                P->chunks.emplace_back((int)P->sorted.size(), (int)g.size());
+                for (int i : g) { P->origin.push_back(i); P->sorted.push_back(jobs[i]); }
             }
         }
         P->next.store(0);

@@ -1,0 +1,184 @@
+// sc_ragged.cpp -- size classes: clones of DIFFERENT ROI sizes through one set of solver launches (round 5).
+//
+// The reference has no batch mode at all (one clone per call, seamlessClone_imp.cu:239-263); its use case -- a mask box per face,
+// per frame -- produces batches in which no two ROIs have the same size.  sc_hip_run_device_batch (sc_api.cpp) solves n same-size
+// clones as one field of 3n channels; a SIZE CLASS extends that to members whose sizes differ but whose solves are the same
+// program: the same hierarchy depth, the same level held by k_mg_tail with the level below it solved directly at the same operand
+// padding, the same mode-block counts of the float-table correction.  Such members share strides (the class's largest width and
+// height on every level) and launch grids; everything else is per member, read by the kernels from a table (RagMember,
+// sc_common.h).  This file is the host side of that table: the planner (what a size needs, which sizes go together) and the
+// per-call setup (tables on the device).  Host arithmetic and copies only; the kernels are where they always were.
+#include "sc_instance.h"
+#include <algorithm>
+#include <cstring>
+
+namespace sc {
+
+// ROI sizes of one class may differ by this factor per direction at most (strides are the largest member's: what a smaller
+// member leaves unused of its planes is never touched, but the grids are sized for the largest)
+static constexpr double RAG_SPREAD = 1.125;
+
+bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p)
+{
+    p = SizePlan();
+    p.W = W; p.H = H;
+    // --- the solve configured in `o` is the default fast path: float16 right-hand side and level 1, composed level-1 schedule,
+    //     output bytes from the judged cycle (sc_multigrid.cpp: mg_reads_half_rhs, mg_level1_half, mg_composes_level1)
+    const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
+    const int blocked = SC_FLAG_FLOAT_RHS | SC_FLAG_FLOAT_U0 | SC_FLAG_NO_COMPOSE_L1 | SC_FLAG_VCYCLE_BOTTOM | SC_FLAG_EXACT_TABLES |
+                        SC_FLAG_LEGACY_PATHS | SC_FLAG_KEEP_FIELD | SC_FLAG_OPENCV_GREY_MASK | SC_FLAG_FLOAT_L1;
+    if ((o.method != SC_METHOD_AUTO && o.method != SC_METHOD_MULTIGRID) || o.tol > 0.f || (o.flags & blocked) || pre != 2 || post != 2 ||
+        o.sweeps_per_launch != 0 || o.reference_warmup || o.mg_direct_max != 0 || (o.mg_level1_sweeps != 0 && o.mg_level1_sweeps != 4) ||
+        (o.max_sweeps > 0 && o.max_sweeps < 3))
+        return false;
+    if (std::min(W, H) - 2 <= 3) return false;
+    // --- its hierarchy ends the default way: a level of at most 127 unknowns per side in k_mg_tail, the one below it solved there
+    mg_plan_levels(W, H, p.g);
+    p.nl = (int)p.g.size();
+    const size_t a = mg_default_tail_level(p.g);
+    if (!a || (int)a + 2 > RAG_MAX_LEVELS || p.nl < (int)a + 2) return false;
+    p.tail = (int)a;
+    const MGGeom &A = p.g[a];
+    if (A.x.n > 127 || A.y.n > 127 || A.x.nc > 63 || A.y.nc > 63 || A.x.nc < 1 || A.y.nc < 1) return false;
+    p.npx = round_up(A.x.nc, 32); p.npy = round_up(A.y.nc, 32);
+    // --- its float-table correction: regular tables, the node correction of the iterate one cycle earlier admissible a priori
+    //     (lowmode_early_kind 1), few enough parts for the expansion to add them itself
+    const int w = W - 2, h = H - 2;
+    p.Kx = lowmode_count(w); p.Ky = lowmode_count(h);
+    p.Kxp = round_up(p.Kx, 32); p.Kyp = round_up(p.Ky, 32);
+    p.nx = (w >> 3) + 2; p.ny = (h >> 3) + 2;
+    p.cells_y = (H + 7) / 8;
+    p.nxt = (p.nx + 63) / 64;
+    p.nrs = lowmode_projection_splits(p.nxt, (p.Kyp + 31) / 32);
+    if (p.nxt * p.nrs >= 32) return false;
+    const bool regular = lowmode_ratio(w, h, p.Kx, p.Ky, p.Kxp, nullptr, p.max_ratio);
+    const float utol = o.update_tol > 0.f ? o.update_tol : 0.25f;
+    if (!regular || !(p.max_ratio * 4.9 * (double)utol <= 0.049)) return false;
+    std::vector<int> m;
+    int br = 0;
+    if (!lowmode_part_map(H, 2, m, br) || !lowmode_part_map(H, 4, m, br)) return false;
+    p.ok = true;
+    return true;
+}
+
+// Greedy, order preserving: a member joins the first open group it fits -- the same size as the group's members, or the same class
+// with the group's spread staying within RAG_SPREAD -- else it opens a new one.
+void plan_groups(const std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups)
+{
+    struct Open { int first; int minW, maxW, minH, maxH; bool uniform; };
+    std::vector<Open> open;
+    groups.clear();
+    for (int i = 0; i < (int)plans.size(); ++i) {
+        const SizePlan &p = plans[i];
+        int into = -1;
+        for (int k = 0; k < (int)open.size() && into < 0; ++k) {
+            if ((int)groups[k].size() >= cap) continue;
+            const Open &g = open[k];
+            const SizePlan &q = plans[g.first];
+            if (g.uniform && q.W == p.W && q.H == p.H) { into = k; break; }
+            if (!p.same_class(q)) continue;
+            const int minW = std::min(g.minW, p.W), maxW = std::max(g.maxW, p.W), minH = std::min(g.minH, p.H), maxH = std::max(g.maxH, p.H);
+            if ((double)maxW <= RAG_SPREAD * minW && (double)maxH <= RAG_SPREAD * minH) into = k;
+        }
+        if (into < 0) {
+            open.push_back({ i, p.W, p.W, p.H, p.H, true });
+            groups.push_back(std::vector<int>(1, i));
+            continue;
+        }
+        Open &g = open[into];
+        if (plans[g.first].W != p.W || plans[g.first].H != p.H) g.uniform = false;
+        g.minW = std::min(g.minW, p.W); g.maxW = std::max(g.maxW, p.W); g.minH = std::min(g.minH, p.H); g.maxH = std::max(g.maxH, p.H);
+        groups[into].push_back(i);
+    }
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// The members' table and everything it points to, on the device, behind whatever the instance's stream still has to do:
+//   h_stage (pinned) = RagMember[n] | R tables | part maps   -> one upload into d_table / d_aux
+//   d_aux            = R tables | part maps | Sx | Sy tables (built by one launch here) | bottom operands (built by build_levels_rag)
+// Sets I->rag.dev; the caller has bound the class's fields (setup_fields) before.
+int rag_begin(Instance *I, const std::vector<SizePlan> &members)
+{
+    RagState &R = I->rag;
+    const int n = (int)members.size();
+    R.dev = nullptr;
+    if (n < 1) return SC_ERR_BAD_ARG;
+    const SizePlan &p0 = members[0];
+    R.n = n; R.nl = p0.tail + 2; R.tail = p0.tail;      // levels 0 .. tail + 1: the one solved directly is the last one anybody visits
+    R.npx = p0.npx; R.npy = p0.npy; R.Kxp = p0.Kxp; R.Kyp = p0.Kyp;
+    R.max_nx = R.max_ny = R.max_nxt = R.max_nrs = R.max_cells_y = 0;
+    R.max_ratio = 0.0;
+    for (const SizePlan &p : members) {
+        if (!p.same_class(p0)) { I->err = "size class: members of different classes"; return SC_ERR_BAD_ARG; }
+        R.max_nx = std::max(R.max_nx, p.nx); R.max_ny = std::max(R.max_ny, p.ny);
+        R.max_nxt = std::max(R.max_nxt, p.nxt); R.max_nrs = std::max(R.max_nrs, p.nrs);
+        R.max_cells_y = std::max(R.max_cells_y, p.cells_y);
+        R.max_ratio = std::max(R.max_ratio, p.max_ratio);
+    }
+    // --- layout of d_aux (per member, 256-byte aligned pieces)
+    const size_t bR = align_up(sizeof(float) * (size_t)R.Kyp * R.Kxp, 256), bMap = align_up(sizeof(int) * 4 * (size_t)R.max_cells_y, 256);
+    const size_t bSx = align_up(sizeof(float) * (size_t)R.max_nx * R.Kxp, 256), bSy = align_up(sizeof(float) * (size_t)R.max_ny * R.Kyp, 256);
+    const size_t bMM = align_up((size_t)fd_mm_bytes(R.npx, R.npy), 256);
+    const size_t host_part = (bR + 2 * bMap) * n;                      // what the host writes: uploaded together with the table
+    const size_t aux_bytes = host_part + (bSx + bSy + bMM) * n;
+    const size_t table_bytes = align_up(sizeof(RagMember) * (size_t)n, 256);
+    int rc;
+    if ((rc = ensure(I, R.d_table, table_bytes))) return rc;
+    if ((rc = ensure(I, R.d_aux, aux_bytes))) return rc;
+    if (!R.ev) SC_HIP(I, hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
+    else SC_HIP(I, hipEventSynchronize(R.ev));                        // the previous upload out of the staging: long complete
+    if ((rc = ensure_pinned(I, R.h_stage, table_bytes + host_part))) return rc;
+    uint8_t *const hs = (uint8_t *)R.h_stage.p, *const da = (uint8_t *)R.d_aux.p;
+    uint8_t *const h_host = hs + table_bytes;                          // staging of d_aux's host-written part
+    R.host.assign(n, RagMember());
+    for (int i = 0; i < n; ++i) {
+        const SizePlan &p = members[i];
+        RagMember &m = R.host[i];
+        std::memset(&m, 0, sizeof(m));
+        m.W = p.W; m.H = p.H;
+        for (int l = 0; l < R.nl; ++l) { m.g[l] = p.g[l]; m.lw[l] = p.g[l].x.n + 2; m.lh[l] = p.g[l].y.n + 2; }
+        for (int l = R.nl; l < RAG_MAX_LEVELS; ++l) { m.lw[l] = 3; m.lh[l] = 3; }
+        m.lm_nx = p.nx; m.lm_ny = p.ny; m.lm_cells_y = p.cells_y; m.lm_nxt = p.nxt; m.lm_nrs = p.nrs; m.lm_nparts = p.nxt * p.nrs;
+        m.lm_Kx = p.Kx; m.lm_Ky = p.Ky;
+        const size_t oR = (bR + 2 * bMap) * i, oMap0 = oR + bR, oMap1 = oMap0 + bMap;
+        m.lm_R = (const float *)(da + oR);
+        m.lm_map[0] = (const int *)(da + oMap0); m.lm_map[1] = (const int *)(da + oMap1);
+        m.lm_Sx = (const float *)(da + host_part + (bSx + bSy + bMM) * i);
+        m.lm_Sy = (const float *)(da + host_part + (bSx + bSy + bMM) * i + bSx);
+        m.mm = da + host_part + (bSx + bSy + bMM) * i + bSx + bSy;
+        // the host-built pieces: the ratio table with the reference's float expressions (libm, as the CPU oracle's), the part maps
+        double mr;
+        std::memset(h_host + oR, 0, bR);
+        lowmode_ratio(p.W - 2, p.H - 2, p.Kx, p.Ky, p.Kxp, (float *)(h_host + oR), mr);
+        std::vector<int> map;
+        int br = 0;
+        for (int t = 0; t < 2; ++t) {
+            int *dst = (int *)(h_host + (t ? oMap1 : oMap0));
+            for (size_t k = 0; k < bMap / sizeof(int); ++k) dst[k] = -1;
+            if (!lowmode_part_map(p.H, t ? 4 : 2, map, br)) { I->err = "size class: more than four parts per cell row"; return SC_ERR_BAD_ARG; }
+            std::memcpy(dst, map.data(), sizeof(int) * map.size());
+        }
+    }
+    std::memcpy(hs, R.host.data(), sizeof(RagMember) * (size_t)n);
+    SC_HIP(I, hipMemcpyAsync(R.d_table.p, hs, table_bytes, hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipMemcpyAsync(da, h_host, host_part, hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipEventRecord(R.ev, I->stream));
+    launch_lm_tables_rag((const RagMember *)R.d_table.p, n, std::max(R.max_nx, R.max_ny), R.Kxp, R.Kyp, I->stream);
+    SC_HIP(I, hipGetLastError());
+    R.dev = (const RagMember *)R.d_table.p;
+    I->info.new_size = 1;
+    return SC_OK;
+}
+
+// the class is done (or failed): the next solve on this instance is an ordinary one and builds its own hierarchy and tables
+void rag_end(Instance *I)
+{
+    if (!I->rag.dev) return;
+    I->rag.dev = nullptr;
+    I->mg.clear();
+    I->lm.w = I->lm.h = 0;
+    field_moved(I);
+}
+
+} // namespace sc

@@ -45,21 +45,33 @@ __device__ __forceinline__ void tb_load(const float *__restrict__ p, int P, int 
 // TB_ZEROIN treats Uin as all-zero without reading it (first smoothing of a coarse correction).
 constexpr int TB_PROLONG = 1, TB_MAXC = 2, TB_ZEROIN = 4;
 constexpr int TB_TAG = 8;   // no effect on the code: a second symbol for the isolated roofline launches (see k_jacobi)
+constexpr int TB_RAG = 16;  // the launch serves a size class (RagMember, sc_common.h): level `lev` of every member's own hierarchy
 
 template <int T, int NW, int R, bool SOR, bool GEN, int FLAGS, int HXQ = 1>
 __global__ __launch_bounds__(NW * 64) void k_rb_tb(Field Uin, Field Uout, Field F, float omega, MGGeom g, Field E,
-                                                   float *__restrict__ partial)
+                                                   float *__restrict__ partial, const RagMember *__restrict__ rag, int lev)
 {
     constexpr int HY = 2 * T, RH = NW * R, HX = 4 * HXQ;   // HXQ halo lanes per side: 4 columns each
     static_assert(2 * T <= HX, "column halo too small for this depth");
     __shared__ float4 edge[2][NW][2][64];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR: row tests become scalar
-    const int W = Uin.W, H = Uin.H, P = Uin.pitch;
+    int W = Uin.W, H = Uin.H;
+    const int P = Uin.pitch;
     // 1-D launch; neighbouring tiles are given to the same XCD so that they share its L2 (sc_wave.h)
     const int nbx = (W + (256 - 2 * HX) - 1) / (256 - 2 * HX), nby = (H + (RH - 2 * HY) - 1) / (RH - 2 * HY);
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int bx = tile % nbx, by = (tile / nbx) % nby, c = tile / (nbx * nby);
+    if constexpr ((FLAGS & TB_RAG) != 0) {      // the member's own level inside the class's strides; tiles beyond it leave (block-uniform, before any barrier)
+        const RagMember &m = rag[c / 3];
+        W = m.lw[lev]; H = m.lh[lev];
+        if (bx * (256 - 2 * HX) >= W || by * (RH - 2 * HY) >= H) {
+            if ((FLAGS & TB_MAXC) && threadIdx.x == 0) partial[tile] = 0.f;
+            return;
+        }
+        g = m.g[lev];
+        if (FLAGS & TB_PROLONG) E.H = m.lh[lev + 1];
+    }
     const int x = bx * (256 - 2 * HX) - HX + 4 * lane;
     const int ry = by * (RH - 2 * HY) - HY;
     const int y0 = ry + wv * R;
@@ -245,12 +257,13 @@ __global__ __launch_bounds__(NW * 64) void k_jacobi_tb(Field Uin, Field Uout, Fi
 constexpr int TB_NW = 8, TB_R = 8;
 
 template <int T, int NW, bool SOR, bool GEN, int FLAGS, int R = TB_R>
-static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom &g, Field E, float *partial, hipStream_t s)
+static int launch_rb_t(Field Uin, Field Uout, Field F, float omega, const MGGeom &g, Field E, float *partial, hipStream_t s,
+                       const RagMember *rag = nullptr, int lev = 0)
 {
     constexpr int HXQ = 2 * T <= 4 ? 1 : 2, HX = 4 * HXQ;
     constexpr int RH = NW * R, HY = 2 * T;
     const int blocks = ((Uin.W + (256 - 2 * HX) - 1) / (256 - 2 * HX)) * ((Uin.H + (RH - 2 * HY) - 1) / (RH - 2 * HY)) * Uin.C;
-    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS, HXQ>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial);
+    hipLaunchKernelGGL((k_rb_tb<T, NW, R, SOR, GEN, FLAGS, HXQ>), dim3(blocks), dim3(NW * 64), 0, s, Uin, Uout, F, omega, g, E, partial, rag, lev);
     return blocks;
 }
 
@@ -332,10 +345,17 @@ int tb_gen_rows_deep(int W, int H, int C, int hx, int hy)
 }
 
 // coarse multigrid levels: Gauss-Seidel only (omega = 1).  mode: 0 plain, TB_ZEROIN, TB_PROLONG (with E).
-bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s)
+bool launch_rb_tb_gen(Field Uin, Field Uout, Field F, int sweeps, const MGGeom &g, int mode, Field E, hipStream_t s, const RagMember *rag, int lev)
 {
     if (sweeps != 1 && sweeps != 2) return false;
     const int R = tb_gen_rows(Uin.W, Uin.H, Uin.C, TB_HX, 2 * sweeps);
+    if (rag) {          // a size class: the post-smoothing form of the default schedule (two sweeps behind the prolongation)
+        if (sweeps != 2 || mode != TB_PROLONG) return false;
+        R == 8 ? launch_rb_t<2, 8, false, true, TB_PROLONG | TB_RAG, 8>(Uin, Uout, F, 1.0f, g, E, nullptr, s, rag, lev)
+      : R == 6 ? launch_rb_t<2, 8, false, true, TB_PROLONG | TB_RAG, 6>(Uin, Uout, F, 1.0f, g, E, nullptr, s, rag, lev)
+               : launch_rb_t<2, 8, false, true, TB_PROLONG | TB_RAG, 4>(Uin, Uout, F, 1.0f, g, E, nullptr, s, rag, lev);
+        return true;
+    }
 #define SC_GEN_R(TT, MODE)                                                                                          \
     (R == 8 ? launch_rb_t<TT, 8, false, true, MODE, 8>(Uin, Uout, F, 1.0f, g, E, nullptr, s)                        \
    : R == 6 ? launch_rb_t<TT, 8, false, true, MODE, 6>(Uin, Uout, F, 1.0f, g, E, nullptr, s)                        \

@@ -103,3 +103,176 @@ def test_two_host_calls_into_disjoint_rois_of_one_destination(oracles):
         assert _dmax(want, body) <= 1
     finally:
         pool.close()
+
+
+def _device_jobs(inst, items):
+    """(dst, patch, mask, cx, cy) -> device-resident sc_batch_jobs on `inst` (bodies refreshed from a pristine copy by every call)."""
+    from seamlesscloneoptimization_amd import capi
+    jobs = capi.Pool.make_jobs(len(items)); keep = []
+    for j, (dst, patch, mask, cx, cy) in zip(jobs, items):
+        f, b0, b, m = inst.to_device(patch), inst.to_device(dst), inst.to_device(np.zeros_like(dst)), inst.to_device(mask)
+        keep.append((f, b0, b, m, dst.shape))
+        j.face, j.face_cols, j.face_rows, j.face_step = f, patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+        j.body, j.body_cols, j.body_rows, j.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+        j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
+        j.centerX, j.centerY, j.body_restore = cx, cy, b0
+    return jobs, keep
+
+
+def _free_jobs(inst, keep):
+    for f, b0, b, m, _ in keep:
+        for p in (f, b0, b, m):
+            inst.free(p)
+
+
+def _solo_results(items):
+    """Every item alone through the multigrid path (what a group member must reproduce): bodies and cycle counts."""
+    from seamlesscloneoptimization_amd import capi
+    seq = capi.Instance(0)
+    seq.set_solver(method=capi.SC_METHOD_MULTIGRID)
+    alone, cycles = [], []
+    try:
+        for dst, patch, mask, cx, cy in items:
+            b = dst.copy(); seq.run(patch, b, mask, cx, cy); alone.append(b); cycles.append(seq.info().sweeps)
+    finally:
+        seq.destroy()
+    return alone, cycles
+
+
+SIZE_CLASSES = {
+    # five sizes whose hierarchies end alike (level 2 in k_mg_tail, a 37..42-wide level solved directly at padding 64)
+    "300s": [(300, 310), (318, 333), (336, 305), (325, 337), (307, 322), (318, 333)],
+    # 1000..1027: level 3 (<= 127 unknowns) in k_mg_tail, a 61..63-wide level solved directly
+    "1000s": [(1003, 1010), (1020, 1001), (1012, 1024), (1025, 1025)],
+    # above 1027 per side the hierarchy is one level deeper (33 x 33 solved directly at padding 64)
+    "1100s": [(1078, 1090), (1099, 1080), (1085, 1075), (1092, 1099)],
+    # one side below, one above that boundary (31 x 32 solved directly at padding 32)
+    "mixed_depth": [(1010, 1060), (1022, 1065), (1001, 1033)],
+    # BASELINE config 3's size and two neighbours
+    "2048s": [(2048, 2048), (2000, 2040), (1990, 2050)],
+}
+
+
+def test_size_classes_are_what_the_tests_think_they_are():
+    """(host arithmetic only, but it guards the GPU tests below: each list must be ONE size class)"""
+    from seamlesscloneoptimization_amd import capi
+    for name, sizes in SIZE_CLASSES.items():
+        g, k = capi.plan_groups(sizes)
+        assert set(g) == {0} and set(k) == {2}, (name, g, k)
+
+
+@pytest.mark.parametrize("name", list(SIZE_CLASSES))
+def test_size_class_members_match_their_solo_runs(oracles, name):
+    """Round 5, size classes (csrc/sc_ragged.cpp): clones of DIFFERENT ROI sizes whose solves are the same program share one set of
+    launches through a per-member geometry table.  Every member must come out with the bytes of its solo run whenever the group
+    took the cycle count the solo run took (the stop rule sees the group's largest correction), within one grey level of the
+    float-table port always, and the call must really have shared its launches (sc_run_info.group_members / group_ragged)."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    sizes = SIZE_CLASSES[name]
+    items = []
+    for k, (W, H) in enumerate(sizes):
+        dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=500 + 7 * k, seed_patch=600 + 11 * k, margin=40)
+        if k == 1:                                           # holes in one member's mask (its bounding box stays the interior)
+            mask = mask.copy(); mask[H // 3:H // 3 + 25, W // 4:W // 4 + 90] = 0
+        items.append((dst, patch, mask, cx + 2 * k - 3, cy - k))
+    alone, cycles = _solo_results(items)
+    inst = capi.Instance(0)                                  # library defaults: a group takes the cycles at every size
+    try:
+        jobs, keep = _device_jobs(inst, items)
+        for rep in range(2):                                 # twice: the second call re-uses every buffer of the first
+            assert inst.run_device_batch(jobs) == 0 and all(j.rc == 0 for j in jobs)
+            inst.sync()
+            i = inst.info()
+            assert i.group_members == len(items) and i.group_ragged == 1, (i.group_members, i.group_ragged)
+            assert i.W == max(w for w, _ in sizes) and i.H == max(h for _, h in sizes)
+            group_cycles = i.sweeps
+            assert group_cycles >= max(cycles) - 1
+            for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
+                got = inst.from_device(b, shape)
+                want = oc.seamless_clone(it[0], it[1], it[2], it[3], it[4], nthreads=min(16, oc.max_threads()), exact_den=False)
+                assert _dmax(got, want) <= 1, (name, k, rep)
+                assert not np.array_equal(got, it[0])
+                if cycles[k] == group_cycles:
+                    assert np.array_equal(got, alone[k]), (name, k, rep, int((got != alone[k]).sum()))
+        # the same members in another order, one of them twice: the table is per slot, not per size
+        order = [2, 0, 1, 0] if len(items) >= 3 else [1, 0]
+        jobs2, keep2 = _device_jobs(inst, [items[q] for q in order])
+        assert inst.run_device_batch(jobs2) == 0
+        inst.sync()
+        assert inst.info().group_members == len(order)
+        if inst.info().sweeps == group_cycles:
+            for (f, b0, b, m, shape), q in zip(keep2, order):
+                if cycles[q] == group_cycles:
+                    assert np.array_equal(inst.from_device(b, shape), alone[q]), (name, q)
+        _free_jobs(inst, keep); _free_jobs(inst, keep2)
+    finally:
+        inst.destroy()
+
+
+def test_mixed_batch_is_partitioned_into_classes_groups_and_singles(oracles):
+    """One call with members of two size classes, a same-size pair, a size that fits nothing and a member whose ROI leaves its
+    destination: every usable member gets the bytes of its solo run (same cycle counts) or is within one of it, the failing member
+    reports its own error and nobody else is affected."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    sizes = [(300, 310), (1003, 1010), (318, 333), (640, 480), (1020, 1001), (640, 480), (90, 70), (340, 305), (1012, 1024)]
+    items = [o.synth_inputs(W, H, seed_dst=40 + k, seed_patch=90 + k, margin=36) for k, (W, H) in enumerate(sizes)]
+    alone, cycles = _solo_results(items)
+    inst = capi.Instance(0)
+    try:
+        jobs, keep = _device_jobs(inst, items)
+        assert inst.run_device_batch(jobs) == 0 and all(j.rc == 0 for j in jobs)
+        inst.sync()
+        for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
+            got = inst.from_device(b, shape)
+            assert _dmax(got, alone[k]) <= 1, k
+            assert not np.array_equal(got, it[0]), k
+            if sizes[k] == (90, 70):                         # alone either way
+                assert np.array_equal(got, alone[k])
+        jobs[4].centerX = 2                                  # its ROI leaves the destination
+        rc = inst.L.sc_hip_run_device_batch(inst.h, jobs, len(jobs))
+        inst.sync()
+        assert rc == capi.SC_ERR_ROI_OOB and jobs[4].rc == capi.SC_ERR_ROI_OOB
+        assert all(j.rc == 0 for q, j in enumerate(jobs) if q != 4)
+        for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
+            if k != 4:
+                assert _dmax(inst.from_device(b, shape), alone[k]) <= 1, k
+        _free_jobs(inst, keep)
+    finally:
+        inst.destroy()
+
+
+def test_pool_buckets_48_random_sizes(oracles):
+    """The driver's test of round 5's first item: 48 random ROI sizes in [1000, 1100]^2 and 48 in [300, 340]^2 through the pool
+    (groups of 16): every member within one grey level of its solo run, byte-identical to it wherever the member's group took
+    the solo run's cycle count -- which the pool cannot report per member, so: identical on at least 90 % of the members."""
+    from seamlesscloneoptimization_amd import capi
+    o, _ = oracles
+    rng = np.random.default_rng(2025)
+    for lo, hi in ((300, 340), (1000, 1100)):
+        sizes = [(int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))) for _ in range(48)]
+        base = {}
+        items = []
+        for k, (W, H) in enumerate(sizes):                   # two image pairs per range, cropped: synthesising 48 is the slow part
+            key = k & 1
+            if key not in base:
+                base[key] = o.synth_inputs(hi, hi, seed_dst=7 + key, seed_patch=17 + key, margin=40)
+            dst, patch, mask, cx, cy = base[key]
+            items.append((dst, np.ascontiguousarray(patch[:H + 2, :W + 2]), np.full((H + 2, W + 2), 255, np.uint8), cx, cy))
+        alone, cycles = _solo_results(items)
+        pool = capi.Pool(0, streams=2, group=16)
+        try:
+            inst = pool.instances[0]
+            jobs, keep = _device_jobs(inst, items)
+            pool.run(jobs, device_resident=True)
+            same = 0
+            for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
+                got = inst.from_device(b, shape)
+                assert _dmax(got, alone[k]) <= 1, (lo, k, sizes[k])
+                assert not np.array_equal(got, it[0])
+                same += int(np.array_equal(got, alone[k]))
+            assert same >= 0.9 * len(items), (lo, same)
+            _free_jobs(inst, keep)
+        finally:
+            pool.close()
