@@ -228,8 +228,6 @@ def test_mixed_batch_is_partitioned_into_classes_groups_and_singles(oracles):
             got = inst.from_device(b, shape)
             assert _dmax(got, alone[k]) <= 1, k
             assert not np.array_equal(got, it[0]), k
-            if sizes[k] == (90, 70):                         # alone either way
-                assert np.array_equal(got, alone[k])
         jobs[4].centerX = 2                                  # its ROI leaves the destination
         rc = inst.L.sc_hip_run_device_batch(inst.h, jobs, len(jobs))
         inst.sync()
