@@ -497,9 +497,10 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->fft.ev_fork) (void)hipEventDestroy(I->fft.ev_fork);
     if (I->fft.ev_built) (void)hipEventDestroy(I->fft.ev_built);
     if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
-    for (DevBuf *b : { &I->rag.d_table, &I->rag.d_aux }) if (b->p) (void)hipFree(b->p);
+    if (I->rag.d_aux.p) (void)hipFree(I->rag.d_aux.p);
     if (I->rag.h_stage.p) (void)hipHostFree(I->rag.h_stage.p);
     if (I->rag.ev) (void)hipEventDestroy(I->rag.ev);
+    if (I->rag.ev_ready) (void)hipEventDestroy(I->rag.ev_ready);
     if (I->ev_fd_fork) (void)hipEventDestroy(I->ev_fd_fork);
     if (I->ev_fd) (void)hipEventDestroy(I->ev_fd);
     if (I->ev_scan) (void)hipEventDestroy(I->ev_scan);
@@ -1153,7 +1154,7 @@ int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[10])
     if (opts) o = *opts; else sc_hip_default_opts(&o);
     SizePlan p;
     plan_size(o, W, H, p);
-    const int v[10] = { p.ok ? 1 : 0, p.nl, p.tail, p.npx, p.npy, p.Kxp, p.Kyp, p.nxt, p.nrs, p.nl > p.tail && p.tail > 0 ? p.g[p.tail].x.nc * 1000 + p.g[p.tail].y.nc : 0 };
+    const int v[10] = { p.ok ? 1 : 0, p.nl, p.tail, p.npx, p.npy, p.Kxp, p.Kyp, p.nxt, p.nrs, (p.t && p.tail > 0) ? p.t->g[p.tail].x.nc * 1000 + p.t->g[p.tail].y.nc : 0 };
     memcpy(out, v, sizeof(v));
     return SC_OK;
 }

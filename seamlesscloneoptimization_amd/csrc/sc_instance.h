@@ -87,7 +87,12 @@ struct SizePlan {
     int npx = 0, npy = 0;               // padding of the directly solved level's operands (32 or 64 per side)
     int Kx = 0, Ky = 0, Kxp = 0, Kyp = 0, nx = 0, ny = 0, cells_y = 0, nxt = 0, nrs = 0;     // float-table correction
     double max_ratio = 0.0;
-    std::vector<MGGeom> g;
+    // the heavy part, shared between copies (plans are memoised per size: sc_ragged.cpp): level geometries, the correction's ratio
+    // table R[Kyp][Kxp] and the part maps of the 2- and the 4-sweep tiling
+    struct Tables { std::vector<MGGeom> g; };
+    std::shared_ptr<const Tables> t;
+    // ... and what only the per-call setup needs (rag_begin, on the worker's thread): built on first use, memoised per size as well
+    struct Heavy { std::vector<float> R; std::vector<int> map[2]; };
     // same compile-time choices and launch shapes, and strides that waste at most ~1/8 per direction
     bool same_class(const SizePlan &o) const
     {
@@ -95,6 +100,7 @@ struct SizePlan {
     }
 };
 bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p);     // fills p; returns p.ok
+std::shared_ptr<const SizePlan::Heavy> plan_heavy(const SizePlan &p);    // nullptr: a tiling with more than four parts per cell row (none exists)
 // members (any order) -> groups that can each share one set of launches: a size class (two or more DIFFERENT sizes), a same-size
 // group, or a single; `cap` = most members per group.  groups[k] lists indices into `plans`.
 void plan_groups(const std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups);
@@ -106,8 +112,11 @@ struct RagState {
     int nl = 0, tail = 0, npx = 0, npy = 0, Kxp = 0, Kyp = 0;     // the class's constants
     int max_nx = 0, max_ny = 0, max_nxt = 0, max_nrs = 0, max_cells_y = 0;
     double max_ratio = 0.0;
-    DevBuf d_table, d_aux, h_stage;     // RagMember[n] | R tables, part maps, Sx, Sy, bottom operands | pinned staging of what the host writes
+    DevBuf d_aux, h_stage;              // RagMember[n], R tables, part maps | Sx, Sy, bottom operands; pinned staging of what the host writes (the head of d_aux)
+    bool levels_built = false;          // the class's hierarchy is in I->mg (mg_build_levels_rag, called from rag_begin)
     hipEvent_t ev = nullptr;            // behind the upload out of h_stage
+    hipEvent_t ev_ready = nullptr;      // second stream: the level planes are zeroed and the correction's tables built (the matrices follow: Instance::ev_fd)
+    bool ready_pending = false;         // ... and the main stream has not waited for that yet
 };
 
 struct Instance {
@@ -251,6 +260,7 @@ int lowmode_projection_splits(int nxt, int nkb);                      // row spl
 void launch_lm_tables_rag(const RagMember *rag, int members, int max_rows, int Kxp, int Kyp, hipStream_t s);
 void mg_plan_levels(int W, int H, std::vector<MGGeom> &g);           // sc_multigrid.cpp
 size_t mg_default_tail_level(const std::vector<MGGeom> &g);
+int mg_build_levels_rag(Instance *I, hipStream_t zero_on);           // sc_multigrid.cpp: the class's level planes, zeroed on the given stream
 int rag_begin(Instance *I, const std::vector<SizePlan> &members);     // sc_ragged.cpp: table + tables of a size class on the device; sets I->rag.dev
 void rag_end(Instance *I);
 int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST

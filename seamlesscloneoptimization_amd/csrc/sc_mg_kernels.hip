@@ -37,16 +37,20 @@ void launch_zero_multi(const ZeroJobs &z, hipStream_t s)
 // mm != nullptr: additionally the same four matrices as the operands of k_mg_bottom_mm (below), each row-major float
 // [NP][NP] with NP = 32, 64 or 96 (zero padded), in the orientation the product that uses it reads row by row:
 //     AX1[i][x] = Vx^-1[i][x]   AX2[x][i] = Vx[x][i]   AY1[j][y] = Vy^-1[j][y]   AY2[y][j] = Vy[y][j]   Dinv[j][i].
+// part / parts: this workgroup's share of the entries: four 256-thread workgroups per build (a 1024-thread one is held to 128 VGPRs
+// and spills; it also needs a whole idle CU and waits behind the level-0 launches of both streams)
 __device__ __forceinline__ void fd_build_block(float *__restrict__ m, int nx, int ny, int nxp, int nyp, float cwx, float dx, float cwy, float dy,
-                                               unsigned char *__restrict__ mm, int NPX, int NPY)
+                                               unsigned char *__restrict__ mm, int NPX, int NPY, int part = 0, int parts = 1)
 {
     __shared__ FdPair px[128], py[128];
-    const int t = threadIdx.x;
-    if (t < nx) px[t] = fd_pair(t, nx, (double)cwx, (double)dx);
-    if (t >= 128 && t - 128 < ny) py[t - 128] = fd_pair(t - 128, ny, (double)cwy, (double)dy);
+    const int t0 = threadIdx.x, stride = (int)blockDim.x * parts, t = part * (int)blockDim.x + t0;
+    for (int q = t0; q < 256; q += (int)blockDim.x) {          // every workgroup needs all pairs: one thread per eigenvalue
+        if (q < nx) px[q] = fd_pair(q, nx, (double)cwx, (double)dx);
+        if (q >= 128 && q - 128 < ny) py[q - 128] = fd_pair(q - 128, ny, (double)cwy, (double)dy);
+    }
     __syncthreads();
     const int nxx = nxp * nxp, nyy = nyp * nyp, total = m ? 2 * nxx + 2 * nyy + nxp * nyp : 0;      // m == nullptr: the matrix-core operands only
-    for (int e = t; e < total; e += 1024) {
+    for (int e = t; e < total; e += stride) {
         float v = 0.f;
         if (e < nxx) {                                   // Mx1[x][i] = Vx^-1[i][x] = q_i(x) ee_x
             const int x = e / nxp, i = e - x * nxp;
@@ -69,7 +73,7 @@ __device__ __forceinline__ void fd_build_block(float *__restrict__ m, int nx, in
     if (!mm) return;
     const int ex = NPX * NPX, ey = NPY * NPY;
     float *ax1 = reinterpret_cast<float *>(mm), *ax2 = ax1 + ex, *ay1 = ax2 + ex, *ay2 = ay1 + ey, *dinv = ay2 + ey;
-    for (int e = t; e < 2 * ex + 2 * ey + NPX * NPY; e += 1024) {
+    for (int e = t; e < 2 * ex + 2 * ey + NPX * NPY; e += stride) {
         if (e < 2 * ex) {                                // AX1[i][x] (e < ex) and AX2[x][i]
             const bool second = e >= ex;
             const int r = second ? e - ex : e, row = r / NPX, k = r - row * NPX;
@@ -92,29 +96,31 @@ __device__ __forceinline__ void fd_build_block(float *__restrict__ m, int nx, in
     }
 }
 
-__global__ __launch_bounds__(1024) void k_fd_build(float *__restrict__ m, int nx, int ny, int nxp, int nyp, float cwx, float dx, float cwy, float dy,
-                                                   unsigned char *__restrict__ mm, int NPX, int NPY)
+__global__ __launch_bounds__(256) void k_fd_build(float *__restrict__ m, int nx, int ny, int nxp, int nyp, float cwx, float dx, float cwy, float dy,
+                                                  unsigned char *__restrict__ mm, int NPX, int NPY)
 {
-    fd_build_block(m, nx, ny, nxp, nyp, cwx, dx, cwy, dy, mm, NPX, NPY);
+    fd_build_block(m, nx, ny, nxp, nyp, cwx, dx, cwy, dy, mm, NPX, NPY, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // the same for every member of a size class in ONE launch (blockIdx.x = member): the matrix-core operands only, each member's
 // where its table entry says (RagMember::mm), from the geometry of its own level `lev` (the level solved directly)
-__global__ __launch_bounds__(1024) void k_fd_build_rag(const RagMember *__restrict__ rag, int lev, int NPX, int NPY)
+__global__ __launch_bounds__(256) void k_fd_build_rag(const RagMember *__restrict__ rag, int lev, int NPX, int NPY)
 {
     const RagMember &m = rag[blockIdx.x];
     const MGGeom g = m.g[lev];
-    fd_build_block(nullptr, g.x.n, g.y.n, 0, 0, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last, const_cast<unsigned char *>(m.mm), NPX, NPY);
+    fd_build_block(nullptr, g.x.n, g.y.n, 0, 0, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last, const_cast<unsigned char *>(m.mm), NPX, NPY,
+                   (int)blockIdx.y, (int)gridDim.y);
 }
 
 void launch_fd_build_rag(const RagMember *rag, int members, int lev, int NPX, int NPY, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fd_build_rag, dim3(members), dim3(1024), 0, s, rag, lev, NPX, NPY);
+    hipLaunchKernelGGL(k_fd_build_rag, dim3(members, 4), dim3(256), 0, s, rag, lev, NPX, NPY);
 }
 
 void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s, unsigned char *mm, int NPX, int NPY)
 {
-    hipLaunchKernelGGL(k_fd_build, dim3(1), dim3(1024), 0, s, mats, g.x.n, g.y.n, nxp, nyp, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last, mm, NPX, NPY);
+    // four 256-thread workgroups (each finds all eigenpairs, then fills its quarter of the entries): no spills at 155 VGPRs, no scratch
+    hipLaunchKernelGGL(k_fd_build, dim3(4), dim3(256), 0, s, mats, g.x.n, g.y.n, nxp, nyp, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last, mm, NPX, NPY);
 }
 
 // ---- general red-black half sweep (levels >= 1; ring = 0) ---------------------------------

@@ -369,11 +369,12 @@ size_t mg_default_tail_level(const std::vector<MGGeom> &g)
     return (a && !(a == 2 && level1_direct)) ? a : 0;
 }
 
-static int build_levels_rag(Instance *I);
-
 static int build_levels(Instance *I)
 {
-    if (I->rag.dev) return build_levels_rag(I);
+    if (I->rag.dev) {          // a size class: rag_begin built the hierarchy (mg_build_levels_rag)
+        if (!I->rag.levels_built || I->mg.empty()) { I->err = "size class: hierarchy missing"; return SC_ERR_BAD_ARG; }
+        return SC_OK;
+    }
     const int W = I->F.W, H = I->F.H, C = I->F.C;
     if (!I->mg.empty() && I->mg[0].F.p == I->F.p && I->mg[0].F.W == W && I->mg[0].F.H == H && I->mg[0].F.C == C)
         return SC_OK;
@@ -434,9 +435,12 @@ static int build_levels(Instance *I)
 // member has on that level --, every plane zeroed (a member's ring and what lies beyond it must be zero, and the slot may have held a
 // larger member a call ago), the members' bottom matrices by one launch on the second stream.  The per-member geometries are in the
 // table on the device; I->mg[l].g holds the class's MAXIMA (grid sizes and the launchers' shape tests read those).
-static int build_levels_rag(Instance *I)
+// Called from rag_begin: the zeroing goes to `zero_on` (the instance's second stream, which the main stream joins in front of its
+// first coarse-level launch, mg_solve) -- the caller has ordered that stream behind everything that read the planes before.
+int mg_build_levels_rag(Instance *I, hipStream_t zero_on)
 {
     RagState &R = I->rag;
+    R.levels_built = false;
     const int C = I->F.C, n = R.n;
     const size_t nl = (size_t)R.nl;
     I->info.new_size = 1;
@@ -463,25 +467,23 @@ static int build_levels_rag(Instance *I)
         L.U = level_field(I->mg_bufs[3 * l + 0].p, Wl, Hl, C);
         L.F = level_field(I->mg_bufs[3 * l + 1].p, Wl, Hl, C);
         L.T = level_field(I->mg_bufs[3 * l + 2].p, Wl, Hl, C);
-        for (const Field *f : { &L.U, &L.F, &L.T }) {
-            if (zj.count == ZeroJobs::MAX) { launch_zero_multi(zj, I->stream); zj.count = 0; }
+        // What must be zero: a member's ring and everything beyond it in the planes a finer level interpolates FROM -- U and its
+        // ping-pong partner T (the launches write a member's own extent only, and the slot may have held a larger member a call
+        // ago).  Right-hand sides are read under the interior masks only: F needs nothing.
+        for (const Field *f : { &L.U, &L.T }) {
+            if (zj.count == ZeroJobs::MAX) { launch_zero_multi(zj, zero_on); zj.count = 0; }
             zj.p[zj.count] = f->p; zj.n16[zj.count] = (f->bytes() + 15) / 16; ++zj.count;
         }
     }
-    launch_zero_multi(zj, I->stream);
+    launch_zero_multi(zj, zero_on);
     SC_HIP(I, hipGetLastError());
     I->mg[0].F = I->F;
     I->mg_bottom = (size_t)R.tail + 1;
-    I->mg_l1_half = false;
-    // the class's bottom: every member's level below `tail` solved directly on the matrix cores inside k_mg_tail, operands padded alike
+    I->mg_l1_half = true;      // a class runs the fast path (plan_size): float16 level 1, and its planes are all zero -- valid in either format, nothing to re-zero in mg_solve
+    // the class's bottom: every member's level below `tail` solved directly on the matrix cores inside k_mg_tail, operands padded
+    // alike; the matrices are being built on the second stream since rag_begin (run_tail waits for them)
     I->fd_level = 0; I->fd_mm = true; I->fd_npx = R.npx; I->fd_npy = R.npy; I->fd_nxp = I->fd_nyp = 0; I->fd_mm_off = 0;
-    if (I->fd_pending) { SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0)); I->fd_pending = false; }
-    SC_HIP(I, hipEventRecord(I->ev_fd_fork, I->stream));          // behind the table's upload and everything that read the previous matrices
-    SC_HIP(I, hipStreamWaitEvent(I->aux, I->ev_fd_fork, 0));
-    launch_fd_build_rag(R.dev, n, R.tail + 1, R.npx, R.npy, I->aux);
-    SC_HIP(I, hipGetLastError());
-    SC_HIP(I, hipEventRecord(I->ev_fd, I->aux));
-    I->fd_pending = true;
+    R.levels_built = true;
     return SC_OK;
 }
 
@@ -690,6 +692,10 @@ int mg_solve(Instance *I)
         if (launch_cycle0(result(I), I->result_in_U1 ? I->U0 : I->U1, I->F, I->mg[1].F, none, I->mg[0].g, pre, false, nullptr,
                           I->stream, false, I->f_half, I->u_half, false, nullptr, l1h, q16, sat, I->rag.dev) < 0) { I->err = "cycle0: unsupported depth"; return SC_ERR_BAD_ARG; }
         I->result_in_U1 = !I->result_in_U1;
+        if (I->rag.dev && I->rag.ready_pending) {      // a size class: its zeroed coarse planes and tables were made on the second stream beside everything up to here
+            SC_HIP(I, hipStreamWaitEvent(I->stream, I->rag.ev_ready, 0));      // (the matrices: run_tail waits for them)
+            I->rag.ready_pending = false;
+        }
         I->u_half = false;             // consumed: both U buffers hold float (or 16-bit fixed point: u_q16) from here on
         I->u_q16 = I->mg_q16_last = q16;
         I->info.sweep_launches += 1;

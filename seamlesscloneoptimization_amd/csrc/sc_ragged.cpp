@@ -11,6 +11,8 @@
 #include "sc_instance.h"
 #include <algorithm>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 namespace sc {
 
@@ -18,10 +20,55 @@ namespace sc {
 // member leaves unused of its planes is never touched, but the grids are sized for the largest)
 static constexpr double RAG_SPREAD = 1.125;
 
+// Plans are pure functions of (W, H) and of the few solver options below: memoised, so that a caller whose ROI sizes recur (video:
+// the same faces frame after frame) plans each size once.  Bounded; shared by every instance and pool of the process.
+namespace {
+struct PlanKey {
+    int W, H, method, flags, pre, post, spl, warm, dmax, l1s, maxs; float tol, utol;
+    bool operator==(const PlanKey &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
+};
+struct PlanKeyHash {
+    size_t operator()(const PlanKey &k) const
+    {
+        size_t h = 1469598103934665603ull;
+        const unsigned char *p = reinterpret_cast<const unsigned char *>(&k);
+        for (size_t i = 0; i < sizeof(k); ++i) h = (h ^ p[i]) * 1099511628211ull;
+        return h;
+    }
+};
+std::mutex g_plan_mu;
+std::unordered_map<PlanKey, SizePlan, PlanKeyHash> g_plan_cache;
+constexpr size_t PLAN_CACHE_MAX = 2048;
+bool plan_size_uncached(const sc_solver_opts &o, int W, int H, SizePlan &p);
+} // namespace
+
 bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p)
+{
+    PlanKey k;
+    memset(&k, 0, sizeof(k));
+    k.W = W; k.H = H; k.method = o.method; k.flags = o.flags; k.pre = o.mg_pre; k.post = o.mg_post; k.spl = o.sweeps_per_launch;
+    k.warm = o.reference_warmup; k.dmax = o.mg_direct_max; k.l1s = o.mg_level1_sweeps; k.maxs = o.max_sweeps; k.tol = o.tol; k.utol = o.update_tol;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        auto it = g_plan_cache.find(k);
+        if (it != g_plan_cache.end()) { p = it->second; return p.ok; }
+    }
+    plan_size_uncached(o, W, H, p);
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (g_plan_cache.size() >= PLAN_CACHE_MAX) g_plan_cache.clear();
+        g_plan_cache.emplace(k, p);
+    }
+    return p.ok;
+}
+
+namespace {
+bool plan_size_uncached(const sc_solver_opts &o, int W, int H, SizePlan &p)
 {
     p = SizePlan();
     p.W = W; p.H = H;
+    auto T = std::make_shared<SizePlan::Tables>();
+    std::vector<MGGeom> &pg = T->g;
     // --- the solve configured in `o` is the default fast path: float16 right-hand side and level 1, composed level-1 schedule,
     //     output bytes from the judged cycle (sc_multigrid.cpp: mg_reads_half_rhs, mg_level1_half, mg_composes_level1)
     const int pre = o.mg_pre > 0 ? o.mg_pre : 2, post = o.mg_post > 0 ? o.mg_post : 2;
@@ -33,12 +80,12 @@ bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p)
         return false;
     if (std::min(W, H) - 2 <= 3) return false;
     // --- its hierarchy ends the default way: a level of at most 127 unknowns per side in k_mg_tail, the one below it solved there
-    mg_plan_levels(W, H, p.g);
-    p.nl = (int)p.g.size();
-    const size_t a = mg_default_tail_level(p.g);
+    mg_plan_levels(W, H, pg);
+    p.nl = (int)pg.size();
+    const size_t a = mg_default_tail_level(pg);
     if (!a || (int)a + 2 > RAG_MAX_LEVELS || p.nl < (int)a + 2) return false;
     p.tail = (int)a;
-    const MGGeom &A = p.g[a];
+    const MGGeom &A = pg[a];
     if (A.x.n > 127 || A.y.n > 127 || A.x.nc > 63 || A.y.nc > 63 || A.x.nc < 1 || A.y.nc < 1) return false;
     p.npx = round_up(A.x.nc, 32); p.npy = round_up(A.y.nc, 32);
     // --- its float-table correction: regular tables, the node correction of the iterate one cycle earlier admissible a priori
@@ -54,11 +101,35 @@ bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p)
     const bool regular = lowmode_ratio(w, h, p.Kx, p.Ky, p.Kxp, nullptr, p.max_ratio);
     const float utol = o.update_tol > 0.f ? o.update_tol : 0.25f;
     if (!regular || !(p.max_ratio * 4.9 * (double)utol <= 0.049)) return false;
-    std::vector<int> m;
-    int br = 0;
-    if (!lowmode_part_map(H, 2, m, br) || !lowmode_part_map(H, 4, m, br)) return false;
+    p.t = T;
     p.ok = true;
     return true;
+}
+
+std::mutex g_heavy_mu;
+std::unordered_map<long long, std::shared_ptr<const SizePlan::Heavy>> g_heavy_cache;
+} // namespace
+
+// The correction's ratio table (the reference's float expressions through libm, as the CPU oracle's) and the two part maps of a size:
+// what rag_begin copies into its staging.  Functions of (W, H) alone; memoised like the plans.
+std::shared_ptr<const SizePlan::Heavy> plan_heavy(const SizePlan &p)
+{
+    const long long key = ((long long)p.W << 32) | (unsigned)p.H;
+    {
+        std::lock_guard<std::mutex> lk(g_heavy_mu);
+        auto it = g_heavy_cache.find(key);
+        if (it != g_heavy_cache.end()) return it->second;
+    }
+    auto Hv = std::make_shared<SizePlan::Heavy>();
+    Hv->R.assign((size_t)p.Kyp * p.Kxp, 0.f);
+    double mr;
+    lowmode_ratio(p.W - 2, p.H - 2, p.Kx, p.Ky, p.Kxp, Hv->R.data(), mr);
+    int br = 0;
+    if (!lowmode_part_map(p.H, 2, Hv->map[0], br) || !lowmode_part_map(p.H, 4, Hv->map[1], br)) return nullptr;
+    std::lock_guard<std::mutex> lk(g_heavy_mu);
+    if (g_heavy_cache.size() >= PLAN_CACHE_MAX) g_heavy_cache.clear();
+    g_heavy_cache.emplace(key, Hv);
+    return Hv;
 }
 
 // Greedy, order preserving: a member joins the first open group it fits -- the same size as the group's members, or the same class
@@ -94,9 +165,12 @@ void plan_groups(const std::vector<SizePlan> &plans, int cap, std::vector<std::v
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// The members' table and everything it points to, on the device, behind whatever the instance's stream still has to do:
-//   h_stage (pinned) = RagMember[n] | R tables | part maps   -> one upload into d_table / d_aux
-//   d_aux            = R tables | part maps | Sx | Sy tables (built by one launch here) | bottom operands (built by build_levels_rag)
+// The members' table and everything it points to, on the device:
+//   h_stage (pinned) = RagMember[n] | R tables | part maps   -> ONE upload into the head of d_aux, on the instance's stream
+//   d_aux            = table | R tables | part maps | Sx | Sy tables | bottom operands
+// and, on the instance's SECOND stream from here on -- beside the scans, the erodes, the pre-process and the first level-0 launch of
+// the solve --, everything the device builds per call: the Sx / Sy tables, the members' bottom matrices, the zeroing of the coarse
+// planes (mg_build_levels_rag).  The main stream waits for all of it in front of its first coarse-level launch (mg_solve).
 // Sets I->rag.dev; the caller has bound the class's fields (setup_fields) before.
 int rag_begin(Instance *I, const std::vector<SizePlan> &members)
 {
@@ -116,58 +190,63 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
         R.max_cells_y = std::max(R.max_cells_y, p.cells_y);
         R.max_ratio = std::max(R.max_ratio, p.max_ratio);
     }
-    // --- layout of d_aux (per member, 256-byte aligned pieces)
+    // --- layout of d_aux (256-byte aligned pieces; the per-member pieces one member after the other)
     const size_t bR = align_up(sizeof(float) * (size_t)R.Kyp * R.Kxp, 256), bMap = align_up(sizeof(int) * 4 * (size_t)R.max_cells_y, 256);
     const size_t bSx = align_up(sizeof(float) * (size_t)R.max_nx * R.Kxp, 256), bSy = align_up(sizeof(float) * (size_t)R.max_ny * R.Kyp, 256);
     const size_t bMM = align_up((size_t)fd_mm_bytes(R.npx, R.npy), 256);
-    const size_t host_part = (bR + 2 * bMap) * n;                      // what the host writes: uploaded together with the table
-    const size_t aux_bytes = host_part + (bSx + bSy + bMM) * n;
     const size_t table_bytes = align_up(sizeof(RagMember) * (size_t)n, 256);
+    const size_t host_part = table_bytes + (bR + 2 * bMap) * n;        // what the host writes: one upload
+    const size_t aux_bytes = host_part + (bSx + bSy + bMM) * n;
     int rc;
-    if ((rc = ensure(I, R.d_table, table_bytes))) return rc;
+    if (I->fd_pending) { SC_HIP(I, hipEventSynchronize(I->ev_fd)); I->fd_pending = false; }      // second-stream work nobody joined (a call that failed early): before its buffers may move
+    R.ready_pending = false;
     if ((rc = ensure(I, R.d_aux, aux_bytes))) return rc;
     if (!R.ev) SC_HIP(I, hipEventCreateWithFlags(&R.ev, hipEventDisableTiming));
     else SC_HIP(I, hipEventSynchronize(R.ev));                        // the previous upload out of the staging: long complete
-    if ((rc = ensure_pinned(I, R.h_stage, table_bytes + host_part))) return rc;
+    if ((rc = ensure_pinned(I, R.h_stage, host_part))) return rc;
     uint8_t *const hs = (uint8_t *)R.h_stage.p, *const da = (uint8_t *)R.d_aux.p;
-    uint8_t *const h_host = hs + table_bytes;                          // staging of d_aux's host-written part
     R.host.assign(n, RagMember());
     for (int i = 0; i < n; ++i) {
         const SizePlan &p = members[i];
         RagMember &m = R.host[i];
         std::memset(&m, 0, sizeof(m));
         m.W = p.W; m.H = p.H;
-        for (int l = 0; l < R.nl; ++l) { m.g[l] = p.g[l]; m.lw[l] = p.g[l].x.n + 2; m.lh[l] = p.g[l].y.n + 2; }
+        const SizePlan::Tables &T = *p.t;
+        for (int l = 0; l < R.nl; ++l) { m.g[l] = T.g[l]; m.lw[l] = T.g[l].x.n + 2; m.lh[l] = T.g[l].y.n + 2; }
         for (int l = R.nl; l < RAG_MAX_LEVELS; ++l) { m.lw[l] = 3; m.lh[l] = 3; }
         m.lm_nx = p.nx; m.lm_ny = p.ny; m.lm_cells_y = p.cells_y; m.lm_nxt = p.nxt; m.lm_nrs = p.nrs; m.lm_nparts = p.nxt * p.nrs;
         m.lm_Kx = p.Kx; m.lm_Ky = p.Ky;
-        const size_t oR = (bR + 2 * bMap) * i, oMap0 = oR + bR, oMap1 = oMap0 + bMap;
+        const size_t oR = table_bytes + (bR + 2 * bMap) * i, oMap0 = oR + bR, oMap1 = oMap0 + bMap;
         m.lm_R = (const float *)(da + oR);
         m.lm_map[0] = (const int *)(da + oMap0); m.lm_map[1] = (const int *)(da + oMap1);
         m.lm_Sx = (const float *)(da + host_part + (bSx + bSy + bMM) * i);
         m.lm_Sy = (const float *)(da + host_part + (bSx + bSy + bMM) * i + bSx);
         m.mm = da + host_part + (bSx + bSy + bMM) * i + bSx + bSy;
-        // the host-built pieces: the ratio table with the reference's float expressions (libm, as the CPU oracle's), the part maps
-        double mr;
-        std::memset(h_host + oR, 0, bR);
-        lowmode_ratio(p.W - 2, p.H - 2, p.Kx, p.Ky, p.Kxp, (float *)(h_host + oR), mr);
-        std::vector<int> map;
-        int br = 0;
-        for (int t = 0; t < 2; ++t) {
-            int *dst = (int *)(h_host + (t ? oMap1 : oMap0));
-            for (size_t k = 0; k < bMap / sizeof(int); ++k) dst[k] = -1;
-            if (!lowmode_part_map(p.H, t ? 4 : 2, map, br)) { I->err = "size class: more than four parts per cell row"; return SC_ERR_BAD_ARG; }
-            std::memcpy(dst, map.data(), sizeof(int) * map.size());
-        }
+        // the host-built pieces (made once per size): the ratio table and the two part maps
+        const std::shared_ptr<const SizePlan::Heavy> Hv = plan_heavy(p);
+        if (!Hv) { I->err = "size class: more than four parts per cell row"; return SC_ERR_BAD_ARG; }
+        std::memcpy(hs + oR, Hv->R.data(), sizeof(float) * Hv->R.size());
+        for (int t = 0; t < 2; ++t) std::memcpy(hs + (t ? oMap1 : oMap0), Hv->map[t].data(), sizeof(int) * Hv->map[t].size());
     }
     std::memcpy(hs, R.host.data(), sizeof(RagMember) * (size_t)n);
-    SC_HIP(I, hipMemcpyAsync(R.d_table.p, hs, table_bytes, hipMemcpyHostToDevice, I->stream));
-    SC_HIP(I, hipMemcpyAsync(da, h_host, host_part, hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipMemcpyAsync(da, hs, host_part, hipMemcpyHostToDevice, I->stream));
     SC_HIP(I, hipEventRecord(R.ev, I->stream));
-    launch_lm_tables_rag((const RagMember *)R.d_table.p, n, std::max(R.max_nx, R.max_ny), R.Kxp, R.Kyp, I->stream);
-    SC_HIP(I, hipGetLastError());
-    R.dev = (const RagMember *)R.d_table.p;
+    R.dev = (const RagMember *)da;
     I->info.new_size = 1;
+    // --- the device-built pieces, on the second stream behind the upload and behind everything that read the previous call's
+    //     tables, matrices and level planes
+    // (the short ones first, with an event of their own: the first coarse-level launch needs the zeroed planes, only the first
+    // k_mg_tail the matrices -- whose build is ~100 us of dependent double-precision arithmetic)
+    SC_HIP(I, hipStreamWaitEvent(I->aux, R.ev, 0));
+    if ((rc = mg_build_levels_rag(I, I->aux))) { R.dev = nullptr; return rc; }
+    launch_lm_tables_rag(R.dev, n, std::max(R.max_nx, R.max_ny), R.Kxp, R.Kyp, I->aux);
+    if (!R.ev_ready) SC_HIP(I, hipEventCreateWithFlags(&R.ev_ready, hipEventDisableTiming));
+    SC_HIP(I, hipEventRecord(R.ev_ready, I->aux));
+    R.ready_pending = true;
+    launch_fd_build_rag(R.dev, n, R.tail + 1, R.npx, R.npy, I->aux);
+    SC_HIP(I, hipGetLastError());
+    SC_HIP(I, hipEventRecord(I->ev_fd, I->aux));
+    I->fd_pending = true;
     return SC_OK;
 }
 
@@ -176,6 +255,7 @@ void rag_end(Instance *I)
 {
     if (!I->rag.dev) return;
     I->rag.dev = nullptr;
+    I->rag.levels_built = false;
     I->mg.clear();
     I->lm.w = I->lm.h = 0;
     field_moved(I);

@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--lo", type=int, default=1000); ap.add_argument("--hi", type=int, default=1100)
     ap.add_argument("--n", type=int, default=64); ap.add_argument("--streams", type=int, default=2); ap.add_argument("--group", type=int, default=16)
     ap.add_argument("--reps", type=int, default=8); ap.add_argument("--seed", type=int, default=2025)
+    ap.add_argument("--legs", default="mixed,ones,same", help="which of the three measurements to run")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     sizes = [(int(rng.integers(a.lo, a.hi + 1)), int(rng.integers(a.lo, a.hi + 1))) for _ in range(a.n)]
@@ -83,10 +84,12 @@ def main():
     mean = int(round(np.sqrt(np.mean([w * h for w, h in sizes]))))
     out = {"range": [a.lo, a.hi], "n": a.n, "streams": a.streams, "group": a.group,
            "planned_groups": sorted(Counter(g).values(), reverse=True), "kinds": dict(Counter(k))}
-    out["mixed_sizes"] = time_pool(a.streams, a.group, sizes, dst, patch, a.reps)
-    out["mixed_sizes_groups_of_one_8_streams"] = time_pool(8, 1, sizes, dst, patch, a.reps)
-    out["same_size_%d" % mean] = time_pool(a.streams, a.group, [(mean, mean)] * a.n, dst, patch, a.reps)
-    out["ratio_to_same_size"] = round(out["mixed_sizes"]["Gpix_per_s"] / out["same_size_%d" % mean]["Gpix_per_s"], 3)
+    legs = a.legs.split(",")
+    if "mixed" in legs: out["mixed_sizes"] = time_pool(a.streams, a.group, sizes, dst, patch, a.reps)
+    if "ones" in legs: out["mixed_sizes_groups_of_one_8_streams"] = time_pool(8, 1, sizes, dst, patch, a.reps)
+    if "same" in legs: out["same_size_%d" % mean] = time_pool(a.streams, a.group, [(mean, mean)] * a.n, dst, patch, a.reps)
+    if "mixed" in legs and "same" in legs:
+        out["ratio_to_same_size"] = round(out["mixed_sizes"]["Gpix_per_s"] / out["same_size_%d" % mean]["Gpix_per_s"], 3)
     print(json.dumps(out), flush=True)
 
 
