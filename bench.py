@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--host-calls", type=int, default=24, help="timed drop-in host-image calls of the `pcie` leg (median / p95 / min are reported)")
     ap.add_argument("--no-float32-leg", action="store_true", help="skip value_float32_storage (the same timed step with float32 fields and right-hand side)")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip value_without_in_step_restore (up to 16 steps, each into its own pre-resident destinations: 0.43 GB of HBM per step)")
+    ap.add_argument("--no-mixed-sizes", action="store_true", help="skip the mixed_sizes leg (64 clones of 64 different ROI sizes through the pool)")
     ap.add_argument("--no-new-size", action="store_true", help="skip the new_size leg (first call at a ROI size the instance has not seen)")
     ap.add_argument("--no-c4", action="store_true", help="skip the roofline_c4 leg (config 4: single-sweep Jacobi kernels at a 4096^2 ROI, HBM bound)")
     ap.add_argument("--reference-table", action="store_true",
@@ -377,6 +378,65 @@ def new_size_leg(capi, seed=4):
                    "never seen, steady = the same call repeated (best of 2); the reference rebuilds its per-size state in every call "
                    "(seamlessClone_imp.cpp:1073-1116), here it is built on the device once per size and cached")
     return out
+
+
+def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, seed=2025):
+    """A batch whose members all have DIFFERENT ROI sizes -- what real clones produce: a mask box per face, per frame -- through the
+    native pool with its default grouping (size classes share one set of launches: csrc/sc_ragged.cpp), beside (a) the same list one
+    clone at a time on 8 streams (what rounds 1-4 did with such a batch) and (b) n same-size clones of the list's mean size (the
+    ceiling).  Device-resident images, destinations refreshed inside the step, wall time of pool.run (median of `reps`)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    sizes = [(int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))) for _ in range(n)]
+    Hd = Wd = hi + 64
+    yy, xx = np.mgrid[0:Hd, 0:Wd].astype(np.float32)
+    dst = np.clip((128.0 + 60.0 * np.sin(2 * np.pi * xx / Wd) * np.cos(2 * np.pi * yy / Hd))[:, :, None] +
+                  12.0 * rng.standard_normal((Hd, Wd, 3), dtype=np.float32), 0, 255).astype(np.uint8)
+    xx = np.arange(hi + 2, dtype=np.float32)[None, :, None]
+    patch = np.clip(110.0 + 50.0 * np.cos(3 * np.pi * xx / hi) + 20.0 * rng.standard_normal((hi + 2, hi + 2, 3), dtype=np.float32), 0, 255).astype(np.uint8)
+    g, k = capi.plan_groups(sizes, group)
+    planned = sorted((g.count(q) for q in set(g)), reverse=True)
+
+    def run(streams_, group_, sz, check=False):
+        pool = capi.Pool(0, streams=streams_, group=group_)
+        try:
+            inst = pool.instances[0]
+            jobs = pool.make_jobs(len(sz)); keep = []
+            d0 = inst.to_device(dst)
+            for j, (W, H) in zip(jobs, sz):
+                f, b, m = inst.to_device(np.ascontiguousarray(patch[:H + 2, :W + 2])), inst.to_device(dst), inst.to_device(np.full((H + 2, W + 2), 255, np.uint8))
+                keep += [f, b, m]
+                j.face, j.face_cols, j.face_rows, j.face_step = f, W + 2, H + 2, 3 * (W + 2)
+                j.body, j.body_cols, j.body_rows, j.body_step = b, Wd, Hd, 3 * Wd
+                j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, W + 2, H + 2, W + 2
+                j.centerX, j.centerY, j.body_restore = Wd // 2, Hd // 2, d0
+            pool.run(jobs, device_resident=True); pool.run(jobs, device_resident=True)
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                pool.run(jobs, device_resident=True)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            first = inst.from_device(keep[1], dst.shape) if check else None
+            for p_ in keep + [d0]:
+                inst.free(p_)
+        finally:
+            pool.close()
+        t = ts[len(ts) // 2]
+        return {"ms_per_step": round(t * 1e3, 3), "Mpix_per_s": round(sum(w * h for w, h in sz) / t / 1e6, 1)}, first
+    mixed, a = run(streams, group, sizes, check=True)
+    ones, b = run(8, 1, sizes, check=True)
+    mean = int(round(float(np.sqrt(np.mean([w * h for w, h in sizes])))))
+    same, _ = run(streams, group, [(mean, mean)] * n)
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    return {"roi_range": [lo, hi], "clones": n, "streams": streams, "group": group, "planned_groups": planned,
+            "Mpix_per_s": mixed["Mpix_per_s"], "ms_per_step": mixed["ms_per_step"],
+            "one_clone_at_a_time_8_streams": ones, "same_size_%d" % mean: same,
+            "ratio_to_same_size": round(mixed["Mpix_per_s"] / same["Mpix_per_s"], 3),
+            "first_member_vs_its_solo_clone": {"maxdiff": int(d.max()), "percent_differing": round(float((d > 0).mean() * 100), 4)},
+            "note": "64 clones with 64 different ROI sizes, random in [%d, %d]^2, through the pool as configured: members of one size class (same "
+                    "hierarchy depth and bottom solve, widths and heights within 1/8) share one set of solver launches through a per-member geometry "
+                    "table; every member's bytes are its solo run's whenever the group takes the solo run's cycle count" % (lo, hi)}
 
 
 def launch_ranks(args):
@@ -845,6 +905,9 @@ def main():
     new_size = None
     if comm.rank == 0 and args.gpus == 1 and not args.no_new_size and args.config == "c3":
         new_size = new_size_leg(capi)
+    mixed_sizes = None
+    if comm.rank == 0 and args.gpus == 1 and not args.no_mixed_sizes and args.config == "c3":
+        mixed_sizes = mixed_sizes_leg(capi)
     total_pix = comm.sum(float(W * H * args.batch)) * args.steps
     value = total_pix / elapsed / 1e6
     step_traffic = profile.get("step_traffic_bytes") if profile else None
@@ -894,6 +957,7 @@ def main():
                               {"bytes_per_step": None, "frac_of_peak": None, "traffic_stale": traffic_stale}),
         "pcie": pcie,
         "new_size": new_size,
+        "mixed_sizes": mixed_sizes,
     }
     if comm.rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(dst, patch, mask, cx, cy, out_float, out_exact, args.cpu_seconds)

@@ -28,21 +28,43 @@ int hip_fail(Instance *I, hipError_t e, const char *what)
     return SC_ERR_HIP;
 }
 
-int ensure(Instance *I, DevBuf &b, size_t bytes)
+// Grow-only, amortised (the reference's SCImage::resize, seamlessClone_imp.h:83,119-121,137-149).  Round 5: growth stays off the
+// stream's critical path -- the new block is allocated FIRST, with no wait on the stream, and the block it replaces is RETIRED, not
+// freed: launches already queued keep reading and writing it, and hipFree (a device-wide synchronisation that also stalls the other
+// instances of a pool) happens once, when the instance is destroyed.  Capacities double, so the retired blocks of a buffer add up to
+// less than its final size.  (Rounds 1-4: stream synchronisation + hipFree + hipMalloc + a memset of the whole new capacity inside
+// the call that happened to need more -- the p95 / max of the first call at a new ROI size: 1.6x / 4.0x the steady call.)
+// zero: the caller reads the block before it writes it (tables with zero padding, accumulation buffers); the large blocks -- fields,
+// level planes, image staging -- are written before they are read (or their unwritten parts only ever reach masked lanes) and skip it.
+int ensure(Instance *I, DevBuf &b, size_t bytes, bool zero)
 {
     if (bytes <= b.cap) return SC_OK;
-    size_t ncap = bytes > 2 * b.cap ? bytes : 2 * b.cap; // grow-only, amortised (seamlessClone_imp.h:83,119-121)
+    size_t ncap = bytes > 2 * b.cap ? bytes : 2 * b.cap;
     ncap = (ncap + 4095) & ~(size_t)4095;
-    if (b.p) {
-        SC_HIP(I, hipStreamSynchronize(I->stream));
-        SC_HIP(I, hipFree(b.p));
-        I->arena_bytes -= b.cap;
-        b.p = nullptr; b.cap = 0;
+    void *np = nullptr;
+    bool own = true;
+    constexpr size_t SLAB_FIRST = (size_t)16 << 20, SLAB_PIECE_MAX = (size_t)8 << 20;
+    if (ncap <= SLAB_PIECE_MAX) {          // a piece of a slab: no hipMalloc unless the slabs are used up
+        if (I->slabs.empty() || I->slabs.back().cap - I->slabs.back().used < ncap) {
+            Instance::Slab sl;
+            sl.cap = I->slabs.empty() ? SLAB_FIRST : 2 * I->slabs.back().cap;
+            SC_HIP(I, hipMalloc((void **)&sl.base, sl.cap));
+            I->arena_bytes += sl.cap;
+            I->slabs.push_back(sl);
+        }
+        Instance::Slab &sl = I->slabs.back();
+        np = sl.base + sl.used;
+        sl.used += ncap;                   // (ncap is a multiple of 4096: every piece is page aligned)
+        own = false;
+    } else {
+        SC_HIP(I, hipMalloc(&np, ncap));
+        I->arena_bytes += ncap;
     }
-    SC_HIP(I, hipMalloc(&b.p, ncap));
-    SC_HIP(I, hipMemsetAsync(b.p, 0, ncap, I->stream));
+    if (zero) SC_HIP(I, hipMemsetAsync(np, 0, ncap, I->stream));
+    if (b.p && b.own) I->retired.push_back(b);      // (a replaced slab piece simply stays unused)
+    b.p = np;
     b.cap = ncap;
-    I->arena_bytes += ncap;
+    b.own = own;
     return SC_OK;
 }
 
@@ -158,9 +180,9 @@ int setup_fields(Instance *I, int W, int H, int C)
     Field proto = make_field(nullptr, W, H, C);
     const size_t bytes = proto.bytes() + 4096;
     int rc;
-    if ((rc = ensure(I, I->d_U0, bytes))) return rc;
-    if ((rc = ensure(I, I->d_U1, bytes))) return rc;
-    if ((rc = ensure(I, I->d_F, bytes))) return rc;
+    if ((rc = ensure(I, I->d_U0, bytes, false))) return rc;
+    if ((rc = ensure(I, I->d_U1, bytes, false))) return rc;
+    if ((rc = ensure(I, I->d_F, bytes, false))) return rc;
     const bool same = I->F.p == I->d_F.p && I->U0.p == I->d_U0.p && I->U1.p == I->d_U1.p && I->F.W == W &&
                       I->F.H == H && I->F.C == C;
     I->U0 = make_field(I->d_U0.p, W, H, C);
@@ -245,7 +267,7 @@ static int bbox_enqueue(Instance *I, const uint8_t *d_mask, int mc, int mr, int 
         // A clone launched on a predicted box needs the scan's answer only at its end: the erode of the predicted ROI goes out
         // alone and the scan rides in the pre-process launch behind it (device_clone, launch_preprocess) -- off the critical path.
         I->mpitch = round_up(predicted->W, 64);
-        rc = ensure(I, I->d_M, (size_t)I->mpitch * predicted->H);
+        rc = ensure(I, I->d_M, (size_t)I->mpitch * predicted->H, false);
         if (rc) return rc;
         // (round 4, late: no erode launch either -- the pre-process tiles form the eroded mask themselves and leave it in d_M)
         I->erode_done = true;
@@ -324,7 +346,7 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
     if (!out_org) { out_org = body_org; ostep = bstep; }
     int rc;
     I->mpitch = round_up(g.W, 64);
-    if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
+    if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H, false))) return rc;
     if ((rc = setup_fields(I, g.W, g.H, 3))) return rc;
     const bool eroded = I->erode_done;
     const bool grey = (I->opts.flags & SC_FLAG_OPENCV_GREY_MASK) != 0;
@@ -473,31 +495,33 @@ void my_seamlessclone_api_imp_destroy(void *p)
     (void)hipSetDevice(I->gpu);
     if (I->stream) (void)hipStreamSynchronize(I->stream);
     if (I->aux) (void)hipStreamSynchronize(I->aux);
+    for (DevBuf &b : I->retired) dev_release(b);                    // blocks that growth replaced (ensure)
+    for (Instance::Slab &sl : I->slabs) if (sl.base) (void)hipFree(sl.base);
     DevBuf *bufs[] = { &I->d_face, &I->d_body_roi, &I->d_out, &I->d_mask, &I->d_M, &I->d_U0, &I->d_U1, &I->d_F };
-    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
-    for (DevBuf &b : I->mg_bufs) if (b.p) (void)hipFree(b.p);
-    if (I->mg_partial.p) (void)hipFree(I->mg_partial.p);
+    for (DevBuf *b : bufs) dev_release(*b);
+    for (DevBuf &b : I->mg_bufs) dev_release(b);
+    dev_release(I->mg_partial);
     if (I->h_partial.p) (void)hipHostFree(I->h_partial.p);
-    for (DevBuf *b : { &I->lm.P, &I->lm.E, &I->lm.CN, &I->lm.B, &I->lm.maps[0].d, &I->lm.maps[1].d }) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : { &I->lm.P, &I->lm.E, &I->lm.CN, &I->lm.B, &I->lm.maps[0].d, &I->lm.maps[1].d }) dev_release(*b);
     for (LowMode::Tables &t : I->lm.tables) {          // (lm.Sx / Sy / R are views of one of these)
-        for (DevBuf *b : { &t.Sx, &t.Sy, &t.R }) if (b->p) (void)hipFree(b->p);
+        for (DevBuf *b : { &t.Sx, &t.Sy, &t.R }) dev_release(*b);
         if (t.hR.p) (void)hipHostFree(t.hR.p);
         if (t.ev) (void)hipEventDestroy(t.ev);
     }
     for (auto &m : I->lm.maps) if (m.h.p) (void)hipHostFree(m.h.p);
-    for (DevBuf *b : { &I->dst.Sw, &I->dst.Sh, &I->dst.fxy, &I->dst.G, &I->dst.T1, &I->dst.T2 }) if (b->p) (void)hipFree(b->p);
+    for (DevBuf *b : { &I->dst.Sw, &I->dst.Sh, &I->dst.fxy, &I->dst.G, &I->dst.T1, &I->dst.T2 }) dev_release(*b);
     if (I->dst.hfxy.p) (void)hipHostFree(I->dst.hfxy.p);
-    for (DevBuf *b : { &I->fft.A, &I->fft.B, &I->fft.tw64 }) if (b->p) (void)hipFree(b->p);
-    for (FftDim &d : I->fft.dims) if (d.chirp.p) (void)hipFree(d.chirp.p);
+    for (DevBuf *b : { &I->fft.A, &I->fft.B, &I->fft.tw64 }) dev_release(*b);
+    for (FftDim &d : I->fft.dims) dev_release(d.chirp);
     for (FftFxy &f : I->fft.fxy) {
-        if (f.d.p) (void)hipFree(f.d.p);
+        dev_release(f.d);
         if (f.hst.p) (void)hipHostFree(f.hst.p);
         if (f.ev) (void)hipEventDestroy(f.ev);
     }
     if (I->fft.ev_fork) (void)hipEventDestroy(I->fft.ev_fork);
     if (I->fft.ev_built) (void)hipEventDestroy(I->fft.ev_built);
-    if (I->mg_fd.p) (void)hipFree(I->mg_fd.p);
-    if (I->rag.d_aux.p) (void)hipFree(I->rag.d_aux.p);
+    dev_release(I->mg_fd);
+    dev_release(I->rag.d_aux);
     if (I->rag.h_stage.p) (void)hipHostFree(I->rag.h_stage.p);
     if (I->rag.ev) (void)hipEventDestroy(I->rag.ev);
     if (I->rag.ev_ready) (void)hipEventDestroy(I->rag.ev_ready);
@@ -505,8 +529,8 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->ev_fd) (void)hipEventDestroy(I->ev_fd);
     if (I->ev_scan) (void)hipEventDestroy(I->ev_scan);
     if (I->d_rect) (void)hipFree(I->d_rect);
-    if (I->d_rects.p) (void)hipFree(I->d_rects.p);
-    if (I->d_bbox_parts.p) (void)hipFree(I->d_bbox_parts.p);
+    dev_release(I->d_rects);
+    dev_release(I->d_bbox_parts);
     if (I->h_rects.p) (void)hipHostFree(I->h_rects.p);
     if (I->d_partials) (void)hipFree(I->d_partials);
     if (I->d_red) (void)hipFree(I->d_red);
@@ -678,7 +702,7 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     // --- mask to the device, bounding box
     const bool whole_m = 4 * (size_t)mc >= 3 * (size_t)ms;      // (not a narrow view of a much wider image): one linear copy at the caller's step
     const int dms = whole_m ? ms : round_up(mc, 256);
-    if ((rc = ensure(I, I->d_mask, (size_t)dms * mr + 64))) return rc;
+    if ((rc = ensure(I, I->d_mask, (size_t)dms * mr + 64, false))) return rc;
     I->stage_marks = true;         // a host-image call is synchronous whatever bSync says: its timeline is always read
     I->marks_ends_only = (I->opts.flags & SC_FLAG_NO_STAGE_MARKS) != 0;      // (... unless the caller gives the per-stage figures up for their ~5 us bubbles)
     if ((rc = tmark(I, 0))) return rc;
@@ -709,9 +733,9 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         const bool whole_b = 4 * 3 * (size_t)g.W >= 3 * (size_t)bs || few_extra(bs);
         const int fpitch = whole_f ? fs : dfs, bpitch = whole_b ? bs : dfs;
         const size_t foff = whole_f ? 3 * (size_t)g.x0 : 0, boff = whole_b ? 3 * (size_t)g.ltx : 0;
-        if ((r = ensure(I, I->d_face, (size_t)fpitch * g.H + 64))) return r;
-        if ((r = ensure(I, I->d_body_roi, (size_t)bpitch * g.H + 64))) return r;
-        if ((r = ensure(I, I->d_out, (size_t)dfs * g.H + 64))) return r;
+        if ((r = ensure(I, I->d_face, (size_t)fpitch * g.H + 64, false))) return r;
+        if ((r = ensure(I, I->d_body_roi, (size_t)bpitch * g.H + 64, false))) return r;
+        if ((r = ensure(I, I->d_out, (size_t)dfs * g.H + 64, false))) return r;
         if (whole_f) SC_HIP(I, hipMemcpyAsync(I->d_face.p, face + (size_t)g.y0 * fs, (size_t)fs * (g.H - 1) + foff + 3 * (size_t)g.W, hipMemcpyHostToDevice, I->stream));
         else if ((r = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return r;
         if (whole_b) SC_HIP(I, hipMemcpyAsync(I->d_body_roi.p, body + (size_t)g.lty * bs, (size_t)bs * (g.H - 1) + boff + 3 * (size_t)g.W, hipMemcpyHostToDevice, I->stream));
@@ -934,7 +958,7 @@ int run_group_members(Instance *I, sc_batch_job *jobs, const std::vector<int> &i
     int rc;
     I->mpitch = round_up(g0.W, 64);
     const size_t mplane = (size_t)I->mpitch * g0.H;
-    if ((rc = ensure(I, I->d_M, mplane * n))) return rc;
+    if ((rc = ensure(I, I->d_M, mplane * n, false))) return rc;
     if ((rc = setup_fields(I, g0.W, g0.H, 3 * n))) return rc;
     RagScope scope{ I };
     if (plans && (rc = rag_begin(I, *plans))) return rc;
@@ -1238,7 +1262,7 @@ int sc_hip_mask_stage(void *p, const uint8_t *mask, int mc, int mr, int ms, int 
     fill_info_geo(I, g);
     geo[0] = g.x0; geo[1] = g.y0; geo[2] = g.W; geo[3] = g.H; geo[4] = g.ltx; geo[5] = g.lty;
     I->mpitch = round_up(g.W, 64);
-    if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H))) return rc;
+    if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H, false))) return rc;
     if (I->opts.flags & SC_FLAG_OPENCV_GREY_MASK) launch_mask_erode_min7((const uint8_t *)I->d_mask.p, dms, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
     else launch_mask_erode3((const uint8_t *)I->d_mask.p, dms, mr, g, (uint8_t *)I->d_M.p, I->mpitch, I->stream);
     SC_HIP(I, hipGetLastError());

@@ -130,17 +130,21 @@ __host__ __device__ __attribute__((always_inline)) inline FdPair fd_pair(int k, 
         p.kind = 2;
         lo = 0.0; hi = 2.0; flo = 1.0;                  // fd_g_hyp -> s / n > 0 at 0+, < 0 at 2
         // regula falsi with the Illinois correction on the bracket (fd_g_hyp is smooth and monotone there): ~10 evaluations
-        double fl = s / n, fh = fd_g_hyp(hi, n, cw, d);
+        // (the false-position estimate converges from one side: the BRACKET need not shrink to a point -- the estimate is the answer,
+        // and it has converged when it stops moving)
+        double fl = s / n, fh = fd_g_hyp(hi, n, cw, d), est = 1.0, prev = -1.0;
         int side = 0;
-        for (int it = 0; it < 80; ++it) {
-            double mid = (lo * fh - hi * fl) / (fh - fl);
-            if (!(mid > lo && mid < hi)) mid = 0.5 * (lo + hi);
-            const double f = fd_g_hyp(mid, n, cw, d);
-            if ((f > 0.0) == (flo > 0.0)) { lo = mid; fl = f; if (side == -1) fh *= 0.5; side = -1; }
-            else { hi = mid; fh = f; if (side == 1) fl *= 0.5; side = 1; }
-            if (f == 0.0 || hi - lo <= 4.5e-16 * hi) break;
+        for (int it = 0; it < 100; ++it) {
+            est = (lo * fh - hi * fl) / (fh - fl);
+            if (!(est > lo && est < hi)) est = 0.5 * (lo + hi);
+            if (fabs(est - prev) <= 4.5e-16 * est) break;
+            prev = est;
+            const double f = fd_g_hyp(est, n, cw, d);
+            if (f == 0.0) break;
+            if ((f > 0.0) == (flo > 0.0)) { lo = est; fl = f; if (side == -1) fh *= 0.5; side = -1; }
+            else { hi = est; fh = f; if (side == 1) fl *= 0.5; side = 1; }
         }
-        p.ang = 0.5 * (lo + hi);
+        p.ang = est;
         const double sh = sinh(0.5 * p.ang);
         p.lam = -4.0 - 4.0 * sh * sh;
     } else if (2 * (k + 1) <= n) {                      // the interval lies in the lower half: theta itself

@@ -13,7 +13,10 @@ namespace sc {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool own = true;       // false: a piece of one of the instance's slabs (Instance::slabs) -- not a hipMalloc block of its own, never hipFree'd
 };
+// releases a device buffer on instance teardown: its own hipMalloc block, or nothing for a piece of a slab
+inline void dev_release(DevBuf &b) { if (b.p && b.own) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
 // eigen-decomposition of one 1-D level operator (sc_multigrid.cpp, fast-diagonalisation bottom solve)
 struct FD1 {
@@ -214,6 +217,11 @@ struct Instance {
     hipEvent_t tm[8]{};   // stage marks of the current run: ev[k], or the previous mark where a stage is empty (no record call)
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     size_t arena_bytes = 0;
+    std::vector<DevBuf> retired;           // device blocks that growth replaced: freed when the instance goes (ensure, sc_api.cpp)
+    // Small device buffers are pieces of a few SLABS (16 MB, then doubling) instead of hipMalloc blocks of their own: an instance owns
+    // ~40 grow-only buffers, and a caller whose ROI sizes wander re-sizes several of them in one call -- each a hipMalloc of 30-100 us
+    struct Slab { uint8_t *base = nullptr; size_t cap = 0, used = 0; };
+    std::vector<Slab> slabs;
 
     bool ok() const { return magic == 0x5C10E001u; }
 };
@@ -233,7 +241,7 @@ int hip_fail(Instance *I, hipError_t e, const char *what);
         if (e_ != hipSuccess) return hip_fail((I), e_, #call);            \
     } while (0)
 
-int ensure(Instance *I, DevBuf &b, size_t bytes);
+int ensure(Instance *I, DevBuf &b, size_t bytes, bool zero = true);
 int ensure_pinned(Instance *I, DevBuf &b, size_t bytes);
 double fd_selftest_error();   // sc_multigrid.cpp
 double fd_closed_selftest_error();

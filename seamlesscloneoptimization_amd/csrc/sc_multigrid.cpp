@@ -395,7 +395,7 @@ static int build_levels(Instance *I)
         const int Wl = L.g.x.n + 2, Hl = L.g.y.n + 2;
         Field proto = level_field(nullptr, Wl, Hl, C);
         for (int k = 0; k < 3; ++k) {
-            int rc = ensure(I, I->mg_bufs[3 * l + k], proto.bytes() + 4096);
+            int rc = ensure(I, I->mg_bufs[3 * l + k], proto.bytes() + 4096, false);      // (zeroed below, by the launch that zeroes every plane)
             if (rc) return rc;
         }
         L.U = level_field(I->mg_bufs[3 * l + 0].p, Wl, Hl, C);
@@ -461,7 +461,7 @@ int mg_build_levels_rag(Instance *I, hipStream_t zero_on)
         const int Wl = L.g.x.n + 2, Hl = L.g.y.n + 2;
         Field proto = level_field(nullptr, Wl, Hl, C);
         for (int k = 0; k < 3; ++k) {
-            int rc = ensure(I, I->mg_bufs[3 * l + k], proto.bytes() + 4096);
+            int rc = ensure(I, I->mg_bufs[3 * l + k], proto.bytes() + 4096, false);      // (zeroed below, by the launch that zeroes every plane)
             if (rc) return rc;
         }
         L.U = level_field(I->mg_bufs[3 * l + 0].p, Wl, Hl, C);
