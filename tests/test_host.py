@@ -376,3 +376,15 @@ def test_per_rank_elapsed_is_gathered_beside_the_maximum(tmp_path):
     stub.write_text(_GATHER)
     rc, out = spawn_ranks(2, [sys.executable, str(stub)], extra_env={"SC_ROOT": ROOT})
     assert rc == 0 and "rank 0 gather ok" in out
+
+
+def test_host_side_sanitizers_are_clean():
+    """the library's host code -- every source compiled for the HOST ONLY by ROCm's clang -- under
+    AddressSanitizer + UndefinedBehaviorSanitizer and, separately, ThreadSanitizer (`make sanitize`, csrc/sanitize_main.cpp): the row
+    copier across its parked helper threads, both eigen-solvers, the part maps, the memoised size plans from six threads at once, the
+    pool's hand-out of jobs (groups formed, every job exactly once, codes copied back) against stub instances.  No GPU involved."""
+    import subprocess
+    csrc = os.path.join(ROOT, "seamlesscloneoptimization_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "-j4", "-s", "sanitize"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert r.stdout.count("sanitize_main: clean") == 2, r.stdout[-2000:]
