@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--host-calls", type=int, default=24, help="timed drop-in host-image calls of the `pcie` leg (median / p95 / min are reported)")
     ap.add_argument("--no-float32-leg", action="store_true", help="skip value_float32_storage (the same timed step with float32 fields and right-hand side)")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip value_without_in_step_restore (up to 16 steps, each into its own pre-resident destinations: 0.43 GB of HBM per step)")
+    ap.add_argument("--no-c5-projection", action="store_true", help="skip the c5_projected_at_8 leg (config 5's 8-image shard on this GPU, x 8)")
     ap.add_argument("--no-mixed-sizes", action="store_true", help="skip the mixed_sizes leg (64 clones of 64 different ROI sizes through the pool)")
     ap.add_argument("--no-new-size", action="store_true", help="skip the new_size leg (first call at a ROI size the instance has not seen)")
     ap.add_argument("--no-c4", action="store_true", help="skip the roofline_c4 leg (config 4: single-sweep Jacobi kernels at a 4096^2 ROI, HBM bound)")
@@ -354,6 +355,7 @@ def new_size_leg(capi, seed=4):
         dev = upload(inst)
         call(inst, dev, 2402, 2402)                 # grow the arena once: from here on a new size costs its per-size state only
         call(inst, dev, 902, 902)
+        call(inst, dev, capi.SC_AUTO_DIRECT_MAX + 2, capi.SC_AUTO_DIRECT_MAX + 2)      # ... and the direct solve's work planes (the two calls above ran the cycles)
         for name, lo, hi in (("roi_100_720", 100, capi.SC_AUTO_DIRECT_MAX), ("roi_1000_2400", 1000, 2400)):
             first, steady, seen = [], [], set()
             while len(first) < 64:
@@ -437,6 +439,57 @@ def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, s
             "note": "64 clones with 64 different ROI sizes, random in [%d, %d]^2, through the pool as configured: members of one size class (same "
                     "hierarchy depth and bottom solve, widths and heights within 1/8) share one set of solver launches through a per-member geometry "
                     "table; every member's bytes are its solo run's whenever the group takes the solo run's cycle count" % (lo, hi)}
+
+
+def c5_projection_leg(capi, reps=8):
+    """BASELINE config 5 at N = 8, projected from ONE GPU (no 8-GPU node is available to this build): at N = 8 every rank clones 8 of
+    the 64 independent 1024 x 1024 images with no interaction whatsoever, so a rank's time is this GPU's time for ITS 8 images and the
+    job's throughput is 8 x that shard's (max over ranks = any rank: the shards are alike).  Times rank 0's shard -- images 0, 8, ...,
+    56 of --config c5 -- under every stream x group split of 8 images, and all 64 images on this GPU (N = 1: 2 streams x groups of
+    32) for the strong-scaling efficiency to expect."""
+    import numpy as np
+    gen = BatchSynth(1024, 3000)
+
+    def run(ids, streams, group):
+        pool = capi.Pool(0, streams=streams, group=group)
+        try:
+            inst = pool.instances[0]
+            jobs = pool.make_jobs(len(ids)); keep = []
+            for j, k in zip(jobs, ids):
+                dst, patch, mask, cx, cy = gen.image(k)
+                f, b0, b, m = inst.to_device(patch), inst.to_device(dst), inst.to_device(dst), inst.to_device(mask)
+                keep += [f, b0, b, m]
+                j.face, j.face_cols, j.face_rows, j.face_step = f, patch.shape[1], patch.shape[0], 3 * patch.shape[1]
+                j.body, j.body_cols, j.body_rows, j.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
+                j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
+                j.centerX, j.centerY, j.body_restore = cx, cy, b0
+            pool.run(jobs, device_resident=True); pool.run(jobs, device_resident=True)
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                pool.run(jobs, device_resident=True)
+                ts.append(time.perf_counter() - t0)
+            for p_ in keep:
+                inst.free(p_)
+        finally:
+            pool.close()
+        ts.sort()
+        return ts[len(ts) // 2]
+    shard = list(range(0, 64, 8))
+    splits = {}
+    for streams, group in ((1, 8), (2, 4), (4, 2), (8, 1)):
+        t = run(shard, streams, group)
+        splits["%dx%d" % (streams, group)] = {"ms": round(t * 1e3, 3), "Mpix_per_s": round(8 * 1024 * 1024 / t / 1e6, 1)}
+    best = max(splits, key=lambda k: splits[k]["Mpix_per_s"])
+    t64 = run(list(range(64)), 2, 32)
+    n1 = 64 * 1024 * 1024 / t64 / 1e6
+    proj = 8 * splits[best]["Mpix_per_s"]
+    return {"Mpix_per_s": round(proj, 1), "shard_of_8": {"images": shard, "split_streams_x_group": best, "Mpix_per_s": splits[best]["Mpix_per_s"], "all_splits": splits},
+            "n1_all_64_images": {"split_streams_x_group": "2x32", "ms": round(t64 * 1e3, 3), "Mpix_per_s": round(n1, 1)},
+            "strong_scaling_efficiency_expected_at_8": round(proj / (8 * n1), 3),
+            "note": "config 5 at N = 8 = 8 images per GPU, no communication: 8 x (this GPU's throughput on rank 0's shard, best stream x group "
+                    "split); the efficiency below 1 is a per-GPU batch-size effect (8 images fill the chip less well than 64), not a "
+                    "communication one -- NOT a measured 8-GPU number"}
 
 
 def launch_ranks(args):
@@ -908,6 +961,9 @@ def main():
     mixed_sizes = None
     if comm.rank == 0 and args.gpus == 1 and not args.no_mixed_sizes and args.config == "c3":
         mixed_sizes = mixed_sizes_leg(capi)
+    c5_projected = None
+    if comm.rank == 0 and args.gpus == 1 and not args.no_c5_projection and args.config == "c3":
+        c5_projected = c5_projection_leg(capi)
     total_pix = comm.sum(float(W * H * args.batch)) * args.steps
     value = total_pix / elapsed / 1e6
     step_traffic = profile.get("step_traffic_bytes") if profile else None
@@ -920,6 +976,11 @@ def main():
         "dtype": ("f32" if (opts["flags"] & capi.SC_FLAG_FLOAT_FIELD and opts["flags"] & capi.SC_FLAG_FLOAT_RHS) or args.method != "mg" else
                   "f32 (arithmetic); storage: 16-bit fixed-point field on the first two level-0 stores of a solve, float16 right-hand side and level 1"),
         "data": "synthetic",
+        "data_generator": ("BatchSynth: SURVEY 8d's smooth parts + ONE pair of unit-variance noise fields per rank (seed %s), image k = smooth + sigma x the "
+                           "noise rolled by a k-dependent offset, clipped to 8 bits -- the statistics of synth(roi, seed), not its exact pixels (round 4: "
+                           "~0.1 s per image instead of ~0.8); image 0 of rank 0 is synth(roi, 0) itself -- the CPU baseline and the parity figures use it%s"
+                           % ("3000 + rank" if image_ids is not None else "1001 + 7919 x rank",
+                              "; config 5's images are NOT the per-image seeds 3000 + i of SURVEY 8d" if image_ids is not None else "")),
         "config": {"workload": (f"BASELINE config 5: 64 independent {W}x{H}-ROI clones in total, image i on rank i mod {args.gpus} (this rank: {args.batch}); "
                                 if args.config == "c5" else "") +
                                f"{args.batch} independent {W}x{H}-ROI NORMAL_CLONEs per GPU per step on {streams} HIP "
@@ -958,6 +1019,7 @@ def main():
         "pcie": pcie,
         "new_size": new_size,
         "mixed_sizes": mixed_sizes,
+        "c5_projected_at_8": c5_projected,
     }
     if comm.rank == 0 and args.gpus == 1 and args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(dst, patch, mask, cx, cy, out_float, out_exact, args.cpu_seconds)

@@ -565,8 +565,8 @@ static int fft_solve_t(Instance *I)
     if ((rc = fft_build_dim<T>(I, dh, h, dw))) { for (int k = 0; k < S.nreq; ++k) S.req[k]->n = 0; S.nreq = 0; return rc; }      // (queued entries hold no tables yet)
     if ((rc = fft_flush_builds<T>(I))) return rc;
     const size_t plane = (size_t)w * h;
-    if ((rc = ensure(I, S.A, sizeof(T) * plane * C))) return rc;
-    if ((rc = ensure(I, S.B, sizeof(T) * plane * C))) return rc;
+    if ((rc = ensure(I, S.A, sizeof(T) * plane * C, false))) return rc;      // (every launch below writes the whole plane it hands on)
+    if ((rc = ensure(I, S.B, sizeof(T) * plane * C, false))) return rc;
     if ((rc = fft_fxy(I, X, w, h))) return rc;
     if (S.pending) {                  // tables of a new length are being built on the second stream
         SC_HIP(I, hipStreamWaitEvent(I->stream, S.ev_built, 0));
