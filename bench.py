@@ -737,10 +737,18 @@ def main():
                             "into two of half the size (flop_per_clone counts what is executed: half of the plain matrix form); peak = MI355X "
                             "FP64 matrix spec; solve stage of one clone by hipEvents (includes the fold / unfold kernels)"}
 
-    nfft = 1
+    nfft = 2                                   # the library's choice (sc_fft.hip fft_len): the shortest r 2^k >= 2n - 1, r in {1, 3, 5}
     while nfft < 2 * (W - 2) - 1:
         nfft *= 2
-    lg = nfft.bit_length() - 1
+    for r_ in (3, 5):
+        k_ = 4
+        while (r_ << k_) < nfft:
+            if (r_ << k_) >= 2 * (W - 2) - 1:
+                nfft = r_ << k_
+                break
+            k_ += 1
+    import math
+    lg = math.log2(nfft)
     fft_flop = 3.0 * 4 * (W - 2) * 2 * 5.0 * nfft * lg            # 4 DST passes x rows x 2 FFTs x 5 M log2 M, 3 channels
     fft_bytes = 3.0 * (W - 2) * (H - 2) * 4 * (2 + 2 + 2 + 2 + 2 + 1)   # five launches read + write a float per unknown; the first reads F, the last writes U
     df = np.abs(out_fft.astype(np.int16) - out_float.astype(np.int16))

@@ -49,8 +49,10 @@ struct FftPlan {                                       // one direction (by valu
     const cx2<T> *chirp;                               // c_m, m = 0 .. n
     const cx2<T> *bhat;                                // transform of the chirp kernel, digit-reversed order, scaled by 1/M
     const cx2<T> *tw;                                  // exp(-2 pi i k / M), k = 0 .. M-1
-    int n, M, logM, npass;
-    int lr[4];                                         // log2 of the radix of each forward pass
+    const cx2<T> *tw2;                                 // exp(-2 pi i k / 2^logM), k = 0 .. 2^logM - 1 (== tw when M is a power of two)
+    int n, M, logM, npass;                             // M = r 2^logM, r = 1, 3 or 5 (round 5: mixed-radix lengths)
+    int r;
+    int lr[4];                                         // log2 of the radix of each forward power-of-two pass
 };
 
 template <typename T> __device__ __forceinline__ cx2<T> cmulf(cx2<T> a, cx2<T> b) { return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -117,14 +119,79 @@ __device__ __forceinline__ void twiddle_powers(cx2<T> (&w)[R], const cx2<T> *__r
     }
 }
 
+// 3- and 5-point DFTs in registers, natural order in and out (the odd factor of a mixed-radix length M = 3 2^k or 5 2^k)
+template <int RR, int SGN, typename T>
+__device__ __forceinline__ void dft_odd(cx2<T> (&v)[RR])
+{
+    if constexpr (RR == 3) {
+        const T S3 = (T)0.86602540378443865;
+        const cx2<T> t1 = mk<T>(v[1].x + v[2].x, v[1].y + v[2].y);
+        const cx2<T> t2 = mk<T>(v[0].x - (T)0.5 * t1.x, v[0].y - (T)0.5 * t1.y);
+        const cx2<T> t3 = mk<T>(S3 * (v[1].x - v[2].x), S3 * (v[1].y - v[2].y));
+        v[0] = mk<T>(v[0].x + t1.x, v[0].y + t1.y);
+        if (SGN < 0) { v[1] = mk<T>(t2.x + t3.y, t2.y - t3.x); v[2] = mk<T>(t2.x - t3.y, t2.y + t3.x); }      // t2 -+ i t3
+        else         { v[1] = mk<T>(t2.x - t3.y, t2.y + t3.x); v[2] = mk<T>(t2.x + t3.y, t2.y - t3.x); }
+    } else {
+        static_assert(RR == 5, "odd factors: 3 and 5");
+        const T C1 = (T)0.30901699437494742, C2 = (T)-0.80901699437494742, S1 = (T)0.95105651629515357, S2 = (T)0.58778525229247313;
+        const cx2<T> t1 = mk<T>(v[1].x + v[4].x, v[1].y + v[4].y), t2 = mk<T>(v[2].x + v[3].x, v[2].y + v[3].y);
+        const cx2<T> t3 = mk<T>(v[1].x - v[4].x, v[1].y - v[4].y), t4 = mk<T>(v[2].x - v[3].x, v[2].y - v[3].y);
+        const cx2<T> m1 = mk<T>(v[0].x + C1 * t1.x + C2 * t2.x, v[0].y + C1 * t1.y + C2 * t2.y);
+        const cx2<T> m2 = mk<T>(v[0].x + C2 * t1.x + C1 * t2.x, v[0].y + C2 * t1.y + C1 * t2.y);
+        const cx2<T> n1 = mk<T>(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y), n2 = mk<T>(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
+        v[0] = mk<T>(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+        if (SGN < 0) {      // y1 = m1 - i n1, y4 = m1 + i n1, y2 = m2 - i n2, y3 = m2 + i n2
+            v[1] = mk<T>(m1.x + n1.y, m1.y - n1.x); v[4] = mk<T>(m1.x - n1.y, m1.y + n1.x);
+            v[2] = mk<T>(m2.x + n2.y, m2.y - n2.x); v[3] = mk<T>(m2.x - n2.y, m2.y + n2.x);
+        } else {
+            v[1] = mk<T>(m1.x - n1.y, m1.y + n1.x); v[4] = mk<T>(m1.x + n1.y, m1.y - n1.x);
+            v[2] = mk<T>(m2.x - n2.y, m2.y + n2.x); v[3] = mk<T>(m2.x + n2.y, m2.y - n2.x);
+        }
+    }
+}
+
+// The odd pass of a mixed-radix length M = RR s (s = 2^k), in front of the power-of-two passes: butterfly t takes elements
+// t + q s, q < RR; output q' = DFT_RR(.)[q'] w_M^(t q') goes back to place q' and is element t of sub-transform q', a power-of-two
+// transform of length s on the block [q' s, (q' + 1) s) -- what the passes below work through.  Twiddle indices t q' < M: no reduction.
+template <int RR, typename T>
+__device__ __forceinline__ void pass_odd_fwd(cx2<T> *__restrict__ S, int s, const cx2<T> *__restrict__ tw, int tid)
+{
+    for (int t = tid; t < s; t += FFT_THREADS) {
+        cx2<T> v[RR];
+#pragma unroll
+        for (int q = 0; q < RR; ++q) v[q] = S[fft_pad(t + q * s)];
+        dft_odd<RR, -1, T>(v);
+#pragma unroll
+        for (int q = 1; q < RR; ++q) v[q] = cmulf<T>(v[q], tw[t * q]);
+#pragma unroll
+        for (int q = 0; q < RR; ++q) S[fft_pad(t + q * s)] = v[q];
+    }
+}
+template <int RR, typename T>
+__device__ __forceinline__ void pass_odd_adj(cx2<T> *__restrict__ S, int s, const cx2<T> *__restrict__ tw, int tid)
+{
+    for (int t = tid; t < s; t += FFT_THREADS) {
+        cx2<T> v[RR];
+#pragma unroll
+        for (int q = 0; q < RR; ++q) v[q] = S[fft_pad(t + q * s)];
+#pragma unroll
+        for (int q = 1; q < RR; ++q) v[q] = cmulcf<T>(v[q], tw[t * q]);
+        dft_odd<RR, +1, T>(v);
+#pragma unroll
+        for (int q = 0; q < RR; ++q) S[fft_pad(t + q * s)] = v[q];
+    }
+}
+
 // One in-place Gentleman-Sande pass over S[0..M): sub-transforms of length L = 2^lL split by radix R = 2^LR.
 // Butterfly b = (blk, t): elements blk L + t + q (L/R); outputs y_q'[t] = DFT_R(.)[q'] w_L^(t q') stored at the same places.
+// (nblk > 1: the nblk independent power-of-two transforms of length 2^logM a mixed-radix length falls into behind its odd pass, laid
+// end to end: block index b >> ls runs over all of them, tw is the table of the power-of-two length)
 template <int LR, typename T>
-__device__ __forceinline__ void pass_fwd(cx2<T> *__restrict__ S, int logM, int lL, const cx2<T> *__restrict__ tw, int tid)
+__device__ __forceinline__ void pass_fwd(cx2<T> *__restrict__ S, int logM, int lL, const cx2<T> *__restrict__ tw, int tid, int nblk = 1)
 {
     constexpr int R = 1 << LR;
     const int M = 1 << logM, ls = lL - LR, s = 1 << ls, twsh = logM - lL;
-    for (int b = tid; b < (M >> LR); b += FFT_THREADS) {
+    for (int b = tid; b < nblk * (M >> LR); b += FFT_THREADS) {
         const int blk = b >> ls, t = b & (s - 1);
         const int base = (blk << lL) + t;
         cx2<T> v[R];
@@ -141,11 +208,11 @@ __device__ __forceinline__ void pass_fwd(cx2<T> *__restrict__ S, int logM, int l
 }
 // its adjoint (the passes of the inverse transform, applied in reverse order)
 template <int LR, typename T>
-__device__ __forceinline__ void pass_adj(cx2<T> *__restrict__ S, int logM, int lL, const cx2<T> *__restrict__ tw, int tid)
+__device__ __forceinline__ void pass_adj(cx2<T> *__restrict__ S, int logM, int lL, const cx2<T> *__restrict__ tw, int tid, int nblk = 1)
 {
     constexpr int R = 1 << LR;
     const int M = 1 << logM, ls = lL - LR, s = 1 << ls, twsh = logM - lL;
-    for (int b = tid; b < (M >> LR); b += FFT_THREADS) {
+    for (int b = tid; b < nblk * (M >> LR); b += FFT_THREADS) {
         const int blk = b >> ls, t = b & (s - 1);
         const int base = (blk << lL) + t;
         cx2<T> v[R];
@@ -163,30 +230,44 @@ __device__ __forceinline__ void pass_adj(cx2<T> *__restrict__ S, int logM, int l
 
 // S holds a_j = x_j c_j at j = 1..n and zeros elsewhere (synchronised).  On return S[k] = sum_j a_j conj(c_{k-j}), k = 1..n
 // (synchronised): forward passes, pointwise product with the chirp's transform, adjoint passes.
+// all forward passes of a plan (synchronised behind each): the odd pass of a mixed-radix length first, then the power-of-two passes
+// over its r blocks
 template <typename T>
-__device__ __forceinline__ void chirp_convolve(cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid)
+__device__ __forceinline__ void fft_forward(cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid)
 {
+    if (P.r == 3) { pass_odd_fwd<3>(S, 1 << P.logM, P.tw, tid); __syncthreads(); }
+    else if (P.r == 5) { pass_odd_fwd<5>(S, 1 << P.logM, P.tw, tid); __syncthreads(); }
     int lL = P.logM;
     for (int p = 0; p < P.npass; ++p) {
         const int lr = P.lr[p];
-        if (lr == 4) pass_fwd<4>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 3) pass_fwd<3>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 2) pass_fwd<2>(S, P.logM, lL, P.tw, tid);
-        else pass_fwd<1>(S, P.logM, lL, P.tw, tid);
+        if (lr == 4) pass_fwd<4>(S, P.logM, lL, P.tw2, tid, P.r);
+        else if (lr == 3) pass_fwd<3>(S, P.logM, lL, P.tw2, tid, P.r);
+        else if (lr == 2) pass_fwd<2>(S, P.logM, lL, P.tw2, tid, P.r);
+        else pass_fwd<1>(S, P.logM, lL, P.tw2, tid, P.r);
         lL -= lr;
         __syncthreads();
     }
+}
+
+template <typename T>
+__device__ __forceinline__ void chirp_convolve(cx2<T> *__restrict__ S, const FftPlan<T> &P, int tid)
+{
+    fft_forward<T>(S, P, tid);
     for (int i = tid; i < P.M; i += FFT_THREADS) S[fft_pad(i)] = cmulf<T>(S[fft_pad(i)], P.bhat[i]);
     __syncthreads();
+    int lL = P.logM;
+    for (int p = 0; p < P.npass; ++p) lL -= P.lr[p];
     for (int p = P.npass - 1; p >= 0; --p) {
         const int lr = P.lr[p];
         lL += lr;
-        if (lr == 4) pass_adj<4>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 3) pass_adj<3>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 2) pass_adj<2>(S, P.logM, lL, P.tw, tid);
-        else pass_adj<1>(S, P.logM, lL, P.tw, tid);
+        if (lr == 4) pass_adj<4>(S, P.logM, lL, P.tw2, tid, P.r);
+        else if (lr == 3) pass_adj<3>(S, P.logM, lL, P.tw2, tid, P.r);
+        else if (lr == 2) pass_adj<2>(S, P.logM, lL, P.tw2, tid, P.r);
+        else pass_adj<1>(S, P.logM, lL, P.tw2, tid, P.r);
         __syncthreads();
     }
+    if (P.r == 3) { pass_odd_adj<3>(S, 1 << P.logM, P.tw, tid); __syncthreads(); }
+    else if (P.r == 5) { pass_odd_adj<5>(S, 1 << P.logM, P.tw, tid); __syncthreads(); }
 }
 
 // folded right-hand side g = lap - ring neighbours (seamlessClone_imp.cpp:1992-2008) at interior point (x, y), 0-based
@@ -275,11 +356,19 @@ __global__ __launch_bounds__(256) void k_fft_transpose(const T *__restrict__ in,
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-static int fft_logm(int n)
+// The circular convolution's length for n unknowns: the shortest M = r 2^k >= 2n - 1 with r in {1, 3, 5} (round 5; powers of two only
+// until then: 592 unknowns -> 2048 where 1280 does, 300 -> 1024 where 640 does).  The reference hands cuFFT 2n + 2 whatever it is
+// (seamlessClone_imp.cpp:1694-1918).  Odd factors only in front of at least a 16-point power-of-two part.
+struct FftLen { int r, logM; int M() const { return r << logM; } };
+static FftLen fft_len(int n)
 {
-    int l = 1;
-    while ((1 << l) < 2 * n - 1) ++l;
-    return l;
+    const int need = std::max(2 * n - 1, 2);
+    FftLen best{ 1, 1 };
+    while (best.M() < need) ++best.logM;
+    for (int r : { 3, 5 })
+        for (int k = 4; (r << k) < best.M(); ++k)
+            if ((r << k) >= need) { best = FftLen{ r, k }; break; }
+    return best;
 }
 
 static void fft_radices(int logM, int lr[4], int &npass)
@@ -306,7 +395,7 @@ static void fft_radices(int logM, int lr[4], int &npass)
 // the workgroup writes chirp and twiddles, then transforms the chirp kernel with the twiddles it has just written (visible to itself
 // behind the barrier).
 template <typename TC, typename T>
-struct FftBuild { cx2<T> *chirp, *bhat, *tw; cx2<double> *tw64; FftPlan<TC> P; };      // P.tw: the twiddles the build's own transform reads (tw, or tw64 when TC is double and T float)
+struct FftBuild { cx2<T> *chirp, *bhat, *tw, *tw2; cx2<double> *tw64, *tw64_2; FftPlan<TC> P; };      // P.tw / P.tw2: the twiddles the build's own transform reads (tw / tw2, or their double twins when TC is double and T float); tw2 == nullptr: a power-of-two length (tw serves)
 template <typename TC, typename T>
 struct FftBuildPair { FftBuild<TC, T> b[2]; };
 
@@ -332,6 +421,12 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_build(FftBuildPair<TC, T> b
             B.tw[i] = mk<T>((T)cs, (T)sn);
             if (B.tw64) B.tw64[i] = mk<double>(cs, sn);
         }
+        if (B.tw2 && i < (1 << P.logM)) {                              // a mixed-radix length: the power-of-two passes' own table
+            double sn, cs;
+            sincospi(-2.0 * (double)i / (double)(1 << P.logM), &sn, &cs);
+            B.tw2[i] = mk<T>((T)cs, (T)sn);
+            if (B.tw64_2) B.tw64_2[i] = mk<double>(cs, sn);
+        }
     }
     for (int i = tid; i < M; i += FFT_THREADS) {                      // the chirp kernel, then its transform
         const int m = i <= M / 2 ? i : M - i;
@@ -347,16 +442,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_build(FftBuildPair<TC, T> b
     }
     __threadfence();
     __syncthreads();
-    int lL = P.logM;
-    for (int p = 0; p < P.npass; ++p) {
-        const int lr = P.lr[p];
-        if (lr == 4) pass_fwd<4>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 3) pass_fwd<3>(S, P.logM, lL, P.tw, tid);
-        else if (lr == 2) pass_fwd<2>(S, P.logM, lL, P.tw, tid);
-        else pass_fwd<1>(S, P.logM, lL, P.tw, tid);
-        lL -= lr;
-        __syncthreads();
-    }
+    fft_forward<TC>(S, P, tid);
     const TC inv = (TC)1 / (TC)M;
     for (int i = tid; i < M; i += FFT_THREADS) {
         const cx2<TC> v = S[fft_pad(i)];
@@ -371,7 +457,8 @@ static FftPlan<T> fft_plan_raw(const cx2<T> *chirp, int n, int logM)
     P.chirp = chirp;
     P.bhat = chirp + (n + 1);
     P.tw = P.bhat + ((size_t)1 << logM);
-    P.n = n; P.logM = logM; P.M = 1 << logM;
+    P.tw2 = P.tw;
+    P.n = n; P.logM = logM; P.M = 1 << logM; P.r = 1;
     fft_radices(logM, P.lr, P.npass);
     return P;
 }
@@ -391,16 +478,17 @@ static int fft_build_dim(Instance *I, FftDim *&out, int n, const FftDim *keep)
     }
     FftDim &D = *victim;
     I->info.new_size = 1;
-    const int logM = fft_logm(n), M = 1 << logM;
+    const FftLen L = fft_len(n);
+    const int logM = L.logM, M = L.M();
     int rc;
     if (S.pending && !S.forked && S.nreq == 0) {     // a build of an EARLIER solve nobody waited for: ordered in front of whatever follows on the main stream
         SC_HIP(I, hipStreamWaitEvent(I->stream, S.ev_built, 0));      // (ensure() waits for that stream before it frees a buffer)
         S.pending = false;
     }
-    const size_t bytes = sizeof(cx2<T>) * (3 * (size_t)M + 1);      // chirp[n + 1 <= M + 1] | bhat[M] | tw[M]: sized by M alone, so an entry is reallocated only when M grows
+    const size_t bytes = sizeof(cx2<T>) * (4 * (size_t)M + 1);      // chirp[n + 1 <= M + 1] | bhat[M] | tw[M] | tw2[2^logM <= M]: sized by M alone, so an entry is reallocated only when M grows
     D.n = 0;
     if ((rc = ensure(I, D.chirp, bytes))) return rc;
-    D.n = n; D.logM = logM; D.dbl = dbl; D.used = ++S.tick;
+    D.n = n; D.logM = logM; D.r = L.r; D.dbl = dbl; D.used = ++S.tick;
     S.req[S.nreq++] = &D;
     out = &D;
     return SC_OK;
@@ -417,10 +505,11 @@ static int fft_flush_builds(Instance *I)
     bool tcd[2] = { false, false };
     size_t maxM = 0;
     for (int k = 0; k < S.nreq; ++k) {
-        tcd[k] = dbl || S.req[k]->logM <= FFT_MAX_LOGM - 1;      // the build's own transform in double whenever its row fits the LDS
-        maxM = std::max(maxM, (size_t)1 << S.req[k]->logM);
+        tcd[k] = dbl || ((size_t)S.req[k]->r << S.req[k]->logM) <= ((size_t)1 << (FFT_MAX_LOGM - 1));      // the build's own transform in double whenever its row fits the LDS
+        maxM = std::max(maxM, (size_t)S.req[k]->r << S.req[k]->logM);
     }
-    if (!dbl && (tcd[0] || tcd[1]) && (rc = ensure(I, S.tw64, sizeof(cx2<double>) * 2 * maxM))) { for (int k = 0; k < S.nreq; ++k) S.req[k]->n = 0; S.nreq = 0; return rc; }
+    // (per direction: tw64[M] | tw64_2[2^logM])
+    if (!dbl && (tcd[0] || tcd[1]) && (rc = ensure(I, S.tw64, sizeof(cx2<double>) * 4 * maxM))) { for (int k = 0; k < S.nreq; ++k) S.req[k]->n = 0; S.nreq = 0; return rc; }
     if (!S.ev_fork) {
         SC_HIP(I, hipEventCreateWithFlags(&S.ev_fork, hipEventDisableTiming));
         SC_HIP(I, hipEventCreateWithFlags(&S.ev_built, hipEventDisableTiming));
@@ -437,34 +526,36 @@ static int fft_flush_builds(Instance *I)
         using TC = typename std::remove_reference<decltype(B.P)>::type;
         (void)sizeof(TC);
         FftDim &D = *S.req[k];
-        const int M = 1 << D.logM;
+        const int M = D.r << D.logM;
         cx2<T> *chirp = (cx2<T> *)D.chirp.p;
         B.chirp = chirp; B.bhat = chirp + (D.n + 1); B.tw = B.bhat + M;
-        B.tw64 = (!dbl && tcd[k]) ? (cx2<double> *)S.tw64.p + (size_t)k * maxM : nullptr;
+        B.tw2 = D.r > 1 ? B.tw + M : nullptr;
+        B.tw64 = (!dbl && tcd[k]) ? (cx2<double> *)S.tw64.p + (size_t)k * 2 * maxM : nullptr;
+        B.tw64_2 = (B.tw64 && D.r > 1) ? B.tw64 + M : nullptr;
         B.P.chirp = nullptr; B.P.bhat = nullptr;
-        B.P.n = D.n; B.P.logM = D.logM; B.P.M = M;
+        B.P.n = D.n; B.P.logM = D.logM; B.P.M = M; B.P.r = D.r;
         fft_radices(D.logM, B.P.lr, B.P.npass);
     };
     // directions whose builds run in the same arithmetic share a launch
     for (int k = 0; k < S.nreq;) {
         const int cnt = (k + 1 < S.nreq && tcd[k + 1] == tcd[k]) ? 2 : 1;
-        const size_t lds_elems = (size_t)fft_pad(1 << std::max(S.req[k]->logM, cnt > 1 ? S.req[k + 1]->logM : 0)) + 1;
+        const size_t lds_elems = (size_t)fft_pad(std::max(S.req[k]->r << S.req[k]->logM, cnt > 1 ? S.req[k + 1]->r << S.req[k + 1]->logM : 0)) + 1;
         if (dbl) {
             if constexpr (sizeof(T) == sizeof(double)) {
                 FftBuildPair<double, double> bp{};
-                for (int q = 0; q < cnt; ++q) { fill(bp.b[q], k + q); bp.b[q].P.tw = bp.b[q].tw; }
+                for (int q = 0; q < cnt; ++q) { fill(bp.b[q], k + q); bp.b[q].P.tw = bp.b[q].tw; bp.b[q].P.tw2 = bp.b[q].tw2 ? bp.b[q].tw2 : bp.b[q].tw; }
                 hipLaunchKernelGGL((k_fft_build<double, double>), dim3(cnt), dim3(FFT_THREADS), sizeof(cx2<double>) * lds_elems, I->aux, bp);
             }
         } else if (tcd[k]) {
             if constexpr (sizeof(T) == sizeof(float)) {
                 FftBuildPair<double, float> bp{};
-                for (int q = 0; q < cnt; ++q) { fill(bp.b[q], k + q); bp.b[q].P.tw = bp.b[q].tw64; }
+                for (int q = 0; q < cnt; ++q) { fill(bp.b[q], k + q); bp.b[q].P.tw = bp.b[q].tw64; bp.b[q].P.tw2 = bp.b[q].tw64_2 ? bp.b[q].tw64_2 : bp.b[q].tw64; }
                 hipLaunchKernelGGL((k_fft_build<double, float>), dim3(cnt), dim3(FFT_THREADS), sizeof(cx2<double>) * lds_elems, I->aux, bp);
             }
         } else {
             if constexpr (sizeof(T) == sizeof(float)) {
                 FftBuildPair<float, float> bp{};
-                for (int q = 0; q < cnt; ++q) { fill(bp.b[q], k + q); bp.b[q].P.tw = bp.b[q].tw; }
+                for (int q = 0; q < cnt; ++q) { fill(bp.b[q], k + q); bp.b[q].P.tw = bp.b[q].tw; bp.b[q].P.tw2 = bp.b[q].tw2 ? bp.b[q].tw2 : bp.b[q].tw; }
                 hipLaunchKernelGGL((k_fft_build<float, float>), dim3(cnt), dim3(FFT_THREADS), sizeof(cx2<float>) * lds_elems, I->aux, bp);
             }
         }
@@ -517,8 +608,10 @@ static FftPlan<T> fft_plan_of(const FftDim &D)
     FftPlan<T> P{};
     P.chirp = (const cx2<T> *)D.chirp.p;
     P.bhat = P.chirp + (D.n + 1);
-    P.tw = P.bhat + ((size_t)1 << D.logM);
-    P.n = D.n; P.logM = D.logM; P.M = 1 << D.logM;
+    const size_t M = (size_t)D.r << D.logM;
+    P.tw = P.bhat + M;
+    P.tw2 = D.r > 1 ? P.tw + M : P.tw;
+    P.n = D.n; P.logM = D.logM; P.M = (int)M; P.r = D.r;
     fft_radices(D.logM, P.lr, P.npass);
     return P;
 }
@@ -546,8 +639,8 @@ static hipError_t fft_opt_in_lds(Instance *I)
 
 bool fft_supported(int w, int h, bool fp64)
 {
-    const int mx = fp64 ? FFT_MAX_LOGM - 1 : FFT_MAX_LOGM;        // double: 16 bytes per element, n <= 4096 per side
-    return w >= 1 && h >= 1 && fft_logm(w) <= mx && fft_logm(h) <= mx;
+    const int mx = 1 << (fp64 ? FFT_MAX_LOGM - 1 : FFT_MAX_LOGM);        // double: 16 bytes per element, n <= 4096 per side
+    return w >= 1 && h >= 1 && fft_len(w).M() <= mx && fft_len(h).M() <= mx;
 }
 
 template <typename T>

@@ -59,7 +59,7 @@ struct DstState {
 // FFT direct solve (sc_fft.hip): per-direction chirp / transform tables and the two work planes.  The tables of a transform
 // length are built ON THE DEVICE (k_fft_build: both directions of a solve in one launch) and kept in a small LRU: a caller whose mask changes with every
 // frame meets new ROI sizes all the time, and alternating between a few sizes costs nothing.
-struct FftDim { int n = 0, logM = 0; bool dbl = false; DevBuf chirp; unsigned long long used = 0; };   // chirp: chirp[n+1] | bhat[M] | tw[M] (complex float or double)
+struct FftDim { int n = 0, logM = 0, r = 1; bool dbl = false; DevBuf chirp; unsigned long long used = 0; };   // M = r 2^logM (r = 1, 3, 5); chirp: chirp[n+1] | bhat[M] | tw[M] | tw2[2^logM] (complex float or double)
 struct FftFxy { int w = 0, h = 0; bool singular = false; DevBuf d, hst; hipEvent_t ev = nullptr; unsigned long long used = 0; };   // the reference's float tables fx[w] + fy[h]: device, pinned staging of its own, upload event
 struct FftState {
     enum { DIMS = 8, FXY = 4 };

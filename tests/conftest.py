@@ -62,3 +62,26 @@ def hip():
     inst.set_solver(method=capi.SC_METHOD_MULTIGRID)
     yield inst
     inst.destroy()
+
+
+def offbyone_band(name, value, rel=0.25, abs_tol=0.0):
+    """the shares of channels that differ by one grey level are FROZEN (tests/golden/offbyone_counts.json,
+    measured on an MI355X by running the GPU suite with SC_FREEZE_GOLDEN=1) and must stay within +-25 % of what they were -- the
+    +-1 contract bounds the size of a difference, this bounds how many there are: a change that triples the count fails here even
+    though every pixel is still within one.  (A count that FALLS by more than the band fails too: re-freeze it, on purpose.)"""
+    import json
+    if os.environ.get("SC_FREEZE_GOLDEN"):
+        out = os.path.join(ROOT, "gpurun_out", "offbyone_measured.json")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        d = json.load(open(out)) if os.path.exists(out) else {}
+        d[name] = float(value)
+        json.dump(d, open(out, "w"), indent=1, sort_keys=True)
+        return
+    path = os.path.join(GOLDEN, "offbyone_counts.json")
+    if not os.path.exists(path):
+        return
+    g = json.load(open(path)).get(name)
+    if g is None:
+        return
+    tol = max(rel * g, abs_tol)
+    assert g - tol <= value <= g + tol, f"{name}: {value:.6g} left the frozen band {g:.6g} +- {tol:.3g}"

@@ -476,6 +476,9 @@ def test_output_and_restriction_variants_agree(hip, oracles, W, H):
     # (a count of channels that sit within ~1e-4 of an integer: 0.029-0.031 % at 2048^2 depending on the last bits of the bottom
     #  solver's matrices -- host QL in round 3, closed form on the device since round 4)
     assert s["max"] <= 1 and s["percent"] < 0.05, compare.format_stats(s)
+    if (W, H) == (2048, 2048):
+        from conftest import offbyone_band
+        offbyone_band("variants_2048_q16_vs_float_percent", s["percent"])
     for flags, body in out.items():
         s = compare.image_diff_stats(want, body)
         assert s["max"] <= 1 and s["percent"] < 0.5, (flags, compare.format_stats(s))

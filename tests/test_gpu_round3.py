@@ -480,6 +480,9 @@ def test_fixed16_field_between_the_level0_launches(hip, oracles):
             assert outs[0][1] == outs[capi.SC_FLAG_FLOAT_FIELD][1], name
             assert (outs[0][0] != outs[capi.SC_FLAG_FLOAT_FIELD][0]).mean() < 0.001, name      # (full-range noise: 0.0004-0.0006 depending on the last bits of the bottom solver's matrices)
             assert outs[0][2] <= outs[capi.SC_FLAG_FLOAT_FIELD][2] + 0.0003, (name, outs[0][2], outs[capi.SC_FLAG_FLOAT_FIELD][2])
+            if name == "noise":
+                from conftest import offbyone_band
+                offbyone_band("q16_vs_float_noise_700x560_share", float((outs[0][0] != outs[capi.SC_FLAG_FLOAT_FIELD][0]).mean()))
     finally:
         hip.set_solver(flags=0)
 
