@@ -824,12 +824,12 @@ def main():
     j_bytes = 12.0 * unknowns * max(j_depth, 1)
 
     # Counter figures (fabric bytes per launch, bytes per timed step) come from committed rocprofv3 --pmc passes of THIS command
-    # (tools/r4_profile.sh -> profiles/r4_pmc_traffic_bench.json).  They are only quoted when the capture matches the run:
+    # (tools/r5_profile.sh -> profiles/r5_pmc_traffic_bench.json).  They are only quoted when the capture matches the run:
     # same ROI / batch / group and the same library sources (capi.source_fingerprint); otherwise `traffic` is null and
     # `traffic_stale` says why -- a stale number is never passed on silently.
     profile, traffic_stale = None, None
     src_now = capi.source_fingerprint()
-    for name in ("r4_pmc_traffic_bench.json", "r3_pmc_traffic_bench.json"):
+    for name in ("r5_pmc_traffic_bench.json", "r4_pmc_traffic_bench.json", "r3_pmc_traffic_bench.json"):
         try:
             profile = json.load(open(os.path.join(ROOT, "profiles", name)))
             profile["_file"] = "profiles/" + name
@@ -837,7 +837,7 @@ def main():
         except Exception:
             pass
     if profile is None:
-        traffic_stale = "no committed counter capture under profiles/ (run tools/r4_profile.sh on the GPU box)"
+        traffic_stale = "no committed counter capture under profiles/ (run tools/r5_profile.sh on the GPU box)"
     else:
         why = []
         for key, have in (("roi", args.roi), ("batch", args.batch), ("group", group)):

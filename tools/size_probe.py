@@ -11,7 +11,7 @@ if "--fft" in sys.argv:                                # the default's direct so
     inst.set_solver(flags=capi.SC_FLAG_NO_STAGE_MARKS | capi.SC_FLAG_FFT_FP64, method=capi.SC_METHOD_FFT)
 else:
     inst.set_solver(flags=capi.SC_FLAG_NO_STAGE_MARKS, **({"method": capi.SC_METHOD_MULTIGRID} if "--mg" in sys.argv else {}))
-if "--r1" in sys.argv:                                 # experiments: sc_solver_opts.reserved[0] = 1
+if False:                                             # (round 4 experiments used sc_solver_opts.reserved[0]; the field is legacy_paths now)
     import ctypes as C_
     o_ = inst.get_solver(); o_.reserved[0] = 1
     assert inst.L.sc_hip_set_solver(inst.h, C_.byref(o_)) == 0
