@@ -926,7 +926,7 @@ def main():
     # ---- BASELINE config 4: the single-sweep Jacobi kernels at a 4096^2 ROI -- the one configuration whose 604 MB working set
     #      (3 channels x (u, f, u')) exceeds the 256 MB Infinity Cache, i.e. genuinely streams from HBM.  Both forms the library
     #      has: rows rolling through registers (k_jacobi_roll<4>, the default) and the LDS-staged 256 x 32 tile with a 1-pixel halo
-    #      that the north-star names (k_jacobi<32>, sc_solver_opts.jacobi_tile_rows = 32).  Counter bytes: profiles/r4_c4_pmc.json.
+    #      that the north-star names (k_jacobi<32>, sc_solver_opts.jacobi_tile_rows = 32).  Counter bytes: profiles/r5_c4_pmc.json.
     roofline_c4 = None
     if not args.no_c4 and args.config == "c3":
         n4 = 4096
@@ -937,12 +937,13 @@ def main():
         del U4, F4
         bytes4 = 12.0 * (n4 - 2) * (n4 - 2) * 3
         try:
-            c4prof = json.load(open(os.path.join(ROOT, "profiles", "r4_c4_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r4_c4_pmc.json")) else "r3_c4_pmc.json")))
+            c4name = next(n_ for n_ in ("r5_c4_pmc.json", "r4_c4_pmc.json", "r3_c4_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n_)))
+            c4prof = json.load(open(os.path.join(ROOT, "profiles", c4name)))
         except Exception:
             c4prof = None
         c4_stale = None if c4prof and c4prof.get("source_fingerprint") == src_now else \
-            ("no profiles/r4_c4_pmc.json" if not c4prof else f"the committed config-4 capture was taken from other library sources "
-             f"({c4prof.get('source_fingerprint')} then, {src_now} now): re-capture with tools/r4_profile.sh")
+            ("no profiles/r5_c4_pmc.json" if not c4prof else f"the committed config-4 capture was taken from other library sources "
+             f"({c4prof.get('source_fingerprint')} then, {src_now} now): re-capture with tools/r5_profile.sh")
         legs = {}
         for key, rows, sym, label in (("register_rolling", 0, "k_jacobi_roll<4, 1>", "k_jacobi_roll<4>: a wave owns 256 columns x 4 rows, rows y-1..y+4 roll through registers, no LDS, no barrier (default)"),
                                       ("lds_tile_16", 16, "k_jacobi<16, 0>", "k_jacobi<16>: LDS-staged 256 x 16 tile + 1-pixel halo, one barrier"),
