@@ -68,10 +68,14 @@ int ensure(Instance *I, DevBuf &b, size_t bytes, bool zero)
     return SC_OK;
 }
 
+// Page-locked host staging, grow-only.  At least 256 KB per buffer (round 5): the small ones -- eigenvalue tables, ratio tables, part
+// maps, the stop rule's maxima -- used to start at a page and re-grow (stream wait + hipHostFree + hipHostMalloc: ~0.3 ms) whenever a
+// caller's ROI size set a new record: the slowest first calls of the new_size leg (2.4-3.0x the steady call) were exactly those.
 int ensure_pinned(Instance *I, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return SC_OK;
     size_t ncap = bytes > 2 * b.cap ? bytes : 2 * b.cap;
+    ncap = std::max(ncap, (size_t)256 << 10);
     ncap = (ncap + 4095) & ~(size_t)4095;
     if (b.p) {
         SC_HIP(I, hipStreamSynchronize(I->stream));
@@ -513,6 +517,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->dst.hfxy.p) (void)hipHostFree(I->dst.hfxy.p);
     for (DevBuf *b : { &I->fft.A, &I->fft.B, &I->fft.tw64 }) dev_release(*b);
     for (FftDim &d : I->fft.dims) dev_release(d.chirp);
+    if (I->fft.hst_all.p) (void)hipHostFree(I->fft.hst_all.p);
     for (FftFxy &f : I->fft.fxy) {
         dev_release(f.d);
         if (f.hst.p) (void)hipHostFree(f.hst.p);

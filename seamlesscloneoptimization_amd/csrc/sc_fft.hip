@@ -587,15 +587,18 @@ static int fft_fxy(Instance *I, FftFxy *&out, int w, int h)
     else SC_HIP(I, hipEventCreateWithFlags(&X.ev, hipEventDisableTiming));
     X.w = 0;
     if ((rc = ensure(I, X.d, sizeof(float) * (size_t)(w + h)))) return rc;
-    if ((rc = ensure_pinned(I, X.hst, sizeof(float) * (size_t)(w + h)))) return rc;
+    // every entry's pinned staging is a piece of ONE block allocated with the first (w + h <= 16 384 floats: fft_supported): a
+    // hipHostMalloc per entry made the first four new sizes of an instance 0.1 ms slower each (new_size leg, calls #0 .. #3)
+    constexpr size_t FXY_STAGE = sizeof(float) * 16384;
+    if ((rc = ensure_pinned(I, S.hst_all, FXY_STAGE * FftState::FXY))) return rc;
+    float *fx = (float *)((unsigned char *)S.hst_all.p + FXY_STAGE * (size_t)(&X - S.fxy)), *fy = fx + w;
     const double PIf = (double)3.14159265358979323846f;
-    float *fx = (float *)X.hst.p, *fy = fx + w;
     for (int i = 0; i < w; ++i) fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
     for (int j = 0; j < h; ++j) fy[j] = (float)(2.0 * std::cos(PIf / (h + 1.0) * (j + 1.0)));
     X.singular = !((fx[0] + fy[0]) - 4.0f < 0.0f);
     // (on the main stream, behind the zero-fill ensure() gives a fresh buffer there: tried on the second stream beside the table
     // build, the upload raced that fill -- eigenvalue tables of zeros whenever the main stream was still busy)
-    SC_HIP(I, hipMemcpyAsync(X.d.p, X.hst.p, sizeof(float) * (size_t)(w + h), hipMemcpyHostToDevice, I->stream));
+    SC_HIP(I, hipMemcpyAsync(X.d.p, fx, sizeof(float) * (size_t)(w + h), hipMemcpyHostToDevice, I->stream));
     SC_HIP(I, hipEventRecord(X.ev, I->stream));
     X.w = w; X.h = h; X.used = ++S.tick;
     out = &X;

@@ -67,6 +67,7 @@ struct FftState {
     FftFxy fxy[FXY];
     unsigned long long tick = 0;
     DevBuf A, B;                           // work planes [C][h][w]
+    DevBuf hst_all;                        // pinned staging of all FXY eigenvalue-table entries (one block; FftFxy::hst is unused since round 5)
     DevBuf tw64;                           // double twiddles of the build's own transform (float tables are built through a double FFT)
     hipEvent_t ev_fork = nullptr, ev_built = nullptr;   // the build runs on the instance's second stream
     bool pending = false;                  // ... and `stream` has not waited for ev_built yet
