@@ -207,6 +207,7 @@ struct RagMember {
     int lw[RAG_MAX_LEVELS], lh[RAG_MAX_LEVELS]; // level-l field, ring included (lw[0] = W): clamp bounds of a member's loads
     MGGeom g[RAG_MAX_LEVELS];                  // level l and its transfer to l + 1
     const unsigned char *mm;                   // matrix-core operands of the member's directly solved level (k_mg_tail)
+    int npx, npy;                              // ... padded to this many per side (32 or 64): the member's own, as in its solo run
     // float-table correction (sc_lowmode.hip): the member's node grid, its split of the projection and its tables
     int lm_nx, lm_ny, lm_cells_y, lm_nxt, lm_nrs, lm_nparts, lm_Kx, lm_Ky;     // nodes, cell rows, column tiles / row splits / parts of the projection, modes kept
     const float *lm_Sx, *lm_Sy, *lm_R;
@@ -244,7 +245,7 @@ hipError_t mg_bottom_prepare();
 // level's two 1-D operators (nx, ny <= 128), and the zeroing of every plane of the levels >= 1 in one launch
 // mm != nullptr: also the operands of the matrix-core form (k_mg_bottom_mm), padded to NPX / NPY (32, 64 or 96)
 void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s, unsigned char *mm = nullptr, int NPX = 0, int NPY = 0);
-void launch_fd_build_rag(const RagMember *rag, int members, int lev, int NPX, int NPY, hipStream_t s);   // the operands of every member of a size class, one launch
+void launch_fd_build_rag(const RagMember *rag, int members, int lev, hipStream_t s);   // the operands of every member of a size class (each at its own padding), one launch
 __host__ __device__ static inline long fd_mm_bytes(int NPX, int NPY) { return 4L * (2L * NPX * NPX + 2L * NPY * NPY + (long)NPX * NPY); }   // AX1 | AX2 | AY1 | AY2 | Dinv, float
 // the bottom's first level solved directly on the matrix cores: right-hand side in (Ftop), correction out (Utop), nx x ny unknowns
 struct MGBottomMM { const unsigned char *mm; Field Ftop, Utop; int nx, ny; };

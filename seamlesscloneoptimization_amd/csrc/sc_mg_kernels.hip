@@ -104,17 +104,17 @@ __global__ __launch_bounds__(256) void k_fd_build(float *__restrict__ m, int nx,
 
 // the same for every member of a size class in ONE launch (blockIdx.x = member): the matrix-core operands only, each member's
 // where its table entry says (RagMember::mm), from the geometry of its own level `lev` (the level solved directly)
-__global__ __launch_bounds__(256) void k_fd_build_rag(const RagMember *__restrict__ rag, int lev, int NPX, int NPY)
+__global__ __launch_bounds__(256) void k_fd_build_rag(const RagMember *__restrict__ rag, int lev)
 {
     const RagMember &m = rag[blockIdx.x];
     const MGGeom g = m.g[lev];
-    fd_build_block(nullptr, g.x.n, g.y.n, 0, 0, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last, const_cast<unsigned char *>(m.mm), NPX, NPY,
+    fd_build_block(nullptr, g.x.n, g.y.n, 0, 0, g.x.cw_last, g.x.d_last, g.y.cw_last, g.y.d_last, const_cast<unsigned char *>(m.mm), m.npx, m.npy,
                    (int)blockIdx.y, (int)gridDim.y);
 }
 
-void launch_fd_build_rag(const RagMember *rag, int members, int lev, int NPX, int NPY, hipStream_t s)
+void launch_fd_build_rag(const RagMember *rag, int members, int lev, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fd_build_rag, dim3(members, 4), dim3(256), 0, s, rag, lev, NPX, NPY);
+    hipLaunchKernelGGL(k_fd_build_rag, dim3(members, 4), dim3(256), 0, s, rag, lev);
 }
 
 void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s, unsigned char *mm, int NPX, int NPY)
@@ -899,17 +899,23 @@ __device__ __forceinline__ void tail_residual(const float2 (&u)[16], const float
     }
 }
 
-template <int SKX, int SKY, bool RAG = false>
-__global__ __launch_bounds__(512) void k_mg_tail(MGTail a)
+// LDS of the launch for operand paddings NPX x NPY: buf0 | bufA (bufA: B's right-hand side, then the second product's result, then B's solution)
+template <int SKX, int SKY>
+struct TailLds {
+    static constexpr int NPX = 16 * SKX, NPY = 16 * SKY, RSX = NPX * 4 + 16, RSY = NPY * 4 + 16;
+    static constexpr int BUF = (NPX * RSY > NPY * RSX) ? NPX * RSY : NPY * RSX;
+    static constexpr int PB = 65;                                           // pitch of B's solution plane (coarse ring coordinates 0 .. 64)
+    static constexpr int BUFA = (BUF > 65 * PB * 4) ? BUF : 65 * PB * 4;
+};
+
+template <int SKX, int SKY, bool RAG>
+__device__ __forceinline__ void tail_body(const MGTail &a, unsigned char *__restrict__ buf0, unsigned char *__restrict__ bufA,
+                                          float2 (*edge)[8][2][64], float (*hedge)[2][64])
 {
     constexpr int NPX = 16 * SKX, NPY = 16 * SKY, TX = NPX / 32, TY = NPY / 32, KX = NPX / 2, KY = NPY / 2;
     constexpr int RSX = NPX * 4 + 16, RSY = NPY * 4 + 16;
-    constexpr int BUF = (NPX * RSY > NPY * RSX) ? NPX * RSY : NPY * RSX;
-    constexpr int PB = 65;                                                  // pitch of B's solution plane (coarse ring coordinates 0 .. 64)
-    constexpr int BUFA = (BUF > 65 * PB * 4) ? BUF : 65 * PB * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char buf0[BUF], bufA[BUFA];   // bufA: B's right-hand side, then the second product's result, then B's solution
-    __shared__ float2 edge[2][8][2][64];
-    __shared__ float hedge[8][2][64];
+    constexpr int PB = TailLds<SKX, SKY>::PB;
+    (void)RSY;
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tm = w / TX, tn = w % TX;
@@ -1111,14 +1117,37 @@ __global__ __launch_bounds__(512) void k_mg_tail(MGTail a)
 #undef SC_TAIL_HALF
 }
 
+template <int SKX, int SKY, bool RAG = false>
+__global__ __launch_bounds__(512) void k_mg_tail(MGTail a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char buf0[TailLds<SKX, SKY>::BUF], bufA[TailLds<SKX, SKY>::BUFA];
+    __shared__ float2 edge[2][8][2][64];
+    __shared__ float hedge[8][2][64];
+    tail_body<SKX, SKY, RAG>(a, buf0, bufA, edge, hedge);
+}
+
+// A size class whose members' directly solved levels need DIFFERENT operand paddings (31 unknowns: 32, 33: 64 -- the boundary sits at ROI
+// sizes around 1075 and 2110 per side): one launch, every channel takes the body of ITS member's paddings -- the instantiation its solo
+// run launches, so the order of the matrix-core sums (a lane half takes k in [h K/2, (h + 1) K/2)) is the solo run's.  LDS for the largest.
+__global__ __launch_bounds__(512) void k_mg_tail_any(MGTail a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char buf0[TailLds<4, 4>::BUF], bufA[TailLds<4, 4>::BUFA];
+    __shared__ float2 edge[2][8][2][64];
+    __shared__ float hedge[8][2][64];
+    const RagMember &m = a.rag[blockIdx.x / 3];
+    const int px = m.npx, py = m.npy;           // block-uniform
+    if (px == 32 && py == 32) tail_body<2, 2, true>(a, buf0, bufA, edge, hedge);
+    else if (px == 32) tail_body<2, 4, true>(a, buf0, bufA, edge, hedge);
+    else if (py == 32) tail_body<4, 2, true>(a, buf0, bufA, edge, hedge);
+    else tail_body<4, 4, true>(a, buf0, bufA, edge, hedge);
+}
+
 // level A: at most 127 unknowns per side (g = its geometry, g.*.nc = level B's sizes <= 63); NPX / NPY: level B padded to 32 or 64
 bool launch_mg_tail(const MGTail &a, int NPX, int NPY, int C, hipStream_t s)
 {
     if (a.g.x.n > 127 || a.g.y.n > 127 || a.g.x.nc > 63 || a.g.y.nc > 63 || a.g.x.nc > NPX || a.g.y.nc > NPY) return false;      // (a size class: a.g holds the class's maxima)
-#define SC_TL(SX, SY) if (NPX == 16 * SX && NPY == 16 * SY) {                                                                           \
-        if (a.rag) hipLaunchKernelGGL((k_mg_tail<SX, SY, true>), dim3(C), dim3(512), 0, s, a);                                          \
-        else hipLaunchKernelGGL((k_mg_tail<SX, SY, false>), dim3(C), dim3(512), 0, s, a);                                               \
-        return true; }
+    if (a.rag) { hipLaunchKernelGGL(k_mg_tail_any, dim3(C), dim3(512), 0, s, a); return true; }      // a size class: per-member paddings
+#define SC_TL(SX, SY) if (NPX == 16 * SX && NPY == 16 * SY) { hipLaunchKernelGGL((k_mg_tail<SX, SY, false>), dim3(C), dim3(512), 0, s, a); return true; }
     SC_TL(2, 2) SC_TL(2, 4) SC_TL(4, 2) SC_TL(4, 4)
 #undef SC_TL
     return false;

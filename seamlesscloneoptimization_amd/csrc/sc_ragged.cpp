@@ -180,7 +180,7 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
     if (n < 1) return SC_ERR_BAD_ARG;
     const SizePlan &p0 = members[0];
     R.n = n; R.nl = p0.tail + 2; R.tail = p0.tail;      // levels 0 .. tail + 1: the one solved directly is the last one anybody visits
-    R.npx = p0.npx; R.npy = p0.npy; R.Kxp = p0.Kxp; R.Kyp = p0.Kyp;
+    R.npx = p0.npx; R.npy = p0.npy; R.Kxp = p0.Kxp; R.Kyp = p0.Kyp;      // (npx / npy: the class's largest, below)
     R.max_nx = R.max_ny = R.max_nxt = R.max_nrs = R.max_cells_y = 0;
     R.max_ratio = 0.0;
     for (const SizePlan &p : members) {
@@ -189,6 +189,7 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
         R.max_nxt = std::max(R.max_nxt, p.nxt); R.max_nrs = std::max(R.max_nrs, p.nrs);
         R.max_cells_y = std::max(R.max_cells_y, p.cells_y);
         R.max_ratio = std::max(R.max_ratio, p.max_ratio);
+        R.npx = std::max(R.npx, p.npx); R.npy = std::max(R.npy, p.npy);
     }
     // --- layout of d_aux (256-byte aligned pieces; the per-member pieces one member after the other)
     const size_t bR = align_up(sizeof(float) * (size_t)R.Kyp * R.Kxp, 256), bMap = align_up(sizeof(int) * 4 * (size_t)R.max_cells_y, 256);
@@ -222,6 +223,7 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
         m.lm_Sx = (const float *)(da + host_part + (bSx + bSy + bMM) * i);
         m.lm_Sy = (const float *)(da + host_part + (bSx + bSy + bMM) * i + bSx);
         m.mm = da + host_part + (bSx + bSy + bMM) * i + bSx + bSy;
+        m.npx = p.npx; m.npy = p.npy;
         // the host-built pieces (made once per size): the ratio table and the two part maps
         const std::shared_ptr<const SizePlan::Heavy> Hv = plan_heavy(p);
         if (!Hv) { I->err = "size class: more than four parts per cell row"; return SC_ERR_BAD_ARG; }
@@ -243,7 +245,7 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
     if (!R.ev_ready) SC_HIP(I, hipEventCreateWithFlags(&R.ev_ready, hipEventDisableTiming));
     SC_HIP(I, hipEventRecord(R.ev_ready, I->aux));
     R.ready_pending = true;
-    launch_fd_build_rag(R.dev, n, R.tail + 1, R.npx, R.npy, I->aux);
+    launch_fd_build_rag(R.dev, n, R.tail + 1, I->aux);
     SC_HIP(I, hipGetLastError());
     SC_HIP(I, hipEventRecord(I->ev_fd, I->aux));
     I->fd_pending = true;
