@@ -100,7 +100,9 @@ struct SizePlan {
     // same compile-time choices and launch shapes, and strides that waste at most ~1/8 per direction
     bool same_class(const SizePlan &o) const
     {
-        return ok && o.ok && tail == o.tail && Kxp == o.Kxp && Kyp == o.Kyp;      // (levels below the directly solved one are never visited: their number is free; operand paddings are per member: k_mg_tail_any)
+        // (levels below the directly solved one are never visited: their number is free; operand paddings are per member:
+        //  k_mg_tail_any; the correction's mode-block padding is the class's largest: a member's extra blocks are exact zeros)
+        return ok && o.ok && tail == o.tail;
     }
 };
 bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p);     // fills p; returns p.ok

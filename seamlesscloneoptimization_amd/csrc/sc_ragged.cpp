@@ -190,6 +190,9 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
         R.max_cells_y = std::max(R.max_cells_y, p.cells_y);
         R.max_ratio = std::max(R.max_ratio, p.max_ratio);
         R.npx = std::max(R.npx, p.npx); R.npy = std::max(R.npy, p.npy);
+        // the correction's tables take the class's largest mode-block padding as their row pitch: what a member does not have is zero
+        // (k_lm_table_rag, the ratio table below), and a zero mode adds exact zeros to every sum -- same bytes as at its own padding
+        R.Kxp = std::max(R.Kxp, p.Kxp); R.Kyp = std::max(R.Kyp, p.Kyp);
     }
     // --- layout of d_aux (256-byte aligned pieces; the per-member pieces one member after the other)
     const size_t bR = align_up(sizeof(float) * (size_t)R.Kyp * R.Kxp, 256), bMap = align_up(sizeof(int) * 4 * (size_t)R.max_cells_y, 256);
@@ -227,7 +230,8 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
         // the host-built pieces (made once per size): the ratio table and the two part maps
         const std::shared_ptr<const SizePlan::Heavy> Hv = plan_heavy(p);
         if (!Hv) { I->err = "size class: more than four parts per cell row"; return SC_ERR_BAD_ARG; }
-        std::memcpy(hs + oR, Hv->R.data(), sizeof(float) * Hv->R.size());
+        std::memset(hs + oR, 0, bR);                                     // re-pitched: the member's Kyp x Kxp table inside the class's
+        for (int j = 0; j < p.Kyp; ++j) std::memcpy(hs + oR + sizeof(float) * (size_t)j * R.Kxp, Hv->R.data() + (size_t)j * p.Kxp, sizeof(float) * p.Kxp);
         for (int t = 0; t < 2; ++t) std::memcpy(hs + (t ? oMap1 : oMap0), Hv->map[t].data(), sizeof(int) * Hv->map[t].size());
     }
     std::memcpy(hs, R.host.data(), sizeof(RagMember) * (size_t)n);

@@ -150,6 +150,9 @@ SIZE_CLASSES = {
     "mixed_depth": [(1010, 1060), (1022, 1065), (1001, 1033)],
     # BASELINE config 3's size and two neighbours
     "2048s": [(2048, 2048), (2000, 2040), (1990, 2050)],
+    # across 2050 unknowns per side the float-table correction keeps 40 instead of 32 modes (mode-block padding 64 / 32) and the
+    # directly solved level flips between 32 and 33 unknowns at ~2110 (operand padding 32 / 64): all four combinations in one class
+    "2100s": [(2040, 2100), (2140, 2120), (2085, 2170), (2200, 2060), (2190, 2195)],
 }
 
 
@@ -320,3 +323,36 @@ def test_fft_lengths_with_odd_factors_every_7th_size(inst, oracles):
         lens.add(M)
     assert any(m % 3 == 0 for m in lens) and any(m % 5 == 0 for m in lens) and any(m & (m - 1) == 0 for m in lens)
     print("worst scaled error: float32 %.2e, double %.2e over %d lengths" % (worst[0], worst[capi.SC_FLAG_FFT_FP64], len(lens)))
+
+
+def test_saturating_member_of_a_size_class_repeats_the_class_on_float_fields(oracles):
+    """The 16-bit field's range check (round 4) inside a size class: one member (rings of inward ramps: a non-conservative guidance
+    field) saturates -> nobody is written by the first solve, the class runs again on float fields -- the table-reading forms of the
+    float-field launches -- and every member is within one of the port; the ordinary members get the bytes SC_FLAG_FLOAT_FIELD
+    gives them alone (same cycle counts)."""
+    from seamlesscloneoptimization_amd import capi
+    from test_gpu_round4 import ring_ramp_inputs
+    o, oc = oracles
+    items = [o.synth_inputs(640, 560, margin=32, seed_dst=11, seed_patch=12), ring_ramp_inputs(652, 571), o.synth_inputs(625, 583, margin=32, seed_dst=13, seed_patch=14)]
+    g, k = capi.plan_groups([(640, 560), (652, 571), (625, 583)])
+    assert set(g) == {0} and set(k) == {2}
+    inst = capi.Instance(0)
+    solo = capi.Instance(0)
+    try:
+        solo.set_solver(method=capi.SC_METHOD_MULTIGRID, flags=capi.SC_FLAG_FLOAT_FIELD)
+        jobs, keep = _device_jobs(inst, items)
+        assert inst.run_device_batch(jobs, ) in (0, capi.SC_ERR_NOT_CONVERGED)
+        i = inst.info()
+        assert i.field_retry == 1 and i.group_ragged == 1 and i.group_members == 3
+        for k_, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
+            got = inst.from_device(b, shape)
+            want = oc.seamless_clone(it[0], it[1], it[2], it[3], it[4], min(16, oc.max_threads()))
+            assert _dmax(got, want) <= 1, k_
+            if k_ != 1:
+                body = it[0].copy()
+                solo.run(it[1], body, it[2], it[3], it[4], allow_not_converged=True)
+                if solo.info().sweeps == i.sweeps:
+                    assert np.array_equal(body, got), k_
+        _free_jobs(inst, keep)
+    finally:
+        inst.destroy(); solo.destroy()
