@@ -388,3 +388,55 @@ def test_host_side_sanitizers_are_clean():
     r = subprocess.run(["make", "-C", csrc, "-j4", "-s", "sanitize"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert r.stdout.count("sanitize_main: clean") == 2, r.stdout[-2000:]
+
+
+def test_group_planner_properties():
+    """The host-only planner behind sc_hip_run_device_batch and the pool (csrc/sc_ragged.cpp through sc_hip_plan_groups /
+    sc_hip_plan_size; no GPU): same-size members form a group of their own kind, members of one size class another, a class never
+    spreads more than 1/8 per direction, `cap` bounds every group, the partition is deterministic and order preserving, options
+    outside the default fast path switch the classes off (same-size groups stay), and the boundaries the classes do NOT depend on any
+    more -- the operand padding of the direct solve, the correction's mode-block padding, the number of levels below the directly
+    solved one -- do not split a class."""
+    from seamlesscloneoptimization_amd import capi
+    rng = np.random.default_rng(5)
+    sizes = [(int(rng.integers(1000, 1101)), int(rng.integers(1000, 1101))) for _ in range(64)] + [(640, 480)] * 5 + [(90, 70), (4000, 130)]
+    g, k = capi.plan_groups(sizes, 16)
+    assert (g, k) == capi.plan_groups(sizes, 16)                                   # deterministic (and memoised plans give the same answer)
+    groups = {}
+    for i, gi in enumerate(g):
+        groups.setdefault(gi, []).append(i)
+    assert all(len(m) <= 16 for m in groups.values())
+    for gi, m in groups.items():
+        kinds = {k[i] for i in m}
+        assert len(kinds) == 1
+        kind = kinds.pop()
+        ws, hs = [sizes[i][0] for i in m], [sizes[i][1] for i in m]
+        if kind == 0:
+            assert len(m) == 1
+        elif kind == 1:
+            assert len(m) >= 2 and len(set(zip(ws, hs))) == 1
+        else:
+            assert len(m) >= 2 and len(set(zip(ws, hs))) > 1
+            assert max(ws) <= 1.125 * min(ws) and max(hs) <= 1.125 * min(hs)
+            assert len({capi.plan_size(*sizes[i])["tail_level"] for i in m}) == 1 and all(capi.plan_size(*sizes[i])["eligible"] for i in m)
+        assert m == sorted(m)                                                       # first-come order inside a group
+    assert k[64] == 1 and g[64:69] == [g[64]] * 5                                   # the five 640 x 480 clones: one same-size group
+    assert k[69] == 0 and k[70] == 0                                                # 90 x 70 and 4000 x 130 fit nothing here
+    assert sum(1 for x in k[:64] if x == 2) >= 60                                   # random sizes in [1000, 1100]^2: classes
+    # what no longer splits a class (all four are one class; paddings 32 / 64 and mode blocks 32 / 64 differ between them)
+    mixed = [(2040, 2100), (2140, 2120), (2085, 2170), (2200, 2060), (2190, 2195)]
+    gm, km = capi.plan_groups(mixed)
+    assert set(gm) == {0} and set(km) == {2}
+    p = [capi.plan_size(*s) for s in mixed]
+    assert len({(q["pad_x"], q["pad_y"]) for q in p}) > 1 and len({(q["Kxp"], q["Kyp"]) for q in p}) > 1
+    assert capi.plan_groups([(282, 284), (300, 310)])[1] == [2, 2] and capi.plan_size(282, 284)["levels"] != capi.plan_size(300, 310)["levels"]
+    # ... and what does: the level k_mg_tail holds (one level deeper above ~1027 unknowns per side)
+    assert capi.plan_size(1020, 1020)["tail_level"] != capi.plan_size(1060, 1060)["tail_level"]
+    assert capi.plan_groups([(1020, 1020), (1060, 1060)])[1] == [0, 0]
+    # options outside the default fast path: no classes, same-size groups stay
+    lib = capi.load()
+    o = capi.SolverOpts(); lib.sc_hip_default_opts(__import__("ctypes").byref(o))
+    o.flags = capi.SC_FLAG_KEEP_FIELD
+    g2, k2 = capi.plan_groups(sizes, 16, o)
+    assert 2 not in k2 and k2[64] == 1
+    assert capi.plan_size(1050, 1050, o)["eligible"] == 0
