@@ -391,9 +391,11 @@ SC_API int sc_hip_time_tail_phases(void *instance, unsigned long long *cycles11)
  * (wh[2i], wh[2i+1]: width and height, ring included) under `opts` (NULL: the defaults), at most `cap` members per group (<= 0: no
  * limit): group_of[i] = the member's group, kind_of[i] (may be NULL) = 0 alone, 1 a same-size group, 2 a size class (different
  * sizes, the same solve: csrc/sc_ragged.cpp).  Returns the number of groups, or SC_ERR_BAD_ARG. */
-/* Host-only: what decides a ROI size's class: out = { eligible, levels, level held by k_mg_tail, operand padding x, y of the level solved
- * directly, mode-block padding x, y of the correction, its column tiles, its row splits, 1000 * nx + ny of the level solved directly } */
-SC_API int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[10]);
+/* Host-only: what decides a ROI size's class: out = { eligible, levels, level held by k_mg_tail (THE class key, beside the 1/8 spread),
+ * operand padding x, y of the level solved directly, mode-block padding x, y of the correction, its column tiles, its row splits,
+ * 1000 * nx + ny of the level solved directly, solo_differs (1: a small ROI whose level 1 a solo clone solves directly -- inside a
+ * class it runs the general hierarchy and comes out within one grey level of its solo run instead of with its bytes), 0 } */
+SC_API int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[12]);
 SC_API int sc_hip_plan_groups(const int *wh, int n, int cap, const sc_solver_opts *opts, int *group_of, int *kind_of);
 
 /* Host-only (needs no GPU): 1 when the reference's float32 eigenvalue tables are singular for an ROI of w x h unknowns --

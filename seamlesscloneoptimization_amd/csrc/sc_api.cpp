@@ -61,7 +61,19 @@ int ensure(Instance *I, DevBuf &b, size_t bytes, bool zero)
         I->arena_bytes += ncap;
     }
     if (zero) SC_HIP(I, hipMemsetAsync(np, 0, ncap, I->stream));
-    if (b.p && b.own) I->retired.push_back(b);      // (a replaced slab piece simply stays unused)
+    if (b.p && b.own) {                              // (a replaced slab piece simply stays unused)
+        I->retired.push_back(b);
+        I->retired_bytes += b.cap;
+        // ... unless the retired blocks have become large (an instance walking up through multi-gigabyte ROI sizes): then, and only
+        // then, wait for the stream and give them back -- a growth step of that size is milliseconds of hipMalloc anyway
+        if (I->retired_bytes > ((size_t)1 << 30)) {
+            SC_HIP(I, hipStreamSynchronize(I->stream));
+            if (I->aux) SC_HIP(I, hipStreamSynchronize(I->aux));
+            for (DevBuf &r : I->retired) { I->arena_bytes -= r.cap; dev_release(r); }
+            I->retired.clear();
+            I->retired_bytes = 0;
+        }
+    }
     b.p = np;
     b.cap = ncap;
     b.own = own;
@@ -1176,14 +1188,15 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     return worst;
 }
 
-int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[10])
+int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[12])
 {
     if (!out) return SC_ERR_BAD_ARG;
     sc_solver_opts o;
     if (opts) o = *opts; else sc_hip_default_opts(&o);
     SizePlan p;
     plan_size(o, W, H, p);
-    const int v[10] = { p.ok ? 1 : 0, p.nl, p.tail, p.npx, p.npy, p.Kxp, p.Kyp, p.nxt, p.nrs, (p.t && p.tail > 0) ? p.t->g[p.tail].x.nc * 1000 + p.t->g[p.tail].y.nc : 0 };
+    const int v[12] = { p.ok ? 1 : 0, p.nl, p.tail, p.npx, p.npy, p.Kxp, p.Kyp, p.nxt, p.nrs, (p.t && p.tail > 0) ? p.t->g[p.tail].x.nc * 1000 + p.t->g[p.tail].y.nc : 0,
+                        p.solo_differs ? 1 : 0, 0 };
     memcpy(out, v, sizeof(v));
     return SC_OK;
 }

@@ -87,6 +87,7 @@ struct MGLevel {
 struct SizePlan {
     int W = 0, H = 0;
     bool ok = false;                    // the default fast path serves this size inside a class (else: same-size groups, or alone)
+    bool solo_differs = false;          // ... on another hierarchy than its solo run's (small ROIs whose level 1 a solo clone solves directly): within one grey level of it, not the same bytes
     int nl = 0, tail = 0;               // levels of its hierarchy; the level k_mg_tail holds (the one below it is solved directly)
     int npx = 0, npy = 0;               // padding of the directly solved level's operands (32 or 64 per side)
     int Kx = 0, Ky = 0, Kxp = 0, Kyp = 0, nx = 0, ny = 0, cells_y = 0, nxt = 0, nrs = 0;     // float-table correction
@@ -220,7 +221,8 @@ struct Instance {
     hipEvent_t tm[8]{};   // stage marks of the current run: ev[k], or the previous mark where a stage is empty (no record call)
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     size_t arena_bytes = 0;
-    std::vector<DevBuf> retired;           // device blocks that growth replaced: freed when the instance goes (ensure, sc_api.cpp)
+    std::vector<DevBuf> retired;           // device blocks that growth replaced: freed when the instance goes, or once they add up to 1 GB (ensure, sc_api.cpp)
+    size_t retired_bytes = 0;
     // Small device buffers are pieces of a few SLABS (16 MB, then doubling) instead of hipMalloc blocks of their own: an instance owns
     // ~40 grow-only buffers, and a caller whose ROI sizes wander re-sizes several of them in one call -- each a hipMalloc of 30-100 us
     struct Slab { uint8_t *base = nullptr; size_t cap = 0, used = 0; };

@@ -19,6 +19,7 @@ namespace sc {
 // ROI sizes of one class may differ by this factor per direction at most (strides are the largest member's: what a smaller
 // member leaves unused of its planes is never touched, but the grids are sized for the largest)
 static constexpr double RAG_SPREAD = 1.125;
+static constexpr int RAG_SPREAD_PIXELS = 64;
 
 // Plans are pure functions of (W, H) and of the few solver options below: memoised, so that a caller whose ROI sizes recur (video:
 // the same faces frame after frame) plans each size once.  Bounded; shared by every instance and pool of the process.
@@ -82,7 +83,17 @@ bool plan_size_uncached(const sc_solver_opts &o, int W, int H, SizePlan &p)
     // --- its hierarchy ends the default way: a level of at most 127 unknowns per side in k_mg_tail, the one below it solved there
     mg_plan_levels(W, H, pg);
     p.nl = (int)pg.size();
-    const size_t a = mg_default_tail_level(pg);
+    size_t a = mg_default_tail_level(pg);
+    if (!a) {
+        // A ladder whose level 1 a solo clone (or a same-size group) solves directly -- at most 96 unknowns per side: ROIs up to ~194
+        // pixels, the reference's own 154 x 100 patch among them.  A class has no such form; it takes the general one -- level 2 in
+        // k_mg_tail, level 3 solved directly -- where that exists.  Same fixed point, different iterates: such a member is within one
+        // grey level of its solo run, not byte-identical to it (`solo_differs`; every larger size is).
+        if (std::min(W, H) >= 48)                            // (below that the directly solved level has a handful of unknowns per side: such clones stay alone)
+            for (size_t l = 2; l + 1 < pg.size() && !a; ++l)
+                if (pg[l].x.n <= 127 && pg[l].y.n <= 127) a = l;
+        p.solo_differs = a != 0;
+    }
     if (!a || (int)a + 2 > RAG_MAX_LEVELS || p.nl < (int)a + 2) return false;
     p.tail = (int)a;
     const MGGeom &A = pg[a];
@@ -149,7 +160,9 @@ void plan_groups(const std::vector<SizePlan> &plans, int cap, std::vector<std::v
             if (g.uniform && q.W == p.W && q.H == p.H) { into = k; break; }
             if (!p.same_class(q)) continue;
             const int minW = std::min(g.minW, p.W), maxW = std::max(g.maxW, p.W), minH = std::min(g.minH, p.H), maxH = std::max(g.maxH, p.H);
-            if ((double)maxW <= RAG_SPREAD * minW && (double)maxH <= RAG_SPREAD * minH) into = k;
+            // (1/8 per direction, or 64 pixels where that is more: a level-0 tile is 232 x 44, small ROIs differ by less than the grid's grain)
+            const bool wx = (double)maxW <= RAG_SPREAD * minW || maxW - minW <= RAG_SPREAD_PIXELS, wy = (double)maxH <= RAG_SPREAD * minH || maxH - minH <= RAG_SPREAD_PIXELS;
+            if (wx && wy) into = k;
         }
         if (into < 0) {
             open.push_back({ i, p.W, p.W, p.H, p.H, true });

@@ -150,6 +150,9 @@ SIZE_CLASSES = {
     "mixed_depth": [(1010, 1060), (1022, 1065), (1001, 1033)],
     # BASELINE config 3's size and two neighbours
     "2048s": [(2048, 2048), (2000, 2040), (1990, 2050)],
+    # the reference's own small patches (154 x 100; its size sets 109 x 164, 181 x 153): a solo clone solves their level 1 directly, a class
+    # runs the general hierarchy -- within one grey level of the solo run, not its bytes (plan_size: solo_differs)
+    "150s": [(154, 160), (150, 171), (165, 158), (158, 164), (161, 152)],
     # across 2050 unknowns per side the float-table correction keeps 40 instead of 32 modes (mode-block padding 64 / 32) and the
     # directly solved level flips between 32 and 33 unknowns at ~2110 (operand padding 32 / 64): all four combinations in one class
     "2100s": [(2040, 2100), (2140, 2120), (2085, 2170), (2200, 2060), (2190, 2195)],
@@ -196,7 +199,8 @@ def test_size_class_members_match_their_solo_runs(oracles, name):
                 want = oc.seamless_clone(it[0], it[1], it[2], it[3], it[4], nthreads=min(16, oc.max_threads()), exact_den=False)
                 assert _dmax(got, want) <= 1, (name, k, rep)
                 assert not np.array_equal(got, it[0])
-                if cycles[k] == group_cycles:
+                assert _dmax(got, alone[k]) <= 1, (name, k, rep)
+                if cycles[k] == group_cycles and not capi.plan_size(*sizes[k])["solo_differs"]:
                     assert np.array_equal(got, alone[k]), (name, k, rep, int((got != alone[k]).sum()))
         # the same members in another order, one of them twice: the table is per slot, not per size
         order = [2, 0, 1, 0] if len(items) >= 3 else [1, 0]
@@ -206,7 +210,7 @@ def test_size_class_members_match_their_solo_runs(oracles, name):
         assert inst.info().group_members == len(order)
         if inst.info().sweeps == group_cycles:
             for (f, b0, b, m, shape), q in zip(keep2, order):
-                if cycles[q] == group_cycles:
+                if cycles[q] == group_cycles and not capi.plan_size(*sizes[q])["solo_differs"]:
                     assert np.array_equal(inst.from_device(b, shape), alone[q]), (name, q)
         _free_jobs(inst, keep); _free_jobs(inst, keep2)
     finally:
