@@ -394,7 +394,9 @@ SC_API int sc_hip_time_tail_phases(void *instance, unsigned long long *cycles11)
 /* Host-only: what decides a ROI size's class: out = { eligible, levels, level held by k_mg_tail (THE class key, beside the 1/8 spread),
  * operand padding x, y of the level solved directly, mode-block padding x, y of the correction, its column tiles, its row splits,
  * 1000 * nx + ny of the level solved directly, solo_differs (1: a small ROI whose level 1 a solo clone solves directly -- inside a
- * class it runs the general hierarchy and comes out within one grey level of its solo run instead of with its bytes), 0 } */
+ * class it runs the general hierarchy and comes out within one grey level of its solo run instead of with its bytes), conditional
+ * (1: the float tables' lowest modes are off by more than 4 % at this size; such members form classes of their own, in which the
+ * judged cycle's measured update decides the output's form for the whole group) } */
 SC_API int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[12]);
 SC_API int sc_hip_plan_groups(const int *wh, int n, int cap, const sc_solver_opts *opts, int *group_of, int *kind_of);
 

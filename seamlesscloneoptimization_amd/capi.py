@@ -544,7 +544,7 @@ def plan_size(W: int, H: int, opts: "SolverOpts | None" = None) -> dict:
     """Host-only: what decides the size class of a W x H ROI (ring included)."""
     out = np.zeros(12, np.int32)
     load().sc_hip_plan_size(int(W), int(H), C.byref(opts) if opts is not None else None, out.ctypes.data_as(i32p))
-    keys = ("eligible", "levels", "tail_level", "pad_x", "pad_y", "Kxp", "Kyp", "column_tiles", "row_splits", "direct_nx_ny", "solo_differs")
+    keys = ("eligible", "levels", "tail_level", "pad_x", "pad_y", "Kxp", "Kyp", "column_tiles", "row_splits", "direct_nx_ny", "solo_differs", "conditional")
     return dict(zip(keys, out.tolist()))
 
 

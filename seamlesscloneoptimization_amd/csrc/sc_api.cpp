@@ -1196,7 +1196,7 @@ int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[12])
     SizePlan p;
     plan_size(o, W, H, p);
     const int v[12] = { p.ok ? 1 : 0, p.nl, p.tail, p.npx, p.npy, p.Kxp, p.Kyp, p.nxt, p.nrs, (p.t && p.tail > 0) ? p.t->g[p.tail].x.nc * 1000 + p.t->g[p.tail].y.nc : 0,
-                        p.solo_differs ? 1 : 0, 0 };
+                        p.solo_differs ? 1 : 0, p.conditional ? 1 : 0 };
     memcpy(out, v, sizeof(v));
     return SC_OK;
 }

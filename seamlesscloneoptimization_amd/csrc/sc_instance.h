@@ -87,6 +87,7 @@ struct MGLevel {
 struct SizePlan {
     int W = 0, H = 0;
     bool ok = false;                    // the default fast path serves this size inside a class (else: same-size groups, or alone)
+    bool conditional = false;           // the float-table correction's a-priori bound does not hold at this size (plan_size): classes of such members only
     bool solo_differs = false;          // ... on another hierarchy than its solo run's (small ROIs whose level 1 a solo clone solves directly): within one grey level of it, not the same bytes
     int nl = 0, tail = 0;               // levels of its hierarchy; the level k_mg_tail holds (the one below it is solved directly)
     int npx = 0, npy = 0;               // padding of the directly solved level's operands (32 or 64 per side)
@@ -103,7 +104,7 @@ struct SizePlan {
     {
         // (levels below the directly solved one are never visited: their number is free; operand paddings are per member:
         //  k_mg_tail_any; the correction's mode-block padding is the class's largest: a member's extra blocks are exact zeros)
-        return ok && o.ok && tail == o.tail;
+        return ok && o.ok && tail == o.tail && conditional == o.conditional;
     }
 };
 bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p);     // fills p; returns p.ok

@@ -111,7 +111,13 @@ bool plan_size_uncached(const sc_solver_opts &o, int W, int H, SizePlan &p)
     if (p.nxt * p.nrs >= 32) return false;
     const bool regular = lowmode_ratio(w, h, p.Kx, p.Ky, p.Kxp, nullptr, p.max_ratio);
     const float utol = o.update_tol > 0.f ? o.update_tol : 0.25f;
-    if (!regular || !(p.max_ratio * 4.9 * (double)utol <= 0.049)) return false;
+    if (!regular) return false;
+    // sizes whose float tables are off by more than 4 % in their lowest modes (one in ten around 2100 a side, most beyond 3000): the
+    // output may carry the earlier iterate's correction only if the judged cycle's MEASURED update allows it (lowmode_early_kind 3,
+    // decided beside the stop rule in mg_solve with the class's largest ratio and the group's largest update).  Classes of their own:
+    // a member whose bound holds a priori never shares that decision -- and such a member is byte-identical to its solo run when the
+    // decision falls as its solo run's does, within one grey level of it otherwise (`conditional`).
+    p.conditional = !(p.max_ratio * 4.9 * (double)utol <= 0.049);
     p.t = T;
     p.ok = true;
     return true;

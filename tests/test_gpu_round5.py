@@ -156,6 +156,9 @@ SIZE_CLASSES = {
     # across 2050 unknowns per side the float-table correction keeps 40 instead of 32 modes (mode-block padding 64 / 32) and the
     # directly solved level flips between 32 and 33 unknowns at ~2110 (operand padding 32 / 64): all four combinations in one class
     "2100s": [(2040, 2100), (2140, 2120), (2085, 2170), (2200, 2060), (2190, 2195)],
+    # sizes whose float tables are off by more than 4 % in their lowest modes (plan_size: conditional): the output's form is decided by
+    # the judged cycle's measured update, for the whole group (smooth inputs: the same way as in each solo run)
+    "2100c": [(2107, 2053), (2137, 2072), (2132, 2077), (2120, 2064)],
 }
 
 
@@ -165,6 +168,10 @@ def test_size_classes_are_what_the_tests_think_they_are():
     for name, sizes in SIZE_CLASSES.items():
         g, k = capi.plan_groups(sizes)
         assert set(g) == {0} and set(k) == {2}, (name, g, k)
+        assert all(capi.plan_size(*sz)["conditional"] == (name == "2100c") for sz in sizes), name
+    # a conditional size never shares a class with one whose bound holds a priori
+    g, k = capi.plan_groups([(2107, 2053), (2090, 2050), (2137, 2072), (2090, 2055)])
+    assert g[0] == g[2] and g[1] == g[3] and g[0] != g[1] and set(k) == {2}, (g, k)
 
 
 @pytest.mark.parametrize("name", list(SIZE_CLASSES))
