@@ -390,7 +390,9 @@ SC_API int sc_hip_time_tail_phases(void *instance, unsigned long long *cycles11)
 /* Host-only (needs no GPU): how sc_hip_run_device_batch / the pool would partition a batch whose members have these ROI sizes
  * (wh[2i], wh[2i+1]: width and height, ring included) under `opts` (NULL: the defaults), at most `cap` members per group (<= 0: no
  * limit): group_of[i] = the member's group, kind_of[i] (may be NULL) = 0 alone, 1 a same-size group, 2 a size class (different
- * sizes, the same solve: csrc/sc_ragged.cpp).  Returns the number of groups, or SC_ERR_BAD_ARG. */
+ * sizes, the same solve: csrc/sc_ragged.cpp; the member's bytes are those of its solo run), 3 a size class on another hierarchy than
+ * the member's solo run takes (a small ROI, or the leftover of a class moved onto the next deeper one: within one grey level of the
+ * solo run).  Returns the number of groups, or SC_ERR_BAD_ARG. */
 /* Host-only: what decides a ROI size's class: out = { eligible, levels, level held by k_mg_tail (THE class key, beside the 1/8 spread),
  * operand padding x, y of the level solved directly, mode-block padding x, y of the correction, its column tiles, its row splits,
  * 1000 * nx + ny of the level solved directly, solo_differs (1: a small ROI whose level 1 a solo clone solves directly -- inside a

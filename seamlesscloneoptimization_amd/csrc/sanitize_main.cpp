@@ -88,7 +88,7 @@ int main()
                     for (int i = 0; i < 700; ++i) { q = q * 1664525u + 1013904223u; other[2 * i] = 100 + (int)((q >> 9) % 3000u); other[2 * i + 1] = 100 + (int)((q >> 3) % 3000u); }
                     std::vector<int> og(700);
                     if (sc_hip_plan_groups(other.data(), 700, 0, nullptr, og.data(), nullptr) < 1) bad++;      // misses, evictions
-                    int out[10];
+                    int out[12];
                     if (sc_hip_plan_size(1000 + r, 1000 + t, nullptr, out) != SC_OK) bad++;
                 }
             });

@@ -1215,7 +1215,7 @@ int sc_hip_plan_groups(const int *wh, int n, int cap, const sc_solver_opts *opts
         for (int i : groups[g]) uniform = uniform && plans[i].W == plans[groups[g][0]].W && plans[i].H == plans[groups[g][0]].H;
         for (int i : groups[g]) {
             group_of[i] = (int)g;
-            if (kind_of) kind_of[i] = groups[g].size() < 2 ? 0 : uniform ? 1 : 2;
+            if (kind_of) kind_of[i] = groups[g].size() < 2 ? 0 : uniform ? 1 : plans[i].solo_differs ? 3 : 2;
         }
     }
     return (int)groups.size();

@@ -111,7 +111,7 @@ bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p);     // fills
 std::shared_ptr<const SizePlan::Heavy> plan_heavy(const SizePlan &p);    // nullptr: a tiling with more than four parts per cell row (none exists)
 // members (any order) -> groups that can each share one set of launches: a size class (two or more DIFFERENT sizes), a same-size
 // group, or a single; `cap` = most members per group.  groups[k] lists indices into `plans`.
-void plan_groups(const std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups);
+void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups);      // (may rewrite a member's plan: sc_ragged.cpp)
 
 struct RagState {
     const RagMember *dev = nullptr;     // the members' table on the device WHILE a size class is being processed, else nullptr

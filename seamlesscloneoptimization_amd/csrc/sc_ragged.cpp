@@ -20,6 +20,7 @@ namespace sc {
 // member leaves unused of its planes is never touched, but the grids are sized for the largest)
 static constexpr double RAG_SPREAD = 1.125;
 static constexpr int RAG_SPREAD_PIXELS = 64;
+static constexpr long RAG_SPREAD_AREA = 100000;
 
 // Plans are pure functions of (W, H) and of the few solver options below: memoised, so that a caller whose ROI sizes recur (video:
 // the same faces frame after frame) plans each size once.  Bounded; shared by every instance and pool of the process.
@@ -149,37 +150,93 @@ std::shared_ptr<const SizePlan::Heavy> plan_heavy(const SizePlan &p)
     return Hv;
 }
 
+// A member's plan one level deeper than its own: the level its solo run holds in k_mg_tail becomes an ordinary coarse level, the one
+// its solo run solves directly goes into k_mg_tail and the next one is solved directly.  Same fixed point, other iterates: within
+// one grey level of the solo run, not its bytes (solo_differs).  false: the ladder has no such level.
+static bool plan_deeper(const SizePlan &p, SizePlan &q)
+{
+    if (!p.ok || !p.t) return false;
+    const int a = p.tail + 1;
+    if (a + 2 > RAG_MAX_LEVELS || p.nl < a + 2) return false;
+    const MGGeom &A = p.t->g[a];
+    if (A.x.n > 127 || A.y.n > 127 || A.x.nc > 63 || A.y.nc > 63 || A.x.nc < 1 || A.y.nc < 1) return false;
+    q = p;
+    q.tail = a;
+    q.npx = round_up(A.x.nc, 32); q.npy = round_up(A.y.nc, 32);
+    q.solo_differs = true;
+    return true;
+}
+
 // Greedy, order preserving: a member joins the first open group it fits -- the same size as the group's members, or the same class
-// with the group's spread staying within RAG_SPREAD -- else it opens a new one.
-void plan_groups(const std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups)
+// with the group's spread staying within bounds -- else it opens a new one.  Then the LEFTOVERS of a class (a group of at most cap / 2
+// members) whose hierarchy is one level shallower than that of a group with room move there, on the deeper hierarchy (plan_deeper:
+// their plans are rewritten in `plans`): sizes straddling 513 / 1027 / 2050 unknowns per side -- where the ladder gains a level --
+// would otherwise always split in two.
+void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups)
 {
     struct Open { int first; int minW, maxW, minH, maxH; bool uniform; };
     std::vector<Open> open;
     groups.clear();
+    // (1/8 per direction, or 64 pixels where that is more -- a level-0 tile is 232 x 44, small ROIs differ by less than the grid's
+    //  grain --, or 100 000 pixels of area: a set of launches costs what ~3 Mpixels of level-0 work cost, whatever its size)
+    auto fits = [](const Open &g, const SizePlan &p, Open &w) {
+        w = g;
+        w.minW = std::min(g.minW, p.W); w.maxW = std::max(g.maxW, p.W); w.minH = std::min(g.minH, p.H); w.maxH = std::max(g.maxH, p.H);
+        const bool wx = (double)w.maxW <= RAG_SPREAD * w.minW || w.maxW - w.minW <= RAG_SPREAD_PIXELS;
+        const bool wy = (double)w.maxH <= RAG_SPREAD * w.minH || w.maxH - w.minH <= RAG_SPREAD_PIXELS;
+        return (wx && wy) || (long)w.maxW * w.maxH - (long)w.minW * w.minH <= RAG_SPREAD_AREA;
+    };
     for (int i = 0; i < (int)plans.size(); ++i) {
         const SizePlan &p = plans[i];
         int into = -1;
+        Open w{};
         for (int k = 0; k < (int)open.size() && into < 0; ++k) {
             if ((int)groups[k].size() >= cap) continue;
             const Open &g = open[k];
             const SizePlan &q = plans[g.first];
-            if (g.uniform && q.W == p.W && q.H == p.H) { into = k; break; }
+            if (g.uniform && q.W == p.W && q.H == p.H) { into = k; w = g; break; }
             if (!p.same_class(q)) continue;
-            const int minW = std::min(g.minW, p.W), maxW = std::max(g.maxW, p.W), minH = std::min(g.minH, p.H), maxH = std::max(g.maxH, p.H);
-            // (1/8 per direction, or 64 pixels where that is more: a level-0 tile is 232 x 44, small ROIs differ by less than the grid's grain)
-            const bool wx = (double)maxW <= RAG_SPREAD * minW || maxW - minW <= RAG_SPREAD_PIXELS, wy = (double)maxH <= RAG_SPREAD * minH || maxH - minH <= RAG_SPREAD_PIXELS;
-            if (wx && wy) into = k;
+            if (fits(g, p, w)) into = k;
         }
         if (into < 0) {
             open.push_back({ i, p.W, p.W, p.H, p.H, true });
             groups.push_back(std::vector<int>(1, i));
             continue;
         }
-        Open &g = open[into];
-        if (plans[g.first].W != p.W || plans[g.first].H != p.H) g.uniform = false;
-        g.minW = std::min(g.minW, p.W); g.maxW = std::max(g.maxW, p.W); g.minH = std::min(g.minH, p.H); g.maxH = std::max(g.maxH, p.H);
+        if (plans[open[into].first].W != p.W || plans[open[into].first].H != p.H) w.uniform = false;
+        open[into] = w;
         groups[into].push_back(i);
     }
+    // --- leftovers onto the deeper hierarchy of a group with room
+    const int small = std::max(1, cap / 2);
+    std::vector<char> received(groups.size(), 0);          // (a group that took leftovers in stays where it is)
+    for (int k = 0; k < (int)groups.size(); ++k) {
+        if (groups[k].empty() || (int)groups[k].size() > small || !plans[groups[k][0]].ok || received[k]) continue;
+        std::vector<int> stay;
+        for (int i : groups[k]) {
+            SizePlan d;
+            bool moved = false;
+            if (plan_deeper(plans[i], d))
+                for (int t = 0; t < (int)groups.size() && !moved; ++t) {
+                    if (t == k || groups[t].empty() || (int)groups[t].size() >= cap) continue;
+                    const SizePlan &q = plans[open[t].first];
+                    Open w{};
+                    if (!d.same_class(q) || q.tail != plans[i].tail + 1 || !fits(open[t], d, w)) continue;
+                    w.uniform = false;
+                    open[t] = w;
+                    groups[t].push_back(i);
+                    plans[i] = d;
+                    received[t] = 1;
+                    moved = true;
+                }
+            if (!moved) stay.push_back(i);
+        }
+        groups[k].swap(stay);
+    }
+    size_t o = 0;
+    for (size_t k = 0; k < groups.size(); ++k)
+        if (!groups[k].empty()) { if (o != k) groups[o] = std::move(groups[k]); ++o; }
+    groups.resize(o);
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

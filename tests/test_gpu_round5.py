@@ -159,7 +159,11 @@ SIZE_CLASSES = {
     # sizes whose float tables are off by more than 4 % in their lowest modes (plan_size: conditional): the output's form is decided by
     # the judged cycle's measured update, for the whole group (smooth inputs: the same way as in each solo run)
     "2100c": [(2107, 2053), (2137, 2072), (2132, 2077), (2120, 2064)],
+    # the first member's hierarchy is one level shallower than the others' (both sides below 1027): the leftover of its class, it is
+    # moved onto theirs (plan_groups kind 3: within one grey level of its solo run, the others keep their solo bytes)
+    "straddle": [(1010, 1015), (1050, 1060), (1070, 1040), (1090, 1080)],
 }
+EXPECTED_KINDS = {"150s": [3] * 5, "straddle": [3, 2, 2, 2]}
 
 
 def test_size_classes_are_what_the_tests_think_they_are():
@@ -167,7 +171,7 @@ def test_size_classes_are_what_the_tests_think_they_are():
     from seamlesscloneoptimization_amd import capi
     for name, sizes in SIZE_CLASSES.items():
         g, k = capi.plan_groups(sizes)
-        assert set(g) == {0} and set(k) == {2}, (name, g, k)
+        assert set(g) == {0} and k == EXPECTED_KINDS.get(name, [2] * len(sizes)), (name, g, k)
         assert all(capi.plan_size(*sz)["conditional"] == (name == "2100c") for sz in sizes), name
     # a conditional size never shares a class with one whose bound holds a priori
     g, k = capi.plan_groups([(2107, 2053), (2090, 2050), (2137, 2072), (2090, 2055)])
@@ -183,6 +187,7 @@ def test_size_class_members_match_their_solo_runs(oracles, name):
     from seamlesscloneoptimization_amd import capi
     o, oc = oracles
     sizes = SIZE_CLASSES[name]
+    kinds = capi.plan_groups(sizes)[1]
     items = []
     for k, (W, H) in enumerate(sizes):
         dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=500 + 7 * k, seed_patch=600 + 11 * k, margin=40)
@@ -207,7 +212,7 @@ def test_size_class_members_match_their_solo_runs(oracles, name):
                 assert _dmax(got, want) <= 1, (name, k, rep)
                 assert not np.array_equal(got, it[0])
                 assert _dmax(got, alone[k]) <= 1, (name, k, rep)
-                if cycles[k] == group_cycles and not capi.plan_size(*sizes[k])["solo_differs"]:
+                if cycles[k] == group_cycles and kinds[k] == 2:
                     assert np.array_equal(got, alone[k]), (name, k, rep, int((got != alone[k]).sum()))
         # the same members in another order, one of them twice: the table is per slot, not per size
         order = [2, 0, 1, 0] if len(items) >= 3 else [1, 0]
@@ -217,7 +222,7 @@ def test_size_class_members_match_their_solo_runs(oracles, name):
         assert inst.info().group_members == len(order)
         if inst.info().sweeps == group_cycles:
             for (f, b0, b, m, shape), q in zip(keep2, order):
-                if cycles[q] == group_cycles and not capi.plan_size(*sizes[q])["solo_differs"]:
+                if cycles[q] == group_cycles and kinds[q] == 2 and name != "straddle":
                     assert np.array_equal(inst.from_device(b, shape), alone[q]), (name, q)
         _free_jobs(inst, keep); _free_jobs(inst, keep2)
     finally:
@@ -259,7 +264,7 @@ def test_pool_buckets_48_random_sizes(oracles):
     """The review's test of round 5's first item: 48 random ROI sizes in [1000, 1100]^2 and 48 in [300, 340]^2 through the pool
     (groups of 16): every member within one grey level of the float-table port AND of its solo run, byte-identical to the latter
     wherever the member's group took the solo run's cycle count -- which the pool cannot report per member, so: identical on at
-    least 90 % of the members (tests/tools/fuzz_classes.py makes the exact comparison: 192 of 192)."""
+    least 90 % of the members that kept their own hierarchy (plan_groups kind 2; the few leftovers moved onto a deeper one are kind 3) (tests/tools/fuzz_classes.py makes the exact comparison: 192 of 192)."""
     from seamlesscloneoptimization_amd import capi
     o, oc = oracles
     rng = np.random.default_rng(2025)
@@ -274,6 +279,8 @@ def test_pool_buckets_48_random_sizes(oracles):
             dst, patch, mask, cx, cy = base[key]
             items.append((dst, np.ascontiguousarray(patch[:H + 2, :W + 2]), np.full((H + 2, W + 2), 255, np.uint8), cx, cy))
         alone, cycles = _solo_results(items)
+        kinds = capi.plan_groups(sizes, 16)[1]                # what the pool does with these sizes (the same planner)
+        assert all(kk in (2, 3) for kk in kinds) and sum(kk == 3 for kk in kinds) <= 8, kinds
         pool = capi.Pool(0, streams=2, group=16)
         try:
             inst = pool.instances[0]
@@ -286,8 +293,8 @@ def test_pool_buckets_48_random_sizes(oracles):
                 want = oc.seamless_clone(it[0], it[1], it[2], it[3], it[4], nthreads=min(16, oc.max_threads()), exact_den=False)
                 assert _dmax(got, want) <= 1, (lo, k, sizes[k])
                 assert not np.array_equal(got, it[0])
-                same += int(np.array_equal(got, alone[k]))
-            assert same >= 0.9 * len(items), (lo, same)
+                same += int(kinds[k] == 2 and np.array_equal(got, alone[k]))
+            assert same >= 0.9 * sum(kk == 2 for kk in kinds), (lo, same)
             _free_jobs(inst, keep)
         finally:
             pool.close()
