@@ -1,6 +1,6 @@
 // seamlessClone_main -- native CLI with the reference's argv (seamlessClone-CUDA/seamlessClone_main.cu:69-94):
 //
-//     seamlessClone_main src.yml dst.yml mask.yml centerX centerY gpu [out.bmp]
+//     seamlessClone_main src.yml dst.yml mask.yml centerX centerY gpu [out.bmp [solver [dump_dir]]]
 //
 // Reads the three OpenCV-FileStorage yml matrices (node "data", seamlessClone_imp.cu:226-237)
 // without OpenCV, runs one warm-up clone and one timed clone through the C ABI (the reference's
@@ -54,6 +54,67 @@ static bool read_yml(const char *path, Mat8 &m)
     return true;
 }
 
+// One OpenCV-FileStorage matrix, node "data" (what compare/vs.py reads): 8-bit (dt u) or float32 (dt f) values.
+template <typename T>
+static bool write_yml(const std::string &path, const char *name, const T *v, int rows, int cols)
+{
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) return false;
+    const bool is_float = sizeof(T) == sizeof(float);
+    fprintf(f, "%%YAML:1.0\n---\nmat_name: %s\ndata: !!opencv-matrix\n   rows: %d\n   cols: %d\n   dt: %s\n", name, rows, cols, is_float ? "f" : "u");
+    std::string cur = "   data: [ ";
+    char tok[48];
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = 0; i < n; ++i) {
+        if (is_float) snprintf(tok, sizeof(tok), "%.9g%s", (double)v[i], i + 1 < n ? ", " : " ]");      // 9 significant digits: a float32 round trip
+        else snprintf(tok, sizeof(tok), "%d%s", (int)v[i], i + 1 < n ? ", " : " ]");
+        if (cur.size() + strlen(tok) > 78) {
+            while (!cur.empty() && cur.back() == ' ') cur.pop_back();
+            fprintf(f, "%s\n", cur.c_str());
+            cur = "       ";
+        }
+        cur += tok;
+    }
+    fprintf(f, "%s\n", cur.c_str());
+    return fclose(f) == 0;
+}
+
+// The reference's SCDEBUG intermediates (seamlessClone_imp.cpp:2110-2117) through the stage-level hooks: DIR/ucMask0.yml (the eroded
+// ROI mask) and DIR/g{0,1,2}.yml -- the right-hand side with the Dirichlet ring folded in (seamlessClone_imp.cpp:1983-2009), planes in
+// the reference's R, G, B order (:374-376) -- i.e. what compare/vs.py:81-86 diffs against OpenCV's mod_diff{2,1,0}.yml.
+static bool dump_rhs(void *inst, const std::string &dir, const Mat8 &patch, const Mat8 &dest, const Mat8 &mask, int cx, int cy)
+{
+    int geo[6];
+    if (sc_hip_mask_stage(inst, mask.data.data(), mask.cols, mask.rows, mask.step(), cx, cy, geo, nullptr, 0) != SC_OK) return false;
+    const int W = geo[2], H = geo[3];
+    std::vector<uint8_t> M((size_t)W * H);
+    if (sc_hip_mask_stage(inst, mask.data.data(), mask.cols, mask.rows, mask.step(), cx, cy, geo, M.data(), M.size()) != SC_OK) return false;
+    const size_t plane = (size_t)W * H;
+    std::vector<float> B(3 * plane), lap(3 * plane);
+    if (sc_hip_build_rhs(inst, patch.data.data(), patch.cols, patch.rows, patch.step(), dest.data.data(), dest.cols, dest.rows, dest.step(),
+                         mask.data.data(), mask.cols, mask.rows, mask.step(), cx, cy, geo, B.data(), lap.data(), plane) != SC_OK) return false;
+    if (!write_yml(dir + "/ucMask0.yml", "ucMask0", M.data(), H, W)) return false;
+    const int w = W - 2, h = H - 2;
+    std::vector<float> g((size_t)w * h);
+    for (int ch = 0; ch < 3; ++ch) {             // file g<ch> = our plane 2 - ch (ours follow the interleaved B, G, R)
+        const float *L = lap.data() + (size_t)(2 - ch) * plane, *D = B.data() + (size_t)(2 - ch) * plane;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                float v = L[(size_t)(y + 1) * W + x + 1];
+                if (x == 0) v -= D[(size_t)(y + 1) * W];
+                if (y == 0) v -= D[x + 1];
+                if (x == w - 1) v -= D[(size_t)(y + 1) * W + W - 1];
+                if (y == h - 1) v -= D[(size_t)(H - 1) * W + x + 1];
+                g[(size_t)y * w + x] = v;
+            }
+        char name[8];
+        snprintf(name, sizeof(name), "g%d", ch);
+        if (!write_yml(dir + "/" + name + ".yml", name, g.data(), h, w)) return false;
+    }
+    printf("wrote %s/ucMask0.yml, g0.yml, g1.yml, g2.yml (%dx%d)\n", dir.c_str(), w, h);
+    return true;
+}
+
 static bool write_bmp(const char *path, const Mat8 &m)
 {
     FILE *f = fopen(path, "wb");
@@ -79,13 +140,14 @@ int main(int argc, const char *argv[])
 {
     printf("argc: %d\n", argc);
     for (int i = 0; i < argc; ++i) printf("argv[%d]: %s\n", i, argv[i]);
-    if (argc < 7 || argc > 9) {
-        fprintf(stderr, "usage: %s src.yml dst.yml mask.yml centerX centerY gpu [out.bmp [auto|mg|exact|dst|fft]]\n"
+    if (argc < 7 || argc > 10) {
+        fprintf(stderr, "usage: %s src.yml dst.yml mask.yml centerX centerY gpu [out.bmp [auto|mg|exact|dst|fft [dump_dir]]]\n"
                         "  auto  (default) direct FFT solve in double up to 720 unknowns per side (and elongated ROIs), mg above (SC_METHOD_AUTO)\n"
                         "  mg    multigrid + float-table correction: the reference's arithmetic\n"
                         "  exact multigrid, exact solution of the 5-point system (SC_FLAG_EXACT_TABLES)\n"
                         "  dst   the reference's direct DST solve on the fp64 matrix cores (SC_METHOD_DST)\n"
-                        "  fft   the reference's default back-end: FFT-based direct solve, float32 (SC_METHOD_FFT)\n", argv[0]);
+                        "  fft   the reference's default back-end: FFT-based direct solve, float32 (SC_METHOD_FFT)\n"
+                        "  dump_dir (an existing directory): the reference's SCDEBUG intermediates ucMask0.yml, g0.yml, g1.yml, g2.yml\n", argv[0]);
         return EXIT_FAILURE;
     }
     Mat8 patch, dest, mask;
@@ -97,7 +159,7 @@ int main(int argc, const char *argv[])
     const int cx = atoi(argv[4]), cy = atoi(argv[5]), gpu = atoi(argv[6]);
     void *inst = my_seamlessclone_api_imp_create_instance(gpu);
     if (!inst) return EXIT_FAILURE;
-    const std::string solver = argc == 9 ? argv[8] : "auto";
+    const std::string solver = argc >= 9 ? argv[8] : "auto";
     if (solver != "auto") {
         sc_solver_opts o;
         sc_hip_get_solver(inst, &o);
@@ -128,6 +190,11 @@ int main(int argc, const char *argv[])
     printf("device stages: %.3f msec (ROI %dx%d); transfers: H2D %.3f msec, D2H %.3f msec; solver %s%s: %d cycle(s)\n", info.ms_device_total, info.W, info.H, info.ms_h2d, info.ms_d2h, solver.c_str(),
            solver == "auto" ? (info.method == SC_METHOD_FFT ? " -> fft (double)" : " -> mg") : "", info.sweeps);
     if (argc >= 8 && !write_bmp(argv[7], out)) fprintf(stderr, "cannot write %s\n", argv[7]);
+    if (argc >= 10 && !dump_rhs(inst, argv[9], patch, dest, mask, cx, cy)) {
+        fprintf(stderr, "cannot write the intermediates to %s: %s\n", argv[9], sc_hip_last_error(inst));
+        my_seamlessclone_api_imp_destroy(inst);
+        return EXIT_FAILURE;
+    }
     my_seamlessclone_api_imp_destroy(inst);
     return EXIT_SUCCESS;
 }
