@@ -439,7 +439,7 @@ def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, s
             "members_on_a_deeper_hierarchy_than_solo": int(sum(1 for x in k if x == 3)),
             "first_member_vs_its_solo_clone": {"member": ci, "maxdiff": int(d.max()), "percent_differing": round(float((d > 0).mean() * 100), 4)},
             "note": "64 clones with 64 different ROI sizes, random in [%d, %d]^2, through the pool as configured: members of one size class (same "
-                    "hierarchy depth and bottom solve, widths and heights within 1/8) share one set of solver launches through a per-member geometry "
+                    "hierarchy depth and bottom solve, widths and heights within 2x; the pool hands its jobs to the planner largest first) share one set of solver launches through a per-member geometry "
                     "table; every member's bytes are its solo run's whenever the group takes the solo run's cycle count -- except the leftovers of a class "
                     "one level shallower, which ride along on the deeper hierarchy (counted above; within one grey level of their solo runs)" % (lo, hi)}
 
@@ -973,6 +973,8 @@ def main():
     mixed_sizes = None
     if comm.rank == 0 and args.gpus == 1 and not args.no_mixed_sizes and args.config == "c3":
         mixed_sizes = mixed_sizes_leg(capi)
+        wide = mixed_sizes_leg(capi, lo=100, hi=2400, reps=4)      # the hardest list: sizes spread over a factor of 24, four hierarchy depths
+        mixed_sizes["wide_range_100_2400"] = {k_: wide[k_] for k_ in wide if k_ not in ("note", "streams", "group", "clones")}
     c5_projected = None
     if comm.rank == 0 and args.gpus == 1 and not args.no_c5_projection and args.config == "c3":
         c5_projected = c5_projection_leg(capi)

@@ -355,7 +355,7 @@ typedef struct sc_batch_job {
  * every member gets the cycle count of the slowest.  The group is launched on predicted bounding boxes (the masks'
  * interiors); a member whose box turns out different is left untouched by the group and repeated alone.
  * Round 5: the members of a call are PARTITIONED -- same-size members share launches as above; members of one SIZE CLASS
- * (different sizes whose solves are the same program: same hierarchy depth and bottom solve, widths and heights within 1/8 of
+ * (different sizes whose solves are the same program: same hierarchy depth and bottom solve, widths and heights within 2x of
  * each other; default solver options) share them through a per-member geometry table the kernels read (csrc/sc_ragged.cpp),
  * each member with the bytes of its solo run; what fits neither (and a failing member) runs alone.  jobs[i].rc receives each
  * clone's code; the call is asynchronous like sc_hip_run_device(..., false): sync the instance before reading bodies. */
@@ -393,7 +393,7 @@ SC_API int sc_hip_time_tail_phases(void *instance, unsigned long long *cycles11)
  * sizes, the same solve: csrc/sc_ragged.cpp; the member's bytes are those of its solo run), 3 a size class on another hierarchy than
  * the member's solo run takes (a small ROI, or the leftover of a class moved onto the next deeper one: within one grey level of the
  * solo run).  Returns the number of groups, or SC_ERR_BAD_ARG. */
-/* Host-only: what decides a ROI size's class: out = { eligible, levels, level held by k_mg_tail (THE class key, beside the 1/8 spread),
+/* Host-only: what decides a ROI size's class: out = { eligible, levels, level held by k_mg_tail (THE class key, beside the 2x spread),
  * operand padding x, y of the level solved directly, mode-block padding x, y of the correction, its column tiles, its row splits,
  * 1000 * nx + ny of the level solved directly, solo_differs (1: a small ROI whose level 1 a solo clone solves directly -- inside a
  * class it runs the general hierarchy and comes out within one grey level of its solo run instead of with its bytes), conditional

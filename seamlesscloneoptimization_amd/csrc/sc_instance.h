@@ -99,7 +99,7 @@ struct SizePlan {
     std::shared_ptr<const Tables> t;
     // ... and what only the per-call setup needs (rag_begin, on the worker's thread): built on first use, memoised per size as well
     struct Heavy { std::vector<float> R; std::vector<int> map[2]; };
-    // same compile-time choices and launch shapes, and strides that waste at most ~1/8 per direction
+    // same compile-time choices and launch shapes (the spread of a group's sizes is plan_groups' business)
     bool same_class(const SizePlan &o) const
     {
         // (levels below the directly solved one are never visited: their number is free; operand paddings are per member:

@@ -198,10 +198,23 @@ int sc_hip_pool_run(void *p, sc_batch_job *jobs, int n, int device_resident)
             // of a batch are the cheap ones.
             sc_solver_opts o;
             sc_hip_get_solver(P->inst[0], &o);
+            // (the planner is first-come; the pool is free to reorder, so it hands the jobs over largest first: the members of a group
+            //  then differ as little as the batch allows, and a class's grids -- sized for its largest member -- waste the least)
+            std::vector<int> order(n);
+            for (int i = 0; i < n; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+                return (long)jobs[x].mask_cols * jobs[x].mask_rows > (long)jobs[y].mask_cols * jobs[y].mask_rows;
+            });
             std::vector<SizePlan> plans(n);
-            for (int i = 0; i < n; ++i) plan_size(o, jobs[i].mask_cols - 2, jobs[i].mask_rows - 2, plans[i]);
+            for (int i = 0; i < n; ++i) plan_size(o, jobs[order[i]].mask_cols - 2, jobs[order[i]].mask_rows - 2, plans[i]);
             std::vector<std::vector<int>> groups;
             plan_groups(plans, P->group, groups);
+            {
+                std::vector<SizePlan> by_job(n);
+                for (int i = 0; i < n; ++i) by_job[order[i]] = plans[i];
+                plans.swap(by_job);
+                for (auto &g : groups) for (int &i : g) i = order[i];
+            }
             std::stable_sort(groups.begin(), groups.end(), [&](const std::vector<int> &x, const std::vector<int> &y) {
                 auto px = [&](const std::vector<int> &g) { long t = 0; for (int i : g) t += (long)plans[i].W * plans[i].H; return t; };
                 return px(x) > px(y);

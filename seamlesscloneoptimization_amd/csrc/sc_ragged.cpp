@@ -18,7 +18,7 @@ namespace sc {
 
 // ROI sizes of one class may differ by this factor per direction at most (strides are the largest member's: what a smaller
 // member leaves unused of its planes is never touched, but the grids are sized for the largest)
-static constexpr double RAG_SPREAD = 1.125;
+static constexpr double RAG_SPREAD = 2.0;
 static constexpr int RAG_SPREAD_PIXELS = 64;
 static constexpr long RAG_SPREAD_AREA = 100000;
 
@@ -177,7 +177,7 @@ void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<
     struct Open { int first; int minW, maxW, minH, maxH; bool uniform; };
     std::vector<Open> open;
     groups.clear();
-    // (1/8 per direction, or 64 pixels where that is more -- a level-0 tile is 232 x 44, small ROIs differ by less than the grid's
+    // (2x per direction, or 64 pixels where that is more -- a level-0 tile is 232 x 44, small ROIs differ by less than the grid's
     //  grain --, or 100 000 pixels of area: a set of launches costs what ~3 Mpixels of level-0 work cost, whatever its size)
     auto fits = [](const Open &g, const SizePlan &p, Open &w) {
         w = g;

@@ -393,7 +393,7 @@ def test_host_side_sanitizers_are_clean():
 def test_group_planner_properties():
     """The host-only planner behind sc_hip_run_device_batch and the pool (csrc/sc_ragged.cpp through sc_hip_plan_groups /
     sc_hip_plan_size; no GPU): same-size members form a group of their own kind, members of one size class another, a class never
-    spreads more than 1/8 (or 64 pixels) per direction or 100 000 pixels of area, `cap` bounds every group, the partition is deterministic and order preserving, options
+    spreads more than 2x (or 64 pixels) per direction or 100 000 pixels of area, `cap` bounds every group, the partition is deterministic and order preserving, options
     outside the default fast path switch the classes off (same-size groups stay), and the boundaries the classes do NOT depend on any
     more -- the operand padding of the direct solve, the correction's mode-block padding, the number of levels below the directly
     solved one -- do not split a class."""
@@ -417,7 +417,7 @@ def test_group_planner_properties():
             assert len(m) >= 2 and len(set(zip(ws, hs))) == 1
         else:
             assert len(m) >= 2 and len(set(zip(ws, hs))) > 1
-            assert ((max(ws) <= 1.125 * min(ws) or max(ws) - min(ws) <= 64) and (max(hs) <= 1.125 * min(hs) or max(hs) - min(hs) <= 64)) or \
+            assert ((max(ws) <= 2 * min(ws) or max(ws) - min(ws) <= 64) and (max(hs) <= 2 * min(hs) or max(hs) - min(hs) <= 64)) or \
                 max(ws) * max(hs) - min(ws) * min(hs) <= 100000
             tails = {capi.plan_size(*sizes[i])["tail_level"] for i in m if k[i] == 2}
             assert len(tails) == 1 and all(capi.plan_size(*sizes[i])["eligible"] for i in m)

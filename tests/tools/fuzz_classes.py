@@ -25,7 +25,7 @@ for bi in range(nb):
     if bi % 4 == 0:
         base_h = base_w = int(rng.choice([100, 160, 195, 320, 520, 1010, 1040, 1090, 2040, 2110, 2120, 3100]))      # near class boundaries
     n = int(rng.integers(2, 7 if base_w * base_h > 2.5e6 else 12))
-    spread = float(rng.choice([0.02, 0.05, 0.10]))
+    spread = float(rng.choice([0.02, 0.05, 0.10, 0.3, 0.45]))
     sizes = [(max(12, int(base_w * (1 + rng.uniform(-spread, spread)))), max(12, int(base_h * (1 + rng.uniform(-spread, spread))))) for _ in range(n)]
     g, kinds = capi.plan_groups(sizes)          # keep the members of the largest size class: the call's statistics then describe THEIR launches
     from collections import Counter
