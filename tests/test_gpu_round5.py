@@ -409,3 +409,41 @@ def test_both_clis_dump_the_reference_intermediates(tmp_path, golden_dir, c1_inp
         assert compare.rhs_diff_bgr_vs_rgb_planes([g_bgr[0], g_bgr[1], g_bgr[2]], planes) == [0.0, 0.0, 0.0]
     bad = subprocess.run([exe] + args + [str(tmp_path / "o.bmp"), "auto", str(tmp_path / "no_such_dir")], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "cannot write the intermediates" in bad.stderr
+
+
+def test_one_call_with_more_members_than_a_job_table_holds(oracles):
+    """The kernels that take their per-member jobs by value hold 16 (MaskJobs / ImageJobs / CopyJobs) and are launched in slices; the
+    size class's own table has no such limit.  27 members of one class (sizes in [250, 500]^2: up to 2x apart) in ONE
+    sc_hip_run_device_batch call: all share the launches, every member within one grey level of the port and with the bytes of its
+    solo run where the cycle counts agree."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    rng = np.random.default_rng(31)
+    sizes = [(int(rng.integers(250, 501)), int(rng.integers(250, 501))) for _ in range(27)]
+    g, kinds = capi.plan_groups(sizes)
+    assert set(g) == {0} and set(kinds) == {2}, (g, kinds)
+    items = []
+    for k, (W, H) in enumerate(sizes):
+        dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=900 + k, seed_patch=950 + k, margin=30)
+        items.append((dst, patch, mask, cx + (k % 5) - 2, cy - (k % 3)))
+    alone, cycles = _solo_results(items)
+    inst = capi.Instance(0)
+    try:
+        jobs, keep = _device_jobs(inst, items)
+        assert inst.run_device_batch(jobs) == 0 and all(j.rc == 0 for j in jobs)
+        inst.sync()
+        i = inst.info()
+        assert i.group_members == 27 and i.group_ragged == 1
+        same = 0
+        for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
+            got = inst.from_device(b, shape)
+            want = oc.seamless_clone(it[0], it[1], it[2], it[3], it[4], nthreads=min(16, oc.max_threads()), exact_den=False)
+            assert _dmax(got, want) <= 1, k
+            assert not np.array_equal(got, it[0])
+            if cycles[k] == i.sweeps:
+                assert np.array_equal(got, alone[k]), (k, sizes[k], int((got != alone[k]).sum()))
+                same += 1
+        assert same >= 20, same
+        _free_jobs(inst, keep)
+    finally:
+        inst.destroy()
