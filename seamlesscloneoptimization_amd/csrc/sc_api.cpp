@@ -69,6 +69,7 @@ int ensure(Instance *I, DevBuf &b, size_t bytes, bool zero)
         if (I->retired_bytes > ((size_t)1 << 30)) {
             SC_HIP(I, hipStreamSynchronize(I->stream));
             if (I->aux) SC_HIP(I, hipStreamSynchronize(I->aux));
+            if (I->aux2) SC_HIP(I, hipStreamSynchronize(I->aux2));
             for (DevBuf &r : I->retired) { I->arena_bytes -= r.cap; dev_release(r); }
             I->retired.clear();
             I->retired_bytes = 0;
@@ -511,6 +512,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     (void)hipSetDevice(I->gpu);
     if (I->stream) (void)hipStreamSynchronize(I->stream);
     if (I->aux) (void)hipStreamSynchronize(I->aux);
+    if (I->aux2) (void)hipStreamSynchronize(I->aux2);
     for (DevBuf &b : I->retired) dev_release(b);                    // blocks that growth replaced (ensure)
     for (Instance::Slab &sl : I->slabs) if (sl.base) (void)hipFree(sl.base);
     DevBuf *bufs[] = { &I->d_face, &I->d_body_roi, &I->d_out, &I->d_mask, &I->d_M, &I->d_U0, &I->d_U1, &I->d_F };
@@ -564,6 +566,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->ev_fork) (void)hipEventDestroy(I->ev_fork);
     if (I->ev_join) (void)hipEventDestroy(I->ev_join);
     if (I->aux) (void)hipStreamDestroy(I->aux);
+    if (I->aux2) (void)hipStreamDestroy(I->aux2);
     if (I->stream) (void)hipStreamDestroy(I->stream);
     I->magic = 0;
     delete I;
@@ -978,7 +981,6 @@ int run_group_members(Instance *I, sc_batch_job *jobs, const std::vector<int> &i
     if ((rc = ensure(I, I->d_M, mplane * n, false))) return rc;
     if ((rc = setup_fields(I, g0.W, g0.H, 3 * n))) return rc;
     RagScope scope{ I };
-    if (plans && (rc = rag_begin(I, *plans))) return rc;
     std::vector<MaskJob> mj(n);
     std::vector<ImageJob> ij(n);
     for (int k = 0; k < n; ++k) {
@@ -1004,6 +1006,10 @@ int run_group_members(Instance *I, sc_batch_job *jobs, const std::vector<int> &i
         I->u_half = I->f_half && !(I->opts.flags & SC_FLAG_FLOAT_U0);
         launch_preprocess_group(ij.data(), n, I->mpitch, I->U0, I->F, I->stream, I->f_half, I->u_half);
         SC_HIP(I, hipGetLastError());
+        // a size class: the members' table, its upload and the second stream's builds (rag_begin: ~50 us of host work) go in HERE, while
+        // the device erodes and pre-processes -- neither reads the table (member sizes travel in the ImageJobs); in front of the erode
+        // the device idled for as long (16 x 320^2: the first level-0 launch started 119 us into the call, now ~85)
+        if (plans && !I->rag.dev && (rc = rag_begin(I, *plans))) return rc;
         // --- one solve for the group, results spliced per clone
         I->info.sweep_launches = 0;
         I->guard = RectGuard();

@@ -72,7 +72,8 @@ __host__ __device__ __attribute__((always_inline)) inline double fd_component(co
 
 // g and dg/dtheta of the lower-half equation at theta = pi tau, from two sincos: with S = sin(n theta), C = cos(n theta),
 // s = sin theta, c = cos theta:  sin((n-1) theta) = S c - C s,  cos((n-1) theta) = C c + S s
-__host__ __device__ __attribute__((always_inline)) inline void fd_g_lo_d(double tau, int n, double cw, double d, double &g, double &dg)
+// (mag: the sum of the magnitudes of g's terms -- |g| <= a few eps x mag is a residual at rounding level)
+__host__ __device__ __attribute__((always_inline)) inline void fd_g_lo_d(double tau, int n, double cw, double d, double &g, double &dg, double &mag)
 {
     double S, C, s, c;
     fd_sincospi(n * tau, &S, &C);
@@ -80,9 +81,10 @@ __host__ __device__ __attribute__((always_inline)) inline void fd_g_lo_d(double 
     const double sh = fd_sinpi(0.5 * tau), q = d - 4.0 * sh * sh;           // d - 2 + 2 cos theta, without the cancellation
     g = cw * (S * c - C * s) - q * S;
     dg = cw * (n - 1) * (C * c + S * s) - q * n * C + 2.0 * s * S;
+    mag = cw * (fabs(S * c) + fabs(C * s)) + fabs(q * S);
 }
 // ... and of the upper-half equation in phi = pi - theta = pi tau
-__host__ __device__ __attribute__((always_inline)) inline void fd_g_hi_d(double tau, int n, double cw, double d, double &g, double &dg)
+__host__ __device__ __attribute__((always_inline)) inline void fd_g_hi_d(double tau, int n, double cw, double d, double &g, double &dg, double &mag)
 {
     double S, C, s, c;
     fd_sincospi(n * tau, &S, &C);
@@ -90,26 +92,56 @@ __host__ __device__ __attribute__((always_inline)) inline void fd_g_hi_d(double 
     const double sh = fd_sinpi(0.5 * tau), q = d - 4.0 + 4.0 * sh * sh;     // d - 2 - 2 cos phi
     g = cw * (S * c - C * s) + q * S;
     dg = cw * (n - 1) * (C * c + S * s) + q * n * C + 2.0 * s * S;
+    mag = cw * (fabs(S * c) + fabs(C * s)) + fabs(q * S);
+}
+
+// either of the two by a flag, in one instruction stream: they differ in two signs
+__host__ __device__ __attribute__((always_inline)) inline void fd_g_trig_d(double tau, int n, double cw, double d, bool upper, double &g, double &dg, double &mag)
+{
+    double S, C, s, c;
+    fd_sincospi(n * tau, &S, &C);
+    fd_sincospi(tau, &s, &c);
+    const double sh = fd_sinpi(0.5 * tau);
+    const double q = upper ? d - 4.0 + 4.0 * sh * sh : -(d - 4.0 * sh * sh);      // (+q S in the upper half, -q S in the lower)
+    g = cw * (S * c - C * s) + q * S;
+    dg = cw * (n - 1) * (C * c + S * s) + q * n * C + 2.0 * s * S;
+    mag = cw * (fabs(S * c) + fabs(C * s)) + fabs(q * S);
+}
+
+// ... and of the hyperbolic-branch equation fd_g_hyp (divided by sinh(n t)), in t:  with r = sinh((n-1)t) / sinh(nt),
+// r' = (n-1) cosh((n-1)t) / sinh(nt) - n r coth(nt), every quotient in the e^{-x} form that neither overflows nor cancels
+__host__ __device__ __attribute__((always_inline)) inline void fd_g_hyp_d(double t, int n, double cw, double d, double &g, double &dg, double &mag)
+{
+    const double e1 = exp(-t), EA = expm1(-2.0 * (n - 1) * t), EB = expm1(-2.0 * n * t);
+    const double r = e1 * (EA / EB);
+    const double sh = sinh(0.5 * t), ch = sqrt(1.0 + sh * sh);
+    g = cw * r + d - 4.0 - 4.0 * sh * sh;
+    const double cA = e1 * ((2.0 + EA) / -EB), cB = (2.0 + EB) / -EB;
+    dg = cw * ((n - 1) * cA - n * r * cB) - 4.0 * sh * ch;
+    mag = cw * r + fabs(d - 4.0) + 4.0 * sh * sh;
 }
 
 // The root of g in (lo, hi) -- angles in units of pi --, where g has the sign of flo at lo and the other one at hi: Newton steps kept
 // inside the bracket (a step that leaves it is replaced by the midpoint, so the worst case is the bisection rounds 1-4 ran: 50 steps;
-// Newton needs 5-8).  KIND 0: fd_g_lo, 1: fd_g_hi.
+// Newton needs 5-8).  KIND 0: fd_g_lo, 1: fd_g_hi, 2: fd_g_hyp (x0: where to start; the midpoint otherwise), 3: fd_g_lo or fd_g_hi by `upper` --
+// ONE loop for the lanes of a wave whose intervals lie in either half (the device build: two loops run one after the other).
 template <int KIND>
-__host__ __device__ __attribute__((always_inline)) inline double fd_root(double lo, double hi, double flo, int n, double cw, double d)
+__host__ __device__ __attribute__((always_inline)) inline double fd_root(double lo, double hi, double flo, int n, double cw, double d, double x0 = -1.0, bool upper = false)
 {
     const double INV_PI = 0.31830988618379067154;
-    double x = 0.5 * (lo + hi);
+    double x = (x0 > lo && x0 < hi) ? x0 : 0.5 * (lo + hi);
     for (int it = 0; it < 60; ++it) {
-        double g, dg;
+        double g, dg, mag;
 #if defined(FD_COUNT_ITERS)
         ++g_iters;
 #endif
-        if (KIND == 0) fd_g_lo_d(x, n, cw, d, g, dg); else fd_g_hi_d(x, n, cw, d, g, dg);
-        const double step = INV_PI * (g / dg);              // dg is d/dtheta; the step in tau = theta / pi
-        // converged when the Newton step is a few units in the last place (tested BEFORE the bracket logic: at the root the sign of g
-        // is noise, and a step of that size towards the freshly moved bracket end would be "outside" and cost a bisection from afar)
-        if (fabs(step) <= 9e-16 * x) return x - step;
+        if (KIND == 0) fd_g_lo_d(x, n, cw, d, g, dg, mag); else if (KIND == 1) fd_g_hi_d(x, n, cw, d, g, dg, mag); else if (KIND == 2) fd_g_hyp_d(x, n, cw, d, g, dg, mag); else fd_g_trig_d(x, n, cw, d, upper, g, dg, mag);
+        const double step = (KIND == 2 ? 1.0 : INV_PI) * (g / dg);      // dg is d/dtheta; the step in tau = theta / pi (KIND 2: in t itself)
+        // converged when the residual is at rounding level or the Newton step is a few units in the last place (tested BEFORE the
+        // bracket logic: at the root the sign of g is noise, and a step of that size towards the freshly moved bracket end would be
+        // "outside" and cost a bisection from afar; where g' is small -- roots near 0 -- the step never gets below the noise of g / g',
+        // and waiting for the bracket to collapse instead took up to 17 evaluations where 6 do)
+        if (fabs(g) <= 8e-16 * mag || fabs(step) <= 9e-16 * x) return x - step;
         if ((g > 0.0) == (flo > 0.0)) lo = x; else hi = x;
         double xn = x - step;
         if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
@@ -120,7 +152,10 @@ __host__ __device__ __attribute__((always_inline)) inline double fd_root(double 
 }
 
 // eigenpair k (0 .. n-1) of the operator (n, cw, d)
-__host__ __device__ __attribute__((always_inline)) inline FdPair fd_pair(int k, int n, double cw, double d)
+// hyp (may be nullptr): receives the n components of the hyperbolic pair's unnormalised vector (kind 2; fd_component's values by the
+// recurrence) -- the device build reads them from there: fd_component's exp / expm1 branch, taken by ONE column of every matrix,
+// made every wave of the fill loop execute both branches (20 of the build's 32 us)
+__host__ __device__ __attribute__((always_inline)) inline FdPair fd_pair(int k, int n, double cw, double d, double *hyp = nullptr)
 {
     FdPair p;
     if (n == 1) { p.ang = 0.5; p.kind = 0; p.lam = -d; p.inv_norm = sqrt(cw); return p; }   // v = (1); E v = 1/sqrt(cw)
@@ -129,47 +164,47 @@ __host__ __device__ __attribute__((always_inline)) inline FdPair fd_pair(int k, 
     if (k == n - 1 && s > 0.0) {                        // the n-th eigenvalue lies below -4
         p.kind = 2;
         lo = 0.0; hi = 2.0; flo = 1.0;                  // fd_g_hyp -> s / n > 0 at 0+, < 0 at 2
-        // regula falsi with the Illinois correction on the bracket (fd_g_hyp is smooth and monotone there): ~10 evaluations
-        // (the false-position estimate converges from one side: the BRACKET need not shrink to a point -- the estimate is the answer,
-        // and it has converged when it stops moving)
-        double fl = s / n, fh = fd_g_hyp(hi, n, cw, d), est = 1.0, prev = -1.0;
-        int side = 0;
-        for (int it = 0; it < 100; ++it) {
-            est = (lo * fh - hi * fl) / (fh - fl);
-            if (!(est > lo && est < hi)) est = 0.5 * (lo + hi);
-            if (fabs(est - prev) <= 4.5e-16 * est) break;
-            prev = est;
-            const double f = fd_g_hyp(est, n, cw, d);
-            if (f == 0.0) break;
-            if ((f > 0.0) == (flo > 0.0)) { lo = est; fl = f; if (side == -1) fh *= 0.5; side = -1; }
-            else { hi = est; fh = f; if (side == 1) fl *= 0.5; side = 1; }
-        }
-        p.ang = est;
+        // Newton from the smaller of two estimates: for n t large r -> e^{-t} and the equation is a quadratic in z = e^t,
+        // z^2 - (d - 2) z - (cw - 1) = 0 (the true root lies just below its root: r < e^{-t}); for n t small
+        // g ~ s / n - K t^2 with K = cw (n-1)(2n-1) / (6n) + 1.  5-6 evaluations; the regula falsi on (0, 2) of rounds 4-5 took 11 on
+        // average and up to 42 -- in ONE thread of the build, while every other one had long finished (31 of k_fd_build_rag's 46 us)
+        const double b = d - 2.0, z = 0.5 * (b + sqrt(b * b + 4.0 * (cw - 1.0)));
+        const double K = cw * (n - 1) * (2.0 * n - 1.0) / (6.0 * n) + 1.0, tT = sqrt(s / (n * K));
+        const double t0 = (z > 1.0) ? log(z) : 2.0;
+        p.ang = fd_root<2>(lo, hi, flo, n, cw, d, t0 < tT ? t0 : tT);
         const double sh = sinh(0.5 * p.ang);
         p.lam = -4.0 - 4.0 * sh * sh;
-    } else if (2 * (k + 1) <= n) {                      // the interval lies in the lower half: theta itself
-        p.kind = 0;
-        lo = (k == 0) ? 1.0 / (4.0 * n) : (double)k / n;  // (units of pi) below the smallest root (~ pi / (n + alpha)); g < 0 there
-        hi = (double)(k + 1) / n;
-        flo = (k == 0) ? -1.0 : ((k & 1) ? 1.0 : -1.0); // g(j pi / n) = cw (-1)^(j+1) sin(j pi / n)
-        p.ang = fd_root<0>(lo, hi, flo, n, cw, d);
+    } else {
+        const bool upper = 2 * (k + 1) > n;
+        if (!upper) {                                   // the interval lies in the lower half: theta itself
+            p.kind = 0;
+            lo = (k == 0) ? 1.0 / (4.0 * n) : (double)k / n;  // (units of pi) below the smallest root (~ pi / (n + alpha)); g < 0 there
+            hi = (double)(k + 1) / n;
+            flo = (k == 0) ? -1.0 : ((k & 1) ? 1.0 : -1.0); // g(j pi / n) = cw (-1)^(j+1) sin(j pi / n)
+        } else {                                        // upper half: phi in ((n-k-1) pi / n, (n-k) pi / n)
+            p.kind = 1;
+            const int j = n - k - 1;                    // 0 for the last interval
+            lo = (double)j / n; hi = (double)(j + 1) / n;   // (units of pi)
+            // fd_g_hi(j pi / n) = cw sin((n-1) j pi / n) = cw (-1)^(j+1) sin(j pi / n) for j >= 1; just right of 0 its sign is s's (< 0 here)
+            flo = (j == 0) ? -1.0 : ((j & 1) ? 1.0 : -1.0);
+        }
+        p.ang = fd_root<3>(lo, hi, flo, n, cw, d, -1.0, upper);
         const double sh = fd_sinpi(0.5 * p.ang);
-        p.lam = -4.0 * sh * sh;
-    } else {                                            // upper half: phi in ((n-k-1) pi / n, (n-k) pi / n)
-        p.kind = 1;
-        const int j = n - k - 1;                        // 0 for the last interval
-        lo = (double)j / n; hi = (double)(j + 1) / n;   // (units of pi)
-        // fd_g_hi(j pi / n) = cw sin((n-1) j pi / n) = cw (-1)^(j+1) sin(j pi / n) for j >= 1; just right of 0 its sign is s's (< 0 here)
-        flo = (j == 0) ? -1.0 : ((j & 1) ? 1.0 : -1.0);
-        p.ang = fd_root<1>(lo, hi, flo, n, cw, d);
-        const double sh = fd_sinpi(0.5 * p.ang);
-        p.lam = -4.0 + 4.0 * sh * sh;
+        p.lam = upper ? -4.0 + 4.0 * sh * sh : -4.0 * sh * sh;
     }
     double ss = 0.0;                                    // |E v|^2, term by term (a closed form cancels for small angles)
     if (p.kind == 2) {
+        // sinh(i t) / sinh(n t) by the same recurrence, s_{i+1} = 2 cosh(t) s_i - s_{i-1}, from s_0 = 0 and s_1 in the form that
+        // neither overflows nor cancels: forwards the growing solution is the stable one (relative error ~ n eps).  n evaluations of
+        // exp + 2 expm1 in ONE thread were 40 us of a 46-us build (every other thread had long finished): the launch a size class of small
+        // ROIs waits for in front of its first k_mg_tail.
+        const double two_ch = 2.0 + 4.0 * sinh(0.5 * p.ang) * sinh(0.5 * p.ang);      // 2 cosh t
+        double sm = 0.0, sc = fd_component(p, 1, n);        // (signs square away)
         for (int i = 1; i <= n; ++i) {
-            const double v = fd_component(p, i, n);
-            ss += (i == n) ? v * v / cw : v * v;
+            if (hyp) hyp[i - 1] = (i & 1) ? sc : -sc;
+            ss += (i == n) ? sc * sc / cw : sc * sc;
+            const double nx = two_ch * sc - sm;
+            sm = sc; sc = nx;
         }
     } else {
         // sin(i a) by the three-term recurrence s_{i+1} = 2 cos(a) s_i - s_{i-1} (the signs (-1)^(i+1) of kind 1 square away): n

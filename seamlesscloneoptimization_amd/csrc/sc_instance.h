@@ -134,6 +134,7 @@ struct Instance {
     // second stream of the instance: the float-table node correction of the next-to-last iterate (three latency-bound launches)
     // runs here beside the coarse levels of the last cycle; forked and joined with events, see mg_solve
     hipStream_t aux = nullptr;
+    hipStream_t aux2 = nullptr;            // a size class's matrix build (rag_begin), beside aux's zeroing and tables; created on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool aux_pending = false;              // work on aux that `stream` has not waited for yet
     sc_solver_opts opts{};

@@ -43,27 +43,34 @@ __device__ __forceinline__ void fd_build_block(float *__restrict__ m, int nx, in
                                                unsigned char *__restrict__ mm, int NPX, int NPY, int part = 0, int parts = 1)
 {
     __shared__ FdPair px[128], py[128];
+    __shared__ double hx[128], hy[128];        // the components of the hyperbolic pair's vector, if the direction has one (fd_pair)
     const int t0 = threadIdx.x, stride = (int)blockDim.x * parts, t = part * (int)blockDim.x + t0;
     for (int q = t0; q < 256; q += (int)blockDim.x) {          // every workgroup needs all pairs: one thread per eigenvalue
-        if (q < nx) px[q] = fd_pair(q, nx, (double)cwx, (double)dx);
-        if (q >= 128 && q - 128 < ny) py[q - 128] = fd_pair(q - 128, ny, (double)cwy, (double)dy);
+        if (q < nx) px[q] = fd_pair(q, nx, (double)cwx, (double)dx, hx);
+        if (q >= 128 && q - 128 < ny) py[q - 128] = fd_pair(q - 128, ny, (double)cwy, (double)dy, hy);
     }
     __syncthreads();
+    // component i (1-based) of pair p's unnormalised vector: one sine for every lane, the hyperbolic pair's from LDS
+    auto fd_component = [](const FdPair &p, const double *h, int i) -> double {
+        if (p.kind == 2) return h[i - 1];
+        const double v = fd_sinpi(i * p.ang);
+        return (p.kind == 1 && !(i & 1)) ? -v : v;
+    };
     const int nxx = nxp * nxp, nyy = nyp * nyp, total = m ? 2 * nxx + 2 * nyy + nxp * nyp : 0;      // m == nullptr: the matrix-core operands only
     for (int e = t; e < total; e += stride) {
         float v = 0.f;
         if (e < nxx) {                                   // Mx1[x][i] = Vx^-1[i][x] = q_i(x) ee_x
             const int x = e / nxp, i = e - x * nxp;
-            if (x < nx && i < nx) v = (float)(fd_component(px[i], x + 1, nx) * px[i].inv_norm * (x == nx - 1 ? 1.0 / (double)cwx : 1.0));
+            if (x < nx && i < nx) v = (float)(fd_component(px[i], hx, x + 1) * px[i].inv_norm * (x == nx - 1 ? 1.0 / (double)cwx : 1.0));
         } else if (e < nxx + nyy) {                      // My1T[y][j] = Vy^-1[j][y]
             const int r = e - nxx, y = r / nyp, j = r - y * nyp;
-            if (y < ny && j < ny) v = (float)(fd_component(py[j], y + 1, ny) * py[j].inv_norm * (y == ny - 1 ? 1.0 / (double)cwy : 1.0));
+            if (y < ny && j < ny) v = (float)(fd_component(py[j], hy, y + 1) * py[j].inv_norm * (y == ny - 1 ? 1.0 / (double)cwy : 1.0));
         } else if (e < nxx + 2 * nyy) {                  // My2T[j][y] = Vy[y][j] = q_j(y) / ee_y
             const int r = e - nxx - nyy, j = r / nyp, y = r - j * nyp;
-            if (y < ny && j < ny) v = (float)(fd_component(py[j], y + 1, ny) * py[j].inv_norm);
+            if (y < ny && j < ny) v = (float)(fd_component(py[j], hy, y + 1) * py[j].inv_norm);
         } else if (e < 2 * nxx + 2 * nyy) {              // Mx2[i][x] = Vx[x][i]
             const int r = e - nxx - 2 * nyy, i = r / nxp, x = r - i * nxp;
-            if (x < nx && i < nx) v = (float)(fd_component(px[i], x + 1, nx) * px[i].inv_norm);
+            if (x < nx && i < nx) v = (float)(fd_component(px[i], hx, x + 1) * px[i].inv_norm);
         } else {                                         // Dinv[j][i] = 1 / (ly_j + lx_i)
             const int r = e - 2 * nxx - 2 * nyy, j = r / nxp, i = r - j * nxp;
             if (j < ny && i < nx) v = (float)(1.0 / (py[j].lam + px[i].lam));
@@ -79,7 +86,7 @@ __device__ __forceinline__ void fd_build_block(float *__restrict__ m, int nx, in
             const int r = second ? e - ex : e, row = r / NPX, k = r - row * NPX;
             const int i = second ? k : row, x = second ? row : k;
             float v = 0.f;
-            if (x < nx && i < nx) v = (float)(fd_component(px[i], x + 1, nx) * px[i].inv_norm * ((!second && x == nx - 1) ? 1.0 / (double)cwx : 1.0));
+            if (x < nx && i < nx) v = (float)(fd_component(px[i], hx, x + 1) * px[i].inv_norm * ((!second && x == nx - 1) ? 1.0 / (double)cwx : 1.0));
             (second ? ax2 : ax1)[r] = v;
         } else if (e < 2 * ex + 2 * ey) {                // AY1[j][y] and AY2[y][j]
             const int q = e - 2 * ex;
@@ -87,7 +94,7 @@ __device__ __forceinline__ void fd_build_block(float *__restrict__ m, int nx, in
             const int r = second ? q - ey : q, row = r / NPY, k = r - row * NPY;
             const int j = second ? k : row, y = second ? row : k;
             float v = 0.f;
-            if (y < ny && j < ny) v = (float)(fd_component(py[j], y + 1, ny) * py[j].inv_norm * ((!second && y == ny - 1) ? 1.0 / (double)cwy : 1.0));
+            if (y < ny && j < ny) v = (float)(fd_component(py[j], hy, y + 1) * py[j].inv_norm * ((!second && y == ny - 1) ? 1.0 / (double)cwy : 1.0));
             (second ? ay2 : ay1)[r] = v;
         } else {
             const int r = e - 2 * ex - 2 * ey, j = r / NPX, i = r - j * NPX;
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void k_fd_build_rag(const RagMember *__restric
 
 void launch_fd_build_rag(const RagMember *rag, int members, int lev, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fd_build_rag, dim3(members, 4), dim3(256), 0, s, rag, lev);
+    hipLaunchKernelGGL(k_fd_build_rag, dim3(members, 4), dim3(256), 0, s, rag, lev);      // (16 workgroups per member: no faster -- the time was one thread's, sc_fd_closed.h -- and they crowd the level-1 launch beside them)
 }
 
 void launch_fd_build(float *mats, const MGGeom &g, int nxp, int nyp, hipStream_t s, unsigned char *mm, int NPX, int NPY)

@@ -325,9 +325,13 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
     if (!R.ev_ready) SC_HIP(I, hipEventCreateWithFlags(&R.ev_ready, hipEventDisableTiming));
     SC_HIP(I, hipEventRecord(R.ev_ready, I->aux));
     R.ready_pending = true;
-    launch_fd_build_rag(R.dev, n, R.tail + 1, I->aux);
+    // (a stream of their own: behind the zeroing and the sine tables they started 13 us later and the first k_mg_tail of a class of
+    //  small ROIs waited that long for them)
+    if (!I->aux2) SC_HIP(I, hipStreamCreateWithFlags(&I->aux2, hipStreamNonBlocking));
+    SC_HIP(I, hipStreamWaitEvent(I->aux2, R.ev, 0));
+    launch_fd_build_rag(R.dev, n, R.tail + 1, I->aux2);
     SC_HIP(I, hipGetLastError());
-    SC_HIP(I, hipEventRecord(I->ev_fd, I->aux));
+    SC_HIP(I, hipEventRecord(I->ev_fd, I->aux2));
     I->fd_pending = true;
     return SC_OK;
 }

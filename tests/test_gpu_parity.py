@@ -657,13 +657,20 @@ def test_grouped_clones_share_one_set_of_launches(oracles):
     for (f, b0, b, m, shape), it in zip(keep3, small):
         want = o.seamless_clone(*it, float_tables=True)
         assert np.abs(inst.from_device(b, shape).astype(np.int16) - want.astype(np.int16)).max() <= 1
-    # mixed sizes -> one after the other, same answers as alone
+    # mixed sizes: one after the other with the bytes of the solo runs (rounds 1-4), or -- round 5 -- a size class; ROIs this small
+    # take another hierarchy inside a class than alone (plan_groups kind 3): within one grey level of the solo run
     other = o.synth_inputs(120, 90, seed_dst=5, seed_patch=6, margin=32)
     b_other = other[0].copy(); seq.run(other[1], b_other, other[2], other[3], other[4])
-    jobs2, keep2 = device_jobs([items[0], other, items[3]])
+    trio = [items[0], other, items[3]]
+    kinds = capi.plan_groups([(it[2].shape[1] - 2, it[2].shape[0] - 2) for it in trio])[1]
+    jobs2, keep2 = device_jobs(trio)
     pool.run(jobs2, device_resident=True)
-    for (f, b0, b, m, shape), w in zip(keep2, (alone[0], b_other, alone[3])):
-        assert np.array_equal(inst.from_device(b, shape), w)
+    for (f, b0, b, m, shape), w, kk in zip(keep2, (alone[0], b_other, alone[3]), kinds):
+        got = inst.from_device(b, shape)
+        if kk in (0, 2):
+            assert np.array_equal(got, w)
+        else:
+            assert np.abs(got.astype(np.int16) - w.astype(np.int16)).max() <= 1
     # a member whose ROI leaves its image fails alone
     jobs[1].centerX = 1
     with pytest.raises(capi.SeamlessCloneError) as e:
