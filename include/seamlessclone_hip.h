@@ -400,6 +400,13 @@ SC_API int sc_hip_time_tail_phases(void *instance, unsigned long long *cycles11)
  * (1: the float tables' lowest modes are off by more than 4 % at this size; such members form classes of their own, in which the
  * judged cycle's measured update decides the output's form for the whole group) } */
 SC_API int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[12]);
+/* Host-only: plans and per-size host tables (the float-table correction's ratio table, its part maps) are pure functions of the ROI
+ * size and memoised process-wide on first use -- 5-20 us of host arithmetic per NEW size, paid inside the first batch call that meets
+ * it.  A caller that knows its sizes ahead (a set of patch templates, the boxes of the previous frame) moves that out of its latency
+ * path: prepares wh[2i], wh[2i+1] (ring included) under `opts` (NULL: the defaults); returns how many of them can join a size class.
+ * sc_hip_plan_cache_clear forgets everything memoised (tests and measurements). */
+SC_API int sc_hip_plan_prepare(const int *wh, int n, const sc_solver_opts *opts);
+SC_API void sc_hip_plan_cache_clear(void);
 SC_API int sc_hip_plan_groups(const int *wh, int n, int cap, const sc_solver_opts *opts, int *group_of, int *kind_of);
 
 /* Host-only (needs no GPU): 1 when the reference's float32 eigenvalue tables are singular for an ROI of w x h unknowns --

@@ -222,6 +222,10 @@ def load():
     L.sc_hip_plan_groups.argtypes = [i32p, C.c_int, C.c_int, C.POINTER(SolverOpts), i32p, i32p]
     L.sc_hip_plan_groups.restype = C.c_int
     L.sc_hip_plan_size.argtypes = [C.c_int, C.c_int, C.POINTER(SolverOpts), i32p]
+    L.sc_hip_plan_prepare.argtypes = [i32p, C.c_int, C.POINTER(SolverOpts)]
+    L.sc_hip_plan_prepare.restype = C.c_int
+    L.sc_hip_plan_cache_clear.argtypes = []
+    L.sc_hip_plan_cache_clear.restype = None
     L.sc_hip_plan_size.restype = C.c_int
     _lib = L
     return L
@@ -546,6 +550,17 @@ def plan_size(W: int, H: int, opts: "SolverOpts | None" = None) -> dict:
     load().sc_hip_plan_size(int(W), int(H), C.byref(opts) if opts is not None else None, out.ctypes.data_as(i32p))
     keys = ("eligible", "levels", "tail_level", "pad_x", "pad_y", "Kxp", "Kyp", "column_tiles", "row_splits", "direct_nx_ny", "solo_differs", "conditional")
     return dict(zip(keys, out.tolist()))
+
+
+def plan_prepare(sizes, opts: "SolverOpts | None" = None) -> int:
+    """Host-only: memoise the plans and per-size host tables of these ROI sizes ahead of the calls that will meet them; returns how
+    many can join a size class."""
+    wh = np.ascontiguousarray(np.asarray(sizes, np.int32).reshape(-1, 2))
+    return int(load().sc_hip_plan_prepare(wh.ctypes.data_as(i32p), wh.shape[0], C.byref(opts) if opts is not None else None))
+
+
+def plan_cache_clear() -> None:
+    load().sc_hip_plan_cache_clear()
 
 
 def plan_groups(sizes, cap: int = 0, opts: "SolverOpts | None" = None):

@@ -1227,6 +1227,21 @@ int sc_hip_plan_groups(const int *wh, int n, int cap, const sc_solver_opts *opts
     return (int)groups.size();
 }
 
+int sc_hip_plan_prepare(const int *wh, int n, const sc_solver_opts *opts)
+{
+    if (!wh || n < 1) return SC_ERR_BAD_ARG;
+    sc_solver_opts o;
+    if (opts) o = *opts; else sc_hip_default_opts(&o);
+    int eligible = 0;
+    for (int i = 0; i < n; ++i) {
+        SizePlan p;
+        if (plan_size(o, wh[2 * i], wh[2 * i + 1], p)) ++eligible;
+    }
+    return eligible;
+}
+
+void sc_hip_plan_cache_clear(void) { plan_cache_clear(); }
+
 int sc_hip_reference_tables_singular(int w, int h)
 {
     if (w < 1 || h < 1) return 0;
@@ -1264,6 +1279,22 @@ int sc_hip_selftest_host(void)
     if (!(sc::fd_closed_selftest_error() < 1e-10)) return 4;
     // 3: which parts of a level-0 launch make up each cell row of the float-table correction (sc_lowmode.hip)
     if (sc::lowmode_part_map_selftest() != 0) return 3;
+    // 5: the pruned search for the correction's largest ratio (plan_size) against the full table's maximum, over sizes of every kind
+    //    (square, elongated, the 2100s and 3000s where one size in ten crosses the 4 % line)
+    {
+        std::vector<float> R(256 * 256);
+        const int ws[] = { 46, 98, 154, 300, 511, 640, 1000, 1027, 1100, 1555, 2046, 2051, 2105, 2118, 2135, 2400, 3118, 3328, 3468, 4096, 6000, 9000 };
+        for (int w : ws)
+            for (int dh = -7; dh <= 7; ++dh) {
+                for (int h : { w + 3 * dh, w / 3 + dh + 40 }) {
+                    if (h < 4) continue;
+                    const int Kx = sc::lowmode_count(w), Ky = sc::lowmode_count(h), Kxp = (Kx + 31) / 32 * 32;
+                    double pruned = -1.0, full = -2.0;
+                    const bool a = sc::lowmode_ratio(w, h, Kx, Ky, Kxp, nullptr, pruned), b = sc::lowmode_ratio(w, h, Kx, Ky, Kxp, R.data(), full);
+                    if (a != b || pruned != full) return 5;
+                }
+            }
+    }
     return 0;
 }
 

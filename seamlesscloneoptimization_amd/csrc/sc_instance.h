@@ -98,7 +98,6 @@ struct SizePlan {
     struct Tables { std::vector<MGGeom> g; };
     std::shared_ptr<const Tables> t;
     // ... and what only the per-call setup needs (rag_begin, on the worker's thread): built on first use, memoised per size as well
-    struct Heavy { std::vector<float> R; std::vector<int> map[2]; };
     // same compile-time choices and launch shapes (the spread of a group's sizes is plan_groups' business)
     bool same_class(const SizePlan &o) const
     {
@@ -108,9 +107,9 @@ struct SizePlan {
     }
 };
 bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p);     // fills p; returns p.ok
-std::shared_ptr<const SizePlan::Heavy> plan_heavy(const SizePlan &p);    // nullptr: a tiling with more than four parts per cell row (none exists)
 // members (any order) -> groups that can each share one set of launches: a size class (two or more DIFFERENT sizes), a same-size
 // group, or a single; `cap` = most members per group.  groups[k] lists indices into `plans`.
+void plan_cache_clear();                                         // forgets every memoised plan and table (tests, measurements)
 void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups);      // (may rewrite a member's plan: sc_ragged.cpp)
 
 struct RagState {
@@ -271,6 +270,7 @@ void lowmode_bands_written(Instance *I, const float *field);       // the launch
 int lowmode_count(int n);
 bool lowmode_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double &max_ratio);   // the correction's ratio table (R may be nullptr: statistics only); false: singular
 bool lowmode_part_map(int H, int sweeps, std::vector<int> &m, int &band_rows);
+bool lowmode_part_map(int H, int sweeps, int *m, int &band_rows);      // ... into 4 ints per cell row, all -1 on entry
 int lowmode_projection_splits(int nxt, int nkb);                      // row splits of the coarse projection for a ROI with nxt column tiles
 void launch_lm_tables_rag(const RagMember *rag, int members, int max_rows, int Kxp, int Kyp, hipStream_t s);
 void mg_plan_levels(int W, int H, std::vector<MGGeom> &g);           // sc_multigrid.cpp

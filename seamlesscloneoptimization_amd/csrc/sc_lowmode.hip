@@ -376,8 +376,9 @@ static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double 
 {
     max_ratio = 0.0;
     const double PIf = (double)3.14159265358979323846f;
-    std::vector<float> fx(Kx), fy(Ky);
-    std::vector<double> sa2(Kx), sb2(Ky);          // sin^2 of the half angles: one sine per mode and direction, not per table entry
+    float fx[256], fy[256];                         // (lowmode_count: at most 256 modes per direction)
+    double sa2[256], sb2[256];                      // sin^2 of the half angles: one sine per mode and direction, not per table entry
+    if (Kx > 256 || Ky > 256) return false;
     for (int i = 0; i < Kx; ++i) {
         fx[i] = (float)(2.0 * std::cos(PIf / (w + 1.0) * (i + 1.0)));
         const double sa = std::sin(0.5 * M_PI * (i + 1.0) / (w + 1.0));
@@ -389,14 +390,42 @@ static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double 
         sb2[j] = sb * sb;
     }
     const double scale = 4.0 / ((w + 1.0) * (h + 1.0));
-    for (int j = 0; j < Ky; ++j)
-        for (int i = 0; i < Kxp; ++i) {
-            if (i >= Kx) { if (R) R[(size_t)j * Kxp + i] = 0.f; continue; }
-            const double den_e = -4.0 * (sa2[i] + sb2[j]);
-            const float den_f = (fx[i] + fy[j]) - 4.0f;
-            if (R) R[(size_t)j * Kxp + i] = (den_f < 0.0f) ? (float)((den_e / (double)den_f - 1.0) * scale) : 0.0f;
-            if (den_f < 0.0f) max_ratio = std::max(max_ratio, std::fabs(den_e / (double)den_f - 1.0));
+    if (R) {
+        // the table: every entry, branch-free so that the compiler vectorises the divisions (a new ROI size pays this once, inside the
+        // first batch call that meets it: 12 us at 2100 x 2100 before, ~4 now)
+        for (int j = 0; j < Ky; ++j) {
+            float *const Rj = R + (size_t)j * Kxp;
+            const float fyj = fy[j];
+            const double sbj = sb2[j];
+            double mr = 0.0;
+            for (int i = 0; i < Kx; ++i) {
+                const double den_e = -4.0 * (sa2[i] + sbj);
+                const float den_f = (fx[i] + fyj) - 4.0f;
+                const bool ok = den_f < 0.0f;
+                const double q = den_e / (ok ? (double)den_f : -1.0) - 1.0;
+                Rj[i] = ok ? (float)(q * scale) : 0.0f;
+                const double aq = std::fabs(q);
+                mr = (ok && aq > mr) ? aq : mr;
+            }
+            for (int i = Kx; i < Kxp; ++i) Rj[i] = 0.f;
+            max_ratio = std::max(max_ratio, mr);
         }
+    } else {
+        // the statistic alone (plan_size): |den_e / den_f - 1| = |den_e - den_f| / |den_f|, and the float denominator is off by a few
+        // units in its last place at most -- 2 cos rounds to float (6e-8 each), the float sum of two values near 2 (1.2e-7), the float
+        // literal PI (relative 5.6e-8 of den) -- so an entry with |den_e| (1 - 1e-6) >= E / max so far cannot raise the maximum; den_e
+        // grows along a row and down a column: the search visits a handful of entries instead of all Kx Ky
+        const double E = 4e-7;
+        for (int j = 0; j < Ky; ++j) {
+            if (max_ratio > 0.0 && 4.0 * sb2[j] * (1.0 - 1e-6) * max_ratio >= E) break;       // this row's FIRST entry is already out
+            for (int i = 0; i < Kx; ++i) {
+                const double den_e = -4.0 * (sa2[i] + sb2[j]);
+                if (max_ratio > 0.0 && -den_e * (1.0 - 1e-6) * max_ratio >= E) break;
+                const float den_f = (fx[i] + fy[j]) - 4.0f;
+                if (den_f < 0.0f) max_ratio = std::max(max_ratio, std::fabs(den_e / (double)den_f - 1.0));
+            }
+        }
+    }
     return (fx[0] + fy[0]) - 4.0f < 0.0f;          // the lowest mode has the denominator closest to zero
 }
 
@@ -477,16 +506,23 @@ static int lm_prepare(Instance *I)
 // cell row (none of the instantiated ones).  Pure host arithmetic on the launch geometry (cycle0_row_geometry).
 bool lowmode_part_map(int H, int sweeps, std::vector<int> &m, int &band_rows)
 {
+    m.assign(4 * (size_t)((H + LM_HAT - 1) / LM_HAT), -1);
+    return lowmode_part_map(H, sweeps, m.data(), band_rows);
+}
+
+// (m: 4 ints per cell row, every one -1 on entry; parts arrive in ascending order, a cell row's list is full when its last slot is taken)
+bool lowmode_part_map(int H, int sweeps, int *m, int &band_rows)
+{
     const int cells_y = (H + LM_HAT - 1) / LM_HAT;
     int nby, step, hy;
     cycle0_row_geometry(H, sweeps, nby, step, hy);
     band_rows = nby * 8;
-    m.assign(4 * (size_t)cells_y, -1);
-    std::vector<int> fill(cells_y, 0);
     bool fits = true;
     auto add = [&](int Yc, int v) {
         if (Yc < 0 || Yc >= cells_y) return;
-        if (fill[Yc] < 4) m[4 * Yc + fill[Yc]++] = v; else fits = false;
+        int *const e = m + 4 * (size_t)Yc;
+        const int k = e[0] < 0 ? 0 : e[1] < 0 ? 1 : e[2] < 0 ? 2 : e[3] < 0 ? 3 : 4;
+        if (k < 4) e[k] = v; else fits = false;
     };
     for (int b = 0; b < band_rows; ++b) {                       // ascending band rows: a fixed order of additions per cell
         const int y0 = (b >> 3) * step - hy + 8 * (b & 7);

@@ -124,31 +124,7 @@ bool plan_size_uncached(const sc_solver_opts &o, int W, int H, SizePlan &p)
     return true;
 }
 
-std::mutex g_heavy_mu;
-std::unordered_map<long long, std::shared_ptr<const SizePlan::Heavy>> g_heavy_cache;
 } // namespace
-
-// The correction's ratio table (the reference's float expressions through libm, as the CPU oracle's) and the two part maps of a size:
-// what rag_begin copies into its staging.  Functions of (W, H) alone; memoised like the plans.
-std::shared_ptr<const SizePlan::Heavy> plan_heavy(const SizePlan &p)
-{
-    const long long key = ((long long)p.W << 32) | (unsigned)p.H;
-    {
-        std::lock_guard<std::mutex> lk(g_heavy_mu);
-        auto it = g_heavy_cache.find(key);
-        if (it != g_heavy_cache.end()) return it->second;
-    }
-    auto Hv = std::make_shared<SizePlan::Heavy>();
-    Hv->R.assign((size_t)p.Kyp * p.Kxp, 0.f);
-    double mr;
-    lowmode_ratio(p.W - 2, p.H - 2, p.Kx, p.Ky, p.Kxp, Hv->R.data(), mr);
-    int br = 0;
-    if (!lowmode_part_map(p.H, 2, Hv->map[0], br) || !lowmode_part_map(p.H, 4, Hv->map[1], br)) return nullptr;
-    std::lock_guard<std::mutex> lk(g_heavy_mu);
-    if (g_heavy_cache.size() >= PLAN_CACHE_MAX) g_heavy_cache.clear();
-    g_heavy_cache.emplace(key, Hv);
-    return Hv;
-}
 
 // A member's plan one level deeper than its own: the level its solo run holds in k_mg_tail becomes an ordinary coarse level, the one
 // its solo run solves directly goes into k_mg_tail and the next one is solved directly.  Same fixed point, other iterates: within
@@ -165,6 +141,11 @@ static bool plan_deeper(const SizePlan &p, SizePlan &q)
     q.npx = round_up(A.x.nc, 32); q.npy = round_up(A.y.nc, 32);
     q.solo_differs = true;
     return true;
+}
+
+void plan_cache_clear()
+{
+    { std::lock_guard<std::mutex> lk(g_plan_mu); g_plan_cache.clear(); }
 }
 
 // Greedy, order preserving: a member joins the first open group it fits -- the same size as the group's members, or the same class
@@ -303,12 +284,19 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
         m.lm_Sy = (const float *)(da + host_part + (bSx + bSy + bMM) * i + bSx);
         m.mm = da + host_part + (bSx + bSy + bMM) * i + bSx + bSy;
         m.npx = p.npx; m.npy = p.npy;
-        // the host-built pieces (made once per size): the ratio table and the two part maps
-        const std::shared_ptr<const SizePlan::Heavy> Hv = plan_heavy(p);
-        if (!Hv) { I->err = "size class: more than four parts per cell row"; return SC_ERR_BAD_ARG; }
-        std::memset(hs + oR, 0, bR);                                     // re-pitched: the member's Kyp x Kxp table inside the class's
-        for (int j = 0; j < p.Kyp; ++j) std::memcpy(hs + oR + sizeof(float) * (size_t)j * R.Kxp, Hv->R.data() + (size_t)j * p.Kxp, sizeof(float) * p.Kxp);
-        for (int t = 0; t < 2; ++t) std::memcpy(hs + (t ? oMap1 : oMap0), Hv->map[t].data(), sizeof(int) * Hv->map[t].size());
+        // the host-built pieces, straight into the staging: the correction's ratio table (the reference's float expressions through libm,
+        // as the CPU oracle's; rows at the class's pitch, what the member does not have is zero) and the two part maps.  Functions of
+        // (W, H) alone, but NOT memoised: 0.5 / 1.5 / 4.5 us per member at 320^2 / 1050^2 / 2100^2, while a memo's fresh 24 KB per new size
+        // cost 20 us in first-touch page faults (rounds of never-repeating sizes: +11 % per step at [1000, 1100]^2) -- and this runs
+        // while the device erodes and pre-processes
+        double mr;
+        std::memset(hs + oR, 0, bR);
+        lowmode_ratio(p.W - 2, p.H - 2, p.Kx, p.Ky, R.Kxp, (float *)(hs + oR), mr);
+        int br = 0;
+        std::memset(hs + oMap0, 0xff, 2 * bMap);
+        if (!lowmode_part_map(p.H, 2, (int *)(hs + oMap0), br) || !lowmode_part_map(p.H, 4, (int *)(hs + oMap1), br)) {
+            I->err = "size class: more than four parts per cell row"; return SC_ERR_BAD_ARG;
+        }
     }
     std::memcpy(hs, R.host.data(), sizeof(RagMember) * (size_t)n);
     SC_HIP(I, hipMemcpyAsync(da, hs, host_part, hipMemcpyHostToDevice, I->stream));

@@ -440,6 +440,10 @@ def test_group_planner_properties():
     assert capi.plan_groups([(1020, 1020), (1060, 1060)]) == ([0, 0], [3, 2])       # the shallower one moves onto the deeper hierarchy
     assert capi.plan_groups([(1020, 1020)] * 9 + [(1060, 1060), (1061, 1060)], 16)[1] == [1] * 9 + [2, 2]   # ... only as a leftover (at most cap / 2 members)
     assert capi.plan_groups([(500, 500), (1060, 1060)])[1] == [0, 0]                # two levels apart: alone
+    # the memo is only a memo: forgetting it changes nothing, preparing sizes ahead reports how many can join a class
+    capi.plan_cache_clear()
+    assert (g, k) == capi.plan_groups(sizes, 16)
+    assert capi.plan_prepare([(1000, 1010), (90, 70), (2107, 2053), (8, 8), (40, 300)]) == 3      # (8 x 8: nothing to coarsen; 40 x 300: under 48 across)
     # options outside the default fast path: no classes, same-size groups stay
     lib = capi.load()
     o = capi.SolverOpts(); lib.sc_hip_default_opts(__import__("ctypes").byref(o))

@@ -46,7 +46,7 @@ def jobs_for(pool, sizes, dst, patch):
     return jobs, keep
 
 
-def time_pool(streams, group, sizes, dst, patch, reps):
+def time_pool(streams, group, sizes, dst, patch, reps, unseen=False):
     pool = capi.Pool(0, streams=streams, group=group)
     try:
         jobs, keep = jobs_for(pool, sizes, dst, patch)
@@ -54,6 +54,8 @@ def time_pool(streams, group, sizes, dst, patch, reps):
         pool.run(jobs, device_resident=True)
         ts = []
         for _ in range(reps):
+            if unseen:
+                capi.plan_cache_clear()      # as if no size had ever been planned: every member pays its plan and its host tables again
             t0 = time.perf_counter()
             pool.run(jobs, device_resident=True)
             ts.append(time.perf_counter() - t0)
@@ -86,6 +88,7 @@ def main():
            "planned_groups": sorted(Counter(g).values(), reverse=True), "kinds": dict(Counter(k))}
     legs = a.legs.split(",")
     if "mixed" in legs: out["mixed_sizes"] = time_pool(a.streams, a.group, sizes, dst, patch, a.reps)
+    if "mixed" in legs: out["mixed_sizes_planner_memo_cleared_every_step"] = time_pool(a.streams, a.group, sizes, dst, patch, a.reps, unseen=True)
     if "ones" in legs: out["mixed_sizes_groups_of_one_8_streams"] = time_pool(8, 1, sizes, dst, patch, a.reps)
     if "same" in legs: out["same_size_%d" % mean] = time_pool(a.streams, a.group, [(mean, mean)] * a.n, dst, patch, a.reps)
     if "mixed" in legs and "same" in legs:
