@@ -443,7 +443,7 @@ def test_group_planner_properties():
     # the memo is only a memo: forgetting it changes nothing, preparing sizes ahead reports how many can join a class
     capi.plan_cache_clear()
     assert (g, k) == capi.plan_groups(sizes, 16)
-    assert capi.plan_prepare([(1000, 1010), (90, 70), (2107, 2053), (8, 8), (40, 300)]) == 3      # (8 x 8: nothing to coarsen; 40 x 300: under 48 across)
+    assert capi.plan_prepare([(1000, 1010), (90, 70), (2107, 2053), (8, 8), (40, 100)]) == 3      # (8 x 8: nothing to coarsen; 40 x 100: its level 1 is solved directly and it is under 48 across)
     # options outside the default fast path: no classes, same-size groups stay
     lib = capi.load()
     o = capi.SolverOpts(); lib.sc_hip_default_opts(__import__("ctypes").byref(o))
