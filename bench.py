@@ -400,7 +400,7 @@ def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, s
     planned = sorted((g.count(q) for q in set(g)), reverse=True)
     ci = k.index(2) if 2 in k else 0           # a member that keeps its own hierarchy inside its class (kind 2): the byte-for-byte check
 
-    def run(streams_, group_, sz, check=False):
+    def run(streams_, group_, sz, check=False, unseen=False):
         pool = capi.Pool(0, streams=streams_, group=group_)
         try:
             inst = pool.instances[0]
@@ -416,6 +416,8 @@ def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, s
             pool.run(jobs, device_resident=True); pool.run(jobs, device_resident=True)
             ts = []
             for _ in range(reps):
+                if unseen:
+                    capi.plan_cache_clear()      # every member pays its plan again, as in a stream of sizes never seen before
                 t0 = time.perf_counter()
                 pool.run(jobs, device_resident=True)
                 ts.append(time.perf_counter() - t0)
@@ -429,18 +431,19 @@ def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, s
         return {"ms_per_step": round(t * 1e3, 3), "Mpix_per_s": round(sum(w * h for w, h in sz) / t / 1e6, 1)}, first
     mixed, a = run(streams, group, sizes, check=True)
     ones, b = run(8, 1, sizes, check=True)
+    fresh, _ = run(streams, group, sizes, unseen=True)
     mean = int(round(float(np.sqrt(np.mean([w * h for w, h in sizes])))))
     same, _ = run(streams, group, [(mean, mean)] * n)
     d = np.abs(a.astype(np.int16) - b.astype(np.int16))
     return {"roi_range": [lo, hi], "clones": n, "streams": streams, "group": group, "planned_groups": planned,
             "Mpix_per_s": mixed["Mpix_per_s"], "ms_per_step": mixed["ms_per_step"],
-            "one_clone_at_a_time_8_streams": ones, "same_size_%d" % mean: same,
+            "planner_memo_cleared_every_step": fresh, "one_clone_at_a_time_8_streams": ones, "same_size_%d" % mean: same,
             "ratio_to_same_size": round(mixed["Mpix_per_s"] / same["Mpix_per_s"], 3),
             "members_on_a_deeper_hierarchy_than_solo": int(sum(1 for x in k if x == 3)),
             "first_member_vs_its_solo_clone": {"member": ci, "maxdiff": int(d.max()), "percent_differing": round(float((d > 0).mean() * 100), 4)},
             "note": "64 clones with 64 different ROI sizes, random in [%d, %d]^2, through the pool as configured: members of one size class (same "
                     "hierarchy depth and bottom solve, widths and heights within 2x; the pool hands its jobs to the planner largest first) share one set of solver launches through a per-member geometry "
-                    "table; every member's bytes are its solo run's whenever the group takes the solo run's cycle count -- except the leftovers of a class "
+                    "table (nothing of it is kept between calls; only the size plans are memoised per size -- planner_memo_cleared_every_step forgets those too); every member's bytes are its solo run's whenever the group takes the solo run's cycle count -- except the leftovers of a class "
                     "one level shallower, which ride along on the deeper hierarchy (counted above; within one grey level of their solo runs)" % (lo, hi)}
 
 
