@@ -447,3 +447,44 @@ def test_one_call_with_more_members_than_a_job_table_holds(oracles):
         _free_jobs(inst, keep)
     finally:
         inst.destroy()
+
+
+def test_size_class_without_speculation_and_with_a_member_guessed_wrong(oracles):
+    """A size class the two other ways a group can be launched: (a) SC_FLAG_NO_SPECULATE -- the call waits for the device's bounding
+    boxes before it plans -- gives every member the bytes of the default (speculative) call; (b) a member whose mask does not fill
+    its image (bounding box smaller than the mask's interior: the predicted box is wrong) is left untouched by the class's splice
+    and repeated alone on its true box, the other members keep their bytes."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    sizes = SIZE_CLASSES["300s"][:5]
+    items = [o.synth_inputs(W, H, seed_dst=700 + k, seed_patch=720 + k, margin=40) for k, (W, H) in enumerate(sizes)]
+    inst = capi.Instance(0)
+    try:
+        jobs, keep = _device_jobs(inst, items)
+        assert inst.run_device_batch(jobs) == 0
+        inst.sync()
+        assert inst.info().group_members == 5 and inst.info().group_ragged == 1
+        base = [inst.from_device(b, shape) for (f, b0, b, m, shape) in keep]
+        inst.set_solver(flags=capi.SC_FLAG_NO_SPECULATE)
+        assert inst.run_device_batch(jobs) == 0
+        inst.sync()
+        assert inst.info().group_members == 5 and inst.info().group_ragged == 1
+        for k, (f, b0, b, m, shape) in enumerate(keep):
+            assert np.array_equal(inst.from_device(b, shape), base[k]), k
+        inst.set_solver(flags=0)
+        # (b) member 2's mask loses rows at the top and columns at the right
+        odd = list(items[2]); m_odd = odd[2].copy(); m_odd[:9, :] = 0; m_odd[:, -13:] = 0; odd[2] = m_odd
+        items_b = items[:2] + [tuple(odd)] + items[3:]
+        jobs_b, keep_b = _device_jobs(inst, items_b)
+        assert inst.run_device_batch(jobs_b) == 0 and all(j.rc == 0 for j in jobs_b)
+        inst.sync()
+        for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep_b, items_b)):
+            got = inst.from_device(b, shape)
+            want = oc.seamless_clone(it[0], it[1], it[2], it[3], it[4], nthreads=min(16, oc.max_threads()), exact_den=False)
+            assert _dmax(got, want) <= 1, k
+            assert not np.array_equal(got, it[0]), k
+            if k != 2:
+                assert _dmax(got, base[k]) <= 1, k
+        _free_jobs(inst, keep); _free_jobs(inst, keep_b)
+    finally:
+        inst.destroy()
