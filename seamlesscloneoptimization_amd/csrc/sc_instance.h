@@ -97,7 +97,7 @@ struct SizePlan {
     // table R[Kyp][Kxp] and the part maps of the 2- and the 4-sweep tiling
     struct Tables { std::vector<MGGeom> g; };
     std::shared_ptr<const Tables> t;
-    // ... and what only the per-call setup needs (rag_begin, on the worker's thread): built on first use, memoised per size as well
+    // (what only the per-call setup needs -- the correction's ratio table, its part maps -- is computed into the staging by every call: rag_begin_table)
     // same compile-time choices and launch shapes (the spread of a group's sizes is plan_groups' business)
     bool same_class(const SizePlan &o) const
     {
@@ -276,7 +276,8 @@ void launch_lm_tables_rag(const RagMember *rag, int members, int max_rows, int K
 void mg_plan_levels(int W, int H, std::vector<MGGeom> &g);           // sc_multigrid.cpp
 size_t mg_default_tail_level(const std::vector<MGGeom> &g);
 int mg_build_levels_rag(Instance *I, hipStream_t zero_on);           // sc_multigrid.cpp: the class's level planes, zeroed on the given stream
-int rag_begin(Instance *I, const std::vector<SizePlan> &members);     // sc_ragged.cpp: table + tables of a size class on the device; sets I->rag.dev
+int rag_begin_table(Instance *I, const std::vector<SizePlan> &members);      // the members' table and host tables, uploaded on the instance's stream (sets I->rag.dev)
+int rag_begin_builds(Instance *I);                                           // ... then everything the device builds per call, on two more streams
 void rag_end(Instance *I);
 int dst_solve(Instance *I);                                           // sc_dst.hip: SC_METHOD_DST
 int fft_solve(Instance *I, bool fp64);                                // sc_fft.hip: SC_METHOD_FFT (fp64: SC_FLAG_FFT_FP64)

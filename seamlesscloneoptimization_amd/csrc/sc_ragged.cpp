@@ -229,7 +229,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // the solve --, everything the device builds per call: the Sx / Sy tables, the members' bottom matrices, the zeroing of the coarse
 // planes (mg_build_levels_rag).  The main stream waits for all of it in front of its first coarse-level launch (mg_solve).
 // Sets I->rag.dev; the caller has bound the class's fields (setup_fields) before.
-int rag_begin(Instance *I, const std::vector<SizePlan> &members)
+int rag_begin_table(Instance *I, const std::vector<SizePlan> &members)
 {
     RagState &R = I->rag;
     const int n = (int)members.size();
@@ -303,6 +303,17 @@ int rag_begin(Instance *I, const std::vector<SizePlan> &members)
     SC_HIP(I, hipEventRecord(R.ev, I->stream));
     R.dev = (const RagMember *)da;
     I->info.new_size = 1;
+    return SC_OK;
+}
+
+// ... second half: five launches and four events on two more streams (12 us of host time).  The caller enqueues the class's erode and
+// pre-process between the halves, so that the device has work while the host is here.
+int rag_begin_builds(Instance *I)
+{
+    RagState &R = I->rag;
+    if (!R.dev) return SC_ERR_BAD_ARG;
+    const int n = R.n;
+    int rc;
     // --- the device-built pieces, on the second stream behind the upload and behind everything that read the previous call's
     //     tables, matrices and level planes
     // (the short ones first, with an event of their own: the first coarse-level launch needs the zeroed planes, only the first

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/tl_c
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_c -- python3 $R/tools/group_host_probe.py --lo ${1:-300} --hi ${2:-340} --reps 5 --only class > /dev/null 2> $R/gpurun_out/tl_c.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_c -- python3 $R/tools/group_host_probe.py --lo ${1:-300} --hi ${2:-340} --reps 5 --only ${3:-class} > /dev/null 2> $R/gpurun_out/tl_c.err || exit 1
 cd $R && python3 - > gpurun_out/r5_class_timeline.txt <<'PY'
 import csv, glob, re
 f = sorted(glob.glob('gpurun_out/tl_c/*/*kernel_trace.csv'))[-1]
