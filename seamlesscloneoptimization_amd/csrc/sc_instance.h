@@ -120,7 +120,7 @@ struct RagState {
     int max_nx = 0, max_ny = 0, max_nxt = 0, max_nrs = 0, max_cells_y = 0;
     double max_ratio = 0.0;
     DevBuf d_aux, h_stage;              // RagMember[n], R tables, part maps | Sx, Sy, bottom operands; pinned staging of what the host writes (the head of d_aux)
-    bool levels_built = false;          // the class's hierarchy is in I->mg (mg_build_levels_rag, called from rag_begin)
+    bool levels_built = false;          // the class's hierarchy is in I->mg (mg_build_levels_rag, called from rag_begin_builds)
     hipEvent_t ev = nullptr;            // behind the upload out of h_stage
     hipEvent_t ev_ready = nullptr;      // second stream: the level planes are zeroed and the correction's tables built (the matrices follow: Instance::ev_fd)
     bool ready_pending = false;         // ... and the main stream has not waited for that yet
@@ -133,7 +133,7 @@ struct Instance {
     // second stream of the instance: the float-table node correction of the next-to-last iterate (three latency-bound launches)
     // runs here beside the coarse levels of the last cycle; forked and joined with events, see mg_solve
     hipStream_t aux = nullptr;
-    hipStream_t aux2 = nullptr;            // a size class's matrix build (rag_begin), beside aux's zeroing and tables; created on first use
+    hipStream_t aux2 = nullptr;            // a size class's matrix build (rag_begin_builds), beside aux's zeroing and tables; created on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool aux_pending = false;              // work on aux that `stream` has not waited for yet
     sc_solver_opts opts{};

@@ -430,7 +430,7 @@ static bool build_ratio(int w, int h, int Kx, int Ky, int Kxp, float *R, double 
 }
 
 // (Re)builds the tables for the fields currently bound to the instance; no-op when the geometry is unchanged.
-// A size class: the members' tables are on the device already (rag_begin, sc_ragged.cpp); what is left are the class-sized work
+// A size class: the members' tables are on the device already (rag_begin_table / rag_begin_builds, sc_ragged.cpp); what is left are the class-sized work
 // buffers.  L's geometry holds the class's strides and maxima.
 static int lm_prepare_rag(Instance *I)
 {

@@ -371,7 +371,7 @@ size_t mg_default_tail_level(const std::vector<MGGeom> &g)
 
 static int build_levels(Instance *I)
 {
-    if (I->rag.dev) {          // a size class: rag_begin built the hierarchy (mg_build_levels_rag)
+    if (I->rag.dev) {          // a size class: rag_begin_builds built the hierarchy (mg_build_levels_rag)
         if (!I->rag.levels_built || I->mg.empty()) { I->err = "size class: hierarchy missing"; return SC_ERR_BAD_ARG; }
         return SC_OK;
     }
@@ -435,7 +435,7 @@ static int build_levels(Instance *I)
 // member has on that level --, every plane zeroed (a member's ring and what lies beyond it must be zero, and the slot may have held a
 // larger member a call ago), the members' bottom matrices by one launch on the second stream.  The per-member geometries are in the
 // table on the device; I->mg[l].g holds the class's MAXIMA (grid sizes and the launchers' shape tests read those).
-// Called from rag_begin: the zeroing goes to `zero_on` (the instance's second stream, which the main stream joins in front of its
+// Called from rag_begin_builds: the zeroing goes to `zero_on` (the instance's second stream, which the main stream joins in front of its
 // first coarse-level launch, mg_solve) -- the caller has ordered that stream behind everything that read the planes before.
 int mg_build_levels_rag(Instance *I, hipStream_t zero_on)
 {
@@ -481,7 +481,7 @@ int mg_build_levels_rag(Instance *I, hipStream_t zero_on)
     I->mg_bottom = (size_t)R.tail + 1;
     I->mg_l1_half = true;      // a class runs the fast path (plan_size): float16 level 1, and its planes are all zero -- valid in either format, nothing to re-zero in mg_solve
     // the class's bottom: every member's level below `tail` solved directly on the matrix cores inside k_mg_tail, operands padded
-    // alike; the matrices are being built on the second stream since rag_begin (run_tail waits for them)
+    // alike; the matrices are being built on the third stream since rag_begin_builds (run_tail waits for them)
     I->fd_level = 0; I->fd_mm = true; I->fd_npx = R.npx; I->fd_npy = R.npy; I->fd_nxp = I->fd_nyp = 0; I->fd_mm_off = 0;
     R.levels_built = true;
     return SC_OK;
