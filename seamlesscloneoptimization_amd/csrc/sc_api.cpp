@@ -515,7 +515,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->aux2) (void)hipStreamSynchronize(I->aux2);
     for (DevBuf &b : I->retired) dev_release(b);                    // blocks that growth replaced (ensure)
     for (Instance::Slab &sl : I->slabs) if (sl.base) (void)hipFree(sl.base);
-    DevBuf *bufs[] = { &I->d_face, &I->d_body_roi, &I->d_out, &I->d_mask, &I->d_M, &I->d_U0, &I->d_U1, &I->d_F };
+    DevBuf *bufs[] = { &I->d_face, &I->d_body_roi, &I->d_out, &I->d_mask, &I->d_in, &I->d_M, &I->d_U0, &I->d_U1, &I->d_F };
     for (DevBuf *b : bufs) dev_release(*b);
     for (DevBuf &b : I->mg_bufs) dev_release(b);
     dev_release(I->mg_partial);
@@ -557,7 +557,7 @@ void my_seamlessclone_api_imp_destroy(void *p)
     if (I->h_maxcorr) (void)hipHostFree(I->h_maxcorr);
     if (I->h_rect) (void)hipHostFree(I->h_rect);
     if (I->h_red) (void)hipHostFree(I->h_red);
-    for (DevBuf *b : { &I->h_face, &I->h_body, &I->h_mask, &I->h_out }) if (b->p) (void)hipHostFree(b->p);
+    for (DevBuf *b : { &I->h_face, &I->h_body, &I->h_mask, &I->h_out, &I->h_in }) if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < 8; ++i) if (I->ev[i]) (void)hipEventDestroy(I->ev[i]);
     for (int i = 0; i < 8; ++i) if (I->ev_chunk[i]) (void)hipEventDestroy(I->ev_chunk[i]);
     if (I->ev_k0) (void)hipEventDestroy(I->ev_k0);
@@ -719,21 +719,57 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     SC_HIP(I, hipSetDevice(I->gpu));
     int rc = validate_images(I, face, fc, fr, fs, body, bc, br, bs, mask, mc, mr, ms);
     if (rc) return rc;
-    // --- mask to the device, bounding box
-    const bool whole_m = 4 * (size_t)mc >= 3 * (size_t)ms;      // (not a narrow view of a much wider image): one linear copy at the caller's step
-    const int dms = whole_m ? ms : round_up(mc, 256);
-    if ((rc = ensure(I, I->d_mask, (size_t)dms * mr + 64, false))) return rc;
+    // --- the predicted box (the previous one for this mask size, else the mask's interior), if any
+    int guess[4];
+    Geo gp{};
+    bool predicted = predict_rect(I, mc, mr, guess);
+    if (predicted) {
+        predicted = geo_from_rect(I, guess, cx, cy, gp) == SC_OK && check_roi(I, gp, bc, br) == SC_OK;
+        I->err.clear();                               // a guess that does not fit the destination is not an error
+    }
+    // --- SMALL calls (the reference's own patches: 154 x 100 ... 592^2 into 1600 x 898): what the clone reads -- mask, patch ROI,
+    //     destination ROI -- is packed row by row into ONE pinned block and crosses PCIe as ONE copy into one device block.  Three
+    //     copies out of pageable memory cost 12-40 us EACH before a byte moves (the runtime stages them itself): h2d 0.037 / 0.050 /
+    //     0.131 ms at 154 x 100 / 300 x 194 / 592^2 for 0.1 / 0.4 / 2.4 MB.  Needs the box before the first copy: predicted calls only.
+    struct PreIn { const uint8_t *face = nullptr; uint8_t *body = nullptr; int pitch = 0; } pre;
+    constexpr size_t SMALL_CALL_MAX = (size_t)1 << 20;      // (measured: 0.138 -> 0.117 ms per call at 154 x 100, 0.177 -> 0.166 at 300 x 194; at 592^2 -- 2.4 MB -- packing on the host loses: 0.415 -> 0.425)
+    const uint8_t *dmask = nullptr;                   // the mask on the device, its row step
+    int dms = 0;
     I->stage_marks = true;         // a host-image call is synchronous whatever bSync says: its timeline is always read
     I->marks_ends_only = (I->opts.flags & SC_FLAG_NO_STAGE_MARKS) != 0;      // (... unless the caller gives the per-stage figures up for their ~5 us bubbles)
-    if ((rc = tmark(I, 0))) return rc;
-    if (whole_m) SC_HIP(I, hipMemcpyAsync(I->d_mask.p, mask, (size_t)ms * (mr - 1) + mc, hipMemcpyHostToDevice, I->stream));
-    else if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
-    if ((rc = tmark(I, 1))) return rc;
+    if (predicted && !I->opts.reference_warmup) {
+        const int sdms = round_up(mc, 256), sdfs = round_up(3 * gp.W, 256);
+        const size_t bm = (size_t)sdms * mr, bi = (size_t)sdfs * gp.H, total = bm + 2 * bi;
+        if (total <= SMALL_CALL_MAX) {
+            if ((rc = ensure(I, I->d_in, total + 64, false))) return rc;
+            if ((rc = ensure_pinned(I, I->h_in, total))) return rc;
+            if ((rc = tmark(I, 0))) return rc;
+            uint8_t *const hs = (uint8_t *)I->h_in.p, *const ds = (uint8_t *)I->d_in.p;
+            copy_rows(I, hs, (size_t)sdms, mask, (size_t)ms, (size_t)mc, mr);
+            copy_rows(I, hs + bm, (size_t)sdfs, face + (size_t)gp.y0 * fs + 3 * (size_t)gp.x0, (size_t)fs, 3 * (size_t)gp.W, gp.H);
+            copy_rows(I, hs + bm + bi, (size_t)sdfs, body + (size_t)gp.lty * bs + 3 * (size_t)gp.ltx, (size_t)bs, 3 * (size_t)gp.W, gp.H);
+            SC_HIP(I, hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, I->stream));
+            dmask = ds; dms = sdms;
+            pre.face = ds + bm; pre.body = ds + bm + bi; pre.pitch = sdfs;
+            if ((rc = tmark(I, 1))) return rc;
+        }
+    }
+    if (!dmask) {
+        // --- mask to the device
+        const bool whole_m = 4 * (size_t)mc >= 3 * (size_t)ms;      // (not a narrow view of a much wider image): one linear copy at the caller's step
+        dms = whole_m ? ms : round_up(mc, 256);
+        if ((rc = ensure(I, I->d_mask, (size_t)dms * mr + 64, false))) return rc;
+        if ((rc = tmark(I, 0))) return rc;
+        if (whole_m) SC_HIP(I, hipMemcpyAsync(I->d_mask.p, mask, (size_t)ms * (mr - 1) + mc, hipMemcpyHostToDevice, I->stream));
+        else if ((rc = upload_rows(I, I->h_mask, I->d_mask.p, dms, mask, ms, mc, mr))) return rc;
+        dmask = (const uint8_t *)I->d_mask.p;
+        if ((rc = tmark(I, 1))) return rc;
+    }
     // One attempt on a given geometry: ROI of face/body to the device (the reference uploads both images whole),
     // clone, [check the predicted box], result back into the caller's image.  SC_GUESS_WRONG = the device found a
     // different box than `guess`; nothing has been written anywhere the caller can see.
     constexpr int SC_GUESS_WRONG = 1;
-    auto attempt = [&](const Geo &g, const int *guess) -> int {
+    auto attempt = [&](const Geo &g, const int *guess, const PreIn *in) -> int {      // in: the ROIs are on the device already (the small call's one copy)
         int r;
         const int dfs = round_up(3 * g.W, 256);
         // An image whose ROI covers most of its rows (>= 3/4 of the row step: the patch always, the destination often) crosses
@@ -749,17 +785,21 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         // (0.20 against 0.25 ms)
         constexpr size_t WHOLE_EXTRA_MAX = (size_t)3 << 20;
         auto few_extra = [&](int step) { const size_t extra = ((size_t)step - 3 * (size_t)g.W) * g.H; return extra <= WHOLE_EXTRA_MAX && extra <= 2 * 3 * (size_t)g.W * g.H; };
-        const bool whole_f = 4 * 3 * (size_t)g.W >= 3 * (size_t)fs || few_extra(fs);
-        const bool whole_b = 4 * 3 * (size_t)g.W >= 3 * (size_t)bs || few_extra(bs);
-        const int fpitch = whole_f ? fs : dfs, bpitch = whole_b ? bs : dfs;
+        const bool whole_f = !in && (4 * 3 * (size_t)g.W >= 3 * (size_t)fs || few_extra(fs));
+        const bool whole_b = !in && (4 * 3 * (size_t)g.W >= 3 * (size_t)bs || few_extra(bs));
+        const int fpitch = in ? in->pitch : whole_f ? fs : dfs, bpitch = in ? in->pitch : whole_b ? bs : dfs;
         const size_t foff = whole_f ? 3 * (size_t)g.x0 : 0, boff = whole_b ? 3 * (size_t)g.ltx : 0;
-        if ((r = ensure(I, I->d_face, (size_t)fpitch * g.H + 64, false))) return r;
-        if ((r = ensure(I, I->d_body_roi, (size_t)bpitch * g.H + 64, false))) return r;
         if ((r = ensure(I, I->d_out, (size_t)dfs * g.H + 64, false))) return r;
-        if (whole_f) SC_HIP(I, hipMemcpyAsync(I->d_face.p, face + (size_t)g.y0 * fs, (size_t)fs * (g.H - 1) + foff + 3 * (size_t)g.W, hipMemcpyHostToDevice, I->stream));
-        else if ((r = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return r;
-        if (whole_b) SC_HIP(I, hipMemcpyAsync(I->d_body_roi.p, body + (size_t)g.lty * bs, (size_t)bs * (g.H - 1) + boff + 3 * (size_t)g.W, hipMemcpyHostToDevice, I->stream));
-        else if ((r = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return r;
+        if (!in) {
+            if ((r = ensure(I, I->d_face, (size_t)fpitch * g.H + 64, false))) return r;
+            if ((r = ensure(I, I->d_body_roi, (size_t)bpitch * g.H + 64, false))) return r;
+            if (whole_f) SC_HIP(I, hipMemcpyAsync(I->d_face.p, face + (size_t)g.y0 * fs, (size_t)fs * (g.H - 1) + foff + 3 * (size_t)g.W, hipMemcpyHostToDevice, I->stream));
+            else if ((r = upload_rows(I, I->h_face, I->d_face.p, dfs, face + (size_t)g.y0 * fs + 3 * g.x0, fs, 3 * (size_t)g.W, g.H))) return r;
+            if (whole_b) SC_HIP(I, hipMemcpyAsync(I->d_body_roi.p, body + (size_t)g.lty * bs, (size_t)bs * (g.H - 1) + boff + 3 * (size_t)g.W, hipMemcpyHostToDevice, I->stream));
+            else if ((r = upload_rows(I, I->h_body, I->d_body_roi.p, dfs, body + (size_t)g.lty * bs + 3 * g.ltx, bs, 3 * (size_t)g.W, g.H))) return r;
+        }
+        const uint8_t *const d_face_roi = in ? in->face : (const uint8_t *)I->d_face.p + foff;
+        uint8_t *const d_body_roi = in ? in->body : (uint8_t *)I->d_body_roi.p + boff;
         if ((r = tmark(I, 3))) return r;
         const int passes = I->opts.reference_warmup ? 2 : 1;
         // the output bytes go to a compact buffer of their own (the interior only is written, and only that comes back); the
@@ -771,10 +811,9 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         // of one image would lose each other's result) -- so the default writes ROI bytes only, as the reference does
         // (seamlessClone_imp.cpp:470-483).
         const bool inplace = whole_b && passes == 1 && (size_t)bs == 3 * (size_t)bc && (I->opts.flags & SC_FLAG_ROWS_RETURN);      // (a view into a wider array keeps the staged path: nothing beyond the view's own pixels is ever written)
-        uint8_t *const out_dev = (passes > 1 || inplace) ? (uint8_t *)I->d_body_roi.p + boff : (uint8_t *)I->d_out.p;
+        uint8_t *const out_dev = (passes > 1 || inplace) ? d_body_roi : (uint8_t *)I->d_out.p;
         const int out_pitch = (passes > 1 || inplace) ? bpitch : dfs;
-        r = device_clone(I, (const uint8_t *)I->d_mask.p, dms, mr, (const uint8_t *)I->d_face.p + foff, fpitch,
-                         (uint8_t *)I->d_body_roi.p + boff, bpitch, g, passes, out_dev, out_pitch);
+        r = device_clone(I, dmask, dms, mr, d_face_roi, fpitch, d_body_roi, bpitch, g, passes, out_dev, out_pitch);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
         if (guess) {      // the scan rode in the pre-process launch and finished long ago: this wait on the event behind that launch is free
             if (I->scan_fence) SC_HIP(I, hipEventSynchronize(I->scan_fence));
@@ -835,35 +874,30 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
     };
     Geo g{};
     bool done = false;
-    int guess[4];
     I->guard = RectGuard();
-    if (predict_rect(I, mc, mr, guess)) {
-        Geo gp{};
-        if (geo_from_rect(I, guess, cx, cy, gp) == SC_OK && check_roi(I, gp, bc, br) == SC_OK) {
-            // launch on the predicted box; the bbox kernel's answer is checked before anything reaches the caller
-            if ((rc = bbox_enqueue(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, &gp))) return rc;
-            I->guard = make_guard(I, guess);
-            rc = attempt(gp, guess);
-            I->guard = RectGuard();
-            if (rc == SC_GUESS_WRONG) {               // repeat on the true box, pause speculation for a while
-                I->spec_cooldown = 8;
-                if ((rc = geo_from_rect(I, I->h_rect + 4, cx, cy, g))) return rc;
-                fill_info_geo(I, g);
-                if ((rc = check_roi(I, g, bc, br))) return rc;
-                rc = attempt(g, nullptr);
-            } else {
-                g = gp;
-            }
-            if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
-            done = true;
+    if (predicted) {
+        // launch on the predicted box; the bbox kernel's answer is checked before anything reaches the caller
+        if ((rc = bbox_enqueue(I, dmask, mc, mr, dms, &gp))) return rc;
+        I->guard = make_guard(I, guess);
+        rc = attempt(gp, guess, pre.face ? &pre : nullptr);
+        I->guard = RectGuard();
+        if (rc == SC_GUESS_WRONG) {               // repeat on the true box (the mask stays where it is, the ROIs go up the ordinary way), pause speculation for a while
+            I->spec_cooldown = 8;
+            if ((rc = geo_from_rect(I, I->h_rect + 4, cx, cy, g))) return rc;
+            fill_info_geo(I, g);
+            if ((rc = check_roi(I, g, bc, br))) return rc;
+            rc = attempt(g, nullptr, nullptr);
+        } else {
+            g = gp;
         }
-        I->err.clear();                               // a guess that did not fit the destination is not an error
+        if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
+        done = true;
     }
     if (!done) {                                      // no usable prediction: wait for the device's box first
-        if ((rc = device_bbox(I, (const uint8_t *)I->d_mask.p, mc, mr, dms, cx, cy, g))) return rc;
+        if ((rc = device_bbox(I, dmask, mc, mr, dms, cx, cy, g))) return rc;
         fill_info_geo(I, g);
         if ((rc = check_roi(I, g, bc, br))) return rc;
-        rc = attempt(g, nullptr);
+        rc = attempt(g, nullptr, nullptr);
         if (rc != SC_OK && rc != SC_ERR_NOT_CONVERGED) return rc;
     }
     fill_info_geo(I, g);

@@ -141,6 +141,7 @@ struct Instance {
     std::string err;
 
     // staging copies for host-pointer runs
+    DevBuf d_in, h_in;                             // a SMALL host-image call: mask | patch ROI | destination ROI packed in one pinned block, one copy, one device block
     DevBuf d_face, d_body_roi, d_mask, d_out;      // d_out: the host path's compact output buffer (ROI bytes that go back across PCIe)
     // page-locked host staging (grow-only): pageable caller images are packed here row by row so
     // each image crosses PCIe as ONE DMA instead of one slow pageable 2-D copy
