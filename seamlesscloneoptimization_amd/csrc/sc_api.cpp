@@ -811,7 +811,12 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         // of one image would lose each other's result) -- so the default writes ROI bytes only, as the reference does
         // (seamlessClone_imp.cpp:470-483).
         const bool inplace = whole_b && passes == 1 && (size_t)bs == 3 * (size_t)bc && (I->opts.flags & SC_FLAG_ROWS_RETURN);      // (a view into a wider array keeps the staged path: nothing beyond the view's own pixels is ever written)
-        uint8_t *const out_dev = (passes > 1 || inplace) ? d_body_roi : (uint8_t *)I->d_out.p;
+        constexpr size_t DIRECT_OUT_MAX = (size_t)2 << 20;
+        // a SMALL output: the output launch writes the ROI's bytes straight into the pinned staging (three words per lane, coalesced: posted
+        // writes across PCIe) -- no device-to-host copy command (~10 us before its first byte moves) behind the last kernel
+        const bool direct_out = passes == 1 && !inplace && (size_t)dfs * g.H <= DIRECT_OUT_MAX;
+        if (direct_out && (r = ensure_pinned(I, I->h_out, (size_t)dfs * g.H + 64))) return r;
+        uint8_t *const out_dev = (passes > 1 || inplace) ? d_body_roi : direct_out ? (uint8_t *)I->h_out.p : (uint8_t *)I->d_out.p;
         const int out_pitch = (passes > 1 || inplace) ? bpitch : dfs;
         r = device_clone(I, dmask, dms, mr, d_face_roi, fpitch, d_body_roi, bpitch, g, passes, out_dev, out_pitch);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
@@ -831,6 +836,10 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
             SC_HIP(I, hipMemcpyAsync(body + (size_t)(g.lty + 1) * bs + 3 * (size_t)(g.ltx + 1), out_dev + (size_t)out_pitch + 3,
                                      (size_t)bs * (orows - 1) + ob, hipMemcpyDeviceToHost, I->stream));
             SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+        } else if (orows > 0 && g.W > 2 && direct_out) {
+            SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
+            SC_HIP(I, hipStreamSynchronize(I->stream));              // the kernel's stores are in host memory when it has ended
+            copy_rows(I, body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1), (size_t)bs, (const uint8_t *)I->h_out.p + dfs + 3, (size_t)dfs, ob, orows);
         } else if (orows > 0 && g.W > 2) {
             const int dfs = out_pitch;            // (shadows the compact pitch: the warm-up variant returns at the body buffer's)
             if ((r = ensure_pinned(I, I->h_out, (size_t)dfs * g.H + 64))) return r;
