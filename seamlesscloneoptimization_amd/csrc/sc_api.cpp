@@ -748,7 +748,13 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
             copy_rows(I, hs, (size_t)sdms, mask, (size_t)ms, (size_t)mc, mr);
             copy_rows(I, hs + bm, (size_t)sdfs, face + (size_t)gp.y0 * fs + 3 * (size_t)gp.x0, (size_t)fs, 3 * (size_t)gp.W, gp.H);
             copy_rows(I, hs + bm + bi, (size_t)sdfs, body + (size_t)gp.lty * bs + 3 * (size_t)gp.ltx, (size_t)bs, 3 * (size_t)gp.W, gp.H);
-            SC_HIP(I, hipMemcpyAsync(ds, hs, total, hipMemcpyHostToDevice, I->stream));
+            {   // ... by a KERNEL that reads the pinned block across PCIe (k_copy_group: sixteen bytes per lane, four loads in flight): a copy
+                // command takes ~20 us before its first byte moves, whatever its size (h2d stage at 154 x 100: 24 us for 0.1 MB)
+                CopyJobs cj{};
+                cj.dst[0] = ds; cj.src[0] = hs; cj.bytes[0] = total;
+                launch_copy_group(cj, 1, I->stream);
+                SC_HIP(I, hipGetLastError());
+            }
             dmask = ds; dms = sdms;
             pre.face = ds + bm; pre.body = ds + bm + bi; pre.pitch = sdfs;
             if ((rc = tmark(I, 1))) return rc;
