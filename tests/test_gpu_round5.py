@@ -488,3 +488,44 @@ def test_size_class_without_speculation_and_with_a_member_guessed_wrong(oracles)
         _free_jobs(inst, keep); _free_jobs(inst, keep_b)
     finally:
         inst.destroy()
+
+
+@pytest.mark.parametrize("W,H", [(154, 100), (300, 194), (420, 300), (592, 592), (900, 700)])
+def test_small_host_call_paths_give_the_ordinary_bytes(oracles, W, H):
+    """Round 5, late: a host-image call whose inputs total at most 1 MB packs mask, patch ROI and destination ROI into one pinned block
+    that a kernel reads across PCIe (one upload), and an output of at most 2 MB is written by the output launch straight into pinned
+    memory (no device-to-host copy command).  Both need nothing but a predicted box; SC_FLAG_NO_SPECULATE takes the ordinary path
+    (three uploads) -- the bytes must be the same, for a patch inside a much larger destination, a strided view of one, and a mask
+    whose box is not its interior (the first call's guess is wrong: the ROI uploads are repeated the ordinary way)."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=41, seed_patch=42, margin=180)
+    big = np.zeros((dst.shape[0] + 7, dst.shape[1] + 13, 3), np.uint8)
+    big[3:3 + dst.shape[0], 5:5 + dst.shape[1]] = dst
+    m_odd = mask.copy(); m_odd[:7, :] = 0; m_odd[:, -11:] = 0
+    want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+    want_odd = oc.seamless_clone(dst, patch, m_odd, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+    results = {}
+    for name, flags in (("default", 0), ("ordinary", capi.SC_FLAG_NO_SPECULATE)):
+        inst = capi.Instance(0)
+        try:
+            inst.set_solver(flags=flags)
+            outs = []
+            for rep in range(2):                              # (the second call predicts the first call's box)
+                body = dst.copy(); inst.run(patch, body, mask, cx, cy); outs.append(body)
+            view = big.copy()
+            inst.run(patch, view[3:3 + dst.shape[0], 5:5 + dst.shape[1]], mask, cx, cy)
+            outs.append(view)
+            body = dst.copy(); inst.run(patch, body, m_odd, cx, cy); outs.append(body)     # predicted: the full mask's box -- wrong
+            body = dst.copy(); inst.run(patch, body, m_odd, cx, cy); outs.append(body)     # predicted right
+            results[name] = outs
+        finally:
+            inst.destroy()
+    for a, b in zip(results["default"], results["ordinary"]):
+        assert np.array_equal(a, b)
+    d = results["default"]
+    assert np.array_equal(d[0], d[1]) and _dmax(d[0], want) <= 1 and not np.array_equal(d[0], dst)
+    assert np.array_equal(d[2][3:3 + dst.shape[0], 5:5 + dst.shape[1]], d[0])
+    frame = d[2].copy(); frame[3:3 + dst.shape[0], 5:5 + dst.shape[1]] = 0
+    assert not frame.any()                                    # nothing outside the view was touched
+    assert np.array_equal(d[3], d[4]) and _dmax(d[3], want_odd) <= 1
