@@ -108,8 +108,10 @@ static bool is_pinned(const void *p)
 }
 
 // Row-wise host copy between a caller image and the pinned staging.  A single core moves ~14 GB/s, which
-// would make the packing (not PCIe, not the GPU) the longest part of a 2048^2 call, so copies above 1 MB are
+// would make the packing (not PCIe, not the GPU) the longest part of a 2048^2 call, so copies above 512 KB are
 // shared between the calling thread and the instance's parked helpers (sc_hostcopy.h) in ~256 KB pieces.
+// (1 MB until late in round 5: the splice of a 592^2 output, 1 037 232 bytes, ran on one core: 71 us of a 0.37-ms call, 25 shared;
+//  256 KB loses: waking the helpers costs more than they save on the 0.4-MB pieces of a small call's upload)
 static void copy_rows(Instance *I, uint8_t *dst, size_t dpitch, const uint8_t *src, size_t spitch, size_t row_bytes, int rows)
 {
     const size_t total = row_bytes * (size_t)rows;
@@ -120,7 +122,7 @@ static void copy_rows(Instance *I, uint8_t *dst, size_t dpitch, const uint8_t *s
         }
         for (int y = y0; y < y1; ++y) memcpy(dst + (size_t)y * dpitch, src + (size_t)y * spitch, row_bytes);
     };
-    if (total < ((size_t)1 << 20)) { span(0, rows); return; }
+    if (total < ((size_t)512 << 10)) { span(0, rows); return; }
     if (!I->copier) {
         const unsigned hw = std::thread::hardware_concurrency();
         int n = 8;                         // measured: packing saturates near 8 threads
