@@ -1153,12 +1153,8 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
     constexpr int RS = GROUP_RS;
     if ((rc = ensure(I, I->d_rects, (size_t)n * RS * sizeof(int)))) return rc;
     if ((rc = ensure_pinned(I, I->h_rects, (size_t)n * 2 * RS * sizeof(int)))) return rc;
-    int *h_in = (int *)I->h_rects.p, *h_out = h_in + RS * n, *d_r = (int *)I->d_rects.p;
-    memset(h_in, 0, (size_t)n * RS * sizeof(int));
-    for (int i = 0; i < n; ++i) {
-        h_in[RS * i + 0] = jobs[i].mask_cols - 1; h_in[RS * i + 1] = 0; h_in[RS * i + 2] = jobs[i].mask_rows - 1; h_in[RS * i + 3] = 0;
-    }
-    SC_HIP(I, hipMemcpyAsync(d_r, h_in, (size_t)n * RS * sizeof(int), hipMemcpyHostToDevice, I->stream));
+    // (the fold launch writes every usable member's rectangle to d_r AND into the pinned h_out: no seeds to upload, nothing to read back)
+    int *h_out = (int *)I->h_rects.p + RS * n, *d_r = (int *)I->d_rects.p;
     {
         std::vector<MaskJob> mj;
         mj.reserve(n);
@@ -1166,14 +1162,13 @@ int sc_hip_run_device_batch(void *p, sc_batch_job *jobs, int n)
             if (!usable[i]) continue;
             MaskJob m{};
             m.mask = jobs[i].mask; m.mw = jobs[i].mask_cols; m.mh = jobs[i].mask_rows; m.mstep = jobs[i].mask_step;
-            m.rect = d_r + RS * i;
+            m.rect = d_r + RS * i; m.rect_host = h_out + RS * i;
             mj.push_back(m);
         }
         if ((rc = ensure(I, I->d_bbox_parts, sizeof(int) * mask_bbox_group_parts(mj.data(), (int)mj.size())))) return rc;
         launch_mask_bbox_group(mj.data(), (int)mj.size(), I->stream, (int *)I->d_bbox_parts.p);
     }
     SC_HIP(I, hipGetLastError());
-    SC_HIP(I, hipMemcpyAsync(h_out, d_r, (size_t)n * RS * sizeof(int), hipMemcpyDeviceToHost, I->stream));
     if (!I->ev_rects) SC_HIP(I, hipEventCreateWithFlags(&I->ev_rects, hipEventDisableTiming));
     SC_HIP(I, hipEventRecord(I->ev_rects, I->stream));
     // Like a single clone (predict_rect), the members are launched on PREDICTED bounding boxes -- the interior of every mask,

@@ -36,6 +36,7 @@ struct Img8 {
 struct MaskJob {
     const uint8_t *mask; int mw, mh, mstep;
     int *rect;
+    int *rect_host;      // (group scans) the same four words in the host's pinned mailbox, written by the fold: no copy command (may be nullptr)
     size_t mask_bytes;
     Geo g;
     uint8_t *M; int mpitch;

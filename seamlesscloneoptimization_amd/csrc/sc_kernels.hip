@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256) void k_mask_bbox_group(MaskJobs t, int *__rest
     mask_bbox_block(j.mask, j.mw, j.mh, j.mstep, BboxFold(), blockIdx.x, blockIdx.y, part);
 }
 
-// one workgroup per mask: extrema of its `per` workgroup parts, combined with the host's seeds in the rectangle
+// one workgroup per mask: extrema of its `per` workgroup parts -- an empty mask gives the "empty" rectangle the host's seeds used to be
+// (mw - 1, 0, mh - 1, 0: round 5 dropped their upload) --, to device memory (the splices' guards read it there) and straight into the
+// host's pinned mailbox (no read-back copy: two copy commands less in front of the group's erode)
 __global__ __launch_bounds__(256) void k_mask_bbox_fold_group(MaskJobs t, const int *__restrict__ parts, int per)
 {
     const int *p = parts + 4 * (size_t)blockIdx.x * per;
@@ -338,8 +340,10 @@ __global__ __launch_bounds__(256) void k_mask_bbox_fold_group(MaskJobs t, const 
             minx = min(minx, red[w][0]); maxx = max(maxx, red[w][1]);
             miny = min(miny, red[w][2]); maxy = max(maxy, red[w][3]);
         }
-        int *rect = t.j[blockIdx.x].rect;
-        if (maxx >= 0) { rect[0] = min(rect[0], minx); rect[1] = max(rect[1], maxx); rect[2] = min(rect[2], miny); rect[3] = max(rect[3], maxy); }
+        const MaskJob &j = t.j[blockIdx.x];
+        if (maxx < 0) { minx = j.mw - 1; maxx = 0; miny = j.mh - 1; maxy = 0; }
+        j.rect[0] = minx; j.rect[1] = maxx; j.rect[2] = miny; j.rect[3] = maxy;
+        if (j.rect_host) { j.rect_host[0] = minx; j.rect_host[1] = maxx; j.rect_host[2] = miny; j.rect_host[3] = maxy; }
     }
 }
 
