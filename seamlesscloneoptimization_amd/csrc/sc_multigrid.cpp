@@ -358,14 +358,16 @@ void mg_plan_levels(int W, int H, std::vector<MGGeom> &g)
 
 // The default hierarchy's deepest launched level (see build_levels): the first level >= 2 with at most 127 unknowns per side, held in
 // registers by k_mg_tail with the level below it solved directly in the same launch; 0: this ladder ends differently (its level 1
-// already fits the matrix-core solve, or no such level exists)
+// is solved directly -- at most 64 unknowns per side: 10-13 us per solve for a group of sixteen, against ~24 for a level-1 launch plus
+// k_mg_tail; up to 96 until late in round 5, but the 96-wide solve takes 31-34 us (ROIs of 131..194 pixels: measured on groups of
+// 16, tools/class_timeline.sh) --, or no such level exists)
 size_t mg_default_tail_level(const std::vector<MGGeom> &g)
 {
     const size_t nl = g.size();
     size_t a = 0;
     for (size_t l = 2; l + 1 < nl && !a; ++l)
         if (g[l].x.n <= 127 && g[l].y.n <= 127) a = l;
-    const bool level1_direct = nl > 1 && g[1].x.n <= 96 && g[1].y.n <= 96;
+    const bool level1_direct = nl > 1 && g[1].x.n <= 64 && g[1].y.n <= 64;
     return (a && !(a == 2 && level1_direct)) ? a : 0;
 }
 
@@ -418,7 +420,8 @@ static int build_levels(Instance *I)
     // cores, inside the same launch.  The LDS-fit rule above chose the bottom in rounds 1-3; where it landed on a level with 97 .. ~190
     // unknowns on a side (ROIs like 2090 x 1632, 2500 x 1300, 3540^2: no matrix-core solve, an LDS-resident V-cycle inside
     // k_mg_bottom instead) a cycle cost 60 us more than at the sizes next to it (0.55 against 0.38 ms for one clone).  Kept: a ROI
-    // whose level 1 already fits the matrix-core solve (<= 96 per side: solved there), the flags that ask for the older bottoms.
+    // whose level 1 fits the matrix-core solve at 64 (solved there; at 65..96 only where the ladder has no level for k_mg_tail),
+    // the flags that ask for the older bottoms.
     if (!(I->opts.flags & SC_FLAG_VCYCLE_BOTTOM) && !legacy_path(I->opts, SC_LEGACY_BOTTOM_F32) && I->opts.mg_direct_max <= 0) {
         const size_t a = mg_default_tail_level(plan);
         const bool level1_direct = nl > 1 && I->mg[1].g.x.n <= 96 && I->mg[1].g.y.n <= 96;

@@ -86,8 +86,8 @@ bool plan_size_uncached(const sc_solver_opts &o, int W, int H, SizePlan &p)
     p.nl = (int)pg.size();
     size_t a = mg_default_tail_level(pg);
     if (!a) {
-        // A ladder whose level 1 a solo clone (or a same-size group) solves directly -- at most 96 unknowns per side: ROIs up to ~194
-        // pixels, the reference's own 154 x 100 patch among them.  A class has no such form; it takes the general one -- level 2 in
+        // A ladder whose level 1 a solo clone (or a same-size group) solves directly -- at most 64 unknowns per side: ROIs up to ~130
+        // pixels (the reference's own 154 x 100 patch runs the general hierarchy alone as well since late in round 5).  A class has no such form; it takes the general one -- level 2 in
         // k_mg_tail, level 3 solved directly -- where that exists.  Same fixed point, different iterates: such a member is within one
         // grey level of its solo run, not byte-identical to it (`solo_differs`; every larger size is).
         if (std::min(W, H) >= 48)                            // (below that the directly solved level has a handful of unknowns per side: such clones stay alone)

@@ -151,9 +151,11 @@ SIZE_CLASSES = {
     "mixed_depth": [(1010, 1060), (1022, 1065), (1001, 1033)],
     # BASELINE config 3's size and two neighbours
     "2048s": [(2048, 2048), (2000, 2040), (1990, 2050)],
-    # the reference's own small patches (154 x 100; its size sets 109 x 164, 181 x 153): a solo clone solves their level 1 directly, a class
-    # runs the general hierarchy -- within one grey level of the solo run, not its bytes (plan_size: solo_differs)
+    # the reference's own small patches (154 x 100; its size sets 109 x 164, 181 x 153): level 2 in k_mg_tail, alone and in a class
     "150s": [(154, 160), (150, 171), (165, 158), (158, 164), (161, 152)],
+    # ROIs of at most ~130 pixels: a solo clone solves their level 1 directly (64 x 64 on the matrix cores), a class runs the general
+    # hierarchy -- within one grey level of the solo run, not its bytes (plan_size: solo_differs)
+    "110s": [(104, 118), (110, 99), (126, 112), (98, 121), (115, 107)],
     # across 2050 unknowns per side the float-table correction keeps 40 instead of 32 modes (mode-block padding 64 / 32) and the
     # directly solved level flips between 32 and 33 unknowns at ~2110 (operand padding 32 / 64): all four combinations in one class
     "2100s": [(2040, 2100), (2140, 2120), (2085, 2170), (2200, 2060), (2190, 2195)],
@@ -164,7 +166,7 @@ SIZE_CLASSES = {
     # moved onto theirs (plan_groups kind 3: within one grey level of its solo run, the others keep their solo bytes)
     "straddle": [(1010, 1015), (1050, 1060), (1070, 1040), (1090, 1080)],
 }
-EXPECTED_KINDS = {"150s": [3] * 5, "straddle": [3, 2, 2, 2]}
+EXPECTED_KINDS = {"110s": [3] * 5, "straddle": [3, 2, 2, 2]}
 
 
 def test_size_classes_are_what_the_tests_think_they_are():
