@@ -382,14 +382,17 @@ def new_size_leg(capi, seed=4):
     return out
 
 
-def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, seed=2025):
+def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, seed=2025, sizes=None):
     """A batch whose members all have DIFFERENT ROI sizes -- what real clones produce: a mask box per face, per frame -- through the
     native pool with its default grouping (size classes share one set of launches: csrc/sc_ragged.cpp), beside (a) the same list one
     clone at a time on 8 streams (what rounds 1-4 did with such a batch) and (b) n same-size clones of the list's mean size (the
     ceiling).  Device-resident images, destinations refreshed inside the step, wall time of pool.run (median of `reps`)."""
     import numpy as np
     rng = np.random.default_rng(seed)
-    sizes = [(int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))) for _ in range(n)]
+    if sizes is None:
+        sizes = [(int(rng.integers(lo, hi + 1)), int(rng.integers(lo, hi + 1))) for _ in range(n)]
+    else:
+        n = len(sizes); lo = min(min(s_) for s_ in sizes); hi = max(max(s_) for s_ in sizes)
     Hd = Wd = hi + 64
     yy, xx = np.mgrid[0:Hd, 0:Wd].astype(np.float32)
     dst = np.clip((128.0 + 60.0 * np.sin(2 * np.pi * xx / Wd) * np.cos(2 * np.pi * yy / Hd))[:, :, None] +
@@ -978,6 +981,10 @@ def main():
         mixed_sizes = mixed_sizes_leg(capi)
         wide = mixed_sizes_leg(capi, lo=100, hi=2400, reps=4)      # the hardest list: sizes spread over a factor of 24, four hierarchy depths
         mixed_sizes["wide_range_100_2400"] = {k_: wide[k_] for k_ in wide if k_ not in ("note", "streams", "group", "clones")}
+        # the reference's own patch sizes (its published table and size sets: seamlessClone-CUDA README / PDF p3), sixteen clones of each in one batch
+        ref = mixed_sizes_leg(capi, reps=8, sizes=[(154, 100), (109, 164), (181, 153), (300, 194)] * 16)
+        ref["us_per_clone"] = round(ref["ms_per_step"] * 1e3 / 64, 2)
+        mixed_sizes["reference_patch_sizes_x16"] = {k_: ref[k_] for k_ in ref if k_ not in ("note", "streams", "group", "clones", "roi_range")}
     c5_projected = None
     if comm.rank == 0 and args.gpus == 1 and not args.no_c5_projection and args.config == "c3":
         c5_projected = c5_projection_leg(capi)
