@@ -382,7 +382,7 @@ def new_size_leg(capi, seed=4):
     return out
 
 
-def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, seed=2025, sizes=None):
+def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=0, reps=6, seed=2025, sizes=None):
     """A batch whose members all have DIFFERENT ROI sizes -- what real clones produce: a mask box per face, per frame -- through the
     native pool with its default grouping (size classes share one set of launches: csrc/sc_ragged.cpp), beside (a) the same list one
     clone at a time on 8 streams (what rounds 1-4 did with such a batch) and (b) n same-size clones of the list's mean size (the
@@ -399,7 +399,7 @@ def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, s
                   12.0 * rng.standard_normal((Hd, Wd, 3), dtype=np.float32), 0, 255).astype(np.uint8)
     xx = np.arange(hi + 2, dtype=np.float32)[None, :, None]
     patch = np.clip(110.0 + 50.0 * np.cos(3 * np.pi * xx / hi) + 20.0 * rng.standard_normal((hi + 2, hi + 2, 3), dtype=np.float32), 0, 255).astype(np.uint8)
-    g, k = capi.plan_groups(sizes, group)
+    g, k = capi.plan_groups_pool(sizes, group, streams)      # (group 0 = SC_POOL_GROUP_AUTO: the pool sizes its groups itself, seamlessclone_hip.h)
     planned = sorted((g.count(q) for q in set(g)), reverse=True)
     ci = k.index(2) if 2 in k else 0           # a member that keeps its own hierarchy inside its class (kind 2): the byte-for-byte check
 
@@ -437,14 +437,16 @@ def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=16, reps=6, s
     fresh, _ = run(streams, group, sizes, unseen=True)
     mean = int(round(float(np.sqrt(np.mean([w * h for w, h in sizes])))))
     same, _ = run(streams, group, [(mean, mean)] * n)
+    of16, _ = run(streams, 16, sizes) if group != 16 else (mixed, None)
     d = np.abs(a.astype(np.int16) - b.astype(np.int16))
-    return {"roi_range": [lo, hi], "clones": n, "streams": streams, "group": group, "planned_groups": planned,
+    return {"roi_range": [lo, hi], "clones": n, "streams": streams, "group": group if group else "auto (SC_POOL_GROUP_AUTO)", "planned_groups": planned,
+            "with_groups_of_16": of16,
             "Mpix_per_s": mixed["Mpix_per_s"], "ms_per_step": mixed["ms_per_step"],
             "planner_memo_cleared_every_step": fresh, "one_clone_at_a_time_8_streams": ones, "same_size_%d" % mean: same,
             "ratio_to_same_size": round(mixed["Mpix_per_s"] / same["Mpix_per_s"], 3),
             "members_on_a_deeper_hierarchy_than_solo": int(sum(1 for x in k if x == 3)),
             "first_member_vs_its_solo_clone": {"member": ci, "maxdiff": int(d.max()), "percent_differing": round(float((d > 0).mean() * 100), 4)},
-            "note": "64 clones with 64 different ROI sizes, random in [%d, %d]^2, through the pool as configured: members of one size class (same "
+            "note": "64 clones with 64 different ROI sizes, random in [%d, %d]^2, through the pool with automatic group sizes (the same-size ceiling too): members of one size class (same "
                     "hierarchy depth and bottom solve, widths and heights within 2x; the pool hands its jobs to the planner largest first) share one set of solver launches through a per-member geometry "
                     "table (nothing of it is kept between calls; only the size plans are memoised per size -- planner_memo_cleared_every_step forgets those too); every member's bytes are its solo run's whenever the group takes the solo run's cycle count -- except the leftovers of a class "
                     "one level shallower, which ride along on the deeper hierarchy (counted above; within one grey level of their solo runs)" % (lo, hi)}

@@ -366,8 +366,12 @@ SC_API int   sc_hip_pool_size(void *pool);
 SC_API void *sc_hip_pool_instance(void *pool, int k);          /* instance k, e.g. for sc_hip_get_info */
 SC_API int   sc_hip_pool_set_solver(void *pool, const sc_solver_opts *opts);
 SC_API int   sc_hip_pool_run(void *pool, sc_batch_job *jobs, int n, int device_resident);
-/* device-resident batches: every worker takes `group` consecutive jobs at a time and runs them through
- * sc_hip_run_device_batch (default 1 = one clone per set of launches) */
+/* device-resident batches: every worker takes up to `group` jobs at a time -- the batch's jobs bucketed by ROI size: same-size
+ * jobs and jobs of one size class -- and runs them through sc_hip_run_device_batch (default 1 = one clone per set of launches; at most 64).
+ * SC_POOL_GROUP_AUTO: sixteen at least where the batch has them, more for small ROIs -- up to n / streams (every stream gets a
+ * group) and 64, while a group's fields stay within what sixteen 2048 x 2048 members occupy (small clones are latency bound:
+ * 64 clones of 120..190 pixels take 0.43 ms in two groups of 32, 0.64 in four of 16) */
+#define SC_POOL_GROUP_AUTO 0
 SC_API int   sc_hip_pool_set_group(void *pool, int group);
 
 /* isolated timing of the fused level-0 multigrid cycle kernel on the state left by the last
@@ -399,6 +403,9 @@ SC_API int sc_hip_time_tail_phases(void *instance, unsigned long long *cycles11)
  * class it runs the general hierarchy and comes out within one grey level of its solo run instead of with its bytes), conditional
  * (1: the float tables' lowest modes are off by more than 4 % at this size; such members form classes of their own, in which the
  * judged cycle's measured update decides the output's form for the whole group) } */
+/* ... and how sc_hip_pool_run would: a pool of `streams` workers with group size `group` (SC_POOL_GROUP_AUTO allowed), jobs handed
+ * to the planner largest first */
+SC_API int sc_hip_plan_groups_pool(const int *wh, int n, int group, int streams, const sc_solver_opts *opts, int *group_of, int *kind_of);
 SC_API int sc_hip_plan_size(int W, int H, const sc_solver_opts *opts, int out[12]);
 /* Host-only: plans and per-size host tables (the float-table correction's ratio table, its part maps) are pure functions of the ROI
  * size and memoised process-wide on first use -- 5-20 us of host arithmetic per NEW size, paid inside the first batch call that meets

@@ -222,6 +222,8 @@ def load():
     L.sc_hip_plan_groups.argtypes = [i32p, C.c_int, C.c_int, C.POINTER(SolverOpts), i32p, i32p]
     L.sc_hip_plan_groups.restype = C.c_int
     L.sc_hip_plan_size.argtypes = [C.c_int, C.c_int, C.POINTER(SolverOpts), i32p]
+    L.sc_hip_plan_groups_pool.argtypes = [i32p, C.c_int, C.c_int, C.c_int, C.POINTER(SolverOpts), i32p, i32p]
+    L.sc_hip_plan_groups_pool.restype = C.c_int
     L.sc_hip_plan_prepare.argtypes = [i32p, C.c_int, C.POINTER(SolverOpts)]
     L.sc_hip_plan_prepare.restype = C.c_int
     L.sc_hip_plan_cache_clear.argtypes = []
@@ -550,6 +552,21 @@ def plan_size(W: int, H: int, opts: "SolverOpts | None" = None) -> dict:
     load().sc_hip_plan_size(int(W), int(H), C.byref(opts) if opts is not None else None, out.ctypes.data_as(i32p))
     keys = ("eligible", "levels", "tail_level", "pad_x", "pad_y", "Kxp", "Kyp", "column_tiles", "row_splits", "direct_nx_ny", "solo_differs", "conditional")
     return dict(zip(keys, out.tolist()))
+
+
+def plan_groups_pool(sizes, group: int = 0, streams: int = 2, opts: "SolverOpts | None" = None):
+    """Host-only: plan_groups as a Pool(streams, group) forms its groups (group 0 = SC_POOL_GROUP_AUTO; jobs largest first)."""
+    wh = np.ascontiguousarray(np.asarray(sizes, np.int32).reshape(-1, 2))
+    n = wh.shape[0]
+    g = np.zeros(n, np.int32); k = np.zeros(n, np.int32)
+    rc = load().sc_hip_plan_groups_pool(wh.ctypes.data_as(i32p), n, int(group), int(streams), C.byref(opts) if opts is not None else None,
+                                        g.ctypes.data_as(i32p), k.ctypes.data_as(i32p))
+    if rc < 0:
+        raise SeamlessCloneError(rc, "sc_hip_plan_groups_pool")
+    return g.tolist(), k.tolist()
+
+
+SC_POOL_GROUP_AUTO = 0
 
 
 def plan_prepare(sizes, opts: "SolverOpts | None" = None) -> int:

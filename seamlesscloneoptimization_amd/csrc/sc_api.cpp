@@ -1280,6 +1280,33 @@ int sc_hip_plan_groups(const int *wh, int n, int cap, const sc_solver_opts *opts
     return (int)groups.size();
 }
 
+int sc_hip_plan_groups_pool(const int *wh, int n, int group, int streams, const sc_solver_opts *opts, int *group_of, int *kind_of)
+{
+    if (!wh || n < 1 || !group_of || group < 0 || group > 64 || streams < 1) return SC_ERR_BAD_ARG;
+    sc_solver_opts o;
+    if (opts) o = *opts; else sc_hip_default_opts(&o);
+    // as sc_hip_pool_run: largest first, then the planner under the pool's caps
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (long)(wh[2 * x] + 2) * (wh[2 * x + 1] + 2) > (long)(wh[2 * y] + 2) * (wh[2 * y + 1] + 2); });
+    std::vector<SizePlan> plans(n);
+    for (int i = 0; i < n; ++i) plan_size(o, wh[2 * order[i]], wh[2 * order[i] + 1], plans[i]);
+    int cap, cap_max;
+    long budget;
+    pool_group_caps(group, n, streams, cap, cap_max, budget);
+    std::vector<std::vector<int>> groups;
+    plan_groups(plans, cap, groups, cap_max, budget);
+    for (size_t g = 0; g < groups.size(); ++g) {
+        bool uniform = true;
+        for (int i : groups[g]) uniform = uniform && plans[i].W == plans[groups[g][0]].W && plans[i].H == plans[groups[g][0]].H;
+        for (int i : groups[g]) {
+            group_of[order[i]] = (int)g;
+            if (kind_of) kind_of[order[i]] = groups[g].size() < 2 ? 0 : uniform ? 1 : plans[i].solo_differs ? 3 : 2;
+        }
+    }
+    return (int)groups.size();
+}
+
 int sc_hip_plan_prepare(const int *wh, int n, const sc_solver_opts *opts)
 {
     if (!wh || n < 1) return SC_ERR_BAD_ARG;

@@ -110,7 +110,8 @@ bool plan_size(const sc_solver_opts &o, int W, int H, SizePlan &p);     // fills
 // members (any order) -> groups that can each share one set of launches: a size class (two or more DIFFERENT sizes), a same-size
 // group, or a single; `cap` = most members per group.  groups[k] lists indices into `plans`.
 void plan_cache_clear();                                         // forgets every memoised plan and table (tests, measurements)
-void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups);      // (may rewrite a member's plan: sc_ragged.cpp)
+void pool_group_caps(int group, int n, int streams, int &cap, int &cap_max, long &budget_px);      // the pool's group policy (group 0: automatic)
+void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups, int cap_max = 0, long budget_px = 0);      // (may rewrite a member's plan: sc_ragged.cpp)
 
 struct RagState {
     const RagMember *dev = nullptr;     // the members' table on the device WHILE a size class is being processed, else nullptr

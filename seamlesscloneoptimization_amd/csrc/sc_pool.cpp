@@ -175,7 +175,7 @@ int sc_hip_pool_set_solver(void *p, const sc_solver_opts *opts)
 int sc_hip_pool_set_group(void *p, int group)
 {
     Pool *P = get_pool(p);
-    if (!P || group < 1 || group > 64) return SC_ERR_BAD_ARG;
+    if (!P || group < 0 || group > 64) return SC_ERR_BAD_ARG;      // 0: SC_POOL_GROUP_AUTO
     std::lock_guard<std::mutex> lk(P->mu);
     P->group = group;
     return SC_OK;
@@ -190,7 +190,7 @@ int sc_hip_pool_run(void *p, sc_batch_job *jobs, int n, int device_resident)
         std::lock_guard<std::mutex> lk(P->mu);
         P->jobs = jobs; P->njobs = n; P->device_resident = device_resident;
         P->chunks.clear();
-        if (device_resident && P->group > 1) {
+        if (device_resident && P->group != 1) {
             // Form the groups a worker takes at a time from the ROI size every job will most likely have -- the interior of its mask,
             // which is what a clone is launched on before the device's bounding box is back: same-size jobs and jobs of one size class
             // (sc_ragged.cpp: different sizes, the same solve) share one set of launches inside sc_hip_run_device_batch.  Round 4 took
@@ -208,7 +208,10 @@ int sc_hip_pool_run(void *p, sc_batch_job *jobs, int n, int device_resident)
             std::vector<SizePlan> plans(n);
             for (int i = 0; i < n; ++i) plan_size(o, jobs[order[i]].mask_cols - 2, jobs[order[i]].mask_rows - 2, plans[i]);
             std::vector<std::vector<int>> groups;
-            plan_groups(plans, P->group, groups);
+            int cap, cap_max;
+            long budget;
+            pool_group_caps(P->group, n, (int)P->workers.size(), cap, cap_max, budget);
+            plan_groups(plans, cap, groups, cap_max, budget);
             {
                 std::vector<SizePlan> by_job(n);
                 for (int i = 0; i < n; ++i) by_job[order[i]] = plans[i];

@@ -153,7 +153,23 @@ void plan_cache_clear()
 // members) whose hierarchy is one level shallower than that of a group with room move there, on the deeper hierarchy (plan_deeper:
 // their plans are rewritten in `plans`): sizes straddling 513 / 1027 / 2050 unknowns per side -- where the ladder gains a level --
 // would otherwise always split in two.
-void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups)
+// What the pool hands plan_groups for a batch of n jobs on `streams` workers (sc_pool.cpp; sc_hip_plan_groups_pool mirrors it):
+// an explicit group size is a hard cap; SC_POOL_GROUP_AUTO (0) means sixteen members at least where the batch has them, more -- up to
+// n / streams, so that every stream gets a group, and up to 64 -- while a group's fields stay within what sixteen 2048^2 members
+// occupy.  Measured (64 jobs, 2 streams; groups of 16 -> 32): [120, 190]^2 0.64 -> 0.43 ms per batch, [300, 340]^2 0.91 -> 0.80,
+// [500, 560]^2 1.73 -> 1.54, [1000, 1100]^2 4.45 -> 4.24; ONE group of 64 loses (the second stream idles).
+void pool_group_caps(int group, int n, int streams, int &cap, int &cap_max, long &budget_px)
+{
+    if (group > 0) { cap = cap_max = group; budget_px = 0; return; }
+    const int per_stream = (n + std::max(1, streams) - 1) / std::max(1, streams);
+    cap = std::max(1, std::min(16, per_stream));             // (a batch smaller than 16 x streams is split among the streams as well: 8 x 1024^2 on two: 2 x 4 beats 1 x 8)
+    cap_max = std::max(cap, std::min(64, per_stream));
+    budget_px = 16L * 2048 * 2048;
+}
+
+// cap_max > cap: a group may grow beyond `cap` members while its fields stay within `budget_px` pixels per channel triple (members x
+// the group's largest width x height), up to cap_max -- small ROIs are latency bound and sixteen of them do not fill a launch.
+void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<int>> &groups, int cap_max, long budget_px)
 {
     struct Open { int first; int minW, maxW, minH, maxH; bool uniform; };
     std::vector<Open> open;
@@ -167,17 +183,24 @@ void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<
         const bool wy = (double)w.maxH <= RAG_SPREAD * w.minH || w.maxH - w.minH <= RAG_SPREAD_PIXELS;
         return (wx && wy) || (long)w.maxW * w.maxH - (long)w.minW * w.minH <= RAG_SPREAD_AREA;
     };
+    auto cap_of = [&](const Open &w) {
+        if (cap_max <= cap || budget_px <= 0) return cap;
+        const long by_area = budget_px / std::max(1L, (long)w.maxW * w.maxH);
+        return (int)std::max<long>(cap, std::min<long>(cap_max, by_area));
+    };
     for (int i = 0; i < (int)plans.size(); ++i) {
         const SizePlan &p = plans[i];
         int into = -1;
         Open w{};
         for (int k = 0; k < (int)open.size() && into < 0; ++k) {
-            if ((int)groups[k].size() >= cap) continue;
             const Open &g = open[k];
             const SizePlan &q = plans[g.first];
-            if (g.uniform && q.W == p.W && q.H == p.H) { into = k; w = g; break; }
+            if (g.uniform && q.W == p.W && q.H == p.H) {
+                if ((int)groups[k].size() >= cap_of(g)) continue;
+                into = k; w = g; break;
+            }
             if (!p.same_class(q)) continue;
-            if (fits(g, p, w)) into = k;
+            if (fits(g, p, w) && (int)groups[k].size() < cap_of(w)) into = k;
         }
         if (into < 0) {
             open.push_back({ i, p.W, p.W, p.H, p.H, true });
@@ -199,10 +222,10 @@ void plan_groups(std::vector<SizePlan> &plans, int cap, std::vector<std::vector<
             bool moved = false;
             if (plan_deeper(plans[i], d))
                 for (int t = 0; t < (int)groups.size() && !moved; ++t) {
-                    if (t == k || groups[t].empty() || (int)groups[t].size() >= cap) continue;
+                    if (t == k || groups[t].empty()) continue;
                     const SizePlan &q = plans[open[t].first];
                     Open w{};
-                    if (!d.same_class(q) || q.tail != plans[i].tail + 1 || !fits(open[t], d, w)) continue;
+                    if (!d.same_class(q) || q.tail != plans[i].tail + 1 || !fits(open[t], d, w) || (int)groups[t].size() >= cap_of(w)) continue;
                     w.uniform = false;
                     open[t] = w;
                     groups[t].push_back(i);

@@ -531,3 +531,38 @@ def test_small_host_call_paths_give_the_ordinary_bytes(oracles, W, H):
     frame = d[2].copy(); frame[3:3 + dst.shape[0], 5:5 + dst.shape[1]] = 0
     assert not frame.any()                                    # nothing outside the view was touched
     assert np.array_equal(d[3], d[4]) and _dmax(d[3], want_odd) <= 1
+
+
+def test_pool_with_automatic_group_sizes(oracles):
+    """SC_POOL_GROUP_AUTO: 48 clones of 48 different small sizes on two streams go out as two groups of 24 (sc_hip_plan_groups_pool
+    says so in advance), every member within one grey level of the port and with the bytes the pool gives it in groups of 16 wherever
+    both runs took the same cycle count (same class, same hierarchy: the group's size does not enter the arithmetic)."""
+    from seamlesscloneoptimization_amd import capi
+    from collections import Counter
+    o, oc = oracles
+    rng = np.random.default_rng(77)
+    sizes = [(int(rng.integers(140, 200)), int(rng.integers(140, 200))) for _ in range(48)]
+    g, k = capi.plan_groups_pool(sizes, capi.SC_POOL_GROUP_AUTO, 2)
+    assert sorted(Counter(g).values()) == [24, 24] and set(k) == {2}
+    base = o.synth_inputs(200, 200, seed_dst=5, seed_patch=6, margin=30)
+    items = [(base[0], np.ascontiguousarray(base[1][:H + 2, :W + 2]), np.full((H + 2, W + 2), 255, np.uint8), base[3], base[4]) for W, H in sizes]
+    outs = {}
+    for group in (16, capi.SC_POOL_GROUP_AUTO):
+        pool = capi.Pool(0, streams=2, group=group)
+        try:
+            inst = pool.instances[0]
+            jobs, keep = _device_jobs(inst, items)
+            pool.run(jobs, device_resident=True)
+            outs[group] = [inst.from_device(b, shape) for (f, b0, b, m, shape) in keep]
+            if group == capi.SC_POOL_GROUP_AUTO:
+                assert max(i.info().group_members for i in pool.instances) == 24
+            _free_jobs(inst, keep)
+        finally:
+            pool.close()
+    same = 0
+    for k_, it in enumerate(items):
+        got = outs[capi.SC_POOL_GROUP_AUTO][k_]
+        want = oc.seamless_clone(it[0], it[1], it[2], it[3], it[4], nthreads=min(16, oc.max_threads()), exact_den=False)
+        assert _dmax(got, want) <= 1 and _dmax(got, outs[16][k_]) <= 1, k_
+        same += int(np.array_equal(got, outs[16][k_]))
+    assert same >= 40, same

@@ -444,6 +444,17 @@ def test_group_planner_properties():
     capi.plan_cache_clear()
     assert (g, k) == capi.plan_groups(sizes, 16)
     assert capi.plan_prepare([(1000, 1010), (90, 70), (2107, 2053), (8, 8), (40, 100)]) == 3      # (8 x 8: nothing to coarsen; 40 x 100: its level 1 is solved directly and it is under 48 across)
+    # the pool's own grouping (sc_hip_plan_groups_pool): an explicit group size is a hard cap; SC_POOL_GROUP_AUTO gives every stream a
+    # group and small ROIs larger groups -- up to n / streams and 64, within the fields of sixteen 2048^2 members
+    from collections import Counter
+    small = [(int(rng.integers(120, 191)), int(rng.integers(120, 191))) for _ in range(64)]
+    assert sorted(Counter(capi.plan_groups_pool(small, 16, 2)[0]).values()) == [16, 16, 16, 16]
+    assert sorted(Counter(capi.plan_groups_pool(small, capi.SC_POOL_GROUP_AUTO, 2)[0]).values()) == [32, 32]
+    assert sorted(Counter(capi.plan_groups_pool(small, capi.SC_POOL_GROUP_AUTO, 4)[0]).values()) == [16, 16, 16, 16]
+    assert sorted(Counter(capi.plan_groups_pool(small * 4, capi.SC_POOL_GROUP_AUTO, 2)[0]).values()) == [64, 64, 64, 64]
+    assert sorted(Counter(capi.plan_groups_pool([(2048, 2048)] * 64, capi.SC_POOL_GROUP_AUTO, 2)[0]).values()) == [16, 16, 16, 16]
+    assert sorted(Counter(capi.plan_groups_pool([(1448, 1448)] * 64, capi.SC_POOL_GROUP_AUTO, 2)[0]).values()) == [32, 32]
+    assert sorted(Counter(capi.plan_groups_pool([(1024, 1024)] * 8, capi.SC_POOL_GROUP_AUTO, 2)[0]).values()) == [4, 4]   # a small batch is split among the streams as well
     # options outside the default fast path: no classes, same-size groups stay
     lib = capi.load()
     o = capi.SolverOpts(); lib.sc_hip_default_opts(__import__("ctypes").byref(o))
