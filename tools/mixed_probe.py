@@ -80,7 +80,7 @@ def main():
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     sizes = [(int(rng.integers(a.lo, a.hi + 1)), int(rng.integers(a.lo, a.hi + 1))) for _ in range(a.n)]
-    g, k = capi.plan_groups(sizes, a.group)
+    g, k = capi.plan_groups_pool(sizes, a.group, a.streams)      # (--group 0: SC_POOL_GROUP_AUTO)
     from collections import Counter
     dst, patch = make_images(a.hi, a.seed)
     mean = int(round(np.sqrt(np.mean([w * h for w, h in sizes]))))
