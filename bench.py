@@ -382,7 +382,7 @@ def new_size_leg(capi, seed=4):
     return out
 
 
-def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=0, reps=6, seed=2025, sizes=None):
+def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=0, reps=15, seed=2025, sizes=None):
     """A batch whose members all have DIFFERENT ROI sizes -- what real clones produce: a mask box per face, per frame -- through the
     native pool with its default grouping (size classes share one set of launches: csrc/sc_ragged.cpp), beside (a) the same list one
     clone at a time on 8 streams (what rounds 1-4 did with such a batch) and (b) n same-size clones of the list's mean size (the
@@ -416,7 +416,8 @@ def mixed_sizes_leg(capi, lo=1000, hi=1100, n=64, streams=2, group=0, reps=6, se
                 j.body, j.body_cols, j.body_rows, j.body_step = b, Wd, Hd, 3 * Wd
                 j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, W + 2, H + 2, W + 2
                 j.centerX, j.centerY, j.body_restore = Wd // 2, Hd // 2, d0
-            pool.run(jobs, device_resident=True); pool.run(jobs, device_resident=True)
+            for _ in range(4):
+                pool.run(jobs, device_resident=True)
             ts = []
             for _ in range(reps):
                 if unseen:
@@ -474,7 +475,8 @@ def c5_projection_leg(capi, reps=8):
                 j.body, j.body_cols, j.body_rows, j.body_step = b, dst.shape[1], dst.shape[0], 3 * dst.shape[1]
                 j.mask, j.mask_cols, j.mask_rows, j.mask_step = m, mask.shape[1], mask.shape[0], mask.shape[1]
                 j.centerX, j.centerY, j.body_restore = cx, cy, b0
-            pool.run(jobs, device_resident=True); pool.run(jobs, device_resident=True)
+            for _ in range(4):
+                pool.run(jobs, device_resident=True)
             ts = []
             for _ in range(reps):
                 t0 = time.perf_counter()
@@ -981,10 +983,10 @@ def main():
     mixed_sizes = None
     if comm.rank == 0 and args.gpus == 1 and not args.no_mixed_sizes and args.config == "c3":
         mixed_sizes = mixed_sizes_leg(capi)
-        wide = mixed_sizes_leg(capi, lo=100, hi=2400, reps=4)      # the hardest list: sizes spread over a factor of 24, four hierarchy depths
+        wide = mixed_sizes_leg(capi, lo=100, hi=2400, reps=8)      # the hardest list: sizes spread over a factor of 24, four hierarchy depths
         mixed_sizes["wide_range_100_2400"] = {k_: wide[k_] for k_ in wide if k_ not in ("note", "streams", "group", "clones")}
         # the reference's own patch sizes (its published table and size sets: seamlessClone-CUDA README / PDF p3), sixteen clones of each in one batch
-        ref = mixed_sizes_leg(capi, reps=8, sizes=[(154, 100), (109, 164), (181, 153), (300, 194)] * 16)
+        ref = mixed_sizes_leg(capi, reps=20, sizes=[(154, 100), (109, 164), (181, 153), (300, 194)] * 16)
         ref["us_per_clone"] = round(ref["ms_per_step"] * 1e3 / 64, 2)
         mixed_sizes["reference_patch_sizes_x16"] = {k_: ref[k_] for k_ in ref if k_ not in ("note", "streams", "group", "clones", "roi_range")}
     c5_projected = None
