@@ -53,6 +53,7 @@ SC_FLAG_FLOAT_L1 = 1 << 10
 SC_FLAG_FLOAT_FIELD = 1 << 11
 SC_FLAG_NO_STAGE_MARKS = 1 << 12
 SC_FLAG_ROWS_RETURN = 1 << 13     # host-image call, opt-in: whole destination rows come back as one linear copy (default: ROI bytes only)
+SC_FLAG_POISON_ARENA = 1 << 14    # testing: blocks handed out without zeroing are filled with 0xFF (NaN) first
 
 def auto_takes_direct(w: int, h: int) -> bool:
     """SC_METHOD_AUTO's choice for ONE clone with w x h unknowns (sc_solver.cpp effective_method): True = the direct solve (SC_METHOD_FFT,

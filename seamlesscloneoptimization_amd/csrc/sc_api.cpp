@@ -61,6 +61,10 @@ int ensure(Instance *I, DevBuf &b, size_t bytes, bool zero)
         I->arena_bytes += ncap;
     }
     if (zero) SC_HIP(I, hipMemsetAsync(np, 0, ncap, I->stream));
+    else if (I->opts.flags & SC_FLAG_POISON_ARENA) {      // (testing: what recycled memory may hold; in place before ANY stream uses the block)
+        SC_HIP(I, hipMemsetAsync(np, 0xFF, ncap, I->stream));
+        SC_HIP(I, hipStreamSynchronize(I->stream));
+    }
     if (b.p && b.own) {                              // (a replaced slab piece simply stays unused)
         I->retired.push_back(b);
         I->retired_bytes += b.cap;

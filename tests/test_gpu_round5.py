@@ -248,7 +248,13 @@ def test_mixed_batch_is_partitioned_into_classes_groups_and_singles(oracles):
         inst.sync()
         for k, ((f, b0, b, m, shape), it) in enumerate(zip(keep, items)):
             got = inst.from_device(b, shape)
-            assert _dmax(got, alone[k]) <= 1, k
+            if _dmax(got, alone[k]) > 1:                     # say WHICH of the two is off, and where (seen once in a full-suite run, never alone)
+                want = oc.seamless_clone(it[0], it[1], it[2], it[3], it[4], nthreads=min(16, oc.max_threads()), exact_den=False)
+                d = np.abs(got.astype(np.int16) - alone[k].astype(np.int16)).max(axis=2)
+                ys, xs = np.nonzero(d > 1)
+                raise AssertionError("member %d %s: batch vs alone differ in %d pixels (box x %d..%d y %d..%d of %s); batch vs port max %d, alone vs port max %d, "
+                                     "batch == untouched destination there: %s" % (k, sizes[k], len(ys), xs.min(), xs.max(), ys.min(), ys.max(), got.shape,
+                                     _dmax(got, want), _dmax(alone[k], want), bool(np.array_equal(got[ys, xs], it[0][ys, xs]))))
             assert not np.array_equal(got, it[0]), k
         jobs[4].centerX = 2                                  # its ROI leaves the destination
         rc = inst.L.sc_hip_run_device_batch(inst.h, jobs, len(jobs))
