@@ -101,6 +101,7 @@ int ensure_pinned(Instance *I, DevBuf &b, size_t bytes)
     }
     SC_HIP(I, hipHostMalloc(&b.p, ncap, hipHostMallocDefault));
     b.cap = ncap;
+    if (I->opts.flags & SC_FLAG_POISON_ARENA) memset(b.p, 0x5A, ncap);      // (testing: what recycled host memory may hold -- the pad bytes of packed rows are never written; 0x5A: neither "inside the mask" nor "outside")
     return SC_OK;
 }
 

@@ -572,3 +572,88 @@ def test_pool_with_automatic_group_sizes(oracles):
         assert _dmax(got, want) <= 1 and _dmax(got, outs[16][k_]) <= 1, k_
         same += int(np.array_equal(got, outs[16][k_]))
     assert same >= 40, same
+
+
+@pytest.mark.parametrize("W,H,method", [(200, 120, "fft"), (900, 520, "mg"), (900, 520, "mg_keep_field")])
+def test_output_rows_at_every_alignment(oracles, W, H, method):
+    """The output launches write words where a row's bytes are word aligned and single bytes around them (store_run, late round 5:
+    three of four ROI positions leave 3 x column odd).  Every alignment: eight consecutive ROI columns in a destination whose row
+    step is NOT a multiple of four (1601 pixels: the alignment also changes from row to row) and in one whose step is -- through the
+    post-process launch (direct solve; multigrid keeping its field) and the planar splice (multigrid default): within one of the
+    port, the ring and everything outside the ROI untouched."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    flags = capi.SC_FLAG_KEEP_FIELD if method == "mg_keep_field" else 0
+    meth = capi.SC_METHOD_FFT if method == "fft" else capi.SC_METHOD_MULTIGRID
+    rng = np.random.default_rng(W + H)
+    inst = capi.Instance(0)
+    try:
+        inst.set_solver(method=meth, flags=flags)
+        for Wd in (1601, 1600):
+            Hd = H + 60
+            dst = np.clip(128.0 + rng.normal(0.0, 20.0, (Hd, Wd, 3)), 0, 255).astype(np.uint8)
+            patch = np.clip(100.0 + rng.normal(0.0, 25.0, (H + 2, W + 2, 3)), 0, 255).astype(np.uint8)
+            mask = np.full((H + 2, W + 2), 255, np.uint8)
+            f, m = inst.to_device(patch), inst.to_device(mask)
+            for shift in range(8):
+                cx, cy = Wd // 2 - 300 + shift, Hd // 2
+                want = oc.seamless_clone(dst, patch, mask, cx, cy, nthreads=min(16, oc.max_threads()), exact_den=False)
+                b = inst.to_device(dst)
+                inst.run_device(f, patch.shape, b, dst.shape, m, mask.shape, cx, cy)
+                got = inst.from_device(b, dst.shape)
+                inst.free(b)
+                assert _dmax(got, want) <= 1, (Wd, shift, int(np.count_nonzero(np.abs(got.astype(np.int16) - want.astype(np.int16)) > 1)))
+                changed = np.nonzero((got != dst).any(axis=2))
+                assert len(changed[0]) > 0.9 * W * H
+                x0 = cx - (W + 2) // 2
+                assert changed[1].min() >= x0 + 1 and changed[1].max() <= x0 + W, (Wd, shift, int(changed[1].min()), int(changed[1].max()), x0)
+            inst.free(f); inst.free(m)
+    finally:
+        inst.destroy()
+
+
+def test_poisoned_arena_gives_the_same_bytes(oracles):
+    """"Zero only what is read before it is written" (round 5's arena) put to the test: with SC_FLAG_POISON_ARENA every device block
+    the arena hands out unzeroed is filled with 0xFF bytes (NaN as float32 / float16) and fresh pinned staging with 0x5A -- what
+    RECYCLED memory may hold, where fresh memory reads as zero and hides a read of something nobody wrote.  The mixed batch (two size
+    classes, a same-size pair, a single), a class on float fields, solo clones through every back-end on host images (the small-input
+    and direct-output paths among them): the same bytes as without the flag."""
+    from seamlesscloneoptimization_amd import capi
+    o, oc = oracles
+    P = capi.SC_FLAG_POISON_ARENA
+
+    def batch(sizes, flags):
+        items = [o.synth_inputs(W, H, seed_dst=40 + k, seed_patch=90 + k, margin=36) for k, (W, H) in enumerate(sizes)]
+        inst = capi.Instance(0)
+        try:
+            inst.set_solver(flags=flags)
+            jobs, keep = _device_jobs(inst, items)
+            outs = []
+            for rep in range(2):
+                inst.run_device_batch(jobs)
+                outs += [inst.from_device(b, shape) for (f, b0, b, m, shape) in keep]
+            _free_jobs(inst, keep)
+            return outs
+        finally:
+            inst.destroy()
+
+    def solo(W, H, flags, method):
+        dst, patch, mask, cx, cy = o.synth_inputs(W, H, seed_dst=7, seed_patch=8, margin=36)
+        inst = capi.Instance(0)
+        try:
+            inst.set_solver(flags=flags, method=method)
+            outs = []
+            for rep in range(2):
+                body = dst.copy(); inst.run(patch, body, mask, cx, cy); outs.append(body)
+            return outs
+        finally:
+            inst.destroy()
+
+    cases = [lambda f: batch([(300, 310), (1003, 1010), (318, 333), (640, 480), (1020, 1001), (640, 480), (90, 70), (340, 305), (1012, 1024)], f),
+             lambda f: batch([(1003, 1010), (1020, 1001), (300, 310), (318, 333), (157, 160), (150, 171)], f),
+             lambda f: batch([(300, 310), (318, 333), (340, 305)], f | capi.SC_FLAG_FLOAT_FIELD | capi.SC_FLAG_FLOAT_RHS),
+             lambda f: solo(1500, 900, f, capi.SC_METHOD_MULTIGRID), lambda f: solo(700, 333, f, capi.SC_METHOD_MULTIGRID),
+             lambda f: solo(592, 592, f, capi.SC_METHOD_FFT), lambda f: solo(300, 194, f, capi.SC_METHOD_DST), lambda f: solo(154, 100, f, capi.SC_METHOD_AUTO)]
+    for ci, fn in enumerate(cases):
+        for k, (a, b) in enumerate(zip(fn(0), fn(P))):
+            assert np.array_equal(a, b), (ci, k, int((a != b).any(axis=2).sum()))
