@@ -132,17 +132,22 @@ __device__ __forceinline__ void mask_bbox_block(const uint8_t *__restrict__ mask
             __hip_atomic_store(&mine[1], maxx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&mine[2], miny, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&mine[3], maxy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // release: the parts above are visible to whoever observes this arrival (the language's ordering, not the hardware's
-            // habit of counting stores in vmcnt); the folding workgroup acquires below
-            const unsigned ticket = __hip_atomic_fetch_add(fold.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // The parts above are agent-scope stores (written through: they do not linger in this XCD's L2) and are DRAINED before the
+            // ticket; the last arriver reads them with agent-scope loads once its add has returned (MI355X_MICROARCH.md: one lane
+            // signals for its own stores, the workgroup whose add came last reads -- a valid form).  The language-level spelling -- a
+            // RELEASE on the add, an ACQUIRE fence in the folding wave (rounds 5's advisory) -- compiles to buffer_wbl2 in every one of
+            // the ~400 scan workgroups and buffer_inv in the folder: a write-back of the XCD's L2 while the same launch's tiles are
+            // writing the fields through it, +7.8 us on the pre-process launch of a 2048^2 clone (29.1 -> 36.9 us, measured with both
+            // trees on one box) for an ordering these eight words already have.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(fold.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             red[0][0] = (ticket == (unsigned)fold.nblocks - 1u) ? 1 : 0;       // (the waves' extrema in red[][] have been consumed above)
         }
     }
     if (part) return;
     __syncthreads();
     if (red[0][0] == 0 || wave != 0) return;
-    // the last workgroup to arrive: every part is in memory
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the last workgroup to arrive: every part is in memory (agent-scope loads below read past this XCD's L2)
     minx = INT_MAX; maxx = -1; miny = INT_MAX; maxy = -1;
     for (int i = lane; i < fold.nblocks; i += 64) {
         const int *p = fold.parts + 4 * i;
@@ -743,34 +748,6 @@ void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_
     hipLaunchKernelGGL(k_half_to_float, dim3(blocks), dim3(256), 0, s, (const __half *)src_half, dst, n);
 }
 
-// N output bytes of one lane (all of them interior pixels) to b: words where they are aligned.  b's alignment is the same for every
-// lane of a row (a lane's run is a multiple of four bytes long), and THREE of four ROI positions leave it odd: 3 x column mod 4.  Such
-// rows were written byte by byte (24 stores per lane; the group splice of sixteen 1050^2 clones at random positions took 87 us
-// against 46 for aligned ones); now the bytes up to the first boundary, words, and the bytes behind the last one.
-template <int N, int R>
-__device__ __forceinline__ void store_run_at(uint8_t *__restrict__ b, const unsigned char (&px)[N])
-{
-    constexpr int head = (4 - R) & 3, nd = (N - head) / 4;
-#pragma unroll
-    for (int k = 0; k < head; ++k) b[k] = px[k];
-    unsigned *d32 = reinterpret_cast<unsigned *>(b + head);
-#pragma unroll
-    for (int k = 0; k < nd; ++k)
-        d32[k] = px[head + 4 * k] | (px[head + 4 * k + 1] << 8) | (px[head + 4 * k + 2] << 16) | ((unsigned)px[head + 4 * k + 3] << 24);
-#pragma unroll
-    for (int k = head + 4 * nd; k < N; ++k) b[k] = px[k];
-}
-template <int N>
-__device__ __forceinline__ void store_run(uint8_t *__restrict__ b, const unsigned char (&px)[N])
-{
-    switch ((unsigned)(uintptr_t)b & 3u) {
-    case 0: store_run_at<N, 0>(b, px); break;
-    case 1: store_run_at<N, 1>(b, px); break;
-    case 2: store_run_at<N, 2>(b, px); break;
-    default: store_run_at<N, 3>(b, px); break;
-    }
-}
-
 // fused post-process: clamp to [0,255], truncate toward zero, interleave, splice into the
 // destination at (lty+y, ltx+x) for the interior only (seamlessClone_imp.cpp:2091-2096 and
 // the host splice loop :470-483).
@@ -781,7 +758,7 @@ template <bool LM>
 __device__ __forceinline__ void postprocess_block(const Field &U, uint8_t *__restrict__ body, int bstep, int c0, const LmNodes &lm)
 {
     // four pixels per lane: one 16-byte load per channel, twelve output bytes; a lane whose twelve bytes are all interior
-    // pixels writes words where they are aligned (store_run), the lanes at the ring bytes
+    // pixels and start on a 4-byte boundary (the same for every lane of a row) writes three words, the others bytes
     const int x = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x > U.W - 2 || y < 1 || y > U.H - 2) return;
@@ -803,8 +780,12 @@ __device__ __forceinline__ void postprocess_block(const Field &U, uint8_t *__res
 #pragma unroll
         for (int k = 0; k < 4; ++k) px[3 * k + c] = (unsigned char)lm_byte(e[k]);
     }
-    if (x >= 1 && x + 3 <= U.W - 2) {
-        store_run<12>(b, px);
+    if (x >= 1 && x + 3 <= U.W - 2 && ((uintptr_t)b & 3) == 0) {
+        unsigned w[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
+        unsigned *d32 = reinterpret_cast<unsigned *>(b);
+        d32[0] = w[0]; d32[1] = w[1]; d32[2] = w[2];
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -853,8 +834,13 @@ __device__ __forceinline__ void splice_block(const Field &Q, uint8_t *__restrict
 #pragma unroll
         for (int k = 0; k < 8; ++k) px[3 * k + c] = (unsigned char)(((k < 4 ? v[c].x : v[c].y) >> (8 * (k & 3))) & 255u);
     uint8_t *b = body + (size_t)y * bstep + 3 * x;
-    if (x >= 1 && x + 7 <= Q.W - 2) {
-        store_run<24>(b, px);
+    // (words where the row is word aligned, bytes otherwise: a variant that wrote the aligned middle of a misaligned run as words --
+    //  one to three bytes, five words, the remaining bytes -- measured SLOWER at every alignment, 0.416 -> 0.428 ms for a 2048^2 clone:
+    //  the memory system merges a wave's byte stores, the longer instruction stream costs more than they do)
+    if (x >= 1 && x + 7 <= Q.W - 2 && ((uintptr_t)b & 3) == 0) {
+        unsigned *d32 = reinterpret_cast<unsigned *>(b);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d32[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
