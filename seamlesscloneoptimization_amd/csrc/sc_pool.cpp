@@ -196,6 +196,24 @@ int sc_hip_pool_run(void *p, sc_batch_job *jobs, int n, int device_resident)
             // (sc_ragged.cpp: different sizes, the same solve) share one set of launches inside sc_hip_run_device_batch.  Round 4 took
             // CONSECUTIVE jobs and ran a group with one odd size one clone at a time.  Largest groups first: the stragglers at the end
             // of a batch are the cheap ones.
+            int cap, cap_max;
+            long budget;
+            pool_group_caps(P->group, n, (int)P->workers.size(), cap, cap_max, budget);
+            bool one_size = true;
+            for (int i = 1; i < n && one_size; ++i) one_size = jobs[i].mask_cols == jobs[0].mask_cols && jobs[i].mask_rows == jobs[0].mask_rows;
+            if (one_size) {
+                // every job has the same mask size (a benchmark's batch, a tiled image): consecutive chunks, nothing to plan
+                const long area = (long)std::max(1, jobs[0].mask_cols) * std::max(1, jobs[0].mask_rows);
+                int per = cap;
+                if (cap_max > cap && budget > 0) per = (int)std::max<long>(cap, std::min<long>(cap_max, budget / area));
+                P->origin.clear();
+                P->sorted.clear();
+                for (int i0 = 0; i0 < n; i0 += per) {
+                    const int cnt = std::min(per, n - i0);
+                    P->chunks.emplace_back(i0, cnt);
+                    for (int i = i0; i < i0 + cnt; ++i) { P->origin.push_back(i); P->sorted.push_back(jobs[i]); }
+                }
+            } else {
             sc_solver_opts o;
             sc_hip_get_solver(P->inst[0], &o);
             // (the planner is first-come; the pool is free to reorder, so it hands the jobs over largest first: the members of a group
@@ -208,9 +226,6 @@ int sc_hip_pool_run(void *p, sc_batch_job *jobs, int n, int device_resident)
             std::vector<SizePlan> plans(n);
             for (int i = 0; i < n; ++i) plan_size(o, jobs[order[i]].mask_cols - 2, jobs[order[i]].mask_rows - 2, plans[i]);
             std::vector<std::vector<int>> groups;
-            int cap, cap_max;
-            long budget;
-            pool_group_caps(P->group, n, (int)P->workers.size(), cap, cap_max, budget);
             plan_groups(plans, cap, groups, cap_max, budget);
             {
                 std::vector<SizePlan> by_job(n);
@@ -227,6 +242,7 @@ int sc_hip_pool_run(void *p, sc_batch_job *jobs, int n, int device_resident)
             for (const auto &g : groups) {
                 P->chunks.emplace_back((int)P->sorted.size(), (int)g.size());
                 for (int i : g) { P->origin.push_back(i); P->sorted.push_back(jobs[i]); }
+            }
             }
         }
         P->next.store(0);
