@@ -365,9 +365,15 @@ static int check_roi(Instance *I, const Geo &g, int bc, int br)
 // out_org / ostep: where the output bytes go (ROI origin, row step): the destination itself for device-resident images; the
 // host path hands a compact buffer of its own so that what comes back across PCIe is the ROI and nothing else
 static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, const uint8_t *face_org, int fstep,
-                        uint8_t *body_org, int bstep, const Geo &g, int passes, uint8_t *out_org = nullptr, int ostep = 0)
+                        uint8_t *body_org, int bstep, const Geo &g, int passes, uint8_t *out_org = nullptr, int ostep = 0,
+                        bool fence_at_end = true)
 {
+    // fence_at_end: the event behind which the scan's rectangle may be read (scan_fence) is the clone's LAST mark, not one of its
+    // own behind the pre-process launch -- every event in the stream is a ~5 us bubble, and a caller that waits for the whole clone
+    // anyway (a device-resident synchronous call, a host call whose output needs no copy command) loses nothing by it.  false: the
+    // host call that still has device-to-host copies to enqueue behind the clone checks the rectangle while the clone's tail runs.
     if (!out_org) { out_org = body_org; ostep = bstep; }
+    bool fence_pending = false;
     int rc;
     I->mpitch = round_up(g.W, 64);
     if ((rc = ensure(I, I->d_M, (size_t)I->mpitch * g.H, false))) return rc;
@@ -395,8 +401,9 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
         if (pass == passes - 1 && (rc = tmark(I, 5))) return rc;
         if (had_scan) {
             // the host compares the scan's rectangle (pinned mailbox) with its guess once THIS point of the stream has passed: mark 5
-            // when it was really recorded just now, else an event of its own (first and last marks only, or no marks at all)
+            // when it was really recorded just now, else the clone's last mark (fence_at_end), else an event of its own
             if (pass == passes - 1 && I->stage_marks && I->tm[5] == I->ev[5]) I->scan_fence = I->ev[5];
+            else if (fence_at_end && I->stage_marks) fence_pending = true;
             else { SC_HIP(I, hipEventRecord(I->ev_scan, I->stream)); I->scan_fence = I->ev_scan; }
         }
         I->info.sweep_launches = 0;
@@ -420,6 +427,10 @@ static int device_clone(Instance *I, const uint8_t *d_mask, int ms, int mr, cons
     }
     if ((rc = tmark(I, 7))) return rc;
     if (!I->tm[6]) I->tm[6] = I->tm[7];
+    if (fence_pending) {
+        if (I->tm[7]) I->scan_fence = I->tm[7];
+        else { SC_HIP(I, hipEventRecord(I->ev_scan, I->stream)); I->scan_fence = I->ev_scan; }
+    }
     return solve_rc;
 }
 
@@ -831,9 +842,12 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         if (direct_out && (r = ensure_pinned(I, I->h_out, (size_t)dfs * g.H + 64))) return r;
         uint8_t *const out_dev = (passes > 1 || inplace) ? d_body_roi : direct_out ? (uint8_t *)I->h_out.p : (uint8_t *)I->d_out.p;
         const int out_pitch = (passes > 1 || inplace) ? bpitch : dfs;
-        r = device_clone(I, dmask, dms, mr, d_face_roi, fpitch, d_body_roi, bpitch, g, passes, out_dev, out_pitch);
+        r = device_clone(I, dmask, dms, mr, d_face_roi, fpitch, d_body_roi, bpitch, g, passes, out_dev, out_pitch, direct_out);
         if (r != SC_OK && r != SC_ERR_NOT_CONVERGED) return r;
-        if (guess) {      // the scan rode in the pre-process launch and finished long ago: this wait on the event behind that launch is free
+        // direct_out: nothing is enqueued behind the clone -- ONE wait for the stream, then the rectangle is compared, then the rows are
+        // spliced (a wrong guess: the guarded output launch wrote nothing, the staging holds nothing the caller will see)
+        const bool check_after_sync = guess && direct_out;
+        if (guess && !check_after_sync) {      // the scan rode in the pre-process launch and finished long ago: this wait on the event behind that launch is free
             if (I->scan_fence) SC_HIP(I, hipEventSynchronize(I->scan_fence));
             else SC_HIP(I, hipStreamSynchronize(I->stream));      // (cannot happen: a clone launched on a guess always carries its scan)
             I->scan_fence = nullptr;
@@ -852,6 +866,10 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
         } else if (orows > 0 && g.W > 2 && direct_out) {
             SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
             SC_HIP(I, hipStreamSynchronize(I->stream));              // the kernel's stores are in host memory when it has ended
+            if (check_after_sync) {
+                I->scan_fence = nullptr;
+                if (memcmp(guess, I->h_rect + 4, 4 * sizeof(int)) != 0) return SC_GUESS_WRONG;
+            }
             copy_rows(I, body + (size_t)(g.lty + 1) * bs + 3 * (g.ltx + 1), (size_t)bs, (const uint8_t *)I->h_out.p + dfs + 3, (size_t)dfs, ob, orows);
         } else if (orows > 0 && g.W > 2) {
             const int dfs = out_pitch;            // (shadows the compact pitch: the warm-up variant returns at the body buffer's)
@@ -892,6 +910,10 @@ int my_seamlessclone_api_imp_run(void *p, const uint8_t *face, int fc, int fr, i
             SC_HIP(I, hipEventRecord(I->ev_k1, I->stream));
         }
         SC_HIP(I, hipStreamSynchronize(I->stream));
+        if (check_after_sync && I->scan_fence) {      // (an ROI without interior rows: nothing was spliced above)
+            I->scan_fence = nullptr;
+            if (memcmp(guess, I->h_rect + 4, 4 * sizeof(int)) != 0) return SC_GUESS_WRONG;
+        }
         return r;
     };
     Geo g{};
