@@ -150,6 +150,13 @@ __global__ __launch_bounds__(256) void k_lm_bands_to_cells(const float4 *__restr
 
 // Upart[part][k][l] = sum_{X in tile} T[k][X] SxN[X][l] (part = column tile x row split; the expansion kernel adds the parts
 // in a fixed order).  Workgroup = 64 node columns (lane = X), the four waves split the node rows and meet in LDS.
+// (RAG a template parameter since late round 5: with the class's overrides in the one kernel the same-size launches ran 45 -> 63 us --
+//  k_lm_cexpand 38 -> 64 -- although their `rag` was null: +0.5 % on the 2048^2 step, found by building round 4's tree beside this one)
+// The sine tables are read-only for the whole launch and a wave reads one row at a time: through a constant-address-space pointer the
+// loads are scalar (SGPRs) whatever the pointer's origin -- a kernel argument marked __restrict__ gets that by itself, a pointer loaded
+// from a class's member table does not (the compiler must assume the kernel's own stores may alias it: vector loads, 189 VGPRs).
+typedef const float __attribute__((address_space(4))) *lm_const_row;
+template <bool RAG>
 __global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ Cell, int cells_x, int cells_y, int nx, int ny, int C,
                                                       const float *__restrict__ SyN, int Kyp, const float *__restrict__ SxN, int Kxp,
                                                       float *__restrict__ Upart, const RagMember *__restrict__ rag)
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ 
     const int xt = blockIdx.x, rs = blockIdx.y / nkb, c = blockIdx.z;
     int nxt = gridDim.x, nrs = gridDim.y / nkb;
     const float4 *__restrict__ cell = Cell + (size_t)c * cells_y * cells_x;      // (strides: before a member's own cell-row count replaces cells_y)
-    if (rag) {
+    if constexpr (RAG) {
         const RagMember &m = rag[c / 3];
         nxt = m.lm_nxt; nrs = m.lm_nrs;
         if (xt >= nxt || rs >= nrs) return;                     // block-uniform, before any barrier
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256) void k_lm_cproject(const float4 *__restrict__ 
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int Y = min(Yq + q, ny - 1);               // rows past Yb carry v = 0
-                const float *__restrict__ s = SyN + (size_t)Y * Kyp + kb;
+                const lm_const_row s = (lm_const_row)(SyN + (size_t)Y * Kyp + kb);
 #pragma unroll
                 for (int k = 0; k < LM_KB; ++k) acc[k] = __builtin_fmaf(s[k], v[q], acc[k]);
             }
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(256) void k_lm_parts_sum(float *__restrict__ Upart,
 // Coarse expansion: Chat[k][l] = R[k][l] * (sum of the projection's parts, in order);  E[k][X] = sum_l Chat[k][l] SxN[X][l];
 // CN[c][Y][X] = sum_k SyN[Y][k] E[k][X] -- the correction at the nodes.  Workgroup = 64 node columns x (4 waves x LM_NPW node rows); E of the 64 columns is formed once per workgroup
 // (wave v takes 8 of every 32 modes, through LDS); then lane = X with the E column in registers, SyN rows as scalar loads.
+template <bool RAG>
 __global__ __launch_bounds__(256) void k_lm_cexpand(const float *__restrict__ Upart, int nparts, int C, const float *__restrict__ R,
                                                     const float *__restrict__ SxN, int Kxp,
                                                     const float *__restrict__ SyN, int Kyp, int nx, int ny, int npitch,
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256) void k_lm_cexpand(const float *__restrict__ Up
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x;
     const int c = blockIdx.z;
     float *__restrict__ const cn_plane = CN + (size_t)c * ny * npitch;      // (strides: the launch's ny, before a member's own replaces it)
-    if (rag) {
+    if constexpr (RAG) {
         const RagMember &m = rag[c / 3];
         if ((int)blockIdx.x >= m.lm_nxt || (int)blockIdx.y * 4 * LM_NPW >= m.lm_ny) return;      // block-uniform, before any barrier
         nparts = m.lm_nparts; R = m.lm_R; SxN = m.lm_Sx; SyN = m.lm_Sy; nx = m.lm_nx; ny = m.lm_ny;
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256) void k_lm_cexpand(const float *__restrict__ Up
 #pragma unroll
         for (int q = 0; q < LM_NPW; ++q) {
             const int Y = min(Y0 + q, ny - 1);
-            const float *__restrict__ s = SyN + (size_t)Y * Kyp + kb;
+            const lm_const_row s = (lm_const_row)(SyN + (size_t)Y * Kyp + kb);
             float a = cn[q];
 #pragma unroll
             for (int k = 0; k < LM_KB; ++k) a = __builtin_fmaf(s[k], e[k], a);
@@ -641,9 +649,9 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on)
         hipLaunchKernelGGL(k_lm_bands_to_cells, dim3((cells_x + 255) / 256, cells_y, U.C), dim3(256), 0, st, (const float4 *)L.B.p,
                            L.band_rows, (const int *)nullptr, (float4 *)L.P.p, cells_x, cells_y, U.W, R.dev, L.rag_tiling);
         L.bands_of = nullptr;
-        hipLaunchKernelGGL(k_lm_cproject, dim3(R.max_nxt, R.max_nrs * nkb, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
+        hipLaunchKernelGGL(k_lm_cproject<true>, dim3(R.max_nxt, R.max_nrs * nkb, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
                            (const float *)nullptr, R.Kyp, (const float *)nullptr, R.Kxp, upart, R.dev);
-        hipLaunchKernelGGL(k_lm_cexpand, dim3(R.max_nxt, (R.max_ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, st, (const float *)upart,
+        hipLaunchKernelGGL(k_lm_cexpand<true>, dim3(R.max_nxt, (R.max_ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, st, (const float *)upart,
                            1, U.C, (const float *)nullptr, (const float *)nullptr, R.Kxp, (const float *)nullptr, R.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p, R.dev);
         SC_HIP(I, hipGetLastError());
         lm.CN = (const float *)L.CN.p;
@@ -661,7 +669,7 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on)
     // 1000, has 16 column tiles and needs none), at most LM_RS (what the parts buffer holds)
     const int nkb = (L.Kyp + LM_KB - 1) / LM_KB;
     const int nrs = lowmode_projection_splits(nxt, nkb);
-    hipLaunchKernelGGL(k_lm_cproject, dim3(nxt, nrs * nkb, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
+    hipLaunchKernelGGL(k_lm_cproject<false>, dim3(nxt, nrs * nkb, U.C), dim3(256), 0, st, (const float4 *)L.P.p, cells_x, cells_y, L.nx, L.ny, U.C,
                        (const float *)L.Sy.p, L.Kyp, (const float *)L.Sx.p, L.Kxp, upart, (const RagMember *)nullptr);
     int nparts = nxt * nrs;
     if (nparts >= 32) {       // many parts (wide ROIs): one launch adds them, in the same order, instead of every expansion workgroup
@@ -669,7 +677,7 @@ int lowmode_nodes(Instance *I, const Field &U, LmNodes &lm, hipStream_t on)
         hipLaunchKernelGGL(k_lm_parts_sum, dim3((unsigned)((per_part + 255) / 256)), dim3(256), 0, st, upart, nparts, per_part, per_part);
         nparts = 1;
     }
-    hipLaunchKernelGGL(k_lm_cexpand, dim3(nxt, (L.ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, st, (const float *)upart,
+    hipLaunchKernelGGL(k_lm_cexpand<false>, dim3(nxt, (L.ny + 4 * LM_NPW - 1) / (4 * LM_NPW), U.C), dim3(256), 0, st, (const float *)upart,
                        nparts, U.C, (const float *)L.R.p, (const float *)L.Sx.p, L.Kxp, (const float *)L.Sy.p, L.Kyp, L.nx, L.ny, L.npitch, (float *)L.CN.p, (const RagMember *)nullptr);
     SC_HIP(I, hipGetLastError());
     lm.CN = (const float *)L.CN.p;
