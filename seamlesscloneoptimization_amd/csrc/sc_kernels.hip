@@ -748,6 +748,23 @@ void launch_half_to_float(const void *src_half, float *dst, size_t n, hipStream_
     hipLaunchKernelGGL(k_half_to_float, dim3(blocks), dim3(256), 0, s, (const __half *)src_half, dst, n);
 }
 
+// N output bytes of one lane (all interior pixels) to a row whose bytes are NOT word aligned (R = address mod 4, 1..3: three of
+// four ROI positions): the bytes up to the first boundary, words, the bytes behind the last one.  Only the group splice takes this
+// (sixteen 1050^2 clones: 46-61 us bytewise against 27 aligned); a single clone's splice is latency bound and keeps the byte path.
+template <int N, int R>
+__device__ __forceinline__ void store_run_at(uint8_t *__restrict__ b, const unsigned char (&px)[N])
+{
+    constexpr int head = 4 - R, nd = (N - head) / 4;
+#pragma unroll
+    for (int k = 0; k < head; ++k) b[k] = px[k];
+    unsigned *d32 = reinterpret_cast<unsigned *>(b + head);
+#pragma unroll
+    for (int k = 0; k < nd; ++k)
+        d32[k] = px[head + 4 * k] | (px[head + 4 * k + 1] << 8) | (px[head + 4 * k + 2] << 16) | ((unsigned)px[head + 4 * k + 3] << 24);
+#pragma unroll
+    for (int k = head + 4 * nd; k < N; ++k) b[k] = px[k];
+}
+
 // fused post-process: clamp to [0,255], truncate toward zero, interleave, splice into the
 // destination at (lty+y, ltx+x) for the interior only (seamlessClone_imp.cpp:2091-2096 and
 // the host splice loop :470-483).
@@ -819,6 +836,7 @@ __global__ __launch_bounds__(256) void k_postprocess_group(Field U, ImageJobs t,
 // The same splice for output values that already exist as bytes: the last multigrid launch of a clone wrote them planar into
 // the memory of its partner field (k_cycle0, TAG bit 5: plane c at Q.p + c Q.plane bytes, rows of Q.pitch bytes).  Eight
 // pixels per lane: two words per channel in, six words (or 24 bytes) out.
+template <bool WORDS_IN_ODD_ROWS = false>
 __device__ __forceinline__ void splice_block(const Field &Q, uint8_t *__restrict__ body, int bstep, int c0)
 {
     const int x = 8 * (blockIdx.x * 64 + (threadIdx.x & 63));
@@ -841,6 +859,12 @@ __device__ __forceinline__ void splice_block(const Field &Q, uint8_t *__restrict
         unsigned *d32 = reinterpret_cast<unsigned *>(b);
 #pragma unroll
         for (int k = 0; k < 6; ++k) d32[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
+    } else if (WORDS_IN_ODD_ROWS && x >= 1 && x + 7 <= Q.W - 2) {
+        switch ((unsigned)(uintptr_t)b & 3u) {
+        case 1: store_run_at<24, 1>(b, px); break;
+        case 2: store_run_at<24, 2>(b, px); break;
+        default: store_run_at<24, 3>(b, px); break;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -866,7 +890,7 @@ __global__ __launch_bounds__(256) void k_splice_planar_group(Field Q, ImageJobs 
     const ImageJob &j = t.j[blockIdx.z];
     if (j.d_rect && (j.d_rect[0] != j.rx0 || j.d_rect[1] != j.rx1 || j.d_rect[2] != j.ry0 || j.d_rect[3] != j.ry1)) return;
     if (j.W > 0) { Q.W = j.W; Q.H = j.H; }          // a member of a size class
-    splice_block(Q, j.body_org, j.bstep, 3 * blockIdx.z);
+    splice_block<true>(Q, j.body_org, j.bstep, 3 * blockIdx.z);
 }
 
 void launch_splice_planar(Field Q, uint8_t *body_org, int bstep, hipStream_t s, RectGuard guard, AbortFlag ab)
