@@ -254,7 +254,7 @@ bool launch_mg_bottom_mm(const MGBottomMM &a, int NPX, int NPY, int C, hipStream
 // the level above the bottom (F: its right-hand side, U: receives its finished correction) and the bottom in one launch
 // (sc_mg_kernels.hip, k_mg_tail); false: not a shape this path serves (the caller launches the three kernels it replaces)
 struct MGTail { const unsigned char *mm; Field F, U; MGGeom g; int pre, post; unsigned long long *stamps;
-                const RagMember *rag; int lev; };      // rag != nullptr: a size class -- g, mm and F's row count are member (channel / 3)'s own, at its level `lev`   // stamps: measurement only (11 shader-clock values of channel 0), else nullptr
+                const RagMember *rag; int lev; bool rag_uniform; };      // (rag_uniform: every member of the class has the class's operand padding)      // rag != nullptr: a size class -- g, mm and F's row count are member (channel / 3)'s own, at its level `lev`   // stamps: measurement only (11 shader-clock values of channel 0), else nullptr
 bool launch_mg_tail(const MGTail &a, int NPX, int NPY, int C, hipStream_t s);
 struct ZeroJobs { enum { MAX = 48 }; void *p[MAX]; size_t n16[MAX]; int count; };     // n16: 16-byte units
 void launch_zero_multi(const ZeroJobs &z, hipStream_t s);

@@ -121,6 +121,7 @@ struct RagState {
     int max_nx = 0, max_ny = 0, max_nxt = 0, max_nrs = 0, max_cells_y = 0;
     double max_ratio = 0.0;
     DevBuf d_aux, h_stage;              // RagMember[n], R tables, part maps | Sx, Sy, bottom operands; pinned staging of what the host writes (the head of d_aux)
+    bool pad_uniform = false;           // every member's operand padding of the directly solved level is the class's (k_mg_tail<SKX, SKY, true> instead of k_mg_tail_any)
     bool levels_built = false;          // the class's hierarchy is in I->mg (mg_build_levels_rag, called from rag_begin_builds)
     hipEvent_t ev = nullptr;            // behind the upload out of h_stage
     hipEvent_t ev_ready = nullptr;      // second stream: the level planes are zeroed and the correction's tables built (the matrices follow: Instance::ev_fd)

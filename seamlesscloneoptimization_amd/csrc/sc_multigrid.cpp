@@ -324,7 +324,7 @@ static int run_tail(Instance *I, size_t l, int pre, int post, bool &done, unsign
     t.stamps = stamps;
     t.mm = (const unsigned char *)((const float *)I->mg_fd.p + I->fd_mm_off);
     t.F = I->mg[l].F; t.U = I->mg[l].U; t.g = I->mg[l].g; t.pre = pre; t.post = post;
-    t.rag = I->rag.dev; t.lev = (int)l;
+    t.rag = I->rag.dev; t.lev = (int)l; t.rag_uniform = I->rag.pad_uniform;
     if (I->fd_pending) {
         SC_HIP(I, hipStreamWaitEvent(I->stream, I->ev_fd, 0));
         I->fd_pending = false;

@@ -274,6 +274,8 @@ int rag_begin_table(Instance *I, const std::vector<SizePlan> &members)
         // (k_lm_table_rag, the ratio table below), and a zero mode adds exact zeros to every sum -- same bytes as at its own padding
         R.Kxp = std::max(R.Kxp, p.Kxp); R.Kyp = std::max(R.Kyp, p.Kyp);
     }
+    R.pad_uniform = true;
+    for (const SizePlan &p : members) R.pad_uniform = R.pad_uniform && p.npx == R.npx && p.npy == R.npy;
     // --- layout of d_aux (256-byte aligned pieces; the per-member pieces one member after the other)
     const size_t bR = align_up(sizeof(float) * (size_t)R.Kyp * R.Kxp, 256), bMap = align_up(sizeof(int) * 4 * (size_t)R.max_cells_y, 256);
     const size_t bSx = align_up(sizeof(float) * (size_t)R.max_nx * R.Kxp, 256), bSy = align_up(sizeof(float) * (size_t)R.max_ny * R.Kyp, 256);
