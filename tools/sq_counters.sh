@@ -7,8 +7,8 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; T=${1:-r3}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && rm -rf $O/${T}_sq
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES \
-    --output-format csv -d $O/${T}_sq -- python3 $R/bench.py --cpu-seconds 0 --no-c4 --warmup 0 --steps 1 --kernel-launches 6 > /dev/null 2> $O/${T}_sq.err || { echo "sq pass failed"; tail -5 $O/${T}_sq.err; exit 1; }
+timeout -k 10 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES \
+    --output-format csv -d $O/${T}_sq -- python3 $R/bench.py --cpu-seconds 0 --no-c4 --no-new-size --no-c5-projection --no-mixed-sizes --warmup 0 --steps 1 --kernel-launches 6 > /dev/null 2> $O/${T}_sq.err || { echo "sq pass failed"; tail -5 $O/${T}_sq.err; exit 1; }
 cd $R && python3 - "$O/${T}_sq" "$O/${T}_sq_counters.json" <<'PY'
 import collections, csv, glob, json, sys
 per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
