@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _poison_everything_if_asked()
 
 
 def _decode_bgr(name):
@@ -85,3 +86,33 @@ def offbyone_band(name, value, rel=0.25, abs_tol=0.0):
         return
     tol = max(rel * g, abs_tol)
     assert g - tol <= value <= g + tol, f"{name}: {value:.6g} left the frozen band {g:.6g} +- {tol:.3g}"
+
+
+def _poison_everything_if_asked():
+    """SC_TEST_POISON=1 (GPU box, by hand): every instance the tests create -- pools' too -- runs with SC_FLAG_POISON_ARENA, whatever
+    flags a test sets: device blocks handed out unzeroed hold NaN bytes, fresh pinned staging 0x5A.  A read of memory nobody wrote
+    then shows as a failing parity test instead of hiding behind fresh (zero) pages."""
+    import os
+    if os.environ.get("SC_TEST_POISON") != "1":
+        return
+    from seamlesscloneoptimization_amd import capi
+    P = capi.SC_FLAG_POISON_ARENA
+    init0, set0, pinit0, pset0 = capi.Instance.__init__, capi.Instance.set_solver, capi.Pool.__init__, capi.Pool.set_solver
+
+    def init(self, *a, **k):
+        init0(self, *a, **k)
+        set0(self, flags=self.get_solver().flags | P)
+
+    def set_solver(self, **kw):
+        kw["flags"] = kw.get("flags", self.get_solver().flags) | P
+        return set0(self, **kw)
+
+    def pinit(self, *a, **k):
+        pinit0(self, *a, **k)
+        pset0(self, flags=self.instances[0].get_solver().flags | P)
+
+    def pset(self, **kw):
+        kw["flags"] = kw.get("flags", self.instances[0].get_solver().flags) | P
+        return pset0(self, **kw)
+
+    capi.Instance.__init__, capi.Instance.set_solver, capi.Pool.__init__, capi.Pool.set_solver = init, set_solver, pinit, pset
