@@ -211,8 +211,8 @@ typedef struct sc_solver_opts {
                                             comes back as the compact ROI through pinned staging and is spliced into the caller's rows -- only
                                             ROI bytes of the caller's image are ever written, as in the reference (seamlessClone_imp.cpp:470-483) */
 
-#define SC_FLAG_POISON_ARENA   (1 << 14) /* testing: every device block the arena hands out WITHOUT zeroing it (fields, level planes, image
-                                            staging: "written before they are read") is filled with 0xFF bytes first -- NaN as float32 and
+#define SC_FLAG_POISON_ARENA   (1 << 14) /* testing: every device block the arena hands out -- or hands out AGAIN -- WITHOUT zeroing it (fields,
+                                            level planes, image staging: "written before they are read") is filled with 0xFF bytes first -- NaN as float32 and
                                             float16 -- which is what RECYCLED device memory may hold (fresh memory reads as zero and hides a
                                             read of something never written).  Results must not change (tests/test_gpu_round5.py)            */
 

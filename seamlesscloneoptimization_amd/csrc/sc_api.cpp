@@ -38,7 +38,18 @@ int hip_fail(Instance *I, hipError_t e, const char *what)
 // level planes, image staging -- are written before they are read (or their unwritten parts only ever reach masked lanes) and skip it.
 int ensure(Instance *I, DevBuf &b, size_t bytes, bool zero)
 {
-    if (bytes <= b.cap) return SC_OK;
+    if (bytes <= b.cap) {
+        // (testing: a buffer that is RE-USED without zeroing holds what the previous call left -- here: NaN bytes, in place before any
+        //  stream touches it; every stream of the instance has drained first, the previous call may still be reading)
+        if (!zero && bytes && (I->opts.flags & SC_FLAG_POISON_ARENA)) {
+            SC_HIP(I, hipStreamSynchronize(I->stream));
+            if (I->aux) SC_HIP(I, hipStreamSynchronize(I->aux));
+            if (I->aux2) SC_HIP(I, hipStreamSynchronize(I->aux2));
+            SC_HIP(I, hipMemsetAsync(b.p, 0xFF, bytes, I->stream));
+            SC_HIP(I, hipStreamSynchronize(I->stream));
+        }
+        return SC_OK;
+    }
     size_t ncap = bytes > 2 * b.cap ? bytes : 2 * b.cap;
     ncap = (ncap + 4095) & ~(size_t)4095;
     void *np = nullptr;

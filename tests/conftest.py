@@ -116,3 +116,4 @@ def _poison_everything_if_asked():
         return pset0(self, **kw)
 
     capi.Instance.__init__, capi.Instance.set_solver, capi.Pool.__init__, capi.Pool.set_solver = init, set_solver, pinit, pset
+    print("[conftest] SC_TEST_POISON=1: every instance runs with SC_FLAG_POISON_ARENA", file=sys.stderr)
