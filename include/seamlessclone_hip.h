@@ -373,8 +373,8 @@ SC_API int   sc_hip_pool_set_solver(void *pool, const sc_solver_opts *opts);
 SC_API int   sc_hip_pool_run(void *pool, sc_batch_job *jobs, int n, int device_resident);
 /* device-resident batches: every worker takes up to `group` jobs at a time -- the batch's jobs bucketed by ROI size: same-size
  * jobs and jobs of one size class -- and runs them through sc_hip_run_device_batch (default 1 = one clone per set of launches; at most 64).
- * SC_POOL_GROUP_AUTO: sixteen at least where the batch has them, more for small ROIs -- up to n / streams (every stream gets a
- * group) and 64, while a group's fields stay within what sixteen 2048 x 2048 members occupy (small clones are latency bound:
+ * SC_POOL_GROUP_AUTO: sixteen at least where the batch has them, more for small ROIs -- up to half the batch (two groups at a time
+ * are what pays: more streams launching small kernels at once only contend) and 64, while a group's fields stay within what sixteen 2048 x 2048 members occupy (small clones are latency bound:
  * 64 clones of 120..190 pixels take 0.43 ms in two groups of 32, 0.64 in four of 16) */
 #define SC_POOL_GROUP_AUTO 0
 SC_API int   sc_hip_pool_set_group(void *pool, int group);

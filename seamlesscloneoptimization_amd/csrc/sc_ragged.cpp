@@ -155,13 +155,17 @@ void plan_cache_clear()
 // would otherwise always split in two.
 // What the pool hands plan_groups for a batch of n jobs on `streams` workers (sc_pool.cpp; sc_hip_plan_groups_pool mirrors it):
 // an explicit group size is a hard cap; SC_POOL_GROUP_AUTO (0) means sixteen members at least where the batch has them, more -- up to
-// n / streams, so that every stream gets a group, and up to 64 -- while a group's fields stay within what sixteen 2048^2 members
+// n / min(streams, 2), so that two streams get a group each, and up to 64 -- while a group's fields stay within what sixteen 2048^2 members
 // occupy.  Measured (64 jobs, 2 streams; groups of 16 -> 32): [120, 190]^2 0.64 -> 0.43 ms per batch, [300, 340]^2 0.91 -> 0.80,
 // [500, 560]^2 1.73 -> 1.54, [1000, 1100]^2 4.45 -> 4.24; ONE group of 64 loses (the second stream idles).
 void pool_group_caps(int group, int n, int streams, int &cap, int &cap_max, long &budget_px)
 {
     if (group > 0) { cap = cap_max = group; budget_px = 0; return; }
-    const int per_stream = (n + std::max(1, streams) - 1) / std::max(1, streams);
+    // (TWO groups at a time are what pays: 64 clones of 120..190 pixels take 0.42 ms as 2 x 32 on two streams, 0.48 as 3 groups on three,
+    //  0.61 as 4 x 16 on four, 0.99 as 8 x 8 on eight -- more host threads launching small kernels at once only contend; 1000..1100:
+    //  4.05 ms as 2 x 32, 4.65 as 4 x 16 -- so a pool with more than two streams still gets half the batch per group)
+    const int lanes = std::max(1, std::min(streams, 2));
+    const int per_stream = (n + lanes - 1) / lanes;
     cap = std::max(1, std::min(16, per_stream));             // (a batch smaller than 16 x streams is split among the streams as well: 8 x 1024^2 on two: 2 x 4 beats 1 x 8)
     cap_max = std::max(cap, std::min(64, per_stream));
     budget_px = 16L * 2048 * 2048;
